@@ -1,0 +1,62 @@
+"""ctypes binding of the ark_amd C-ABI (include/ark_amd.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).
+There is deliberately NO fallback: if the library is missing, every op raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libark_amd.so")
+
+PREC_F32, PREC_BF16 = 0, 1
+LAY_KMAJ, LAY_MMAJ = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL_DGELU, EPI_MUL_AUX = 0, 1, 2, 3, 4
+
+_lib = None
+
+
+class ArkError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ArkError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'). No CPU fallback exists."
+            )
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = "hipError_t" if rc > 0 else "argument error"
+        raise ArkError(f"{what} failed: {kind} {rc}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None) as c_void_p"""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def i64(x):
+    return ctypes.c_int64(int(x))
+
+
+def i32(x):
+    return ctypes.c_int(int(x))
+
+
+def f32(x):
+    return ctypes.c_float(float(x))

@@ -1,0 +1,50 @@
+// Shared device/host helpers for the ark_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ark {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+enum : int { PREC_F32 = 0, PREC_BF16 = 1 };
+// Operand layouts.  KMAJ: element (row, k) lives at base[row * ld + k]  (reduction index contiguous).
+//                   MMAJ: element (row, k) lives at base[k * ld + row]  (row index contiguous).
+enum : int { LAY_KMAJ = 0, LAY_MMAJ = 1 };
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// exact-erf GELU, as torch.nn.GELU() default (reference kgvae/model/models.py:37)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+}  // namespace ark
+
+// Error plumbing for the C-ABI: 0 = ok, >0 = hipError_t, <0 = argument error.
+#define ARK_ERR_ARG (-1)
+#define ARK_ERR_SHAPE (-2)
+#define ARK_ERR_ALIGN (-3)
+#define ARK_LAUNCH_CHECK()                       \
+  do {                                           \
+    hipError_t e__ = hipGetLastError();          \
+    if (e__ != hipSuccess) return (int)e__;      \
+  } while (0)

@@ -1,0 +1,298 @@
+"""CPU oracle for the ARK / SAIL training hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch, functional restatement (PyTorch-CPU fp32, explicit math) of what
+the reference computes on the path named in BASELINE.json `north_star`.  It is imported only by
+tests/, by `__graft_entry__.smoke()` and by bench.py's `cpu_baseline` leg — never by the product
+path (ark_amd/, kgvae/), which must fail loudly when the HIP extension is missing.
+
+Parity pin: every function here is checked in tests/test_oracle_golden.py against golden vectors
+that tools/make_golden.py produced by importing the real reference (`/root/reference`,
+kgvae.model.models.SAIL / ARK) in the build container.  The reference ships no tests or golden
+vectors of its own, so those generated fixtures are the pin.
+
+Reference call sites restated (paths relative to the reference repo):
+  encoder gather / masked mean pool ........ kgvae/model/models.py:46-58
+  encoder MLP (Linear+GELU)^n .............. kgvae/model/models.py:32-41,60
+  mu / logv heads, clamp, reparameterise ... kgvae/model/models.py:43-44,61-63
+  kl_mean .................................. kgvae/model/models.py:199-200
+  GRU decoder (tok_emb, z_proj, GRU, out) .. kgvae/model/models.py:116-142
+  decoder-only ARK (tok+pos emb, GRU, out) . kgvae/model/models.py:323-345, 395-405
+  ELBO assembly (ce + b*kl) ................ kgvae/experiments/ablation_study.py:59-73
+  Adam step ................................ kgvae/experiments/ablation_study.py:571,76
+  greedy decode (beam=1) ................... kgvae/model/models.py:262-266, 282-300
+  sequence codec ........................... kgvae/model/utils.py:70-78, 102-108
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+PAD, BOS, EOS = 0, 1, 2
+
+
+# --------------------------------------------------------------------------------------------
+# parameters
+# --------------------------------------------------------------------------------------------
+def init_params(cfg, seed):
+    """Create the state-dict the reference would create under ``torch.manual_seed(seed)``.
+
+    The reference builds stock torch modules in constructor order (models.py:26-44 for the
+    encoder, :119-128 for the decoder, :149-186 for SAIL; :327-338 for ARK); stock initialisers
+    consume the global CPU generator in that order, so re-creating the same stock modules in the
+    same order reproduces every tensor bit-for-bit.  ``dec.out.weight`` is drawn
+    and then discarded by the weight tie (models.py:130-134).
+    """
+    import torch.nn as nn
+
+    torch.manual_seed(seed)
+    D, n = cfg["d_model"], cfg["n_layers"]
+    V = cfg["vocab_size"]
+    P = OrderedDict()
+    mt = cfg["model_type"]
+    if mt == "SAIL":
+        Z = cfg["d_latent"]
+        e = nn.Embedding(cfg["n_entities"], D, padding_idx=cfg.get("pad_eid"))
+        r = nn.Embedding(cfg["n_relations"], D, padding_idx=cfg.get("pad_rid"))
+        P["enc.e_emb.weight"], P["enc.r_emb.weight"] = e.weight, r.weight
+        hid = max(3 * D, 2 * D)
+        in_dim = 3 * D
+        for i in range(n):
+            lin = nn.Linear(in_dim, hid)
+            P[f"enc.mlp.{2 * i}.weight"], P[f"enc.mlp.{2 * i}.bias"] = lin.weight, lin.bias
+            in_dim = hid
+        mu, lv = nn.Linear(hid, Z), nn.Linear(hid, Z)
+        P["enc.mu.weight"], P["enc.mu.bias"] = mu.weight, mu.bias
+        P["enc.logv.weight"], P["enc.logv.bias"] = lv.weight, lv.bias
+        tok = nn.Embedding(V, D)
+        zp = nn.Linear(Z, D)
+        P["dec.tok_emb.weight"] = tok.weight
+        P["dec.z_proj.weight"], P["dec.z_proj.bias"] = zp.weight, zp.bias
+    elif mt == "ARK":
+        tok = nn.Embedding(V, D)
+        pos = nn.Embedding(cfg["seq_len"], D)
+        P["dec.tok_emb.weight"], P["dec.pos_emb.weight"] = tok.weight, pos.weight
+    else:
+        raise NotImplementedError(f"Unknown model_type: {mt}")
+    gru = nn.GRU(D, D, n, batch_first=True, dropout=0.0)
+    for l in range(n):
+        for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            P[f"dec.gru.{nm}_l{l}"] = getattr(gru, f"{nm}_l{l}")
+    out = nn.Linear(D, V)
+    tied = cfg.get("tie_weights", True) and out.weight.shape == tok.weight.shape
+    P["dec.out.weight"] = tok.weight if tied else out.weight
+    P["dec.out.bias"] = out.bias
+    return OrderedDict((k, v.detach().clone() if k != "dec.out.weight" or not tied else None) for k, v in P.items()) \
+        if False else _detach_tied(P, tied)
+
+
+def _detach_tied(P, tied):
+    out = OrderedDict()
+    for k, v in P.items():
+        out[k] = v.detach().clone()
+    if tied:
+        out["dec.out.weight"] = out["dec.tok_emb.weight"]  # same tensor object, as in the reference
+    return out
+
+
+def leaf_params(P):
+    """unique trainable tensors in state-dict order (tied weight appears once)"""
+    seen, out = set(), []
+    for k, v in P.items():
+        if id(v) not in seen:
+            seen.add(id(v))
+            out.append((k, v))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# forward pieces
+# --------------------------------------------------------------------------------------------
+def encoder_pool(P, triples, pad_rid=None):
+    """g[b] = masked mean over triples of [E[h] | R[r] | E[t]]   (models.py:47-58)"""
+    E, R = P["enc.e_emb.weight"], P["enc.r_emb.weight"]
+    x = torch.cat([E[triples[:, :, 0]], R[triples[:, :, 1]], E[triples[:, :, 2]]], dim=-1)
+    if pad_rid is not None:
+        m = (triples[:, :, 1] != pad_rid)
+        cnt = m.sum(dim=1, keepdim=True).clamp(min=1)
+        return (x * m.unsqueeze(-1)).sum(dim=1) / cnt
+    return x.mean(dim=1)
+
+
+def encoder_forward(P, triples, eps, cfg):
+    """-> z, mu, logv   (models.py:46-64); eps replaces torch.randn_like(mu)"""
+    g = encoder_pool(P, triples, cfg.get("pad_rid"))
+    for i in range(cfg["n_layers"]):
+        g = F.gelu(g @ P[f"enc.mlp.{2 * i}.weight"].t() + P[f"enc.mlp.{2 * i}.bias"])
+    mu = g @ P["enc.mu.weight"].t() + P["enc.mu.bias"]
+    logv = (g @ P["enc.logv.weight"].t() + P["enc.logv.bias"]).clamp(-10, 10)
+    z = mu + eps * torch.exp(0.5 * logv)
+    return z, mu, logv
+
+
+def gru_stack(P, x, h0, n_layers, drop_masks=None):
+    """Multi-layer GRU, batch_first, gate row order (r, z, n) as torch.nn.GRU (models.py:121-127).
+
+    x [B,L,D]; h0 [n,B,D].  drop_masks: optional list of n-1 tensors [B,L,D] already scaled by
+    1/(1-p), applied to the output of layers 0..n-2 (torch's inter-layer dropout)."""
+    B, L, D = x.shape
+    inp = x
+    for l in range(n_layers):
+        Wih, Whh = P[f"dec.gru.weight_ih_l{l}"], P[f"dec.gru.weight_hh_l{l}"]
+        bih, bhh = P[f"dec.gru.bias_ih_l{l}"], P[f"dec.gru.bias_hh_l{l}"]
+        gi_all = inp @ Wih.t() + bih  # time-batched input projection
+        h = h0[l]
+        outs = []
+        for t in range(L):
+            gi = gi_all[:, t]
+            gh = h @ Whh.t() + bhh
+            r = torch.sigmoid(gi[:, :D] + gh[:, :D])
+            zt = torch.sigmoid(gi[:, D:2 * D] + gh[:, D:2 * D])
+            nt = torch.tanh(gi[:, 2 * D:] + r * gh[:, 2 * D:])
+            h = (1.0 - zt) * nt + zt * h
+            outs.append(h)
+        inp = torch.stack(outs, dim=1)
+        if drop_masks is not None and l < n_layers - 1:
+            inp = inp * drop_masks[l]
+    return inp
+
+
+def decoder_forward(P, z, seq_in, cfg, drop_masks=None):
+    """SAIL decoder: logits[B,L,V]   (models.py:136-142)"""
+    n = cfg["n_layers"]
+    x = P["dec.tok_emb.weight"][seq_in]
+    h0 = torch.tanh(z @ P["dec.z_proj.weight"].t() + P["dec.z_proj.bias"])
+    y = gru_stack(P, x, h0.unsqueeze(0).repeat(n, 1, 1), n, drop_masks)
+    return y @ P["dec.out.weight"].t() + P["dec.out.bias"]
+
+
+def ark_forward(P, seq_in, cfg, drop_masks=None):
+    """decoder-only ARK: logits[B,L,V]   (models.py:340-345)"""
+    n = cfg["n_layers"]
+    B, L = seq_in.shape
+    x = P["dec.tok_emb.weight"][seq_in] + P["dec.pos_emb.weight"][torch.arange(L)].unsqueeze(0)
+    h0 = torch.zeros(n, B, cfg["d_model"], dtype=x.dtype)
+    y = gru_stack(P, x, h0, n, drop_masks)
+    return y @ P["dec.out.weight"].t() + P["dec.out.bias"]
+
+
+def kl_mean(mu, logv):
+    """mean over ALL B*Z elements (models.py:199-200)"""
+    return -0.5 * torch.mean(1 + logv - mu.pow(2) - logv.exp())
+
+
+def token_ce(logits, targets):
+    """mean over non-PAD targets (ablation_study.py:65-69)"""
+    V = logits.shape[-1]
+    return F.cross_entropy(logits.reshape(-1, V), targets.reshape(-1), ignore_index=PAD)
+
+
+def sail_elbo(P, triples, seq, eps, beta, cfg, drop_masks=None):
+    """one SAIL training forward: loss = ce + beta*kl  (ablation_study.py:59-73)"""
+    z, mu, logv = encoder_forward(P, triples, eps, cfg)
+    logits = decoder_forward(P, z, seq[:, :-1], cfg, drop_masks)
+    ce = token_ce(logits, seq[:, 1:])
+    kl = kl_mean(mu, logv)
+    return ce + beta * kl, ce, kl, logits, mu, logv
+
+
+def ark_loss(P, seq, cfg, drop_masks=None):
+    """one ARK training forward (train.py:42-58)"""
+    logits = ark_forward(P, seq[:, :-1], cfg, drop_masks)
+    ce = token_ce(logits, seq[:, 1:])
+    return ce, logits
+
+
+# --------------------------------------------------------------------------------------------
+# optimiser
+# --------------------------------------------------------------------------------------------
+def adam_init(leaves):
+    return {"step": 0, "m": [torch.zeros_like(p) for _, p in leaves], "v": [torch.zeros_like(p) for _, p in leaves]}
+
+
+def adam_step(leaves, grads, state, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults (no weight decay, no amsgrad), in place."""
+    state["step"] += 1
+    t = state["step"]
+    bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+    for (_, p), g, m, v in zip(leaves, grads, state["m"], state["v"]):
+        m.mul_(b1).add_(g, alpha=1.0 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def cosine_lr(base_lr, epoch, t_max, eta_min=1e-6):
+    """closed form of CosineAnnealingLR stepped once per epoch (ablation_study.py:577-581)"""
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * epoch / t_max)) / 2
+
+
+def beta_schedule(cfg, epoch):
+    """ablation_study.py:590-591"""
+    return cfg["beta0"] + (cfg["beta1"] - cfg["beta0"]) * epoch / cfg["num_epochs"]
+
+
+def train_step(P, state, batch, cfg, lr, beta=1.0, eps=None, drop_masks=None):
+    """forward + backward + Adam on the oracle's own tensors; returns (loss, ce, kl, grads)"""
+    leaves = leaf_params(P)
+    for _, p in leaves:
+        p.requires_grad_(True)
+        p.grad = None
+    triples, seq = batch
+    if cfg["model_type"] == "SAIL":
+        loss, ce, kl, *_ = sail_elbo(P, triples, seq, eps, beta, cfg, drop_masks)
+    else:
+        ce, _ = ark_loss(P, seq, cfg, drop_masks)
+        loss, kl = ce, torch.zeros(())
+    loss.backward()
+    grads = [p.grad.detach().clone() for _, p in leaves]
+    # nn.Embedding(padding_idx=...) rows never receive gradient
+    if cfg["model_type"] == "SAIL":
+        names = [k for k, _ in leaves]
+        if cfg.get("pad_eid") is not None:
+            grads[names.index("enc.e_emb.weight")][cfg["pad_eid"]] = 0
+        if cfg.get("pad_rid") is not None:
+            grads[names.index("enc.r_emb.weight")][cfg["pad_rid"]] = 0
+    with torch.no_grad():
+        for _, p in leaves:
+            p.requires_grad_(False)
+        adam_step(leaves, grads, state, lr)
+    return loss.item(), ce.item(), float(kl), grads
+
+
+# --------------------------------------------------------------------------------------------
+# decode + codec
+# --------------------------------------------------------------------------------------------
+@torch.no_grad()
+def greedy_decode(P, z, cfg):
+    """token sequences of SAIL.decode_latent(z, beam=1): start at BOS, re-run the decoder on the
+    whole prefix, take argmax of the last position, stop when every row ends in EOS
+    (models.py:282-300 with beam=1; log_softmax is monotone so argmax(logits) == topk(1))."""
+    B = z.shape[0]
+    s = torch.full((B, 1), BOS, dtype=torch.long)
+    for _ in range(cfg["seq_len"] - 1):
+        nxt = decoder_forward(P, z, s, cfg)[:, -1].argmax(dim=-1, keepdim=True)
+        s = torch.cat([s, nxt], dim=1)
+        if bool((s[:, -1] == EOS).all()):
+            break
+    return s
+
+
+def triples_to_seq(triples, ent_base, rel_base, seq_len):
+    """[BOS, (ent_base+h, rel_base+r, ent_base+t)*, EOS, PAD...]  (utils.py:102-108)"""
+    s = [BOS]
+    for h, r, t in triples:
+        s += [ent_base + h, rel_base + r, ent_base + t]
+    s.append(EOS)
+    return s + [PAD] * (seq_len - len(s))
+
+
+def seq_to_triples(seq, ent_base, rel_base):
+    """inverse codec: skip BOS, read 3 tokens at a time until EOS at a triple boundary or fewer
+    than 3 tokens remain (utils.py:70-78)"""
+    seq = [int(x) for x in seq]
+    out, i = [], 1
+    while i + 2 < len(seq) and seq[i] != EOS:
+        out.append((seq[i] - ent_base, seq[i + 1] - rel_base, seq[i + 2] - ent_base))
+        i += 3
+    return out
