@@ -82,8 +82,7 @@ def init_params(cfg, seed):
     tied = cfg.get("tie_weights", True) and out.weight.shape == tok.weight.shape
     P["dec.out.weight"] = tok.weight if tied else out.weight
     P["dec.out.bias"] = out.bias
-    return OrderedDict((k, v.detach().clone() if k != "dec.out.weight" or not tied else None) for k, v in P.items()) \
-        if False else _detach_tied(P, tied)
+    return _detach_tied(P, tied)
 
 
 def _detach_tied(P, tied):
@@ -257,7 +256,7 @@ def train_step(P, state, batch, cfg, lr, beta=1.0, eps=None, drop_masks=None):
         for _, p in leaves:
             p.requires_grad_(False)
         adam_step(leaves, grads, state, lr)
-    return loss.item(), ce.item(), float(kl), grads
+    return loss.item(), ce.item(), float(kl.detach()), grads
 
 
 # --------------------------------------------------------------------------------------------

@@ -1,0 +1,152 @@
+"""Pin the CPU oracle (oracle/sail_oracle.py) to golden vectors produced by the REAL reference
+(tools/make_golden.py imported /root/reference's kgvae.model.models in the build container)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sail_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    cfg = json.loads(str(z["cfg_json"]))
+    return z, cfg
+
+
+FULL = ["sail_tiny", "sail_tiny_pad", "ark_tiny", "sail_small", "sail_small_pad"]
+SCALAR = ["sail_synpaths_b32_s0", "sail_synpaths_b32_s1", "ark_synpaths_b32_s0"]
+
+
+@pytest.mark.parametrize("name", FULL + SCALAR)
+def test_init_order_reproduces_reference_weights(name):
+    z, cfg = load(name)
+    P = O.init_params(cfg, int(z["seed"]))
+    if name in FULL:
+        for k, v in P.items():
+            assert np.array_equal(v.numpy(), z["w0/" + k]), k
+    assert P["dec.out.weight"] is P["dec.tok_emb.weight"]
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_forward_backward_adam_match_reference(name):
+    z, cfg = load(name)
+    P = OrderedDictFrom(z, "w0/")
+    triples, seq = torch.from_numpy(z["triples"]), torch.from_numpy(z["seq"])
+    state = O.adam_init(O.leaf_params(P))
+    lr = float(z["lr"])
+    for s in range(len(z["losses"])):
+        eps = torch.from_numpy(z[f"eps{s}"]) if cfg["model_type"] == "SAIL" else None
+        if s == 0:
+            with torch.no_grad():
+                if cfg["model_type"] == "SAIL":
+                    _, _, _, logits, mu, logv = O.sail_elbo(P, triples, seq, eps, float(z["betas"][0]), cfg)
+                    np.testing.assert_allclose(mu.numpy(), z["mu0"], rtol=1e-5, atol=1e-6)
+                    np.testing.assert_allclose(logv.numpy(), z["logv0"], rtol=1e-5, atol=1e-6)
+                else:
+                    _, logits = O.ark_loss(P, seq, cfg)
+                np.testing.assert_allclose(logits.numpy(), z["logits0"], rtol=1e-4, atol=2e-5)
+        loss, ce, kl, grads = O.train_step(P, state, (triples, seq), cfg, lr, beta=float(z["betas"][s]), eps=eps)
+        ref = z["losses"][s]
+        assert abs(loss - ref[0]) <= 2e-6 * abs(ref[0]) + 1e-6, (s, loss, ref)
+        assert abs(ce - ref[1]) <= 2e-6 * abs(ref[1]) + 1e-6
+        assert abs(kl - ref[2]) <= 1e-5 * abs(ref[2]) + 1e-7
+        if s == 0:
+            for (k, _), g in zip(O.leaf_params(P), grads):
+                np.testing.assert_allclose(g.numpy(), z["g0/" + k], rtol=2e-4, atol=2e-6, err_msg=k)
+        if f"w{s + 1}/dec.out.bias" in z:
+            for k, v in P.items():
+                assert_close_frac(v.numpy(), z[f"w{s + 1}/" + k], lr, f"{k}@{s + 1}")
+
+
+@pytest.mark.parametrize("name", SCALAR)
+def test_full_size_scalars(name):
+    torch.set_num_threads(8)
+    z, cfg = load(name)
+    P = O.init_params(cfg, int(z["seed"]))
+    triples, seq = torch.from_numpy(z["triples"]), torch.from_numpy(z["seq"])
+    state = O.adam_init(O.leaf_params(P))
+    for s in range(len(z["losses"])):
+        eps = torch.from_numpy(z[f"eps{s}"]) if cfg["model_type"] == "SAIL" else None
+        loss, ce, kl, grads = O.train_step(P, state, (triples, seq), cfg, float(z["lr"]), beta=float(z["betas"][s]),
+                                           eps=eps)
+        ref = z["losses"][s]
+        assert abs(loss - ref[0]) <= 1e-5 * abs(ref[0]), (s, loss, ref)
+        if s == 0:
+            for (k, _), g in zip(O.leaf_params(P), grads):
+                n = float(np.sqrt((g.numpy().astype(np.float64) ** 2).sum()))
+                assert abs(n - float(z["g0norm/" + k])) <= 1e-4 * float(z["g0norm/" + k]) + 1e-9, k
+        for k, v in P.items():
+            want = float(z[f"w{s + 1}sum/" + k])
+            assert abs(float(v.double().sum()) - want) <= 1e-5 * abs(want) + 1e-3, (k, s)
+
+
+@pytest.mark.parametrize("name", ["sail_tiny", "sail_tiny_pad", "sail_small", "sail_small_pad"])
+def test_greedy_decode_bit_exact(name):
+    z, cfg = load(name)
+    P = OrderedDictFrom(z, f"w{len(z['losses'])}/")
+    toks = O.greedy_decode(P, torch.from_numpy(z["dec_z"]), cfg)
+    for i in range(toks.shape[0]):
+        tr = O.seq_to_triples(toks[i].tolist(), cfg["ENT_BASE"], cfg["REL_BASE"])
+        n = int(z["dec_ntriples"][i])
+        assert len(tr) == n
+        assert [list(t) for t in tr] == z["dec_triples"][i, :n].tolist()
+
+
+def test_codec_vectors():
+    cases = json.load(open(os.path.join(GOLD, "codec.json")))
+    for c in cases:
+        T = (len(c["seq"]) - 2) // 3
+        if c["triples"] is not None:
+            assert O.triples_to_seq([tuple(t) for t in c["triples"]], 3, 13, len(c["seq"])) == c["seq"]
+        assert [list(t) for t in O.seq_to_triples(c["seq"], 3, 13)] == c["decoded"]
+
+
+def test_adam_matches_torch_optim():
+    torch.manual_seed(0)
+    p = torch.randn(50)
+    q = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([q], lr=3e-3)
+    st = O.adam_init([("p", p)])
+    for i in range(5):
+        g = torch.randn(50)
+        q.grad = g.clone()
+        opt.step()
+        O.adam_step([("p", p)], [g], st, 3e-3)
+    np.testing.assert_allclose(p.numpy(), q.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_schedules():
+    sched_p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([sched_p], lr=1e-3)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=20, eta_min=1e-6)
+    for ep in range(20):
+        assert abs(opt.param_groups[0]["lr"] - O.cosine_lr(1e-3, ep, 20)) < 1e-9
+        opt.step()
+        sch.step()
+    assert O.beta_schedule({"beta0": 0.1, "beta1": 1.0, "num_epochs": 100}, 50) == pytest.approx(0.55)
+
+
+def assert_close_frac(got, want, lr, msg):
+    """post-Adam weights: an element whose gradient is ~1e-8 (Adam's eps) legitimately moves by
+    anything in [-lr, lr] depending on last-bit gradient noise, so allow <=0.1% of elements to
+    differ by up to 2*lr*steps; everything else must agree to 1e-4 relative."""
+    bad = np.abs(got - want) > (1e-4 * np.abs(want) + 3e-6)
+    assert bad.mean() <= 1e-3, (msg, bad.mean())
+    assert np.abs(got - want).max() <= 8 * lr, (msg, np.abs(got - want).max())
+
+
+def OrderedDictFrom(z, prefix):
+    from collections import OrderedDict
+    P = OrderedDict()
+    for k in z.files:
+        if k.startswith(prefix):
+            P[k[len(prefix):]] = torch.from_numpy(z[k].copy())
+    if "dec.out.weight" in P and np.array_equal(P["dec.out.weight"].numpy(), P["dec.tok_emb.weight"].numpy()):
+        P["dec.out.weight"] = P["dec.tok_emb.weight"]
+    return P
