@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libark_amd.so")
 
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 LAY_KMAJ, LAY_MMAJ = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL_DGELU, EPI_MUL_AUX = 0, 1, 2, 3, 4
 
@@ -60,3 +60,7 @@ def i32(x):
 
 def f32(x):
     return ctypes.c_float(float(x))
+
+
+def u64(x):
+    return ctypes.c_uint64(int(x) & 0xFFFFFFFFFFFFFFFF)

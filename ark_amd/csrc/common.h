@@ -8,8 +8,10 @@ namespace ark {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-enum : int { PREC_F32 = 0, PREC_BF16 = 1 };
+enum : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
 // Operand layouts.  KMAJ: element (row, k) lives at base[row * ld + k]  (reduction index contiguous).
 //                   MMAJ: element (row, k) lives at base[k * ld + row]  (row index contiguous).
 enum : int { LAY_KMAJ = 0, LAY_MMAJ = 1 };

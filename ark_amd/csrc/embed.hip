@@ -1,0 +1,194 @@
+// Embedding gathers and their scatter-add gradients (HBM/LDS-bound; no MFMA here).
+// Replaces: nn.Embedding x3 + torch.cat + masked mean pool (reference kgvae/model/models.py:47-58),
+// tok_emb / pos_emb lookup (models.py:138, 343) and autograd's embedding_backward.
+#include "common.h"
+#include "../../include/ark_amd.h"
+
+namespace ark {
+
+// ---- encoder: g[b, :] = (1/max(1,cnt_b)) * sum_t m[b,t] * [E[h] | R[r] | E[t]] -----------------
+// One workgroup per graph; each thread owns float4 columns of the 3D-wide row, so every table row
+// read is a coalesced 16 B/lane stream (tables of the syn-* sets are L2-resident).
+__global__ __launch_bounds__(256) void enc_pool_fwd_kernel(const int64_t* __restrict__ triples, const float* __restrict__ E,
+                                                           const float* __restrict__ R, float* __restrict__ g,
+                                                           float* __restrict__ inv_cnt, int T, int D, long pad_rid) {
+  const int b = blockIdx.x;
+  const int64_t* tr = triples + (long)b * T * 3;
+  int cnt = 0;
+  for (int t = 0; t < T; ++t) cnt += (pad_rid < 0 || tr[t * 3 + 1] != pad_rid) ? 1 : 0;
+  // reference: masked sum / clamp(cnt,1) when pad_rid is set, plain mean over T otherwise
+  const float w = 1.0f / (float)(pad_rid < 0 ? T : (cnt > 0 ? cnt : 1));
+  if (threadIdx.x == 0 && inv_cnt) inv_cnt[b] = w;
+  const int D4 = D >> 2;
+  for (int c = threadIdx.x; c < 3 * D4; c += blockDim.x) {
+    const int part = c / D4, d4 = c % D4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) {
+      if (pad_rid >= 0 && tr[t * 3 + 1] == pad_rid) continue;
+      const long id = tr[t * 3 + part];
+      const float* tab = (part == 1) ? R : E;
+      s += *reinterpret_cast<const f32x4*>(tab + id * D + 4 * d4);
+    }
+    *reinterpret_cast<f32x4*>(g + (long)b * 3 * D + 4 * c) = s * w;
+  }
+}
+
+// ---- decoder input: x[(t,b), :] = W_tok[seq[b, t]] (+ W_pos[t])   (time-major rows) -----------
+__global__ __launch_bounds__(256) void tok_gather_kernel(const int64_t* __restrict__ seq, long ld_seq,
+                                                         const float* __restrict__ Wt, const float* __restrict__ Wp,
+                                                         float* __restrict__ x, int B, int L, int D) {
+  const int D4 = D >> 2;
+  const long total = (long)B * L * D4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d4 = (int)(i % D4);
+    const long row = i / D4;
+    const int t = (int)(row / B), b = (int)(row % B);
+    const long tok = seq[(long)b * ld_seq + t];
+    f32x4 v = *reinterpret_cast<const f32x4*>(Wt + tok * D + 4 * d4);
+    if (Wp) v += *reinterpret_cast<const f32x4*>(Wp + (long)t * D + 4 * d4);
+    *reinterpret_cast<f32x4*>(x + row * D + 4 * d4) = v;
+  }
+}
+
+// ---- scatter-add of gradient rows into a table --------------------------------------------
+// Source item i (0..n_items-1) adds  scale * src[src_row(i), col_off + 0..D)  into dst[id(i), :].
+// Small tables (syn-*: <= 192 rows) are privatised in LDS per workgroup: 64-column slices x item
+// chunks, ds_add_f32 inside, then ONE global atomic per (row, column) per workgroup -- this keeps
+// the float-atomic traffic at table-size x chunks instead of one contended add per item
+// (MI355X: every workgroup adding into one row runs 14x below the atomic rate).
+// Large tables (wd-*) use direct global atomics, one wave per item, 256 contiguous bytes per
+// wave-instruction.
+struct ScatterArgs {
+  float* dst; const float* src; long ld_src; int col_off;
+  const int64_t* ids; long id_stride_outer, id_stride_inner; int inner;  // id(i) = ids[(i/inner)*outer + (i%inner)*inner_stride + id_off]
+  int id_off;
+  const int64_t* mask_ids; int mask_off; long mask_val;   // skip item when mask_ids[... + mask_off] == mask_val
+  const float* scale;     // per source row, nullable
+  int src_div;            // src_row(i) = time_major ? (i%inner)*B_outer + i/inner : i / src_div
+  int time_major; int n_outer;
+  long skip_id;           // padding_idx row: never receives gradient (-1: none)
+  int n_items, D, n_rows;
+};
+
+__device__ __forceinline__ bool scatter_item(const ScatterArgs& p, int i, long& id, long& srow, float& sc) {
+  const int o = i / p.inner, j = i % p.inner;
+  const long base = (long)o * p.id_stride_outer + (long)j * p.id_stride_inner;
+  id = p.ids[base + p.id_off];
+  if (id == p.skip_id) return false;
+  if (p.mask_ids && p.mask_ids[base + p.mask_off] == p.mask_val) return false;
+  srow = p.time_major ? ((long)j * p.n_outer + o) : (long)(i / p.src_div);
+  sc = p.scale ? p.scale[srow] : 1.0f;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void scatter_lds_kernel(ScatterArgs p, int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tab = reinterpret_cast<float*>(smem);  // [n_rows][64]
+  const int slice = blockIdx.x / n_chunks, chunk = blockIdx.x % n_chunks;
+  const int c0 = slice * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < p.n_rows * 64; i += 256) tab[i] = 0.f;
+  __syncthreads();
+  const int per = (p.n_items + n_chunks - 1) / n_chunks;
+  const int i0 = chunk * per, i1 = min(p.n_items, i0 + per);
+  const bool col_ok = (c0 + lane) < p.D;
+  for (int i = i0 + wave; i < i1; i += 4) {
+    long id, srow; float sc;
+    if (!scatter_item(p, i, id, srow, sc)) continue;
+    if (col_ok) atomicAdd(&tab[id * 64 + lane], sc * p.src[srow * p.ld_src + p.col_off + c0 + lane]);
+  }
+  __syncthreads();
+  if (col_ok)
+    for (int r = wave; r < p.n_rows; r += 4) {
+      const float v = tab[r * 64 + lane];
+      if (v != 0.f) atomicAdd(&p.dst[(long)r * p.D + c0 + lane], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_global_kernel(ScatterArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * 4;
+  for (int i = wave_global; i < p.n_items; i += n_waves) {
+    long id, srow; float sc;
+    if (!scatter_item(p, i, id, srow, sc)) continue;
+    const float* s = p.src + srow * p.ld_src + p.col_off;
+    float* d = p.dst + id * p.D;
+    for (int c = lane; c < p.D; c += 64) atomicAdd(&d[c], sc * s[c]);
+  }
+}
+
+static int launch_scatter(const ScatterArgs& p, hipStream_t st) {
+  if (p.n_items <= 0) return 0;
+  if ((long)p.n_rows * 64 * 4 <= 48 * 1024) {
+    const int slices = (p.D + 63) / 64;
+    int n_chunks = 256 / slices; if (n_chunks < 1) n_chunks = 1;
+    if (n_chunks > (p.n_items + 15) / 16) n_chunks = (p.n_items + 15) / 16;
+    hipLaunchKernelGGL(scatter_lds_kernel, dim3(slices * n_chunks), dim3(256), (size_t)p.n_rows * 64 * 4, st, p, n_chunks);
+  } else {
+    int grid = (p.n_items + 3) / 4; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(scatter_global_kernel, dim3(grid), dim3(256), 0, st, p);
+  }
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ark
+
+extern "C" int ark_enc_pool_fwd(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt,
+                                int B, int T, int D, int64_t pad_rid, void* stream) {
+  using namespace ark;
+  if (!triples || !E || !R || !g || B <= 0 || T <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (D % 4 != 0) return ARK_ERR_SHAPE;
+  hipLaunchKernelGGL(enc_pool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, triples, E, R, g, inv_cnt, T, D,
+                     (long)pad_rid);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// dE / dR += scatter of dg (gradient of the pooled encoder input); accumulates into dE, dR.
+extern "C" int ark_enc_pool_bwd(const int64_t* triples, const float* dg, const float* inv_cnt, float* dE, float* dR,
+                                int B, int T, int D, int n_ent, int n_rel, int64_t pad_eid, int64_t pad_rid,
+                                void* stream) {
+  using namespace ark;
+  if (!triples || !dg || !inv_cnt || !dE || !dR || B <= 0 || T <= 0 || D <= 0) return ARK_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  for (int part = 0; part < 3; ++part) {
+    ScatterArgs p{};
+    p.dst = (part == 1) ? dR : dE; p.src = dg; p.ld_src = 3L * D; p.col_off = part * D;
+    p.ids = triples; p.id_stride_outer = 3L * T; p.id_stride_inner = 3; p.inner = T; p.id_off = part;
+    p.mask_ids = pad_rid >= 0 ? triples : nullptr; p.mask_off = 1; p.mask_val = (long)pad_rid;
+    p.scale = inv_cnt; p.src_div = T; p.time_major = 0; p.n_outer = B;
+    p.skip_id = (part == 1) ? (long)pad_rid : (long)pad_eid;
+    p.n_items = B * T; p.D = D; p.n_rows = (part == 1) ? n_rel : n_ent;
+    int rc = launch_scatter(p, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int ark_tok_gather(const int64_t* seq, int64_t ld_seq, const float* w_tok, const float* w_pos, float* x,
+                              int B, int L, int D, void* stream) {
+  using namespace ark;
+  if (!seq || !w_tok || !x || B <= 0 || L <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (D % 4 != 0) return ARK_ERR_SHAPE;
+  long total = (long)B * L * (D / 4);
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(tok_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, seq, (long)ld_seq, w_tok, w_pos,
+                     x, B, L, D);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// dW_tok[seq[b,t], :] += dx[(t,b), :]   (accumulates; the tied projection gradient is already in dW_tok)
+extern "C" int ark_tok_scatter(const int64_t* seq, int64_t ld_seq, const float* dx, float* d_w_tok, int B, int L, int D,
+                               int vocab, void* stream) {
+  using namespace ark;
+  if (!seq || !dx || !d_w_tok || B <= 0 || L <= 0 || D <= 0 || vocab <= 0) return ARK_ERR_ARG;
+  ScatterArgs p{};
+  p.dst = d_w_tok; p.src = dx; p.ld_src = D; p.col_off = 0;
+  p.ids = seq; p.id_stride_outer = (long)ld_seq; p.id_stride_inner = 1; p.inner = L; p.id_off = 0;
+  p.mask_ids = nullptr; p.scale = nullptr; p.src_div = 1; p.time_major = 1; p.n_outer = B; p.skip_id = -1;
+  p.n_items = B * L; p.D = D; p.n_rows = vocab;
+  return launch_scatter(p, (hipStream_t)stream);
+}

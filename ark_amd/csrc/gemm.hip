@@ -85,5 +85,6 @@ extern "C" int ark_gemm(int prec, int a_lay, int b_lay, int epi, const float* A,
   hipStream_t st = (hipStream_t)stream;
   if (prec == PREC_F32) return dispatch_lay<PREC_F32>(a_lay, b_lay, p, st);
   if (prec == PREC_BF16) return dispatch_lay<PREC_BF16>(a_lay, b_lay, p, st);
+  if (prec == PREC_F16) return dispatch_lay<PREC_F16>(a_lay, b_lay, p, st);
   return ARK_ERR_ARG;
 }

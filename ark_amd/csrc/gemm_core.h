@@ -13,7 +13,9 @@
 //    the fragment reads are the same conflict-free ds_read_b128 for every layout.
 //  * PREC_F32  : v_mfma_f32_16x16x4_f32 (exact f32 fma chain; parity / decode mode)
 //    PREC_BF16 : v_mfma_f32_16x16x32_bf16 with f32 accumulation (operands rounded RNE to bf16
-//                while staging; HBM copies stay f32)
+//                while staging; HBM copies stay f32) -- range-safe, used for backward products
+//    PREC_F16  : v_mfma_f32_16x16x32_f16, same rate, 3 more mantissa bits -- forward products
+//                (activations / weights are O(1); saturating conversion)
 //  * Next K-step's global loads are issued right after the LDS image of the current step is
 //    complete, so they are in flight underneath the MFMA block (issue-early / write-late).
 #pragma once
@@ -29,6 +31,17 @@ template <> struct PrecTraits<PREC_F32> {
 template <> struct PrecTraits<PREC_BF16> {
   static constexpr int BK = 64;   // 128 B of bf16
   static constexpr int FPC = 2;
+  using h_t = __bf16; using h8 = bf16x8; using h4 = bf16x4;
+  static __device__ __forceinline__ h_t cvt(float x) { return (__bf16)x; }
+  static __device__ __forceinline__ f32x4 mfma(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct PrecTraits<PREC_F16> {
+  static constexpr int BK = 64;   // 128 B of fp16
+  static constexpr int FPC = 2;
+  using h_t = _Float16; using h8 = f16x8; using h4 = f16x4;
+  // saturate instead of overflowing to inf (fp16 max 65504); forward activations/weights only
+  static __device__ __forceinline__ h_t cvt(float x) { return (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f); }
+  static __device__ __forceinline__ f32x4 mfma(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
 // byte offset of 16-byte chunk `chunk` (0..7) of tile row `row` in the swizzled LDS image
@@ -86,13 +99,14 @@ struct StageK {
       if constexpr (PREC == PREC_F32) {
         *reinterpret_cast<f32x4*>(p) = v[i];
       } else {
-        bf16x8 h;
+        using PT = PrecTraits<PREC>;
+        typename PT::h8 h;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          h[e] = (__bf16)v[i * 2][e];
-          h[4 + e] = (__bf16)v[i * 2 + 1][e];
+          h[e] = PT::cvt(v[i * 2][e]);
+          h[4 + e] = PT::cvt(v[i * 2 + 1][e]);
         }
-        *reinterpret_cast<bf16x8*>(p) = h;
+        *reinterpret_cast<typename PT::h8*>(p) = h;
       }
     }
   }
@@ -178,9 +192,10 @@ struct StageM {
             f32x4 t = {v[i * 4 + 0][rr], v[i * 4 + 1][rr], v[i * 4 + 2][rr], v[i * 4 + 3][rr]};
             *reinterpret_cast<f32x4*>(lds + lds_off(row, kq)) = t;
           } else {
-            bf16x4 h = {(__bf16)v[i * 4 + 0][rr], (__bf16)v[i * 4 + 1][rr], (__bf16)v[i * 4 + 2][rr],
-                        (__bf16)v[i * 4 + 3][rr]};
-            *reinterpret_cast<bf16x4*>(lds + lds_off(row, kq >> 1) + (kq & 1) * 8) = h;
+            using PT = PrecTraits<PREC>;
+            typename PT::h4 h = {PT::cvt(v[i * 4 + 0][rr]), PT::cvt(v[i * 4 + 1][rr]), PT::cvt(v[i * 4 + 2][rr]),
+                                 PT::cvt(v[i * 4 + 3][rr])};
+            *reinterpret_cast<typename PT::h4*>(lds + lds_off(row, kq >> 1) + (kq & 1) * 8) = h;
           }
         }
       }
@@ -254,18 +269,18 @@ struct GemmTile {
               for (int tn = 0; tn < TN; ++tn)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
         } else {
-          bf16x8 a[TM], b[TN];
+          using PT = PrecTraits<PREC>;
+          typename PT::h8 a[TM], b[TN];
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm)
-            a[tm] = *reinterpret_cast<const bf16x8*>(ldsA + lds_off(wm * WTM + tm * 16 + lr, 4 * s + lq));
+            a[tm] = *reinterpret_cast<const typename PT::h8*>(ldsA + lds_off(wm * WTM + tm * 16 + lr, 4 * s + lq));
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
-            b[tn] = *reinterpret_cast<const bf16x8*>(ldsB + lds_off(wn * WTN + tn * 16 + lr, 4 * s + lq));
+            b[tn] = *reinterpret_cast<const typename PT::h8*>(ldsB + lds_off(wn * WTN + tn * 16 + lr, 4 * s + lq));
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = PT::mfma(a[tm], b[tn], acc[tm][tn]);
         }
       }
       __syncthreads();

@@ -1,0 +1,290 @@
+// Latent head (clamp / reparameterise / KL), z-projection, token cross-entropy and the ELBO scalar.
+// Replaces: models.py:61-63 (clamp, randn_like reparam), models.py:199-200 (kl_mean),
+// models.py:139 (tanh(z_proj(z))), F.cross_entropy(ignore_index=PAD) + `ce + b*kl`
+// (kgvae/experiments/ablation_study.py:65-71) and their autograd backward.
+//
+// Scalars that change from step to step live in a small DEVICE array `hyper` (see ark_amd.h
+// ARK_HP_*), so a captured hipGraph of the whole step can be replayed unchanged.
+#include "common.h"
+#include "../../include/ark_amd.h"
+
+namespace ark {
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (wave == 0) {
+    t = (lane < (int)(blockDim.x >> 6)) ? red[lane] : 0.f;
+    t = wave_sum(t);
+  }
+  __syncthreads();
+  return t;  // valid in wave 0
+}
+
+// head[b, 0:Z] = mu, head[b, Z:2Z] = raw logv.  Single workgroup -> deterministic KL sum.
+__global__ __launch_bounds__(1024) void latent_fwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
+                                                          float* __restrict__ mu, float* __restrict__ logv,
+                                                          float* __restrict__ z, float* __restrict__ kl_out, int B, int Z) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  const int n = B * Z;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int b = i / Z, j = i % Z;
+    const float m = head[(long)b * 2 * Z + j];
+    float lv = head[(long)b * 2 * Z + Z + j];
+    lv = fminf(fmaxf(lv, -10.0f), 10.0f);
+    mu[i] = m;
+    logv[i] = lv;
+    z[i] = m + (eps ? eps[i] : 0.f) * expf(0.5f * lv);
+    acc += 1.0f + lv - m * m - expf(lv);
+  }
+  const float tot = block_sum_1024(acc, red);
+  if (threadIdx.x == 0) kl_out[0] = -0.5f * tot / (float)n;
+}
+
+// dhead = d(beta*kl)/d(mu,logv) + dz routed through the reparameterisation; clamp passes gradient
+// only where the raw logv lies inside [-10, 10] (torch.clamp semantics, boundary inclusive).
+__global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ head,
+                                                         const float* __restrict__ eps, const float* __restrict__ hyper,
+                                                         float* __restrict__ dhead, int B, int Z) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Z) return;
+  const int b = i / Z, j = i % Z;
+  const float ks = hyper[ARK_HP_BETA] * hyper[ARK_HP_KL_NORM];  // beta / (B_global * Z)
+  const float m = head[(long)b * 2 * Z + j];
+  const float raw = head[(long)b * 2 * Z + Z + j];
+  const float lv = fminf(fmaxf(raw, -10.0f), 10.0f);
+  const float g = dz[i];
+  const float dmu = g + ks * m;
+  float dlv = g * (eps ? eps[i] : 0.f) * 0.5f * expf(0.5f * lv) + ks * 0.5f * (expf(lv) - 1.0f);
+  if (raw < -10.0f || raw > 10.0f) dlv = 0.f;
+  dhead[(long)b * 2 * Z + j] = dmu;
+  dhead[(long)b * 2 * Z + Z + j] = dlv;
+}
+
+// h0[b, d] = tanh(bz[d] + sum_j z[b,j] Wz[d,j]), written to n_copies layer slots
+__global__ __launch_bounds__(256) void zproj_fwd_kernel(const float* __restrict__ z, const float* __restrict__ Wz,
+                                                        const float* __restrict__ bz, float* __restrict__ h0,
+                                                        long copy_stride, int n_copies, int B, int Z, int D) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * D) return;
+  const int b = (int)(i / D), d = (int)(i % D);
+  float a = bz[d];
+  for (int j = 0; j < Z; ++j) a += z[(long)b * Z + j] * Wz[(long)d * Z + j];
+  const float h = tanhf(a);
+  for (int c = 0; c < n_copies; ++c) h0[c * copy_stride + i] = h;
+}
+
+// dzp = dh0 * (1 - h0^2)  (in place)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(float* __restrict__ dh0, const float* __restrict__ h0, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float h = h0[i]; dh0[i] *= (1.0f - h * h); }
+}
+
+// dz[b,j] = sum_d dzp[b,d] Wz[d,j]      one wave per (b), lanes over d, then wave reduction per j
+__global__ __launch_bounds__(256) void zproj_bwd_dz_kernel(const float* __restrict__ dzp, const float* __restrict__ Wz,
+                                                           float* __restrict__ dz, int B, int Z, int D) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  for (int j = 0; j < Z; ++j) {
+    float a = 0.f;
+    for (int d = lane; d < D; d += 64) a += dzp[(long)b * D + d] * Wz[(long)d * Z + j];
+    a = wave_sum(a);
+    if (lane == 0) dz[(long)b * Z + j] = a;
+  }
+}
+
+// dWz[d,j] = sum_b dzp[b,d] z[b,j] ; dbz[d] = sum_b dzp[b,d]     thread per d, loop b (coalesced over d)
+__global__ __launch_bounds__(256) void zproj_bwd_dw_kernel(const float* __restrict__ dzp, const float* __restrict__ z,
+                                                           float* __restrict__ dWz, float* __restrict__ dbz, int B, int Z,
+                                                           int D, int b_chunk) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b0 = blockIdx.y * b_chunk, b1 = min(B, b0 + b_chunk);
+  if (d >= D) return;
+  constexpr int ZMAX = 128;
+  float acc[ZMAX];
+  float sb = 0.f;
+  for (int j = 0; j < Z; ++j) acc[j] = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const float g = dzp[(long)b * D + d];
+    sb += g;
+    for (int j = 0; j < Z; ++j) acc[j] += g * z[(long)b * Z + j];
+  }
+  for (int j = 0; j < Z; ++j) atomicAdd(&dWz[(long)d * Z + j], acc[j]);
+  atomicAdd(&dbz[d], sb);
+}
+
+// ---- token cross-entropy over time-major logits rows (t,b); target = seq[b, t+1] ---------------
+// One wave per row: running max / sum-exp over V in 64-wide strides, wavefront reductions.
+// Writes the per-row loss and (optionally, in place) dlogits = (softmax - onehot) * inv_count.
+__global__ __launch_bounds__(256) void ce_kernel(float* logits, long ld, const int64_t* __restrict__ seq,
+                                                 long ld_seq, const float* __restrict__ hyper, float* __restrict__ row_loss,
+                                                 float* dlogits, int B, int L, int V) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * L) return;
+  const int t = row / B, b = row % B;
+  const long tgt = seq[(long)b * ld_seq + t + 1];
+  const float* x = logits + (long)row * ld;
+  float mx = -INFINITY;
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, x[c]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < V; c += 64) se += expf(x[c] - mx);
+  se = wave_sum(se);
+  const float lse = mx + logf(se);
+  const bool live = (tgt != ARK_TOK_PAD);
+  if (lane == 0) row_loss[row] = live ? (lse - x[tgt]) : 0.f;
+  if (dlogits) {
+    const float s = live ? hyper[ARK_HP_CE_INV_COUNT] : 0.f;
+    float* d = dlogits + (long)row * ld;
+    for (int c = lane; c < ld; c += 64) {
+      float g = 0.f;
+      if (c < V) g = (expf(x[c] - lse) - ((long)c == tgt ? 1.0f : 0.f)) * s;
+      d[c] = g;
+    }
+  }
+}
+
+// count of non-PAD targets -> hyper[CE_COUNT], hyper[CE_INV_COUNT] (single-rank case; data-parallel
+// runs overwrite both with the all-reduced global count before the CE kernel runs)
+__global__ __launch_bounds__(1024) void count_targets_kernel(const int64_t* __restrict__ seq, long ld_seq, int B, int L,
+                                                             float* __restrict__ hyper) {
+  __shared__ float red[16];
+  float c = 0.f;
+  for (int i = threadIdx.x; i < B * L; i += blockDim.x) {
+    const int b = i / L, t = i % L;
+    c += (seq[(long)b * ld_seq + t + 1] != ARK_TOK_PAD) ? 1.f : 0.f;
+  }
+  const float tot = block_sum_1024(c, red);
+  if (threadIdx.x == 0) { hyper[ARK_HP_CE_COUNT] = tot; hyper[ARK_HP_CE_INV_COUNT] = tot > 0.f ? 1.0f / tot : 0.f; }
+}
+
+// out[0] = loss = ce + beta*kl, out[1] = ce, out[2] = kl.  Deterministic single-workgroup sum.
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const float* __restrict__ row_loss, int n_rows,
+                                                             const float* __restrict__ kl, const float* __restrict__ hyper,
+                                                             float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_rows; i += blockDim.x) s += row_loss[i];
+  const float tot = block_sum_1024(s, red);
+  if (threadIdx.x == 0) {
+    const float ce = tot * hyper[ARK_HP_CE_INV_COUNT];
+    const float k = kl ? kl[0] : 0.f;
+    out[0] = ce + hyper[ARK_HP_BETA] * k;
+    out[1] = ce;
+    out[2] = k;
+    out[3] = tot;  // un-normalised token loss sum (for data-parallel reporting)
+  }
+}
+
+// greedy decode helper: argmax over the vocabulary of selected logits rows (first index on ties,
+// as torch.topk / argmax on CPU)
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long ld, int64_t* __restrict__ out,
+                                                          int rows, int V) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float best = -INFINITY; int bi = 0x7fffffff;
+  for (int c = lane; c < V; c += 64) {
+    const float v = x[(long)row * ld + c];
+    if (v > best) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) out[row] = bi;
+}
+
+}  // namespace ark
+
+extern "C" int ark_latent_fwd(const float* head, const float* eps, float* mu, float* logv, float* z, float* kl_out,
+                              int B, int Z, void* stream) {
+  using namespace ark;
+  if (!head || !mu || !logv || !z || !kl_out || B <= 0 || Z <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, head, eps, mu, logv, z, kl_out, B, Z);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_latent_bwd(const float* dz, const float* head, const float* eps, const float* hyper, float* dhead,
+                              int B, int Z, void* stream) {
+  using namespace ark;
+  if (!dz || !head || !hyper || !dhead || B <= 0 || Z <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3((B * Z + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz, head, eps, hyper,
+                     dhead, B, Z);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_zproj_fwd(const float* z, const float* w_z, const float* b_z, float* h0, int64_t copy_stride,
+                             int n_copies, int B, int Z, int D, void* stream) {
+  using namespace ark;
+  if (!z || !w_z || !b_z || !h0 || B <= 0 || Z <= 0 || D <= 0 || n_copies <= 0) return ARK_ERR_ARG;
+  const long n = (long)B * D;
+  hipLaunchKernelGGL(zproj_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, w_z, b_z, h0,
+                     (long)copy_stride, n_copies, B, Z, D);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// dh0 (in: dL/dh0 summed over layers; out: overwritten with dL/d(pre-tanh)), dz / dWz / dbz outputs
+// (dWz, dbz are overwritten).
+extern "C" int ark_zproj_bwd(float* dh0, const float* h0, const float* z, const float* w_z, float* dz, float* d_w_z,
+                             float* d_b_z, int B, int Z, int D, void* stream) {
+  using namespace ark;
+  if (!dh0 || !h0 || !z || !w_z || !dz || !d_w_z || !d_b_z || B <= 0 || Z <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (Z > 128) return ARK_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)B * D;
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dh0, h0, n);
+  hipLaunchKernelGGL(zproj_bwd_dz_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dh0, w_z, dz, B, Z, D);
+  hipError_t e = hipMemsetAsync(d_w_z, 0, sizeof(float) * (size_t)D * Z, st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(d_b_z, 0, sizeof(float) * (size_t)D, st);
+  if (e != hipSuccess) return (int)e;
+  const int b_chunk = 64;
+  hipLaunchKernelGGL(zproj_bwd_dw_kernel, dim3((D + 255) / 256, (B + b_chunk - 1) / b_chunk), dim3(256), 0, st, dh0, z,
+                     d_w_z, d_b_z, B, Z, D, b_chunk);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_count_targets(const int64_t* seq, int64_t ld_seq, int B, int L, float* hyper, void* stream) {
+  using namespace ark;
+  if (!seq || !hyper || B <= 0 || L <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(count_targets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, seq, (long)ld_seq, B, L, hyper);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int64_t ld_seq, const float* hyper,
+                              float* row_loss, float* dlogits, int B, int L, int V, void* stream) {
+  using namespace ark;
+  if (!logits || !seq || !hyper || !row_loss || B <= 0 || L <= 0 || V <= 0 || ld < V) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(ce_kernel, dim3((B * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, seq, (long)ld_seq,
+                     hyper, row_loss, dlogits, B, L, V);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_loss_finalize(const float* row_loss, int n_rows, const float* kl, const float* hyper, float* out4,
+                                 void* stream) {
+  using namespace ark;
+  if (!row_loss || !hyper || !out4 || n_rows <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, n_rows, kl, hyper, out4);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_argmax_rows(const float* x, int64_t ld, int64_t* out, int rows, int V, void* stream) {
+  using namespace ark;
+  if (!x || !out || rows <= 0 || V <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (long)ld, out, rows, V);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,519 @@
+"""Host-side engine for the SAIL / ARK training step on MI355X.
+
+Owns the flat fp32 parameter / gradient / Adam-moment buffers and the per-batch activation
+workspace in HBM, and drives the hand-written HIP kernels (include/ark_amd.h) in the order of
+the reference's train step:
+
+    SAIL.forward          kgvae/model/models.py:317-320   (encoder :46-64, decoder :136-142)
+    ARK.forward           kgvae/model/models.py:395-405   (decoder :340-345)
+    ce + b*kl, backward   kgvae/experiments/ablation_study.py:59-76
+    optim.Adam.step       kgvae/experiments/ablation_study.py:571
+
+PyTorch is used for device memory, streams and (optionally) hipGraph capture only; there is no
+torch arithmetic and no CPU fallback on this path.
+
+Layout notes
+  * decoder activations are time-major: row (t, b) = t*B + b, so each GRU timestep is one
+    contiguous [B, D] block; layer outputs are stored with an extra leading slot holding h0.
+  * the two latent heads share one [2Z, 3D] weight block (mu rows first) so they run as one GEMM.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import _lib as L
+
+HP = dict(LR=0, BETA=1, KL_NORM=2, CE_INV_COUNT=3, CE_COUNT=4, ADAM_STEP=5, ADAM_BC1=6, ADAM_BC2=7, ADAM_B1=8,
+          ADAM_B2=9, ADAM_EPS=10, GRAD_SCALE=11, COUNT=16)
+
+# precision policy -> (forward products, backward products)
+#   "mixed": fp16 operands forward (3 more mantissa bits than bf16 at the same MFMA rate keeps the
+#            ELBO within 1e-4 of the fp32 reference), bf16 operands backward (gradient range-safe)
+PREC = {"f32": (L.PREC_F32, L.PREC_F32), "fp32": (L.PREC_F32, L.PREC_F32), "float32": (L.PREC_F32, L.PREC_F32),
+        "bf16": (L.PREC_BF16, L.PREC_BF16), "bfloat16": (L.PREC_BF16, L.PREC_BF16),
+        "f16": (L.PREC_F16, L.PREC_F16), "mixed": (L.PREC_F16, L.PREC_BF16)}
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def _call(name, *args):
+    L.check(getattr(L.lib(), name)(*args), name)
+
+
+class ParamLayout:
+    """name -> (offset, shape) inside the flat buffers.  Blocks start on 16-byte boundaries."""
+
+    def __init__(self, cfg):
+        mt = cfg["model_type"]
+        D, n, V = cfg["d_model"], cfg["n_layers"], cfg["vocab_size"]
+        self.tied = bool(cfg.get("tie_weights", True))
+        blocks = []  # list of lists of (name, shape): tensors inside a block are packed back to back
+        if mt == "SAIL":
+            Z, H = cfg["d_latent"], 3 * D
+            blocks += [[("enc.e_emb.weight", (cfg["n_entities"], D))], [("enc.r_emb.weight", (cfg["n_relations"], D))]]
+            for i in range(n):
+                blocks += [[(f"enc.mlp.{2 * i}.weight", (H, H))], [(f"enc.mlp.{2 * i}.bias", (H,))]]
+            blocks += [[("enc.mu.weight", (Z, H)), ("enc.logv.weight", (Z, H))],
+                       [("enc.mu.bias", (Z,)), ("enc.logv.bias", (Z,))]]
+            blocks += [[("dec.tok_emb.weight", (V, D))], [("dec.z_proj.weight", (D, Z))], [("dec.z_proj.bias", (D,))]]
+        elif mt == "ARK":
+            blocks += [[("dec.tok_emb.weight", (V, D))], [("dec.pos_emb.weight", (cfg["seq_len"], D))]]
+        else:
+            raise NotImplementedError(f"Unknown model_type: {mt}")
+        for l in range(n):
+            blocks += [[(f"dec.gru.weight_ih_l{l}", (3 * D, D))], [(f"dec.gru.weight_hh_l{l}", (3 * D, D))],
+                       [(f"dec.gru.bias_ih_l{l}", (3 * D,))], [(f"dec.gru.bias_hh_l{l}", (3 * D,))]]
+        if not self.tied:
+            blocks += [[("dec.out.weight", (V, D))]]
+        blocks += [[("dec.out.bias", (V,))]]
+        self.entries = OrderedDict()
+        off = 0
+        for blk in blocks:
+            off = _rup(off, 4)
+            for name, shape in blk:
+                numel = 1
+                for s in shape:
+                    numel *= s
+                self.entries[name] = (off, tuple(shape), numel)
+                off += numel
+        self.total = _rup(off, 4)
+
+    def state_dict_names(self, cfg):
+        """names in the reference's state_dict order (tied weight listed under both keys)"""
+        names = list(self.entries.keys())
+        # reference order: ..., enc.mu.weight, enc.mu.bias, enc.logv.weight, enc.logv.bias, ...
+        if "enc.mu.weight" in self.entries:
+            i = names.index("enc.mu.weight")
+            names[i:i + 4] = ["enc.mu.weight", "enc.mu.bias", "enc.logv.weight", "enc.logv.bias"]
+        if self.tied:
+            names.insert(names.index("dec.out.bias"), "dec.out.weight")
+        return names
+
+
+class Engine:
+    def __init__(self, cfg, device, precision="f32", world_size=1):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.ArkError("ark_amd.Engine needs a GPU device (no CPU fallback exists)")
+        L.lib()  # fail loudly if the extension is missing
+        self.prec_fwd, self.prec_bwd = PREC[precision]
+        self.prec = self.prec_fwd  # products issued by the next kernel wrapper call
+        self.precision = precision
+        self.mt = cfg["model_type"]
+        self.D, self.n, self.V = cfg["d_model"], cfg["n_layers"], cfg["vocab_size"]
+        self.Z = cfg.get("d_latent", 0) if self.mt == "SAIL" else 0
+        self.seq_len = cfg["seq_len"]
+        self.L = self.seq_len - 1
+        self.pad_eid = cfg.get("pad_eid")
+        self.pad_rid = cfg.get("pad_rid")
+        self.p_drop = float(cfg.get("dec_dropout", 0.1)) if self.n > 1 else 0.0
+        self.world_size = world_size
+        if self.D % 32 != 0:
+            raise L.ArkError("d_model must be a multiple of 32 for the gfx950 GRU tiles")
+        self.layout = ParamLayout(cfg)
+        n = self.layout.total
+        dev = self.device
+        self.P = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.G = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.M = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.Vv = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.p = OrderedDict()
+        self.g = OrderedDict()
+        for name, (off, shape, numel) in self.layout.entries.items():
+            self.p[name] = self.P[off:off + numel].view(shape)
+            self.g[name] = self.G[off:off + numel].view(shape)
+        if self.layout.tied:
+            self.p["dec.out.weight"] = self.p["dec.tok_emb.weight"]
+            self.g["dec.out.weight"] = self.g["dec.tok_emb.weight"]
+        self.hyper_host = torch.zeros(HP["COUNT"], dtype=torch.float32)
+        self.hyper = torch.zeros(HP["COUNT"], device=dev, dtype=torch.float32)
+        self.hyper_host[HP["ADAM_B1"]] = 0.9
+        self.hyper_host[HP["ADAM_B2"]] = 0.999
+        self.hyper_host[HP["ADAM_EPS"]] = 1e-8
+        self.hyper_host[HP["GRAD_SCALE"]] = 1.0
+        self.hyper_host[HP["BETA"]] = 1.0
+        self.hyper_host[HP["LR"]] = float(cfg.get("learning_rate", 1e-3))
+        self.hyper.copy_(self.hyper_host)
+        self._hp = {"LR": float(self.hyper_host[HP["LR"]]), "BETA": 1.0, "GRAD_SCALE": 1.0}
+        self.adam_steps = 0
+        self.ws = None
+        self.ws_key = None
+        self.training = True
+        self.drop_seed = int(cfg.get("dropout_seed", 0x5A11))
+        self._graphs = {}
+
+    # ------------------------------------------------------------------ parameters
+    def load_params(self, named):
+        with torch.no_grad():
+            for k, v in named.items():
+                if k == "dec.out.weight" and self.layout.tied:
+                    continue
+                self.p[k].copy_(v.to(self.device, dtype=torch.float32))
+
+    def set_hyper(self, lr=None, beta=None, kl_norm=None, ce_count=None, grad_scale=None):
+        """update device-resident step scalars (tiny async fills, only when a value changes)"""
+        for key, val in (("LR", lr), ("BETA", beta), ("KL_NORM", kl_norm), ("GRAD_SCALE", grad_scale)):
+            if val is not None and self._hp.get(key) != float(val):
+                self._hp[key] = float(val)
+                self.hyper[HP[key]:HP[key] + 1].fill_(float(val))
+        if ce_count is not None and self._hp.get("CE_COUNT") != float(ce_count):
+            self._hp["CE_COUNT"] = float(ce_count)
+            self.hyper[HP["CE_COUNT"]:HP["CE_COUNT"] + 1].fill_(float(ce_count))
+            self.hyper[HP["CE_INV_COUNT"]:HP["CE_INV_COUNT"] + 1].fill_(1.0 / float(ce_count) if ce_count > 0 else 0.0)
+
+    def reset_optimizer(self):
+        self.M.zero_()
+        self.Vv.zero_()
+        self.adam_steps = 0
+        self.hyper[HP["ADAM_STEP"]:HP["ADAM_BC2"] + 1].zero_()
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, B, T):
+        key = B
+        if self.ws_key == key:
+            return self.ws
+        dev, D, n, Lq, V, Z = self.device, self.D, self.n, self.L, self.V, self.Z
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        w = {}
+        R = Lq * B
+        if self.mt == "SAIL":
+            H = 3 * D
+            w["g"] = f(B, H)
+            w["inv_cnt"] = f(B)
+            w["pre"] = [f(B, H) for _ in range(n)]
+            w["act"] = [f(B, H) for _ in range(n)]
+            w["head"] = f(B, 2 * Z)
+            w["mu"], w["logv"], w["z"] = f(B, Z), f(B, Z), f(B, Z)
+            w["kl"] = torch.zeros(1, device=dev)
+            w["eps0"] = torch.zeros(B, Z, device=dev)
+            w["dz"], w["dhead"] = f(B, Z), f(B, 2 * Z)
+            w["dH0"] = f(B, D)
+            w["dA"], w["dB"] = f(B, H), f(B, H)
+        w["X0"] = f(R, D)
+        w["GI"] = [f(R, 3 * D) for _ in range(n)]       # gi forward, overwritten by dgi in backward
+        w["dGH"] = [f(R, 3 * D) for _ in range(n)]
+        w["Y"] = [torch.zeros((Lq + 1) * B, D, device=dev) for _ in range(n)]  # slot 0 = h0
+        for nm in ("SR", "SZ", "SN", "SHN"):
+            w[nm] = [f(R, D) for _ in range(n)]
+        if self.p_drop > 0:
+            w["mask"] = [f(R, D) for _ in range(n - 1)]
+            w["Ydrop"] = [f(R, D) for _ in range(n - 1)]
+        self.ldl = _rup(V, 4)
+        w["logits"] = torch.zeros(R, self.ldl, device=dev)
+        w["row_loss"] = f(R)
+        w["out4"] = torch.zeros(4, device=dev)
+        w["dYa"], w["dYb"] = f(R, D), f(R, D)
+        w["carry"] = f(B, D)
+        w["tok_next"] = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.ws, self.ws_key = w, key
+        self._graphs = {}
+        return w
+
+    # ------------------------------------------------------------------ kernel wrappers
+    def _gemm(self, a_lay, b_lay, epi, A, lda, Bm, ldb, C, ldc, M, N, K, C2=None, bias=None, aux=None, acc=0):
+        _call("ark_gemm", L.i32(self.prec), L.i32(a_lay), L.i32(b_lay), L.i32(epi), L.ptr(A), L.i64(lda), L.ptr(Bm),
+              L.i64(ldb), L.ptr(C), L.i64(ldc), L.ptr(C2), L.ptr(bias), L.ptr(aux), L.i32(M), L.i32(N), L.i32(K),
+              L.i32(acc), L.cur_stream())
+
+    def _colsum(self, X, ld, out, M, N, n_batch=1, bs_in=0, bs_out=0):
+        _call("ark_colsum", L.ptr(X), L.i64(ld), L.i64(bs_in), L.ptr(out), L.i64(bs_out if n_batch > 1 else N), L.i32(M),
+              L.i32(N), L.i32(n_batch), L.cur_stream())
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, triples, seq, eps=None, with_loss=True, with_dlogits=True, L_run=None, ce_count=None):
+        """Launch the forward pass.  triples [B,T,3] int64 (SAIL), seq [B,seq_len] int64 (device).
+        Results stay on the device in the workspace (out4 = loss, ce, kl, token-loss sum)."""
+        self.prec = self.prec_fwd
+        B = seq.shape[0]
+        T = triples.shape[1] if (self.mt == "SAIL" and triples is not None) else 0
+        w = self._workspace(B, T)
+        D, n, V, Z = self.D, self.n, self.V, self.Z
+        Lq = self.L if L_run is None else L_run
+        R = Lq * B
+        st = L.cur_stream()
+        KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
+        p = self.p
+        assert seq.dtype == torch.int64 and seq.is_contiguous() and seq.device == self.device
+        ld_seq = seq.shape[1]
+        self._seq, self._triples, self._B, self._T, self._Lrun = seq, triples, B, T, Lq
+        use_drop = self.training and self.p_drop > 0
+
+        if self.mt == "SAIL":
+            assert triples.dtype == torch.int64 and triples.is_contiguous() and triples.device == self.device
+            H = 3 * D
+            _call("ark_enc_pool_fwd", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
+                  L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.i32(B), L.i32(T), L.i32(D),
+                  L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
+            a = w["g"]
+            for i in range(n):
+                self._gemm(KM, KM, L.EPI_BIAS_GELU, a, H, p[f"enc.mlp.{2 * i}.weight"], H, w["pre"][i], H, B, H, H,
+                           C2=w["act"][i], bias=p[f"enc.mlp.{2 * i}.bias"])
+                a = w["act"][i]
+            self._gemm(KM, KM, L.EPI_BIAS, a, H, p["enc.mu.weight"], H, w["head"], 2 * Z, B, 2 * Z, H,
+                       bias=p["enc.mu.bias"])
+            if eps is None:
+                eps = w["eps0"]
+            self._eps = eps
+            _call("ark_latent_fwd", L.ptr(w["head"]), L.ptr(eps), L.ptr(w["mu"]), L.ptr(w["logv"]), L.ptr(w["z"]),
+                  L.ptr(w["kl"]), L.i32(B), L.i32(Z), st)
+            self._decode_h0(w, w["z"], B)
+        else:
+            for l in range(n):
+                w["Y"][l][:B].zero_()
+        self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop)
+        if with_loss:
+            if ce_count is None:
+                _call("ark_count_targets", L.ptr(seq), L.i64(ld_seq), L.i32(B), L.i32(Lq), L.ptr(self.hyper), st)
+            _call("ark_ce_fwd_bwd", L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper),
+                  L.ptr(w["row_loss"]), L.ptr(w["logits"] if with_dlogits else None), L.i32(B), L.i32(Lq), L.i32(V), st)
+            _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R), L.ptr(w["kl"] if self.mt == "SAIL" else None),
+                  L.ptr(self.hyper), L.ptr(w["out4"]), st)
+        return w
+
+    def _decode_h0(self, w, z, B):
+        p = self.p
+        # layer buffers are separate allocations: write h0 into slot 0 of every layer
+        for l in range(self.n):
+            _call("ark_zproj_fwd", L.ptr(z), L.ptr(p["dec.z_proj.weight"]), L.ptr(p["dec.z_proj.bias"]), L.ptr(w["Y"][l]),
+                  L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(self.D), L.cur_stream())
+
+    def _decoder_forward(self, w, seq, ld_seq, B, Lq, use_drop, save=True):
+        D, n, V = self.D, self.n, self.V
+        R = Lq * B
+        st = L.cur_stream()
+        p = self.p
+        KM = L.LAY_KMAJ
+        _call("ark_tok_gather", L.ptr(seq), L.i64(ld_seq), L.ptr(p["dec.tok_emb.weight"]),
+              L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0"]), L.i32(B), L.i32(Lq), L.i32(D), st)
+        xin = w["X0"]
+        for l in range(n):
+            self._gemm(KM, KM, L.EPI_BIAS, xin, D, p[f"dec.gru.weight_ih_l{l}"], D, w["GI"][l], 3 * D, R, 3 * D, D,
+                       bias=p[f"dec.gru.bias_ih_l{l}"])
+            Y = w["Y"][l]
+            drop = use_drop and l < n - 1
+            if drop:
+                _call("ark_dropout_mask", L.ptr(w["mask"][l]), L.i64(R * D), L.f32(self.p_drop),
+                      L.u64(self.drop_seed + 7919 * l), L.ptr(self.hyper), st)
+            for t in range(Lq):
+                sl = slice(t * B, (t + 1) * B)
+                _call("ark_gru_cell_fwd", L.i32(self.prec), L.ptr(Y[t * B:]), L.ptr(p[f"dec.gru.weight_hh_l{l}"]),
+                      L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l][sl]), L.ptr(Y[(t + 1) * B:]),
+                      L.ptr(w["Ydrop"][l][sl] if drop else None), L.ptr(w["mask"][l][sl] if drop else None),
+                      L.ptr(w["SR"][l][sl] if save else None), L.ptr(w["SZ"][l][sl] if save else None),
+                      L.ptr(w["SN"][l][sl] if save else None), L.ptr(w["SHN"][l][sl] if save else None),
+                      L.i32(B), L.i32(D), st)
+            xin = w["Ydrop"][l] if drop else Y[B:]
+        self._xin_top = xin
+        self._gemm(KM, KM, L.EPI_BIAS, w["Y"][n - 1][B:], D, p["dec.out.weight"], D, w["logits"], self.ldl, R, V, D,
+                   bias=p["dec.out.bias"])
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ext_dhead=None):
+        """Launch the backward pass of the last forward (dlogits already sit in ws['logits'])."""
+        self.prec = self.prec_bwd
+        w, B, T, Lq = self.ws, self._B, self._T, self._Lrun
+        D, n, V, Z = self.D, self.n, self.V, self.Z
+        R = Lq * B
+        st = L.cur_stream()
+        KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
+        p, g = self.p, self.g
+        seq = self._seq
+        ld_seq = seq.shape[1]
+        use_drop = self.training and self.p_drop > 0
+        dlog = w["logits"]
+        ytop = w["Y"][n - 1][B:]
+        # tied vocabulary projection
+        self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
+        self._gemm(MM, MM, L.EPI_NONE, dlog, self.ldl, ytop, D, g["dec.out.weight"], D, V, D, R)
+        self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dYa"], D, R, D, V)
+        dy, dy_other = w["dYa"], w["dYb"]
+        for l in range(n - 1, -1, -1):
+            Y = w["Y"][l]
+            dGI, dGH = w["GI"][l], w["dGH"][l]
+            whh = p[f"dec.gru.weight_hh_l{l}"]
+            for t in range(Lq - 1, -1, -1):
+                sl = slice(t * B, (t + 1) * B)
+                first = (t == Lq - 1)
+                _call("ark_gru_cell_bwd", L.i32(self.prec), L.ptr(None if first else dGH[(t + 1) * B:]), L.ptr(whh),
+                      L.ptr(dy[sl]), L.ptr(w["carry"]), L.ptr(w["SR"][l][sl]), L.ptr(w["SZ"][l][sl]), L.ptr(w["SN"][l][sl]),
+                      L.ptr(w["SHN"][l][sl]), L.ptr(Y[sl]), L.ptr(dGI[sl]), L.ptr(dGH[sl]), L.i32(B), L.i32(D),
+                      L.i32(1 if first else 0), st)
+            if self.mt == "SAIL":
+                _call("ark_gru_h0_bwd", L.i32(self.prec), L.ptr(dGH), L.ptr(whh), L.ptr(w["carry"]), L.ptr(w["dH0"]),
+                      L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
+            drop_below = use_drop and l > 0
+            xin = w["X0"] if l == 0 else (w["Ydrop"][l - 1] if drop_below else w["Y"][l - 1][B:])
+            self._gemm(MM, MM, L.EPI_NONE, dGH, 3 * D, Y, D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R)
+            self._gemm(MM, MM, L.EPI_NONE, dGI, 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)
+            self._colsum(dGI, 3 * D, g[f"dec.gru.bias_ih_l{l}"], R, 3 * D)
+            self._colsum(dGH, 3 * D, g[f"dec.gru.bias_hh_l{l}"], R, 3 * D)
+            self._gemm(KM, MM, L.EPI_MUL_AUX if drop_below else L.EPI_NONE, dGI, 3 * D, p[f"dec.gru.weight_ih_l{l}"], D,
+                       dy_other, D, R, D, 3 * D, aux=w["mask"][l - 1] if drop_below else None)
+            dy, dy_other = dy_other, dy
+        dX0 = dy
+        if not self.layout.tied:
+            g["dec.tok_emb.weight"].zero_()
+        _call("ark_tok_scatter", L.ptr(seq), L.i64(ld_seq), L.ptr(dX0), L.ptr(g["dec.tok_emb.weight"]), L.i32(B), L.i32(Lq),
+              L.i32(D), L.i32(V), st)
+        if self.mt == "ARK":
+            gp = g["dec.pos_emb.weight"]
+            if Lq < gp.shape[0]:
+                gp[Lq:].zero_()
+            self._colsum(dX0, D, gp, B, D, n_batch=Lq, bs_in=B * D, bs_out=D)
+            return
+        # latent path
+        H = 3 * D
+        _call("ark_zproj_bwd", L.ptr(w["dH0"]), L.ptr(w["Y"][0]), L.ptr(w["z"]), L.ptr(p["dec.z_proj.weight"]),
+              L.ptr(w["dz"]), L.ptr(g["dec.z_proj.weight"]), L.ptr(g["dec.z_proj.bias"]), L.i32(B), L.i32(Z), L.i32(D), st)
+        _call("ark_latent_bwd", L.ptr(w["dz"]), L.ptr(w["head"]), L.ptr(self._eps), L.ptr(self.hyper), L.ptr(w["dhead"]),
+              L.i32(B), L.i32(Z), st)
+        if ext_dhead is not None:
+            w["dhead"].add_(ext_dhead)
+        self._colsum(w["dhead"], 2 * Z, g["enc.mu.bias"], B, 2 * Z)
+        self._gemm(MM, MM, L.EPI_NONE, w["dhead"], 2 * Z, w["act"][n - 1], H, g["enc.mu.weight"], H, 2 * Z, H, B)
+        self._gemm(KM, MM, L.EPI_MUL_DGELU, w["dhead"], 2 * Z, p["enc.mu.weight"], H, w["dA"], H, B, H, 2 * Z,
+                   aux=w["pre"][n - 1])
+        dpre, other = w["dA"], w["dB"]
+        for i in range(n - 1, -1, -1):
+            inp = w["act"][i - 1] if i > 0 else w["g"]
+            self._colsum(dpre, H, g[f"enc.mlp.{2 * i}.bias"], B, H)
+            self._gemm(MM, MM, L.EPI_NONE, dpre, H, inp, H, g[f"enc.mlp.{2 * i}.weight"], H, H, H, B)
+            if i > 0:
+                self._gemm(KM, MM, L.EPI_MUL_DGELU, dpre, H, p[f"enc.mlp.{2 * i}.weight"], H, other, H, B, H, H,
+                           aux=w["pre"][i - 1])
+            else:
+                self._gemm(KM, MM, L.EPI_NONE, dpre, H, p[f"enc.mlp.{2 * i}.weight"], H, other, H, B, H, H)
+            dpre, other = other, dpre
+        dg = dpre
+        g["enc.e_emb.weight"].zero_()
+        g["enc.r_emb.weight"].zero_()
+        _call("ark_enc_pool_bwd", L.ptr(self._triples), L.ptr(dg), L.ptr(w["inv_cnt"]), L.ptr(g["enc.e_emb.weight"]),
+              L.ptr(g["enc.r_emb.weight"]), L.i32(B), L.i32(T), L.i32(D), L.i32(g["enc.e_emb.weight"].shape[0]),
+              L.i32(g["enc.r_emb.weight"].shape[0]), L.i64(-1 if self.pad_eid is None else self.pad_eid),
+              L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
+
+    # ------------------------------------------------------------------ optimiser
+    def adam(self):
+        st = L.cur_stream()
+        _call("ark_adam_tick", L.ptr(self.hyper), st)
+        _call("ark_adam_step", L.ptr(self.P), L.ptr(self.G), L.ptr(self.M), L.ptr(self.Vv), L.i64(self.layout.total),
+              L.ptr(self.hyper), st)
+        self.adam_steps += 1
+
+    # ------------------------------------------------------------------ whole step
+    def _default_norms(self, B):
+        if self.mt == "SAIL":
+            self.set_hyper(kl_norm=1.0 / (B * self.world_size * self.Z))
+
+    def train_step(self, triples, seq, eps=None, grad_sync=None, ce_count=None):
+        """forward + ELBO + backward (+ gradient all-reduce) + Adam.  Returns the device tensor
+        out4 = [loss, ce, kl, token-loss sum] (no host sync)."""
+        self._default_norms(seq.shape[0])
+        if ce_count is not None:
+            self.set_hyper(ce_count=ce_count)
+        w = self.forward(triples, seq, eps, ce_count=ce_count)
+        self.backward()
+        if grad_sync is not None:
+            grad_sync(self.G)
+        self.adam()
+        return w["out4"]
+
+    def eval_loss(self, triples, seq, eps=None):
+        self._default_norms(seq.shape[0])
+        was = self.training
+        self.training = False
+        try:
+            w = self.forward(triples, seq, eps, with_dlogits=False)
+        finally:
+            self.training = was
+        return w["out4"]
+
+    # ------------------------------------------------------------------ graph capture
+    def capture_train_step(self, triples, seq, eps=None, ce_count=None, grad_sync=None):
+        """Capture the train step for fixed-address inputs into hipGraphs; returns replay().
+
+        Without `grad_sync` the whole step (fwd + bwd + Adam) is ONE graph.  With `grad_sync`
+        (data parallel) it is two graphs with the gradient all-reduce launched between them on
+        the same stream.  The caller refreshes the CONTENTS of `triples`, `seq`, `eps` in place
+        between replays; step scalars live in the device `hyper` array."""
+        self._default_norms(seq.shape[0])
+        if ce_count is not None:
+            self.set_hyper(ce_count=ce_count)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):  # warm-up outside capture (allocates the workspace)
+            self.train_step(triples, seq, eps, ce_count=ce_count, grad_sync=grad_sync)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        g2 = None
+        if grad_sync is None:
+            with torch.cuda.graph(g1):
+                self.forward(triples, seq, eps, ce_count=ce_count)
+                self.backward()
+                self.adam()
+        else:
+            with torch.cuda.graph(g1):
+                self.forward(triples, seq, eps, ce_count=ce_count)
+                self.backward()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                self.adam()
+            self.adam_steps -= 1
+        self.adam_steps -= 1  # capture does not execute
+        out4 = self.ws["out4"]
+
+        def replay():
+            g1.replay()
+            if g2 is not None:
+                grad_sync(self.G)
+                g2.replay()
+            self.adam_steps += 1
+            return out4
+
+        self._graphs["train"] = (g1, g2)
+        return replay
+
+    # ------------------------------------------------------------------ greedy decode (next row of SURVEY 8f)
+    @torch.no_grad()
+    def greedy_decode(self, z, max_len=None):
+        """token sequences of SAIL.decode_latent(z, beam=1) (reference models.py:282-300): the decoder
+        is a causal GRU, so instead of re-running the whole prefix we advance one step per token."""
+        assert self.mt == "SAIL"
+        self.prec = self.prec_fwd
+        B = z.shape[0]
+        Lmax = (self.seq_len - 1) if max_len is None else max_len
+        w = self._workspace(B, 0)
+        D, n, V = self.D, self.n, self.V
+        st = L.cur_stream()
+        p = self.p
+        KM = L.LAY_KMAJ
+        z = z.to(self.device, dtype=torch.float32).contiguous()
+        self._decode_h0(w, z, B)
+        toks = torch.full((B, self.seq_len), 2, dtype=torch.int64, device=self.device)
+        toks[:, 0] = 1
+        cur = torch.full((B, 1), 1, dtype=torch.int64, device=self.device)
+        for t in range(Lmax):
+            _call("ark_tok_gather", L.ptr(cur), L.i64(1), L.ptr(p["dec.tok_emb.weight"]), L.ptr(None), L.ptr(w["X0"]),
+                  L.i32(B), L.i32(1), L.i32(D), st)
+            xin = w["X0"]
+            for l in range(n):
+                self._gemm(KM, KM, L.EPI_BIAS, xin, D, p[f"dec.gru.weight_ih_l{l}"], D, w["GI"][l], 3 * D, B, 3 * D, D,
+                           bias=p[f"dec.gru.bias_ih_l{l}"])
+                Y = w["Y"][l]
+                _call("ark_gru_cell_fwd", L.i32(self.prec), L.ptr(Y[(t % 2) * B:]), L.ptr(p[f"dec.gru.weight_hh_l{l}"]),
+                      L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l]), L.ptr(Y[((t + 1) % 2) * B:]), L.ptr(None),
+                      L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), L.i32(B), L.i32(D), st)
+                xin = Y[((t + 1) % 2) * B:]
+            self._gemm(KM, KM, L.EPI_BIAS, xin, D, p["dec.out.weight"], D, w["logits"], self.ldl, B, V, D,
+                       bias=p["dec.out.bias"])
+            _call("ark_argmax_rows", L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(w["tok_next"]), L.i32(B), L.i32(V), st)
+            toks[:, t + 1] = w["tok_next"][:B]
+            cur = w["tok_next"][:B].clone().view(B, 1)
+            if bool((cur == 2).all()):
+                return toks[:, :t + 2]
+        return toks[:, :Lmax + 1]

@@ -21,6 +21,7 @@ extern "C" {
 
 #define ARK_PREC_F32 0  /* v_mfma_f32_16x16x4_f32, exact fp32 products (parity / decode)   */
 #define ARK_PREC_BF16 1 /* v_mfma_f32_16x16x32_bf16, operands rounded to bf16, fp32 accum  */
+#define ARK_PREC_F16 2  /* v_mfma_f32_16x16x32_f16, operands rounded to fp16 (saturating), fp32 accum */
 #define ARK_LAY_KMAJ 0  /* element (row,k) at base[row*ld + k] */
 #define ARK_LAY_MMAJ 1  /* element (row,k) at base[k*ld + row] */
 
@@ -38,6 +39,79 @@ int ark_version(void);
 int ark_gemm(int prec, int a_lay, int b_lay, int epi, const float* A, int64_t lda, const float* B, int64_t ldb,
              float* C, int64_t ldc, float* C2, const float* bias, const float* aux, int M, int N, int K,
              int accumulate, void* stream);
+
+/* ---- device-resident step scalars ("hyper" array, ARK_HP_COUNT floats) -------------------------
+ * Everything that changes between steps lives in device memory so a captured hipGraph of the
+ * whole train step can be replayed; the host (or ark_adam_tick / ark_count_targets) updates it. */
+#define ARK_HP_LR 0            /* Adam learning rate (CosineAnnealingLR value, ablation_study.py:577) */
+#define ARK_HP_BETA 1          /* KL weight b of `ce + b*kl` (ablation_study.py:71,590-591)            */
+#define ARK_HP_KL_NORM 2       /* 1 / (B_global * Z): kl_mean is a mean over all B*Z elements          */
+#define ARK_HP_CE_INV_COUNT 3  /* 1 / (#non-PAD targets in the GLOBAL batch)                           */
+#define ARK_HP_CE_COUNT 4      /* #non-PAD targets                                                     */
+#define ARK_HP_ADAM_STEP 5     /* optimiser step count t (float)                                       */
+#define ARK_HP_ADAM_BC1 6      /* 1 - b1^t                                                             */
+#define ARK_HP_ADAM_BC2 7      /* 1 - b2^t                                                             */
+#define ARK_HP_ADAM_B1 8
+#define ARK_HP_ADAM_B2 9
+#define ARK_HP_ADAM_EPS 10
+#define ARK_HP_GRAD_SCALE 11   /* multiplies every gradient inside Adam (1 for summed DP gradients)    */
+#define ARK_HP_COUNT 16
+
+#define ARK_TOK_PAD 0 /* special_tokens["PAD"], the ignore_index of the reference's cross-entropy */
+
+/* ---- GRU recurrence (reference: nn.GRU inside AutoRegDecoderGRU / DecoderOnlyGRU,
+ *      kgvae/model/models.py:121-127,141 and :329-335,344) ------------------------------------ */
+/* one timestep of one layer: h_out = GRUCell(gi (= x W_ih^T + b_ih, precomputed), h_prev).
+ * save_* ([B,D] each, nullable together) keep r, z, n and (W_hn h + b_hn) for the backward pass;
+ * h_drop (nullable) additionally receives h_out * drop_mask (inter-layer dropout). */
+int ark_gru_cell_fwd(int prec, const float* h_prev, const float* w_hh, const float* b_hh, const float* gi,
+                     float* h_out, float* h_drop, const float* drop_mask, float* save_r, float* save_z,
+                     float* save_n, float* save_hn, int B, int D, void* stream);
+/* BPTT for one timestep: dh_t = dy_t + carry + dgh_next W_hh (first != 0: last timestep, no
+ * successor), then gate derivatives -> dgi_t, dgh_t [B,3D]; carry <- dh_t * z_t (in place). */
+int ark_gru_cell_bwd(int prec, const float* dgh_next, const float* w_hh, const float* dy, float* carry,
+                     const float* save_r, const float* save_z, const float* save_n, const float* save_hn,
+                     const float* h_prev, float* dgi, float* dgh, int B, int D, int first, void* stream);
+/* gradient wrt the layer's initial state: dh0 (+)= dgh_0 W_hh + carry */
+int ark_gru_h0_bwd(int prec, const float* dgh0, const float* w_hh, const float* carry, float* dh0, int accumulate,
+                   int B, int D, void* stream);
+
+/* ---- embeddings (reference: models.py:47-58 encoder gather+concat+masked mean; :138,:343
+ *      decoder token / position lookup; autograd embedding_backward) --------------------------- */
+int ark_enc_pool_fwd(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt, int B, int T,
+                     int D, int64_t pad_rid /* -1: none */, void* stream);
+int ark_enc_pool_bwd(const int64_t* triples, const float* dg, const float* inv_cnt, float* dE, float* dR, int B,
+                     int T, int D, int n_ent, int n_rel, int64_t pad_eid, int64_t pad_rid, void* stream);
+int ark_tok_gather(const int64_t* seq, int64_t ld_seq, const float* w_tok, const float* w_pos /* nullable */,
+                   float* x, int B, int L, int D, void* stream);
+int ark_tok_scatter(const int64_t* seq, int64_t ld_seq, const float* dx, float* d_w_tok, int B, int L, int D,
+                    int vocab, void* stream);
+
+/* ---- latent head / ELBO (reference: models.py:61-63,139,199-200; ablation_study.py:65-71) ------ */
+int ark_latent_fwd(const float* head /* [B,2Z] = mu | raw logv */, const float* eps /* [B,Z], nullable = 0 */,
+                   float* mu, float* logv, float* z, float* kl_out, int B, int Z, void* stream);
+int ark_latent_bwd(const float* dz, const float* head, const float* eps, const float* hyper, float* dhead, int B,
+                   int Z, void* stream);
+int ark_zproj_fwd(const float* z, const float* w_z, const float* b_z, float* h0, int64_t copy_stride, int n_copies,
+                  int B, int Z, int D, void* stream);
+int ark_zproj_bwd(float* dh0, const float* h0, const float* z, const float* w_z, float* dz, float* d_w_z,
+                  float* d_b_z, int B, int Z, int D, void* stream);
+int ark_count_targets(const int64_t* seq, int64_t ld_seq, int B, int L, float* hyper, void* stream);
+/* rows are time-major (t,b); target of row (t,b) is seq[b, t+1]; dlogits may alias logits or be NULL */
+int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int64_t ld_seq, const float* hyper,
+                   float* row_loss, float* dlogits, int B, int L, int V, void* stream);
+/* out4 = {loss = ce + beta*kl, ce, kl, sum of token losses}; kl nullable (ARK) */
+int ark_loss_finalize(const float* row_loss, int n_rows, const float* kl, const float* hyper, float* out4,
+                      void* stream);
+int ark_argmax_rows(const float* x, int64_t ld, int64_t* out, int rows, int V, void* stream);
+
+/* ---- optimiser and reductions (reference: optim.Adam, ablation_study.py:571,76) ---------------- */
+int ark_adam_tick(float* hyper, void* stream);
+int ark_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, void* stream);
+int ark_colsum(const float* x, int64_t ld, int64_t batch_stride_in, float* out, int64_t batch_stride_out, int M,
+               int N, int n_batch, void* stream);
+int ark_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, const float* hyper, void* stream);
+int ark_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,181 @@
+"""GPU parity of the whole HIP train step (ark_amd.engine through the C-ABI) against
+(a) golden vectors generated from the real reference and (b) the CPU oracle on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from tests.parity_util import load_golden, weights_from, make_engine, synth_batch, rel_err, smoke_check
+
+pytestmark = pytest.mark.gpu
+
+FULL = ["sail_tiny", "sail_tiny_pad", "ark_tiny", "sail_small", "sail_small_pad"]
+
+
+def test_smoke():
+    assert smoke_check()
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_train_steps_match_reference_golden(name):
+    """fp32 MFMA mode: loss/ce/kl of 3 consecutive steps, every gradient of step 0, weights after
+    step 1 and 3 -- all against tensors produced by the reference itself."""
+    z, cfg = load_golden(name)
+    lr = float(z["lr"])
+    eng = make_engine(cfg, weights_from(z, "w0/"), "f32", lr=lr)
+    dev = eng.device
+    triples, seq = torch.from_numpy(z["triples"]).to(dev), torch.from_numpy(z["seq"]).to(dev)
+    sail = cfg["model_type"] == "SAIL"
+    for s in range(len(z["losses"])):
+        eps = torch.from_numpy(z[f"eps{s}"]).to(dev) if sail else None
+        eng.set_hyper(beta=float(z["betas"][s]))
+        w = eng.forward(triples if sail else None, seq, eps)
+        if s == 0:
+            # logits before the CE kernel overwrote them are not kept; check mu/logv and the loss
+            if sail:
+                np.testing.assert_allclose(w["mu"].cpu().numpy(), z["mu0"], rtol=1e-4, atol=1e-6)
+                np.testing.assert_allclose(w["logv"].cpu().numpy(), z["logv0"], rtol=1e-4, atol=1e-6)
+        eng._default_norms(seq.shape[0])
+        eng.backward()
+        out4 = w["out4"].cpu().numpy()
+        ref = z["losses"][s]
+        # tolerance: ELBO within 1e-5 relative in exact-fp32 mode (north_star asks 1e-4)
+        assert rel_err(float(out4[0]), ref[0]) < 1e-5, (s, out4, ref)
+        assert rel_err(float(out4[1]), ref[1]) < 1e-5
+        if sail:
+            assert rel_err(float(out4[2]), ref[2]) < 1e-4
+        if s == 0:
+            for k in [f[3:] for f in z.files if f.startswith("g0/")]:
+                got = eng.g[k].cpu().numpy()
+                want = z["g0/" + k]
+                scale = np.abs(want).max() + 1e-12
+                assert np.abs(got - want).max() <= 2e-4 * scale + 1e-7, (k, np.abs(got - want).max(), scale)
+        eng.adam()
+        if f"w{s + 1}/dec.out.bias" in z.files:
+            for k, v in eng.p.items():
+                want = z[f"w{s + 1}/" + k]
+                got = v.cpu().numpy()
+                bad = np.abs(got - want) > (1e-4 * np.abs(want) + 5e-6)
+                assert bad.mean() <= 2e-3, (k, s, bad.mean())
+                assert np.abs(got - want).max() <= 8 * lr, (k, s)
+
+
+def test_kl_norm_default():
+    z, cfg = load_golden("sail_tiny")
+    eng = make_engine(cfg, weights_from(z, "w0/"), "f32")
+    eng._default_norms(4)
+    assert eng._hp["KL_NORM"] == pytest.approx(1.0 / (4 * cfg["d_latent"]))
+
+
+@pytest.mark.parametrize("name", ["sail_synpaths_b32_s0", "sail_synpaths_b32_s1", "ark_synpaths_b32_s0"])
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-5), ("mixed", 3e-4), ("bf16", 2e-3)])
+def test_fullsize_synpaths_scalars(name, precision, tol):
+    """syn-paths (D=512) B=32: weights re-created from the seed by the init-order-compatible
+    oracle code; 3 steps of loss + per-parameter gradient norms against reference goldens.
+    bf16 tolerance on this 320-token batch is statistical: 2e-3."""
+    from oracle import sail_oracle as O
+    z, cfg = load_golden(name)
+    P = O.init_params(cfg, int(z["seed"]))
+    eng = make_engine(cfg, P, precision, lr=float(z["lr"]))
+    dev = eng.device
+    sail = cfg["model_type"] == "SAIL"
+    triples, seq = torch.from_numpy(z["triples"]).to(dev), torch.from_numpy(z["seq"]).to(dev)
+    for s in range(len(z["losses"])):
+        eps = torch.from_numpy(z[f"eps{s}"]).to(dev) if sail else None
+        eng.set_hyper(beta=float(z["betas"][s]))
+        out4 = eng.train_step(triples if sail else None, seq, eps).cpu().numpy()
+        if precision == "f32" or s == 0:
+            assert rel_err(float(out4[0]), z["losses"][s][0]) < tol * (1 + 4 * s), (s, out4, z["losses"][s])
+        if s == 0 and precision == "f32":
+            for k in [f[7:] for f in z.files if f.startswith("g0norm/")]:
+                n = float(eng.g[k].double().norm())
+                assert rel_err(n, float(z["g0norm/" + k])) < 2e-4, k
+
+
+@pytest.mark.parametrize("name", ["sail_tiny", "sail_tiny_pad", "sail_small", "sail_small_pad"])
+def test_greedy_decode_bit_exact(name):
+    """'bit-exact sampled triple indices': greedy decode (beam=1) in exact-fp32 MFMA mode equals the
+    reference's decode_latent output token for token."""
+    from oracle import sail_oracle as O
+    z, cfg = load_golden(name)
+    eng = make_engine(cfg, weights_from(z, f"w{len(z['losses'])}/"), "f32")
+    toks = eng.greedy_decode(torch.from_numpy(z["dec_z"])).cpu()
+    for i in range(toks.shape[0]):
+        tr = O.seq_to_triples(toks[i].tolist(), cfg["ENT_BASE"], cfg["REL_BASE"])
+        n = int(z["dec_ntriples"][i])
+        assert len(tr) == n
+        assert [list(t) for t in tr] == z["dec_triples"][i, :n].tolist()
+
+
+def _big_cfg():
+    _, cfg = load_golden("sail_synpaths_b32_s0")
+    return cfg
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-5), ("mixed", 1e-4), ("bf16", 1e-3)])
+def test_elbo_parity_b1024(precision, tol):
+    """BASELINE config 1 (syn-paths, B=1024): ELBO of the HIP forward vs the CPU oracle on the same
+    weights / batch / eps.  Tolerance = north_star's 1e-4 relative for the shipped fast mode
+    ("mixed": fp16 forward operands), 1e-5 for exact fp32; pure-bf16 forward operands measure
+    ~2.5e-4 here and are kept only as a documented comparison (tol 1e-3)."""
+    from oracle import sail_oracle as O
+    cfg = _big_cfg()
+    P = O.init_params(cfg, 0)
+    triples, seq = synth_batch(cfg, 1024, seed=1)
+    torch.manual_seed(1000)
+    eps = torch.randn(1024, cfg["d_latent"])
+    with torch.no_grad():
+        loss, ce, kl, *_ = O.sail_elbo(P, triples, seq, eps, 0.1, cfg)
+    eng = make_engine(cfg, P, precision)
+    eng.set_hyper(beta=0.1)
+    out4 = eng.eval_loss(triples.to(eng.device), seq.to(eng.device), eps.to(eng.device)).cpu().numpy()
+    assert rel_err(float(out4[0]), float(loss)) < tol, (out4, float(loss), float(ce), float(kl))
+
+
+def test_shard_gradients_sum_to_full_batch():
+    """size-independent DP property at B=1024: gradients of 4 shards (global CE count and global
+    KL normaliser) sum to the full-batch gradient."""
+    from oracle import sail_oracle as O
+    cfg = _big_cfg()
+    P = O.init_params(cfg, 0)
+    B = 1024
+    triples, seq = synth_batch(cfg, B, seed=2)
+    torch.manual_seed(7)
+    eps = torch.randn(B, cfg["d_latent"])
+    eng = make_engine(cfg, P, "f32")
+    dev = eng.device
+    triples, seq, eps = triples.to(dev), seq.to(dev), eps.to(dev)
+    eng._default_norms(B)
+    eng.forward(triples, seq, eps)
+    eng.backward()
+    torch.cuda.synchronize()
+    full = eng.G.clone()
+    count = float(eng.hyper[4])
+    acc = torch.zeros_like(full)
+    for k in range(4):
+        sl = slice(k * 256, (k + 1) * 256)
+        eng.set_hyper(kl_norm=1.0 / (B * cfg["d_latent"]), ce_count=count)
+        eng.forward(triples[sl].contiguous(), seq[sl].contiguous(), eps[sl].contiguous(), ce_count=count)
+        eng.backward()
+        acc += eng.G
+    scale = full.abs().max()
+    assert (acc - full).abs().max() <= 2e-4 * scale, ((acc - full).abs().max(), scale)
+
+
+def test_graph_replay_matches_eager():
+    from oracle import sail_oracle as O
+    cfg = _big_cfg()
+    P = O.init_params(cfg, 0)
+    B = 256
+    triples, seq = synth_batch(cfg, B, seed=3)
+    torch.manual_seed(8)
+    eps = torch.randn(B, cfg["d_latent"])
+    cfg = dict(cfg, dec_dropout=0.0)
+    a = make_engine(cfg, P, "f32", lr=1e-4)
+    b = make_engine(cfg, P, "f32", lr=1e-4)
+    dev = a.device
+    triples, seq, eps = triples.to(dev), seq.to(dev), eps.to(dev)
+    la = [float(a.train_step(triples, seq, eps)[0]) for _ in range(4)]
+    replay = b.capture_train_step(triples, seq, eps)  # performs 1 eager warm-up step itself
+    lb = [la[0]] + [float(replay()[0]) for _ in range(3)]
+    assert np.allclose(la, lb, rtol=1e-5), (la, lb)
+    assert la[-1] < la[0]

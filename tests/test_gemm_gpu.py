@@ -29,6 +29,8 @@ def run_gemm(prec, a_lay, b_lay, M, N, K, epi=L.EPI_NONE, seed=0, accumulate=Fal
     torch.cuda.synchronize()
     if prec == L.PREC_BF16:
         ref = A.bfloat16().float().double() @ B.bfloat16().float().double().t()
+    elif prec == L.PREC_F16:
+        ref = A.half().float().double() @ B.half().float().double().t()
     else:
         ref = A.double() @ B.double().t()
     if epi in (L.EPI_BIAS, L.EPI_BIAS_GELU):
@@ -51,7 +53,7 @@ SHAPES = [(64, 64, 32), (128, 128, 64), (100, 55, 72), (1024, 1536, 1536), (333,
           (70, 130, 55), (2048, 2048, 96)]
 
 
-@pytest.mark.parametrize("prec", [L.PREC_F32, L.PREC_BF16])
+@pytest.mark.parametrize("prec", [L.PREC_F32, L.PREC_BF16, L.PREC_F16])
 @pytest.mark.parametrize("a_lay", [L.LAY_KMAJ, L.LAY_MMAJ])
 @pytest.mark.parametrize("b_lay", [L.LAY_KMAJ, L.LAY_MMAJ])
 @pytest.mark.parametrize("shape", SHAPES)

@@ -167,9 +167,9 @@ def main():
     torch.set_num_threads(4)
     M, U = import_reference()
     # tiny-D full-tensor goldens
-    dump_case(M, U, "sail_tiny", "SAIL", D=16, Z=4, n=3, nE=20, nR=3, T=3, B=4, padded=False, seed=0)
-    dump_case(M, U, "sail_tiny_pad", "SAIL", D=16, Z=4, n=3, nE=20, nR=3, T=5, B=4, padded=True, seed=1)
-    dump_case(M, U, "ark_tiny", "ARK", D=16, Z=4, n=3, nE=20, nR=3, T=3, B=4, padded=False, seed=2)
+    dump_case(M, U, "sail_tiny", "SAIL", D=32, Z=4, n=3, nE=20, nR=3, T=3, B=4, padded=False, seed=0)
+    dump_case(M, U, "sail_tiny_pad", "SAIL", D=32, Z=4, n=3, nE=20, nR=3, T=5, B=4, padded=True, seed=1)
+    dump_case(M, U, "ark_tiny", "ARK", D=32, Z=4, n=3, nE=20, nR=3, T=3, B=4, padded=False, seed=2)
     dump_case(M, U, "sail_small", "SAIL", D=64, Z=10, n=3, nE=49, nR=3, T=3, B=96, padded=False, seed=3)
     dump_case(M, U, "sail_small_pad", "SAIL", D=32, Z=8, n=2, nE=70, nR=5, T=7, B=40, padded=True, seed=4)
     # full-size syn-paths scalars (weights are regenerated from the seed by the init-order-compatible code)
