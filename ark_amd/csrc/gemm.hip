@@ -7,12 +7,15 @@
 
 namespace ark {
 
+static int g_split_k_enabled = 1;
+
 struct GemmArgs {
   const float* A; const float* B; float* C; float* C2; const float* bias; const float* aux;
   long lda, ldb, ldc;
   int M, N, K;
   int epi, accumulate;
   int tiles_n;
+  int split_k, k_chunk;  // split_k > 1: blockIdx.y owns K range [y*k_chunk, ...) and adds atomically into zeroed C
 };
 
 template <int PREC, int ALAY, int BLAY, int BM, int BN>
@@ -23,9 +26,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int M = p.M, N = p.N;
   f32x4 acc[G::TM][G::TN];
-  G::run(acc, p.A, p.lda, [=](int r) -> long { return (m0 + r < M) ? (long)(m0 + r) : -1L; },
-         p.B, p.ldb, [=](int r) -> long { return (n0 + r < N) ? (long)(n0 + r) : -1L; }, p.K, smem);
+  // split-K: this workgroup reduces k in [kb, ke); operands are offset along their reduction index
+  const int kb = blockIdx.y * p.k_chunk;
+  const int ke = min(p.K, kb + p.k_chunk);
+  const float* Ab = p.A + (ALAY == LAY_KMAJ ? (long)kb : (long)kb * p.lda);
+  const float* Bb = p.B + (BLAY == LAY_KMAJ ? (long)kb : (long)kb * p.ldb);
+  G::run(acc, Ab, p.lda, [=](int r) -> long { return (m0 + r < M) ? (long)(m0 + r) : -1L; },
+         Bb, p.ldb, [=](int r) -> long { return (n0 + r < N) ? (long)(n0 + r) : -1L; }, ke - kb, smem);
 
+  if (p.split_k > 1) {  // EPI_NONE only (checked on the host); C was zeroed on the stream
+    G::for_each(acc, [&](int r, int c, float v) {
+      const int row = m0 + r, col = n0 + c;
+      if (row < M && col < N) atomicAdd(&p.C[(long)row * p.ldc + col], v);
+    });
+    return;
+  }
   const int epi = p.epi;
   G::for_each(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
@@ -47,6 +62,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 template <int PREC, int ALAY, int BLAY>
 static int launch_gemm(GemmArgs p, hipStream_t st) {
   const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  constexpr int BK = PrecTraits<PREC>::BK;
+  p.split_k = 1;
+  p.k_chunk = p.K;
   if (t128 >= 192) {
     p.tiles_n = (p.N + 127) / 128;
     using G = GemmTile<PREC, ALAY, BLAY, 128, 128, 2, 2>;
@@ -54,8 +72,27 @@ static int launch_gemm(GemmArgs p, hipStream_t st) {
   } else {
     p.tiles_n = (p.N + 63) / 64;
     const long t64 = (long)((p.M + 63) / 64) * p.tiles_n;
+    // Long-K products with few output tiles (weight gradients: K = B*L) are latency-bound at
+    // <= 1 workgroup per CU; split K across workgroups until ~4 workgroups per CU are resident,
+    // keeping >= 4 K-steps per split, and reduce with fp32 atomics into the zeroed output.
+    if (p.epi == ARK_EPI_NONE && !p.accumulate && g_split_k_enabled) {
+      int split = 1;
+      while (t64 * split < 1024 && p.K / (split * 2) >= 4 * BK && split < 64) split *= 2;
+      if (split > 1) {
+        p.split_k = split;
+        p.k_chunk = ((p.K + split - 1) / split + BK - 1) / BK * BK;
+        p.split_k = (p.K + p.k_chunk - 1) / p.k_chunk;
+      }
+    }
+    if (p.split_k > 1) {
+      // rows of C are ldc apart; zero the [M, N] window (dense when ldc == N)
+      hipError_t e = (p.ldc == p.N) ? hipMemsetAsync(p.C, 0, sizeof(float) * (size_t)p.M * p.N, st)
+                                    : hipMemset2DAsync(p.C, sizeof(float) * p.ldc, 0, sizeof(float) * p.N, p.M, st);
+      if (e != hipSuccess) return (int)e;
+    }
     using G = GemmTile<PREC, ALAY, BLAY, 64, 64, 2, 2>;
-    hipLaunchKernelGGL((gemm_kernel<PREC, ALAY, BLAY, 64, 64>), dim3((unsigned)t64), dim3(256), G::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_kernel<PREC, ALAY, BLAY, 64, 64>), dim3((unsigned)t64, (unsigned)p.split_k), dim3(256),
+                       G::LDS_BYTES, st, p);
   }
   ARK_LAUNCH_CHECK();
   return 0;
@@ -72,6 +109,12 @@ static int dispatch_lay(int a_lay, int b_lay, const GemmArgs& p, hipStream_t st)
 
 }  // namespace ark
 
+// tuning / test knob: 0 disables split-K (bitwise run-to-run reproducible weight gradients)
+extern "C" int ark_set_split_k(int enabled) {
+  ark::g_split_k_enabled = enabled ? 1 : 0;
+  return 0;
+}
+
 extern "C" int ark_gemm(int prec, int a_lay, int b_lay, int epi, const float* A, int64_t lda, const float* B,
                         int64_t ldb, float* C, int64_t ldc, float* C2, const float* bias, const float* aux,
                         int M, int N, int K, int accumulate, void* stream) {
@@ -81,7 +124,7 @@ extern "C" int ark_gemm(int prec, int a_lay, int b_lay, int epi, const float* A,
   if (epi == ARK_EPI_BIAS_GELU && !C2) return ARK_ERR_ARG;
   if ((epi == ARK_EPI_MUL_DGELU || epi == ARK_EPI_MUL_AUX) && !aux) return ARK_ERR_ARG;
   if (epi < 0 || epi > ARK_EPI_MUL_AUX) return ARK_ERR_ARG;
-  GemmArgs p{A, B, C, C2, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, accumulate, 0};
+  GemmArgs p{A, B, C, C2, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, accumulate, 0, 1, K};
   hipStream_t st = (hipStream_t)stream;
   if (prec == PREC_F32) return dispatch_lay<PREC_F32>(a_lay, b_lay, p, st);
   if (prec == PREC_BF16) return dispatch_lay<PREC_BF16>(a_lay, b_lay, p, st);

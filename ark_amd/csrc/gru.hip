@@ -23,9 +23,9 @@ struct GruFwdArgs {
   int B, D;
 };
 
-template <int PREC>
+template <int PREC, int BM>
 __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(GruFwdArgs p) {
-  constexpr int BM = 64, BU = 32, BN = 3 * BU;
+  constexpr int BU = 32, BN = 3 * BU;
   using G = GemmTile<PREC, LAY_KMAJ, LAY_KMAJ, BM, BN, 2, 2>;  // wave tile 32 x 48 (16 units x 3 gates)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int units_tiles = p.D / BU;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(GruFwdArgs p) {
   for (int tm = 0; tm < G::TM; ++tm) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = m0 + wm * 32 + tm * 16 + 4 * (lane >> 4) + i;
+      const int row = m0 + wm * G::WTM + tm * 16 + 4 * (lane >> 4) + i;
       if (row >= B) continue;
       const float* gi = p.gi + (long)row * 3 * D;
       const long o = (long)row * D + u;
@@ -70,9 +70,8 @@ struct GruBwdArgs {
 };
 
 // final_ == 0: regular step t.   final_ == 1: only dh0 = dgh_0 W_hh + carry (gradient wrt the initial state).
-template <int PREC>
+template <int PREC, int BM, int BN>
 __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(GruBwdArgs p) {
-  constexpr int BM = 64, BN = 64;
   using G = GemmTile<PREC, LAY_KMAJ, LAY_MMAJ, BM, BN, 2, 2>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (p.D + BN - 1) / BN;
@@ -107,6 +106,48 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(GruBwdArgs p) {
 
 }  // namespace ark
 
+namespace ark {
+static int g_fwd_bm = 32;      // rows per forward-cell workgroup (64 | 32)
+static int g_bwd_tile = 2;     // backward-cell tile: 0 = 64x64, 1 = 32x64, 2 = 32x32
+
+template <int PREC, int BM>
+static void launch_fwd(const GruFwdArgs& p, hipStream_t st) {
+  const unsigned grid = (unsigned)(((p.B + BM - 1) / BM) * (p.D / 32));
+  hipLaunchKernelGGL((gru_cell_fwd_kernel<PREC, BM>), dim3(grid), dim3(256), (BM + 96) * 128, st, p);
+}
+template <int PREC>
+static void launch_fwd_prec(const GruFwdArgs& p, hipStream_t st) {
+  if (g_fwd_bm == 64) launch_fwd<PREC, 64>(p, st); else launch_fwd<PREC, 32>(p, st);
+}
+template <int PREC, int BM, int BN>
+static void launch_bwd(const GruBwdArgs& p, hipStream_t st) {
+  const unsigned grid = (unsigned)(((p.B + BM - 1) / BM) * ((p.D + BN - 1) / BN));
+  hipLaunchKernelGGL((gru_cell_bwd_kernel<PREC, BM, BN>), dim3(grid), dim3(256), (BM + BN) * 128, st, p);
+}
+template <int PREC>
+static void launch_bwd_prec(const GruBwdArgs& p, hipStream_t st) {
+  if (g_bwd_tile == 0) launch_bwd<PREC, 64, 64>(p, st);
+  else if (g_bwd_tile == 1) launch_bwd<PREC, 32, 64>(p, st);
+  else launch_bwd<PREC, 32, 32>(p, st);
+}
+static int launch_bwd_any(int prec, const GruBwdArgs& p, hipStream_t st) {
+  if (prec == PREC_F32) launch_bwd_prec<PREC_F32>(p, st);
+  else if (prec == PREC_BF16) launch_bwd_prec<PREC_BF16>(p, st);
+  else if (prec == PREC_F16) launch_bwd_prec<PREC_F16>(p, st);
+  else return ARK_ERR_ARG;
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace ark
+
+// tuning knobs (speed only, results identical up to fp32 summation order): key 1 = forward-cell
+// rows per workgroup {64,32}; key 2 = backward-cell tile {0: 64x64, 1: 32x64, 2: 32x32}
+extern "C" int ark_set_tuning(int key, int value) {
+  if (key == 1 && (value == 64 || value == 32)) { ark::g_fwd_bm = value; return 0; }
+  if (key == 2 && value >= 0 && value <= 2) { ark::g_bwd_tile = value; return 0; }
+  return ARK_ERR_ARG;
+}
+
 extern "C" int ark_gru_cell_fwd(int prec, const float* h_prev, const float* w_hh, const float* b_hh, const float* gi,
                                 float* h_out, float* h_drop, const float* drop_mask, float* save_r, float* save_z,
                                 float* save_n, float* save_hn, int B, int D, void* stream) {
@@ -116,12 +157,10 @@ extern "C" int ark_gru_cell_fwd(int prec, const float* h_prev, const float* w_hh
   if (h_drop && !drop_mask) return ARK_ERR_ARG;
   if (save_r && (!save_z || !save_n || !save_hn)) return ARK_ERR_ARG;
   GruFwdArgs p{h_prev, w_hh, b_hh, gi, h_out, h_drop, drop_mask, save_r, save_z, save_n, save_hn, B, D};
-  const unsigned grid = (unsigned)(((B + 63) / 64) * (D / 32));
   hipStream_t st = (hipStream_t)stream;
-  constexpr int LDS = (64 + 96) * 128;
-  if (prec == PREC_F32) hipLaunchKernelGGL(gru_cell_fwd_kernel<PREC_F32>, dim3(grid), dim3(256), LDS, st, p);
-  else if (prec == PREC_BF16) hipLaunchKernelGGL(gru_cell_fwd_kernel<PREC_BF16>, dim3(grid), dim3(256), LDS, st, p);
-  else if (prec == PREC_F16) hipLaunchKernelGGL(gru_cell_fwd_kernel<PREC_F16>, dim3(grid), dim3(256), LDS, st, p);
+  if (prec == PREC_F32) launch_fwd_prec<PREC_F32>(p, st);
+  else if (prec == PREC_BF16) launch_fwd_prec<PREC_BF16>(p, st);
+  else if (prec == PREC_F16) launch_fwd_prec<PREC_F16>(p, st);
   else return ARK_ERR_ARG;
   ARK_LAUNCH_CHECK();
   return 0;
@@ -136,15 +175,7 @@ extern "C" int ark_gru_cell_bwd(int prec, const float* dgh_next, const float* w_
   if (!first && !dgh_next) return ARK_ERR_ARG;
   GruBwdArgs p{dgh_next ? dgh_next : dgh, w_hh, dy, carry, save_r, save_z, save_n, save_hn, h_prev, dgi, dgh,
                nullptr, 0, B, D, first ? 1 : 0, 0};
-  const unsigned grid = (unsigned)(((B + 63) / 64) * ((D + 63) / 64));
-  hipStream_t st = (hipStream_t)stream;
-  constexpr int LDS = (64 + 64) * 128;
-  if (prec == PREC_F32) hipLaunchKernelGGL(gru_cell_bwd_kernel<PREC_F32>, dim3(grid), dim3(256), LDS, st, p);
-  else if (prec == PREC_BF16) hipLaunchKernelGGL(gru_cell_bwd_kernel<PREC_BF16>, dim3(grid), dim3(256), LDS, st, p);
-  else if (prec == PREC_F16) hipLaunchKernelGGL(gru_cell_bwd_kernel<PREC_F16>, dim3(grid), dim3(256), LDS, st, p);
-  else return ARK_ERR_ARG;
-  ARK_LAUNCH_CHECK();
-  return 0;
+  return launch_bwd_any(prec, p, (hipStream_t)stream);
 }
 
 extern "C" int ark_gru_h0_bwd(int prec, const float* dgh0, const float* w_hh, const float* carry, float* dh0,
@@ -153,13 +184,5 @@ extern "C" int ark_gru_h0_bwd(int prec, const float* dgh0, const float* w_hh, co
   if (!dgh0 || !w_hh || !carry || !dh0 || B <= 0 || D <= 0) return ARK_ERR_ARG;
   GruBwdArgs p{dgh0, w_hh, nullptr, const_cast<float*>(carry), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                nullptr, dh0, accumulate ? 1 : 0, B, D, 0, 1};
-  const unsigned grid = (unsigned)(((B + 63) / 64) * ((D + 63) / 64));
-  hipStream_t st = (hipStream_t)stream;
-  constexpr int LDS = (64 + 64) * 128;
-  if (prec == PREC_F32) hipLaunchKernelGGL(gru_cell_bwd_kernel<PREC_F32>, dim3(grid), dim3(256), LDS, st, p);
-  else if (prec == PREC_BF16) hipLaunchKernelGGL(gru_cell_bwd_kernel<PREC_BF16>, dim3(grid), dim3(256), LDS, st, p);
-  else if (prec == PREC_F16) hipLaunchKernelGGL(gru_cell_bwd_kernel<PREC_F16>, dim3(grid), dim3(256), LDS, st, p);
-  else return ARK_ERR_ARG;
-  ARK_LAUNCH_CHECK();
-  return 0;
+  return launch_bwd_any(prec, p, (hipStream_t)stream);
 }

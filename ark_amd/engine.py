@@ -466,12 +466,23 @@ class Engine:
             self.adam_steps -= 1
         self.adam_steps -= 1  # capture does not execute
         out4 = self.ws["out4"]
+        gstream = torch.cuda.Stream(device=self.device)
 
         def replay():
-            g1.replay()
-            if g2 is not None:
-                grad_sync(self.G)
-                g2.replay()
+            # hipGraphLaunch is NOT ordered against plain work queued on the legacy null stream
+            # (measured on ROCm 7.2: input-refresh copies raced with the replay), so replays always
+            # run on an explicit stream that is fenced against the caller's current stream.
+            cur = torch.cuda.current_stream()
+            use = cur if cur.cuda_stream != 0 else gstream
+            if use is not cur:
+                use.wait_stream(cur)
+            with torch.cuda.stream(use):
+                g1.replay()
+                if g2 is not None:
+                    grad_sync(self.G)
+                    g2.replay()
+            if use is not cur:
+                cur.wait_stream(use)
             self.adam_steps += 1
             return out4
 

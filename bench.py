@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--tuning", default="", help="speed-only kernel knobs, e.g. '1=32,2=1' (ark_set_tuning)")
+    ap.add_argument("--no-splitk", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,6 +145,13 @@ def main():
 
     from ark_amd.engine import Engine
     from ark_amd import initlib
+
+    from ark_amd import _lib as L
+    for kv in filter(None, args.tuning.split(",")):
+        k, v = kv.split("=")
+        L.check(L.lib().ark_set_tuning(int(k), int(v)), "ark_set_tuning")
+    if args.no_splitk:
+        L.lib().ark_set_split_k(0)
 
     cfg = build_cfg(args.dropout)
     B = args.batch
@@ -175,29 +184,34 @@ def main():
         seq_in.copy_(b, non_blocking=True)
         eps_in.copy_(c, non_blocking=True)
 
-    if args.no_graph:
-        def step():
-            return eng.train_step(tri_in, seq_in, eps_in, grad_sync=grad_sync, ce_count=ce_count)
-    else:
-        step = eng.capture_train_step(tri_in, seq_in, eps_in, ce_count=ce_count, grad_sync=grad_sync)
+    # everything (input refresh copies, graph replays, collectives) runs on ONE explicit stream:
+    # ordering between plain copies on the legacy null stream and hipGraphLaunch is not relied on
+    run_stream = torch.cuda.Stream(device=dev)
+    run_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(run_stream):
+        if args.no_graph:
+            def step():
+                return eng.train_step(tri_in, seq_in, eps_in, grad_sync=grad_sync, ce_count=ce_count)
+        else:
+            step = eng.capture_train_step(tri_in, seq_in, eps_in, ce_count=ce_count, grad_sync=grad_sync)
 
-    log('captured/ready; warmup')
-    for i in range(args.warmup):
-        feed(i)
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        feed(args.warmup + i)
-        out4 = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+        log('captured/ready; warmup')
+        for i in range(args.warmup):
+            feed(i)
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            feed(args.warmup + i)
+            out4 = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

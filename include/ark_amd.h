@@ -40,6 +40,11 @@ int ark_gemm(int prec, int a_lay, int b_lay, int epi, const float* A, int64_t ld
              float* C, int64_t ldc, float* C2, const float* bias, const float* aux, int M, int N, int K,
              int accumulate, void* stream);
 
+/* 0 disables split-K (atomic) reduction of long-K products: bitwise reproducible, slower */
+int ark_set_split_k(int enabled);
+/* speed-only tuning knobs of the GRU cell kernels (see ark_amd/csrc/gru.hip) */
+int ark_set_tuning(int key, int value);
+
 /* ---- device-resident step scalars ("hyper" array, ARK_HP_COUNT floats) -------------------------
  * Everything that changes between steps lives in device memory so a captured hipGraph of the
  * whole train step can be replayed; the host (or ark_adam_tick / ark_count_targets) updates it. */
