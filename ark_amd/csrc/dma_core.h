@@ -1,0 +1,127 @@
+// Second-generation tile engine for the latency-critical recurrent products: 16-bit operands
+// are streamed HBM/L2 -> LDS by LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging), a whole
+// K-stage (KS reduction elements, up to 2 stages = the full panel for d_model 512) in flight per
+// workgroup, counted `s_waitcnt vmcnt(N)` + raw `s_barrier` so the next stage keeps flying
+// underneath the MFMA block.
+//
+// Why: the register-staged engine (gemm_core.h) holds at most ~32 KB in flight per CU, and a GRU
+// timestep is one short dependent launch -- Little's law capped it at ~8 TB/s of L2->CU traffic
+// (profiles/r01_*).  LDS-DMA keeps 64-128 KB in flight per CU without spending registers.
+//
+// LDS image per stage and operand: KS/64 "k-images" of R rows x 128 B, same XOR swizzle and the
+// same ds_read_b128 fragment reads as gemm_core.h.  LDS-DMA writes are lane-linear (wave-uniform
+// base + lane*16), so the swizzle is applied to the per-lane SOURCE address instead: lane i of
+// the wave-instruction that fills rows 8p..8p+7 of an image supplies row 8p + i/8, logical chunk
+// (i%8) ^ ((row>>1)&7).
+#pragma once
+#include "gemm_core.h"
+
+namespace ark {
+
+template <int PREC, int BM, int BN, int KS, int WGM, int WGN>
+struct DmaTile {
+  static_assert(PREC == PREC_F16 || PREC == PREC_BF16, "LDS-DMA engine takes 16-bit operands");
+  static_assert(BM % 32 == 0 && BN % 32 == 0 && KS % 64 == 0, "tile shape");
+  static_assert(WGM * WGN == 4, "4 waves");
+  using PT = PrecTraits<PREC>;
+  using h_t = typename PT::h_t;
+  static constexpr int NIMG = KS / 64;
+  static constexpr int A_STAGE = BM * NIMG * 128, B_STAGE = BN * NIMG * 128;
+  static constexpr int STAGE_BYTES = A_STAGE + B_STAGE;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static constexpr int NPA = BM / 32, NPB = BN / 32;              // 1-KB pieces per image per wave
+  static constexpr int LPS = (NPA + NPB) * NIMG;                  // LDS-DMA instructions per stage per wave
+  static_assert(LPS <= 31, "two stages must fit the 6-bit vmcnt");
+  static constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  static constexpr int TM = WTM / 16, TN = WTN / 16;
+
+  template <int N>
+  static __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  }
+
+  // rma / rmb: tile row -> memory row (must be a valid row; clamp out-of-range rows on the caller side)
+  template <class RMA, class RMB>
+  static __device__ __forceinline__ void run(f32x4 (&acc)[TM][TN], const h_t* A, long lda, RMA rma, const h_t* B,
+                                             long ldb, RMB rmb, int K, char* lds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    const h_t* ap[NPA];
+    const h_t* bp[NPB];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int row = 8 * (wave + 4 * i) + (lane >> 3);
+      ap[i] = A + rma(row) * lda + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      const int row = 8 * (wave + 4 * i) + (lane >> 3);
+      bp[i] = B + rmb(row) * ldb + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+    }
+    auto issue = [&](int s, int buf) {
+      char* base = lds + buf * STAGE_BYTES;
+      const int k0 = s * KS;
+#pragma unroll
+      for (int j = 0; j < NIMG; ++j) {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(ap[i] + k0 + 64 * j),
+              (__attribute__((address_space(3))) void*)(base + j * (BM * 128) + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NPB; ++i)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(bp[i] + k0 + 64 * j),
+              (__attribute__((address_space(3))) void*)(base + A_STAGE + j * (BN * 128) + (wave + 4 * i) * 1024), 16, 0, 0);
+      }
+    };
+
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int NS = K / KS;  // host guarantees K % KS == 0
+    if (NS <= 0) return;
+    issue(0, 0);
+    if (NS > 1) issue(1, 1);
+    for (int s = 0; s < NS; ++s) {
+      if (s + 1 < NS) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const char* bufA = lds + (s & 1) * STAGE_BYTES;
+      const char* bufB = bufA + A_STAGE;
+#pragma unroll
+      for (int j = 0; j < NIMG; ++j) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          typename PT::h8 a[TM], b[TN];
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+            a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + j * (BM * 128) +
+                                                              lds_off(wm * WTM + tm * 16 + lr, 4 * s2 + lq));
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + j * (BN * 128) +
+                                                              lds_off(wn * WTN + tn * 16 + lr, 4 * s2 + lq));
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = PT::mfma(a[tm], b[tn], acc[tm][tn]);
+        }
+      }
+      if (s + 2 < NS) {
+        // every wave has consumed buffer (s&1): its fragment reads were waited for by the MFMAs
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue(s + 2, s & 1);
+      }
+    }
+  }
+};
+
+}  // namespace ark

@@ -145,6 +145,16 @@ class Engine:
         self.training = True
         self.drop_seed = int(cfg.get("dropout_seed", 0x5A11))
         self._graphs = {}
+        # LDS-DMA recurrent kernels: 16-bit shadows of W_hh (forward) and W_hh^T (backward)
+        self.use_dma = (self.prec_fwd != L.PREC_F32 and self.prec_bwd != L.PREC_F32 and self.D % 64 == 0
+                        and not cfg.get("ark_no_dma", False))
+        if self.use_dma:
+            D = self.D
+            self.whh16 = torch.empty(self.n, 3 * D, D, device=dev, dtype=torch.int16)
+            self.whhT16 = torch.empty(self.n, D, 3 * D, device=dev, dtype=torch.int16)
+            e = self.layout.entries
+            self._whh_stride = (e["dec.gru.weight_hh_l1"][0] - e["dec.gru.weight_hh_l0"][0]) if self.n > 1 else 0
+        self._shadow_ok = False
 
     # ------------------------------------------------------------------ parameters
     def load_params(self, named):
@@ -153,6 +163,18 @@ class Engine:
                 if k == "dec.out.weight" and self.layout.tied:
                     continue
                 self.p[k].copy_(v.to(self.device, dtype=torch.float32))
+        self._shadow_ok = False
+
+    def mark_params_dirty(self):
+        """call after anything other than Engine.adam() changed the parameters"""
+        self._shadow_ok = False
+
+    def refresh_shadows(self):
+        if self.use_dma:
+            _call("ark_gru_weight_shadows", L.i32(self.prec_fwd), L.i32(self.prec_bwd), L.ptr(self.p["dec.gru.weight_hh_l0"]),
+                  L.i64(self._whh_stride), L.ptr(self.whh16), L.ptr(self.whhT16), L.i32(self.D), L.i32(self.n),
+                  L.cur_stream())
+        self._shadow_ok = True
 
     def set_hyper(self, lr=None, beta=None, kl_norm=None, ce_count=None, grad_scale=None):
         """update device-resident step scalars (tiny async fills, only when a value changes)"""
@@ -199,6 +221,9 @@ class Engine:
         w["Y"] = [torch.zeros((Lq + 1) * B, D, device=dev) for _ in range(n)]  # slot 0 = h0
         for nm in ("SR", "SZ", "SN", "SHN"):
             w[nm] = [f(R, D) for _ in range(n)]
+        if self.use_dma:
+            w["Y16"] = [torch.zeros((Lq + 1) * B, D, device=dev, dtype=torch.int16) for _ in range(n)]
+            w["dGH16"] = [torch.empty(R, 3 * D, device=dev, dtype=torch.int16) for _ in range(n)]
         if self.p_drop > 0:
             w["mask"] = [f(R, D) for _ in range(n - 1)]
             w["Ydrop"] = [f(R, D) for _ in range(n - 1)]
@@ -228,6 +253,8 @@ class Engine:
         """Launch the forward pass.  triples [B,T,3] int64 (SAIL), seq [B,seq_len] int64 (device).
         Results stay on the device in the workspace (out4 = loss, ce, kl, token-loss sum)."""
         self.prec = self.prec_fwd
+        if not self._shadow_ok:
+            self.refresh_shadows()
         B = seq.shape[0]
         T = triples.shape[1] if (self.mt == "SAIL" and triples is not None) else 0
         w = self._workspace(B, T)
@@ -264,6 +291,8 @@ class Engine:
         else:
             for l in range(n):
                 w["Y"][l][:B].zero_()
+                if self.use_dma:
+                    w["Y16"][l][:B].zero_()
         self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop)
         if with_loss:
             if ce_count is None:
@@ -280,6 +309,9 @@ class Engine:
         for l in range(self.n):
             _call("ark_zproj_fwd", L.ptr(z), L.ptr(p["dec.z_proj.weight"]), L.ptr(p["dec.z_proj.bias"]), L.ptr(w["Y"][l]),
                   L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(self.D), L.cur_stream())
+            if self.use_dma:
+                _call("ark_cast16", L.i32(self.prec_fwd), L.ptr(w["Y"][l]), L.ptr(w["Y16"][l]), L.i64(B * self.D),
+                      L.cur_stream())
 
     def _decoder_forward(self, w, seq, ld_seq, B, Lq, use_drop, save=True):
         D, n, V = self.D, self.n, self.V
@@ -300,12 +332,18 @@ class Engine:
                       L.u64(self.drop_seed + 7919 * l), L.ptr(self.hyper), st)
             for t in range(Lq):
                 sl = slice(t * B, (t + 1) * B)
-                _call("ark_gru_cell_fwd", L.i32(self.prec), L.ptr(Y[t * B:]), L.ptr(p[f"dec.gru.weight_hh_l{l}"]),
-                      L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l][sl]), L.ptr(Y[(t + 1) * B:]),
-                      L.ptr(w["Ydrop"][l][sl] if drop else None), L.ptr(w["mask"][l][sl] if drop else None),
-                      L.ptr(w["SR"][l][sl] if save else None), L.ptr(w["SZ"][l][sl] if save else None),
-                      L.ptr(w["SN"][l][sl] if save else None), L.ptr(w["SHN"][l][sl] if save else None),
-                      L.i32(B), L.i32(D), st)
+                common = (L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l][sl]), L.ptr(Y[(t + 1) * B:]))
+                tail = (L.ptr(w["Ydrop"][l][sl] if drop else None), L.ptr(w["mask"][l][sl] if drop else None),
+                        L.ptr(w["SR"][l][sl] if save else None), L.ptr(w["SZ"][l][sl] if save else None),
+                        L.ptr(w["SN"][l][sl] if save else None), L.ptr(w["SHN"][l][sl] if save else None),
+                        L.i32(B), L.i32(D), st)
+                if self.use_dma:
+                    Y16 = w["Y16"][l]
+                    _call("ark_gru_cell_fwd_dma", L.i32(self.prec), L.ptr(Y16[t * B:]), L.ptr(self.whh16[l]), L.ptr(Y[t * B:]),
+                          *common, L.ptr(Y16[(t + 1) * B:]), *tail)
+                else:
+                    _call("ark_gru_cell_fwd", L.i32(self.prec), L.ptr(Y[t * B:]), L.ptr(p[f"dec.gru.weight_hh_l{l}"]),
+                          *common, *tail)
             xin = w["Ydrop"][l] if drop else Y[B:]
         self._xin_top = xin
         self._gemm(KM, KM, L.EPI_BIAS, w["Y"][n - 1][B:], D, p["dec.out.weight"], D, w["logits"], self.ldl, R, V, D,
@@ -338,13 +376,22 @@ class Engine:
             for t in range(Lq - 1, -1, -1):
                 sl = slice(t * B, (t + 1) * B)
                 first = (t == Lq - 1)
-                _call("ark_gru_cell_bwd", L.i32(self.prec), L.ptr(None if first else dGH[(t + 1) * B:]), L.ptr(whh),
-                      L.ptr(dy[sl]), L.ptr(w["carry"]), L.ptr(w["SR"][l][sl]), L.ptr(w["SZ"][l][sl]), L.ptr(w["SN"][l][sl]),
-                      L.ptr(w["SHN"][l][sl]), L.ptr(Y[sl]), L.ptr(dGI[sl]), L.ptr(dGH[sl]), L.i32(B), L.i32(D),
-                      L.i32(1 if first else 0), st)
+                mid = (L.ptr(dy[sl]), L.ptr(w["carry"]), L.ptr(w["SR"][l][sl]), L.ptr(w["SZ"][l][sl]), L.ptr(w["SN"][l][sl]),
+                       L.ptr(w["SHN"][l][sl]), L.ptr(Y[sl]), L.ptr(dGI[sl]), L.ptr(dGH[sl]))
+                if self.use_dma:
+                    d16 = w["dGH16"][l]
+                    _call("ark_gru_cell_bwd_dma", L.i32(self.prec), L.ptr(None if first else d16[(t + 1) * B:]),
+                          L.ptr(self.whhT16[l]), *mid, L.ptr(d16[sl]), L.i32(B), L.i32(D), L.i32(1 if first else 0), st)
+                else:
+                    _call("ark_gru_cell_bwd", L.i32(self.prec), L.ptr(None if first else dGH[(t + 1) * B:]), L.ptr(whh),
+                          *mid, L.i32(B), L.i32(D), L.i32(1 if first else 0), st)
             if self.mt == "SAIL":
-                _call("ark_gru_h0_bwd", L.i32(self.prec), L.ptr(dGH), L.ptr(whh), L.ptr(w["carry"]), L.ptr(w["dH0"]),
-                      L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
+                if self.use_dma:
+                    _call("ark_gru_h0_bwd_dma", L.i32(self.prec), L.ptr(w["dGH16"][l]), L.ptr(self.whhT16[l]), L.ptr(w["carry"]),
+                          L.ptr(w["dH0"]), L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
+                else:
+                    _call("ark_gru_h0_bwd", L.i32(self.prec), L.ptr(dGH), L.ptr(whh), L.ptr(w["carry"]), L.ptr(w["dH0"]),
+                          L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
             drop_below = use_drop and l > 0
             xin = w["X0"] if l == 0 else (w["Ydrop"][l - 1] if drop_below else w["Y"][l - 1][B:])
             self._gemm(MM, MM, L.EPI_NONE, dGH, 3 * D, Y, D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R)
@@ -403,6 +450,7 @@ class Engine:
         _call("ark_adam_step", L.ptr(self.P), L.ptr(self.G), L.ptr(self.M), L.ptr(self.Vv), L.i64(self.layout.total),
               L.ptr(self.hyper), st)
         self.adam_steps += 1
+        self.refresh_shadows()
 
     # ------------------------------------------------------------------ whole step
     def _default_norms(self, B):

@@ -81,6 +81,23 @@ int ark_gru_cell_bwd(int prec, const float* dgh_next, const float* w_hh, const f
 int ark_gru_h0_bwd(int prec, const float* dgh0, const float* w_hh, const float* carry, float* dh0, int accumulate,
                    int B, int D, void* stream);
 
+/* LDS-DMA editions of the three calls above for 16-bit precisions and d_model % 64 == 0: the
+ * recurrent operands are 16-bit copies (h written by the previous cell, W_hh / W_hh^T shadows from
+ * ark_gru_weight_shadows); fp32 state, saves and gradients are unchanged. */
+int ark_gru_cell_fwd_dma(int prec, const void* h_prev16, const void* w_hh16, const float* h_prev, const float* b_hh,
+                         const float* gi, float* h_out, void* h_out16, float* h_drop, const float* drop_mask,
+                         float* save_r, float* save_z, float* save_n, float* save_hn, int B, int D, void* stream);
+int ark_gru_cell_bwd_dma(int prec, const void* dgh_next16, const void* w_hhT16, const float* dy, float* carry,
+                         const float* save_r, const float* save_z, const float* save_n, const float* save_hn,
+                         const float* h_prev, float* dgi, float* dgh, void* dgh16, int B, int D, int first,
+                         void* stream);
+int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_hhT16, const float* carry, float* dh0,
+                       int accumulate, int B, int D, void* stream);
+/* w16[l] = cast(W_hh_l) [3D,D] in prec_fwd, wT16[l] = cast(W_hh_l^T) [D,3D] in prec_bwd, all layers */
+int ark_gru_weight_shadows(int prec_fwd, int prec_bwd, const float* w_hh_l0, int64_t layer_stride, void* w16,
+                           void* wT16, int D, int n_layers, void* stream);
+int ark_cast16(int prec, const float* x, void* out, int64_t n, void* stream);
+
 /* ---- embeddings (reference: models.py:47-58 encoder gather+concat+masked mean; :138,:343
  *      decoder token / position lookup; autograd embedding_backward) --------------------------- */
 int ark_enc_pool_fwd(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt, int B, int T,
