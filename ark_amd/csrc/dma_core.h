@@ -18,26 +18,49 @@
 
 namespace ark {
 
-template <int PREC, int BM, int BN, int KS, int WGM, int WGN>
+// 16x16-tile-native addressing shared by producers and consumers of per-element fp32 state (GRU
+// gate saves, gi): element (row, col) of a [rows, ld] logical matrix lives at
+//   ((row>>4) * (ld>>4) + (col>>4)) * 256 + (((row>>2)&3)*16 + (col&15)) * 4 + (row&3)
+// i.e. exactly the MFMA C/D fragment order: one lane's 4 accumulator rows are one float4, one
+// wave's 16x16 tile is one contiguous 1-KB line -> every epilogue access is a full-rate dwordx4.
+__device__ __forceinline__ long tile_native_off(int row, int col, int ld) {
+  return ((long)(row >> 4) * (ld >> 4) + (col >> 4)) * 256 + ((((row >> 2) & 3) << 4) + (col & 15)) * 4 + (row & 3);
+}
+
+template <int PREC, int BM, int BN, int NBUF, int WGM, int WGN>
 struct DmaTile {
   static_assert(PREC == PREC_F16 || PREC == PREC_BF16, "LDS-DMA engine takes 16-bit operands");
-  static_assert(BM % 32 == 0 && BN % 32 == 0 && KS % 64 == 0, "tile shape");
+  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile shape");
   static_assert(WGM * WGN == 4, "4 waves");
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
-  static constexpr int NIMG = KS / 64;
-  static constexpr int A_STAGE = BM * NIMG * 128, B_STAGE = BN * NIMG * 128;
+  // one pipeline stage = one 64-wide k-image of both operands; NBUF stages ride a ring in LDS
+  static constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;
   static constexpr int STAGE_BYTES = A_STAGE + B_STAGE;
-  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
-  static constexpr int NPA = BM / 32, NPB = BN / 32;              // 1-KB pieces per image per wave
-  static constexpr int LPS = (NPA + NPB) * NIMG;                  // LDS-DMA instructions per stage per wave
-  static_assert(LPS <= 31, "two stages must fit the 6-bit vmcnt");
+  static constexpr int LDS_BYTES = NBUF * STAGE_BYTES;
+  static constexpr int NPA = BM / 32, NPB = BN / 32;   // 1-KB LDS-DMA pieces per stage per wave
+  static constexpr int LPS = NPA + NPB;                // LDS-DMA instructions per stage per wave
+  static_assert((NBUF - 1) * LPS <= 63, "in-flight stages must fit the 6-bit vmcnt");
+  static_assert(NBUF >= 2 && NBUF <= 8, "ring depth");
   static constexpr int WTM = BM / WGM, WTN = BN / WGN;
   static constexpr int TM = WTM / 16, TN = WTN / 16;
 
   template <int N>
   static __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  }
+  // wait until all but the youngest `stages` stages of this wave's LDS-DMA have landed
+  static __device__ __forceinline__ void wait_stages(int stages) {
+    switch (stages) {
+      case 0: wait_vmcnt<0>(); break;
+      case 1: wait_vmcnt<LPS>(); break;
+      case 2: wait_vmcnt<(NBUF > 2 ? 2 : 0) * LPS>(); break;
+      case 3: wait_vmcnt<(NBUF > 3 ? 3 : 0) * LPS>(); break;
+      case 4: wait_vmcnt<(NBUF > 4 ? 4 : 0) * LPS>(); break;
+      case 5: wait_vmcnt<(NBUF > 5 ? 5 : 0) * LPS>(); break;
+      case 6: wait_vmcnt<(NBUF > 6 ? 6 : 0) * LPS>(); break;
+      default: wait_vmcnt<(NBUF > 7 ? 7 : 0) * LPS>(); break;
+    }
   }
 
   // rma / rmb: tile row -> memory row (must be a valid row; clamp out-of-range rows on the caller side)
@@ -61,22 +84,17 @@ struct DmaTile {
       const int row = 8 * (wave + 4 * i) + (lane >> 3);
       bp[i] = B + rmb(row) * ldb + 8 * ((lane & 7) ^ ((row >> 1) & 7));
     }
-    auto issue = [&](int s, int buf) {
-      char* base = lds + buf * STAGE_BYTES;
-      const int k0 = s * KS;
+    auto issue = [&](int s) {
+      char* base = lds + (s % NBUF) * STAGE_BYTES;
+      const int k0 = s * 64;
 #pragma unroll
-      for (int j = 0; j < NIMG; ++j) {
+      for (int i = 0; i < NPA; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NPA; ++i)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(ap[i] + k0 + 64 * j),
-              (__attribute__((address_space(3))) void*)(base + j * (BM * 128) + (wave + 4 * i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NPB; ++i)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(bp[i] + k0 + 64 * j),
-              (__attribute__((address_space(3))) void*)(base + A_STAGE + j * (BN * 128) + (wave + 4 * i) * 1024), 16, 0, 0);
-      }
+      for (int i = 0; i < NPB; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(base + A_STAGE + (wave + 4 * i) * 1024), 16, 0, 0);
     };
 
 #pragma unroll
@@ -84,41 +102,38 @@ struct DmaTile {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int NS = K / KS;  // host guarantees K % KS == 0
+    const int NS = K / 64;  // host guarantees K % 64 == 0
     if (NS <= 0) return;
-    issue(0, 0);
-    if (NS > 1) issue(1, 1);
+    const int pre = NS < NBUF ? NS : NBUF;
+    for (int s = 0; s < pre; ++s) issue(s);
     for (int s = 0; s < NS; ++s) {
-      if (s + 1 < NS) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+      // stages s+1 .. min(NS, s+NBUF)-1 may stay in flight while stage s is consumed
+      const int ahead = (NS - 1 - s) < (NBUF - 1) ? (NS - 1 - s) : (NBUF - 1);
+      wait_stages(ahead);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      const char* bufA = lds + (s & 1) * STAGE_BYTES;
+      const char* bufA = lds + (s % NBUF) * STAGE_BYTES;
       const char* bufB = bufA + A_STAGE;
 #pragma unroll
-      for (int j = 0; j < NIMG; ++j) {
+      for (int s2 = 0; s2 < 2; ++s2) {
+        typename PT::h8 a[TM], b[TN];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          typename PT::h8 a[TM], b[TN];
+        for (int tm = 0; tm < TM; ++tm)
+          a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + lds_off(wm * WTM + tm * 16 + lr, 4 * s2 + lq));
 #pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-            a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + j * (BM * 128) +
-                                                              lds_off(wm * WTM + tm * 16 + lr, 4 * s2 + lq));
+        for (int tn = 0; tn < TN; ++tn)
+          b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + lds_off(wn * WTN + tn * 16 + lr, 4 * s2 + lq));
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + j * (BN * 128) +
-                                                              lds_off(wn * WTN + tn * 16 + lr, 4 * s2 + lq));
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = PT::mfma(a[tm], b[tn], acc[tm][tn]);
-        }
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = PT::mfma(a[tm], b[tn], acc[tm][tn]);
       }
-      if (s + 2 < NS) {
-        // every wave has consumed buffer (s&1): its fragment reads were waited for by the MFMAs
+      if (s + NBUF < NS) {
+        // every wave has consumed ring slot s%NBUF (its fragment reads are complete) -> refill it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        issue(s + 2, s & 1);
+        issue(s + NBUF);
       }
     }
   }

@@ -18,9 +18,9 @@ struct GemmArgs {
   int split_k, k_chunk;  // split_k > 1: blockIdx.y owns K range [y*k_chunk, ...) and adds atomically into zeroed C
 };
 
-template <int PREC, int ALAY, int BLAY, int BM, int BN>
+template <int PREC, int ALAY, int BLAY, int BM, int BN, int ASRC16 = 0, int BSRC16 = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
-  using G = GemmTile<PREC, ALAY, BLAY, BM, BN, 2, 2>;
+  using G = GemmTile<PREC, ALAY, BLAY, BM, BN, 2, 2, ASRC16, BSRC16>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -29,8 +29,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   // split-K: this workgroup reduces k in [kb, ke); operands are offset along their reduction index
   const int kb = blockIdx.y * p.k_chunk;
   const int ke = min(p.K, kb + p.k_chunk);
-  const float* Ab = p.A + (ALAY == LAY_KMAJ ? (long)kb : (long)kb * p.lda);
-  const float* Bb = p.B + (BLAY == LAY_KMAJ ? (long)kb : (long)kb * p.ldb);
+  // (16-bit sources are half as wide: offsets are in elements of the operand's own type)
+  const char* Ab = reinterpret_cast<const char*>(p.A) + (ALAY == LAY_KMAJ ? (long)kb : (long)kb * p.lda) * (ASRC16 ? 2 : 4);
+  const char* Bb = reinterpret_cast<const char*>(p.B) + (BLAY == LAY_KMAJ ? (long)kb : (long)kb * p.ldb) * (BSRC16 ? 2 : 4);
   G::run(acc, Ab, p.lda, [=](int r) -> long { return (m0 + r < M) ? (long)(m0 + r) : -1L; },
          Bb, p.ldb, [=](int r) -> long { return (n0 + r < N) ? (long)(n0 + r) : -1L; }, ke - kb, smem);
 
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   });
 }
 
-template <int PREC, int ALAY, int BLAY>
+template <int PREC, int ALAY, int BLAY, int ASRC16 = 0, int BSRC16 = 0>
 static int launch_gemm(GemmArgs p, hipStream_t st) {
   const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   constexpr int BK = PrecTraits<PREC>::BK;
@@ -67,8 +68,8 @@ static int launch_gemm(GemmArgs p, hipStream_t st) {
   p.k_chunk = p.K;
   if (t128 >= 192) {
     p.tiles_n = (p.N + 127) / 128;
-    using G = GemmTile<PREC, ALAY, BLAY, 128, 128, 2, 2>;
-    hipLaunchKernelGGL((gemm_kernel<PREC, ALAY, BLAY, 128, 128>), dim3((unsigned)t128), dim3(256), G::LDS_BYTES, st, p);
+    using G = GemmTile<PREC, ALAY, BLAY, 128, 128, 2, 2, ASRC16, BSRC16>;
+    hipLaunchKernelGGL((gemm_kernel<PREC, ALAY, BLAY, 128, 128, ASRC16, BSRC16>), dim3((unsigned)t128), dim3(256), G::LDS_BYTES, st, p);
   } else {
     p.tiles_n = (p.N + 63) / 64;
     const long t64 = (long)((p.M + 63) / 64) * p.tiles_n;
@@ -90,8 +91,8 @@ static int launch_gemm(GemmArgs p, hipStream_t st) {
                                     : hipMemset2DAsync(p.C, sizeof(float) * p.ldc, 0, sizeof(float) * p.N, p.M, st);
       if (e != hipSuccess) return (int)e;
     }
-    using G = GemmTile<PREC, ALAY, BLAY, 64, 64, 2, 2>;
-    hipLaunchKernelGGL((gemm_kernel<PREC, ALAY, BLAY, 64, 64>), dim3((unsigned)t64, (unsigned)p.split_k), dim3(256),
+    using G = GemmTile<PREC, ALAY, BLAY, 64, 64, 2, 2, ASRC16, BSRC16>;
+    hipLaunchKernelGGL((gemm_kernel<PREC, ALAY, BLAY, 64, 64, ASRC16, BSRC16>), dim3((unsigned)t64, (unsigned)p.split_k), dim3(256),
                        G::LDS_BYTES, st, p);
   }
   ARK_LAUNCH_CHECK();
@@ -130,4 +131,25 @@ extern "C" int ark_gemm(int prec, int a_lay, int b_lay, int epi, const float* A,
   if (prec == PREC_BF16) return dispatch_lay<PREC_BF16>(a_lay, b_lay, p, st);
   if (prec == PREC_F16) return dispatch_lay<PREC_F16>(a_lay, b_lay, p, st);
   return ARK_ERR_ARG;
+}
+
+// Weight-gradient products C[M,N] = sum_k A[k, M] * B[k, N] (both operands reduction-major) where
+// one or both operands are stored in 16 bits (the type `prec` computes in).  Same kernel family as
+// ark_gemm; a_is16 / b_is16 select the storage of each operand (0: fp32, 1: 16-bit).
+extern "C" int ark_gemm_wgrad(int prec, const void* A, int a_is16, int64_t lda, const void* B, int b_is16, int64_t ldb,
+                              float* C, int64_t ldc, int M, int N, int K, void* stream) {
+  using namespace ark;
+  if (M <= 0 || N <= 0 || K < 0 || !A || !B || !C) return ARK_ERR_ARG;
+  if (prec != PREC_BF16 && prec != PREC_F16) return ARK_ERR_ARG;
+  GemmArgs p{reinterpret_cast<const float*>(A), reinterpret_cast<const float*>(B), C, nullptr, nullptr, nullptr,
+             (long)lda, (long)ldb, (long)ldc, M, N, K, ARK_EPI_NONE, 0, 0, 1, K};
+  hipStream_t st = (hipStream_t)stream;
+#define ARK_WG(P)                                                                                         \
+  if (a_is16 && b_is16) return launch_gemm<P, LAY_MMAJ, LAY_MMAJ, 1, 1>(p, st);                          \
+  if (!a_is16 && b_is16) return launch_gemm<P, LAY_MMAJ, LAY_MMAJ, 0, 1>(p, st);                         \
+  if (!a_is16 && !b_is16) return launch_gemm<P, LAY_MMAJ, LAY_MMAJ, 0, 0>(p, st);                        \
+  return ARK_ERR_ARG;
+  if (prec == PREC_BF16) { ARK_WG(PREC_BF16) }
+  ARK_WG(PREC_F16)
+#undef ARK_WG
 }

@@ -1,0 +1,220 @@
+// C[M,N] = A16[M,K] * B16[N,K]^T on the LDS-DMA ring engine (dma_core.h): both operands are 16-bit,
+// K-contiguous, row-major; fp32 accumulate; fused bias / mask epilogue; C either row-major or in
+// the MFMA-tile-native order the GRU cell epilogues consume (tile_native_off).
+// Serves the time-batched GRU input products, the tied vocabulary projection and the
+// input-gradient products (against transposed 16-bit weight shadows).  Reference ops replaced:
+// nn.GRU input projection (kgvae/model/models.py:121-127), nn.Linear `out` (:128,142) and their
+// autograd input-gradients.
+#include "dma_core.h"
+#include "../../include/ark_amd.h"
+
+namespace ark {
+
+struct Gemm16Args {
+  const void* A; const void* B; float* C; const float* bias; const float* aux;
+  long lda, ldb, ldc;
+  int M, N, K, epi, c_tiled, tiles_n;
+};
+
+template <int PREC, int BM, int BN, int NBUF>
+__global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2>;
+  using h_t = typename G::h_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int m0 = (blockIdx.x / p.tiles_n) * BM, n0 = (blockIdx.x % p.tiles_n) * BN;
+  const int M = p.M, N = p.N;
+  f32x4 acc[G::TM][G::TN];
+  G::run(acc, reinterpret_cast<const h_t*>(p.A), p.lda, [=](int r) -> long { return (long)min(m0 + r, M - 1); },
+         reinterpret_cast<const h_t*>(p.B), p.ldb, [=](int r) -> long { return (long)min(n0 + r, N - 1); }, p.K, smem);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int tm = 0; tm < G::TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < G::TN; ++tn) {
+      const int row0 = m0 + wm * G::WTM + tm * 16 + 4 * (lane >> 4);
+      const int col = n0 + wn * G::WTN + tn * 16 + (lane & 15);
+      if (row0 >= M || col >= N) continue;
+      f32x4 v = acc[tm][tn];
+      if (p.epi == ARK_EPI_BIAS) v += p.bias[col];
+      if (p.c_tiled) {  // M % 16 == 0 and ldc % 16 == 0 (checked on the host): the quad is whole
+        const long o = tile_native_off(row0, col, (int)p.ldc);
+        if (p.epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
+        *reinterpret_cast<f32x4*>(p.C + o) = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (row0 + i >= M) break;
+          const long o = (long)(row0 + i) * p.ldc + col;
+          float x = v[i];
+          if (p.epi == ARK_EPI_MUL_AUX) x *= p.aux[o];
+          p.C[o] = x;
+        }
+      }
+    }
+}
+
+template <class K>
+static void allow_lds16(K kernel, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int PREC>
+static int launch16(Gemm16Args p, hipStream_t st) {
+  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  if (t128 >= 192) {
+    using G = DmaTile<PREC, 128, 128, 4, 2, 2>;
+    static bool once = (allow_lds16(gemm16_kernel<PREC, 128, 128, 4>, G::LDS_BYTES), true); (void)once;
+    p.tiles_n = (p.N + 127) / 128;
+    hipLaunchKernelGGL((gemm16_kernel<PREC, 128, 128, 4>), dim3((unsigned)t128), dim3(256), G::LDS_BYTES, st, p);
+  } else {
+    using G = DmaTile<PREC, 64, 64, 4, 2, 2>;
+    static bool once = (allow_lds16(gemm16_kernel<PREC, 64, 64, 4>, G::LDS_BYTES), true); (void)once;
+    p.tiles_n = (p.N + 63) / 64;
+    const long t64 = (long)((p.M + 63) / 64) * p.tiles_n;
+    hipLaunchKernelGGL((gemm16_kernel<PREC, 64, 64, 4>), dim3((unsigned)t64), dim3(256), G::LDS_BYTES, st, p);
+  }
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- decoder input: x16[(t,b), :] = cast(W_tok[seq[b,t]] (+ W_pos[t])) in one or two 16-bit types ----
+template <int PA, int PB2>
+__global__ __launch_bounds__(256) void tok_gather16_kernel(const int64_t* __restrict__ seq, long ld_seq,
+                                                           const float* __restrict__ Wt, const float* __restrict__ Wp,
+                                                           void* xa_, void* xb_, int B, int L, int D) {
+  using HA = typename PrecTraits<PA>::h_t;
+  using HB = typename PrecTraits<PB2>::h_t;
+  typedef HA ha4 __attribute__((ext_vector_type(4)));
+  typedef HB hb4 __attribute__((ext_vector_type(4)));
+  const int D4 = D >> 2;
+  const long total = (long)B * L * D4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d4 = (int)(i % D4);
+    const long row = i / D4;
+    const int t = (int)(row / B), b = (int)(row % B);
+    const long tok = seq[(long)b * ld_seq + t];
+    f32x4 v = *reinterpret_cast<const f32x4*>(Wt + tok * D + 4 * d4);
+    if (Wp) v += *reinterpret_cast<const f32x4*>(Wp + (long)t * D + 4 * d4);
+    reinterpret_cast<ha4*>(xa_)[row * D4 + d4] = ha4{PrecTraits<PA>::cvt(v[0]), PrecTraits<PA>::cvt(v[1]), PrecTraits<PA>::cvt(v[2]), PrecTraits<PA>::cvt(v[3])};
+    if (xb_) reinterpret_cast<hb4*>(xb_)[row * D4 + d4] = hb4{PrecTraits<PB2>::cvt(v[0]), PrecTraits<PB2>::cvt(v[1]), PrecTraits<PB2>::cvt(v[2]), PrecTraits<PB2>::cvt(v[3])};
+  }
+}
+
+// out[n] = sum_m X16[m, n]   (bias gradients from the 16-bit gate-gradient panels)
+template <int PREC>
+__global__ __launch_bounds__(256) void colsum16_kernel(const void* X_, long ld, float* __restrict__ out, int M, int N, int rows_per_wg) {
+  using H = typename PrecTraits<PREC>::h_t;
+  const H* X = reinterpret_cast<const H*>(X_);
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int m0 = blockIdx.y * rows_per_wg, m1 = min(M, m0 + rows_per_wg);
+  float s = 0.f;
+  if (col < N)
+    for (int r = m0 + wave; r < m1; r += 4) s += (float)X[(long)r * ld + col];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && col < N) atomicAdd(&out[col], red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ x, void* out_, long n) {
+  using H = typename PrecTraits<PREC>::h_t;
+  H* out = reinterpret_cast<H*>(out_);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = PrecTraits<PREC>::cvt(x[i]);
+}
+
+// row-major fp32 [rows, ld] -> tile-native fp32 (rows % 16 == 0, ld % 16 == 0)
+__global__ __launch_bounds__(256) void to_tiled_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int ld) {
+  const long n4 = (long)rows * ld / 4;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
+    // q indexes tile-native float4s: decode (row0, col)
+    const long tile = q >> 6;
+    const int lane = (int)(q & 63);
+    const int tr = (int)(tile / (ld >> 4)), tc = (int)(tile % (ld >> 4));
+    const int row0 = tr * 16 + 4 * (lane >> 4), col = tc * 16 + (lane & 15);
+    f32x4 v = {x[(long)row0 * ld + col], x[(long)(row0 + 1) * ld + col], x[(long)(row0 + 2) * ld + col], x[(long)(row0 + 3) * ld + col]};
+    reinterpret_cast<f32x4*>(out)[q] = v;
+  }
+}
+
+}  // namespace ark
+
+extern "C" int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
+                          int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled,
+                          void* stream) {
+  using namespace ark;
+  if (!A16 || !B16 || !C || M <= 0 || N <= 0 || K <= 0) return ARK_ERR_ARG;
+  if (K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0) return ARK_ERR_SHAPE;
+  if (((uintptr_t)A16 | (uintptr_t)B16) & 15) return ARK_ERR_ALIGN;
+  if (epi != ARK_EPI_NONE && epi != ARK_EPI_BIAS && epi != ARK_EPI_MUL_AUX) return ARK_ERR_ARG;
+  if (epi == ARK_EPI_BIAS && !bias) return ARK_ERR_ARG;
+  if (epi == ARK_EPI_MUL_AUX && !aux) return ARK_ERR_ARG;
+  if (c_tiled && (M % 16 != 0 || ldc % 16 != 0 || N > ldc)) return ARK_ERR_SHAPE;
+  Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0};
+  if (prec == PREC_F16) return launch16<PREC_F16>(p, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch16<PREC_BF16>(p, (hipStream_t)stream);
+  return ARK_ERR_ARG;
+}
+
+extern "C" int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,
+                                const float* w_pos, void* x16a, void* x16b, int B, int L, int D, void* stream) {
+  using namespace ark;
+  if (!seq || !w_tok || !x16a || B <= 0 || L <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (D % 4 != 0) return ARK_ERR_SHAPE;
+  long total = (long)B * L * (D / 4);
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipStream_t st = (hipStream_t)stream;
+#define ARK_TG(PA, PB2) hipLaunchKernelGGL((tok_gather16_kernel<PA, PB2>), dim3(grid), dim3(256), 0, st, seq, (long)ld_seq, w_tok, w_pos, x16a, x16b, B, L, D)
+  if (prec_a == PREC_F16 && prec_b == PREC_BF16) ARK_TG(PREC_F16, PREC_BF16);
+  else if (prec_a == PREC_F16 && prec_b == PREC_F16) ARK_TG(PREC_F16, PREC_F16);
+  else if (prec_a == PREC_BF16 && prec_b == PREC_BF16) ARK_TG(PREC_BF16, PREC_BF16);
+  else return ARK_ERR_ARG;
+#undef ARK_TG
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, void* stream) {
+  using namespace ark;
+  if (!x16 || !out || M <= 0 || N <= 0) return ARK_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
+  if (e != hipSuccess) return (int)e;
+  int rows_per_wg = 128;
+  const int col_tiles = (N + 63) / 64;
+  while (rows_per_wg > 16 && (long)col_tiles * ((M + rows_per_wg - 1) / rows_per_wg) < 512) rows_per_wg >>= 1;
+  dim3 grid(col_tiles, (M + rows_per_wg - 1) / rows_per_wg);
+  if (prec == PREC_F16) hipLaunchKernelGGL(colsum16_kernel<PREC_F16>, grid, dim3(256), 0, st, x16, (long)ld, out, M, N, rows_per_wg);
+  else if (prec == PREC_BF16) hipLaunchKernelGGL(colsum16_kernel<PREC_BF16>, grid, dim3(256), 0, st, x16, (long)ld, out, M, N, rows_per_wg);
+  else return ARK_ERR_ARG;
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_cast16(int prec, const float* x, void* out, int64_t n, void* stream) {
+  using namespace ark;
+  if (!x || !out || n <= 0) return ARK_ERR_ARG;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (prec == PREC_F16) hipLaunchKernelGGL(cast16_kernel<PREC_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
+  else if (prec == PREC_BF16) hipLaunchKernelGGL(cast16_kernel<PREC_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
+  else return ARK_ERR_ARG;
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_to_tiled(const float* x, float* out, int rows, int ld, void* stream) {
+  using namespace ark;
+  if (!x || !out || rows <= 0 || ld <= 0) return ARK_ERR_ARG;
+  if (rows % 16 != 0 || ld % 16 != 0) return ARK_ERR_SHAPE;
+  long n4 = (long)rows * ld / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(to_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, rows, ld);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}

@@ -19,6 +19,7 @@
 //  * Next K-step's global loads are issued right after the LDS image of the current step is
 //    complete, so they are in flight underneath the MFMA block (issue-early / write-late).
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace ark {
@@ -204,12 +205,97 @@ struct StageM {
   static __device__ __forceinline__ int tid_() { return threadIdx.x; }
 };
 
-template <int PREC, int LAY, int R> struct StageSel;
-template <int PREC, int R> struct StageSel<PREC, LAY_KMAJ, R> { using type = StageK<PREC, R>; };
-template <int PREC, int R> struct StageSel<PREC, LAY_MMAJ, R> { using type = StageM<PREC, R>; };
+// ---- row-contiguous operand stored in 16 bits (same type as the MFMA operands): element (row,k) at
+// base[k*ld + row].  Units of 4(k) x 8(rows): four 16-byte loads, transposed in registers into
+// eight 8-byte LDS writes of the canonical K-contiguous image.
+template <int PREC, int R>
+struct StageM16 {
+  static_assert(R % 32 == 0 && PREC != PREC_F32, "16-bit staging");
+  using PT = PrecTraits<PREC>;
+  using h_t = typename PT::h_t;
+  using h8 = typename PT::h8;
+  using h4 = typename PT::h4;
+  static constexpr int BK = PT::BK;           // 64
+  static constexpr int RO = R / 8;            // row-octets per k-row
+  static constexpr int UNITS = (BK / 4) * RO;
+  static constexpr int NU = (UNITS + 255) / 256;
+  const h_t* cp[NU];
+  int nv[NU];
+  h8 v[NU * 4];
+  long ld;
+  bool vec_ok;
+
+  template <class RM>
+  __device__ __forceinline__ void init(const void* base_, long ld_, RM rmap, int tid) {
+    const h_t* base = reinterpret_cast<const h_t*>(base_);
+    ld = ld_;
+    vec_ok = ((ld_ & 7) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int id = tid + 256 * i;
+      cp[i] = nullptr;
+      nv[i] = 0;
+      if (id < UNITS) {
+        const int ro = id % RO;
+        const long mr0 = rmap(8 * ro);
+        if (mr0 >= 0) {
+          int n = 1;
+          while (n < 8 && rmap(8 * ro + n) == mr0 + n) ++n;
+          cp[i] = base + mr0;
+          nv[i] = n;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void load(int k0, int K) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int id = threadIdx.x + 256 * i;
+      const int kq = id / RO;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = k0 + 4 * kq + j;
+        h8 x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (h_t)0.0f;
+        if (cp[i] != nullptr && kk < K) {
+          const h_t* p = cp[i] + (long)kk * ld;
+          if (vec_ok && nv[i] == 8 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+            x = *reinterpret_cast<const h8*>(p);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (e < nv[i]) x[e] = p[e];
+          }
+        }
+        v[i * 4 + j] = x;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int id = tid + 256 * i;
+      if (id < UNITS) {
+        const int kq = id / RO, ro = id % RO;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int row = 8 * ro + rr;
+          h4 h = {v[i * 4 + 0][rr], v[i * 4 + 1][rr], v[i * 4 + 2][rr], v[i * 4 + 3][rr]};
+          *reinterpret_cast<h4*>(lds + lds_off(row, kq >> 1) + (kq & 1) * 8) = h;
+        }
+      }
+    }
+  }
+};
+
+template <int PREC, int LAY, int R, int SRC16 = 0> struct StageSel;
+template <int PREC, int R> struct StageSel<PREC, LAY_KMAJ, R, 0> { using type = StageK<PREC, R>; };
+template <int PREC, int R> struct StageSel<PREC, LAY_MMAJ, R, 0> { using type = StageM<PREC, R>; };
+template <int PREC, int R> struct StageSel<PREC, LAY_MMAJ, R, 1> { using type = StageM16<PREC, R>; };
 
 // ---- the tile engine ---------------------------------------------------------------------
-template <int PREC, int ALAY, int BLAY, int BM, int BN, int WGM, int WGN>
+template <int PREC, int ALAY, int BLAY, int BM, int BN, int WGM, int WGN, int ASRC16 = 0, int BSRC16 = 0>
 struct GemmTile {
   static_assert(WGM * WGN == 4, "256-thread workgroups: 4 waves");
   static constexpr int BK = PrecTraits<PREC>::BK;
@@ -221,8 +307,12 @@ struct GemmTile {
   // acc[tm][tn][i] <-> C[row = wm*WTM + tm*16 + 4*(lane>>4) + i][col = wn*WTN + tn*16 + (lane&15)]
   // rma / rmb map a tile row (0..BM-1 / 0..BN-1) to the operand's memory row, or -1 (zero row).
   template <class RMA, class RMB>
-  static __device__ __forceinline__ void run(f32x4 (&acc)[TM][TN], const float* A, long lda, RMA rma,
-                                             const float* B, long ldb, RMB rmb, int K, char* lds) {
+  static __device__ __forceinline__ void run(f32x4 (&acc)[TM][TN], const void* A_, long lda, RMA rma,
+                                             const void* B_, long ldb, RMB rmb, int K, char* lds) {
+    using AP = typename std::conditional<ASRC16 != 0, const void*, const float*>::type;
+    using BP = typename std::conditional<BSRC16 != 0, const void*, const float*>::type;
+    AP A = reinterpret_cast<AP>(A_);
+    BP B = reinterpret_cast<BP>(B_);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -230,8 +320,8 @@ struct GemmTile {
     char* ldsA = lds;
     char* ldsB = lds + BM * 128;
 
-    typename StageSel<PREC, ALAY, BM>::type sa;
-    typename StageSel<PREC, BLAY, BN>::type sb;
+    typename StageSel<PREC, ALAY, BM, ASRC16>::type sa;
+    typename StageSel<PREC, BLAY, BN, BSRC16>::type sb;
     sa.init(A, lda, rma, tid);
     sb.init(B, ldb, rmb, tid);
 

@@ -1,25 +1,45 @@
-// GRU recurrence, LDS-DMA edition (see dma_core.h): same math and epilogues as gru.hip, but the
-// recurrent operands arrive as 16-bit copies (h_{t-1} written by the previous cell's epilogue,
-// W_hh / W_hh^T shadows refreshed after every optimiser step by ark_gru_weight_shadows), so the
-// whole K panel is in flight at once and no VGPRs or conversions are spent on staging.
-// Used when d_model % 64 == 0 and the precision is 16-bit; gru.hip remains the exact-fp32 path.
+// GRU recurrence, LDS-DMA edition (engine: dma_core.h).  Same math as gru.hip; what changes is
+// where every byte lives so that a timestep is one short, fully coalesced launch:
+//   * recurrent operands are 16-bit row-major copies (h_{t-1} written by the previous cell,
+//     W_hh / W_hh^T shadows refreshed after each optimiser step) streamed by LDS-DMA;
+//   * everything only epilogues touch (fp32 state h, gi, gate saves, dy, carry) is stored in the
+//     16x16 MFMA-tile-native order (tile_native_off): one lane's 4 rows = one 16-byte access,
+//     one wave's tile = one contiguous 1-KB line;
+//   * row-major 16-bit outputs that later products read (h, dgi, dgh) are assembled in LDS and
+//     written as whole 64/128-byte row segments.
+// Used when the precision is 16-bit, d_model % 64 == 0 and batch % 16 == 0; gru.hip remains the
+// exact-fp32 / odd-shape path.  Reference op replaced: torch.nn.GRU (kgvae/model/models.py:121-127).
 #include "dma_core.h"
 #include "../../include/ark_amd.h"
 
 namespace ark {
 
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld_half4(const _Float16* p) {
+  const half4_t h = *reinterpret_cast<const half4_t*>(p);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ __forceinline__ void st_half4(_Float16* p, f32x4 v) {
+  *reinterpret_cast<half4_t*>(p) = half4_t{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+}
+
 struct GruFwdDmaArgs {
-  const void* h_prev16; const void* w_hh16; const float* h_prev; const float* b_hh; const float* gi;
-  float* h_out; void* h_out16; float* h_drop; const float* drop_mask;
-  float* sr; float* sz; float* sn; float* shn;
+  const void* h_prev16; const void* w_hh16;      // DMA operands (prec type), row-major [B,D] / [3D,D]
+  const float* y_prev; const float* b_hh; const float* gi;   // tile-native fp32 [B,D], [3D], tile-native [B,3D]
+  float* y_out;                                  // tile-native fp32 [B,D]
+  void* y16a; void* y16b;                        // row-major 16-bit copies of h: forward type / backward type (nullable)
+  void* yd16a; void* yd16b; const float* mask;   // dropped copies h*mask (mask tile-native fp32), nullable
+  _Float16* sr; _Float16* sz; _Float16* sn; _Float16* shn;   // tile-native fp16 saves, nullable
   int B, D;
 };
 
-template <int PREC, int KS>
+template <int PREC, int PRECB, int NBUF>
 __global__ __launch_bounds__(256) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) {
   constexpr int BM = 32, BU = 32, BN = 3 * BU;
-  using G = DmaTile<PREC, BM, BN, KS, 2, 2>;  // wave tile 16 x 48 (16 units x 3 gates)
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2>;  // wave tile 16 x 48 (16 units x 3 gates)
   using h_t = typename G::h_t;
+  using hb_t = typename PrecTraits<PRECB>::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int units_tiles = p.D / BU;
   const int m0 = (blockIdx.x / units_tiles) * BM, u0 = (blockIdx.x % units_tiles) * BU;
@@ -31,43 +51,80 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) 
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int u = u0 + wn * 16 + (lane & 15);
+  const int ul = wn * 16 + (lane & 15);           // unit within the workgroup tile
+  const int u = u0 + ul;
+  const int rl = wm * 16 + 4 * (lane >> 4);       // first of this lane's 4 rows within the tile
+  const int row0 = m0 + rl;
   const float bhr = p.b_hh[u], bhz = p.b_hh[D + u], bhn = p.b_hh[2 * D + u];
-  h_t* h16 = reinterpret_cast<h_t*>(p.h_out16);
-#pragma unroll
-  for (int tm = 0; tm < G::TM; ++tm) {
+  // the LDS ring is free now; reuse it to assemble row-major 16-bit rows [32][32+pad]
+  __syncthreads();
+  h_t* ta = reinterpret_cast<h_t*>(smem);                 // h        (forward type)
+  hb_t* tb = reinterpret_cast<hb_t*>(smem + 4096);        // h        (backward type)
+  h_t* tda = reinterpret_cast<h_t*>(smem + 8192);         // h*mask
+  hb_t* tdb = reinterpret_cast<hb_t*>(smem + 12288);
+  constexpr int TS = 40;  // row stride in elements (80 B: 16-B aligned rows, spreads banks)
+  if (row0 < B) {
+    const long og = tile_native_off(row0, u, 3 * D);
+    const long o = tile_native_off(row0, u, D);
+    const f32x4 gr = *reinterpret_cast<const f32x4*>(p.gi + og);
+    const f32x4 gz = *reinterpret_cast<const f32x4*>(p.gi + og + (long)(D >> 4) * 256);
+    const f32x4 gn = *reinterpret_cast<const f32x4*>(p.gi + og + (long)(D >> 4) * 512);
+    const f32x4 hp = *reinterpret_cast<const f32x4*>(p.y_prev + o);
+    f32x4 r, z, n, hn, h;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = m0 + wm * G::WTM + tm * 16 + 4 * (lane >> 4) + i;
-      if (row >= B) continue;
-      const float* gi = p.gi + (long)row * 3 * D;
-      const long o = (long)row * D + u;
-      const float r = sigmoidf_(gi[u] + acc[tm][0][i] + bhr);
-      const float z = sigmoidf_(gi[D + u] + acc[tm][1][i] + bhz);
-      const float hn = acc[tm][2][i] + bhn;
-      const float n = tanhf(gi[2 * D + u] + r * hn);
-      const float hp = p.h_prev[o];
-      const float h = (1.0f - z) * n + z * hp;
-      p.h_out[o] = h;
-      h16[o] = G::PT::cvt(h);
-      if (p.h_drop) p.h_drop[o] = h * p.drop_mask[o];
-      if (p.sr) { p.sr[o] = r; p.sz[o] = z; p.sn[o] = n; p.shn[o] = hn; }
+      r[i] = sigmoidf_(gr[i] + acc[0][0][i] + bhr);
+      z[i] = sigmoidf_(gz[i] + acc[0][1][i] + bhz);
+      hn[i] = acc[0][2][i] + bhn;
+      n[i] = tanhf(gn[i] + r[i] * hn[i]);
+      h[i] = (1.0f - z[i]) * n[i] + z[i] * hp[i];
+    }
+    *reinterpret_cast<f32x4*>(p.y_out + o) = h;
+    if (p.sr) { st_half4(p.sr + o, r); st_half4(p.sz + o, z); st_half4(p.sn + o, n); st_half4(p.shn + o, hn); }
+    f32x4 hd = h;
+    if (p.mask) hd = h * *reinterpret_cast<const f32x4*>(p.mask + o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ta[(rl + i) * TS + ul] = G::PT::cvt(h[i]);
+      if (p.y16b) tb[(rl + i) * TS + ul] = PrecTraits<PRECB>::cvt(h[i]);
+      if (p.mask) {
+        tda[(rl + i) * TS + ul] = G::PT::cvt(hd[i]);
+        tdb[(rl + i) * TS + ul] = PrecTraits<PRECB>::cvt(hd[i]);
+      }
+    }
+  }
+  __syncthreads();
+  // 32 rows x 64 B per array: thread t -> row t/4 (0..31 for t<128), 16-byte chunk t%4
+  const int t = threadIdx.x;
+  if (t < 128) {
+    const int rr = t >> 2, ch = t & 3;
+    const int row = m0 + rr;
+    if (row < B) {
+      const long go = (long)row * D + u0 + ch * 8;
+      *reinterpret_cast<uint4*>(reinterpret_cast<h_t*>(p.y16a) + go) = *reinterpret_cast<const uint4*>(ta + rr * TS + ch * 8);
+      if (p.y16b) *reinterpret_cast<uint4*>(reinterpret_cast<hb_t*>(p.y16b) + go) = *reinterpret_cast<const uint4*>(tb + rr * TS + ch * 8);
+      if (p.mask) {
+        *reinterpret_cast<uint4*>(reinterpret_cast<h_t*>(p.yd16a) + go) = *reinterpret_cast<const uint4*>(tda + rr * TS + ch * 8);
+        if (p.yd16b) *reinterpret_cast<uint4*>(reinterpret_cast<hb_t*>(p.yd16b) + go) = *reinterpret_cast<const uint4*>(tdb + rr * TS + ch * 8);
+      }
     }
   }
 }
 
 struct GruBwdDmaArgs {
-  const void* dgh_next16; const void* w_hhT16; const float* dy; float* carry;
-  const float* sr; const float* sz; const float* sn; const float* shn; const float* h_prev;
-  float* dgi; float* dgh; void* dgh16;
-  float* dh0; int dh0_accumulate;
+  const void* dgh_next16; const void* w_hhT16;   // DMA operands: row-major [B,3D] / [D,3D] (prec type)
+  const float* dy; float* carry;                 // tile-native fp32 [B,D]
+  const _Float16* sr; const _Float16* sz; const _Float16* sn; const _Float16* shn;   // tile-native fp16
+  const float* y_prev;                           // tile-native fp32 [B,D]
+  void* dgi16; void* dgh16;                      // row-major [B,3D] (prec type)
+  float* dh0; int dh0_accumulate;                // row-major fp32 [B,D] (final_ only)
   int B, D, first, final_;
 };
 
-template <int PREC, int KS>
+template <int PREC, int NBUF>
 __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) {
   constexpr int BM = 32, BN = 64;
-  using G = DmaTile<PREC, BM, BN, KS, 2, 2>;
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2>;   // wave tile 16 x 32
   using h_t = typename G::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = p.D / BN;
@@ -80,66 +137,93 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) 
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  h_t* dgh16 = reinterpret_cast<h_t*>(p.dgh16);
+  const int rl = wm * 16 + 4 * (lane >> 4);
+  const int row0 = m0 + rl;
+  __syncthreads();
+  // LDS assembly of the six row-major 16-bit output panels: [gate 0..2][32 rows][64+8] for dgi and dgh
+  constexpr int TS = 72;
+  h_t* tgi = reinterpret_cast<h_t*>(smem);
+  h_t* tgh = tgi + 3 * 32 * TS;
 #pragma unroll
-  for (int tm = 0; tm < G::TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < G::TN; ++tn)
+  for (int tn = 0; tn < G::TN; ++tn) {
+    const int ul = wn * 32 + tn * 16 + (lane & 15);
+    const int u = n0 + ul;
+    if (row0 >= B) continue;
+    const long o = tile_native_off(row0, u, D);
+    f32x4 dh = acc[0][tn];
+    if (!p.first) dh += *reinterpret_cast<const f32x4*>(p.carry + o);
+    if (p.final_) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = m0 + wm * G::WTM + tm * 16 + 4 * (lane >> 4) + i;
-        const int u = n0 + wn * G::WTN + tn * 16 + (lane & 15);
-        if (row >= B) continue;
-        const long o = (long)row * D + u;
-        float dh = acc[tm][tn][i];
-        if (!p.first) dh += p.carry[o];
-        if (p.final_) {
-          p.dh0[o] = p.dh0_accumulate ? p.dh0[o] + dh : dh;
-          continue;
-        }
-        if (p.dy) dh += p.dy[o];
-        const float r = p.sr[o], z = p.sz[o], n = p.sn[o], hn = p.shn[o], hp = p.h_prev[o];
-        const float dn_pre = dh * (1.0f - z) * (1.0f - n * n);
-        const float dz_pre = dh * (hp - n) * z * (1.0f - z);
-        const float dr_pre = dn_pre * hn * r * (1.0f - r);
-        p.carry[o] = dh * z;
-        const long g = (long)row * 3 * D + u;
-        p.dgi[g] = dr_pre; p.dgi[g + D] = dz_pre; p.dgi[g + 2 * D] = dn_pre;
-        p.dgh[g] = dr_pre; p.dgh[g + D] = dz_pre; p.dgh[g + 2 * D] = dn_pre * r;
-        dgh16[g] = G::PT::cvt(dr_pre); dgh16[g + D] = G::PT::cvt(dz_pre); dgh16[g + 2 * D] = G::PT::cvt(dn_pre * r);
+        const long ro = (long)(row0 + i) * D + u;
+        p.dh0[ro] = p.dh0_accumulate ? p.dh0[ro] + dh[i] : dh[i];
       }
+      continue;
+    }
+    if (p.dy) dh += *reinterpret_cast<const f32x4*>(p.dy + o);
+    const f32x4 r = ld_half4(p.sr + o), z = ld_half4(p.sz + o), n = ld_half4(p.sn + o), hn = ld_half4(p.shn + o);
+    const f32x4 hp = *reinterpret_cast<const f32x4*>(p.y_prev + o);
+    f32x4 cz;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dn_pre = dh[i] * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
+      const float dz_pre = dh[i] * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
+      const float dr_pre = dn_pre * hn[i] * r[i] * (1.0f - r[i]);
+      cz[i] = dh[i] * z[i];
+      const int ro = (rl + i) * TS + ul;
+      tgi[ro] = G::PT::cvt(dr_pre); tgi[32 * TS + ro] = G::PT::cvt(dz_pre); tgi[64 * TS + ro] = G::PT::cvt(dn_pre);
+      tgh[ro] = G::PT::cvt(dr_pre); tgh[32 * TS + ro] = G::PT::cvt(dz_pre); tgh[64 * TS + ro] = G::PT::cvt(dn_pre * r[i]);
+    }
+    *reinterpret_cast<f32x4*>(p.carry + o) = cz;
+  }
+  if (p.final_) return;
+  __syncthreads();
+  // 3 gates x 32 rows x 128 B per array: thread t -> (row t/8, chunk t%8) for each gate
+  const int t = threadIdx.x;
+  const int rr = t >> 3, ch = t & 7;
+  const int row = m0 + rr;
+  if (row < B) {
+    h_t* gi16 = reinterpret_cast<h_t*>(p.dgi16);
+    h_t* gh16 = reinterpret_cast<h_t*>(p.dgh16);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const long go = (long)row * 3 * D + (long)g * D + n0 + ch * 8;
+      *reinterpret_cast<uint4*>(gi16 + go) = *reinterpret_cast<const uint4*>(tgi + g * 32 * TS + rr * TS + ch * 8);
+      *reinterpret_cast<uint4*>(gh16 + go) = *reinterpret_cast<const uint4*>(tgh + g * 32 * TS + rr * TS + ch * 8);
+    }
+  }
 }
 
-// 16-bit shadows of the recurrent weights of every layer in one launch:
-//   w16 [n_layers][3D][D]  (forward-cell B operand)   and   wT16 [n_layers][D][3D] (backward-cell B operand)
-// 32x32 tiles transposed through LDS so both outputs are written in full lines.
-template <int PF, int PB>
-__global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restrict__ w, long layer_stride, void* w16_, void* wT16_,
-                                                            int D) {
-  using HF = typename PrecTraits<PF>::h_t;
-  using HB = typename PrecTraits<PB>::h_t;
+// ---- 16-bit shadows (plain and transposed) of a list of fp32 matrices, one launch ------------
+struct ShadowJob { const float* src; void* dst; void* dstT; int R, C, prec, precT; };
+struct ShadowJobs { ShadowJob j[12]; int n; };
+
+__device__ __forceinline__ void shadow_put(void* base, long idx, float v, int prec) {
+  if (prec == PREC_F16) reinterpret_cast<_Float16*>(base)[idx] = PrecTraits<PREC_F16>::cvt(v);
+  else reinterpret_cast<__bf16*>(base)[idx] = (__bf16)v;
+}
+
+__global__ __launch_bounds__(256) void weight_shadow_kernel(ShadowJobs jobs) {
   __shared__ float tile[32][33];
-  const int l = blockIdx.z;
-  const float* src = w + l * layer_stride;
-  HF* w16 = reinterpret_cast<HF*>(w16_) + (long)l * 3 * D * D;
-  HB* wT16 = reinterpret_cast<HB*>(wT16_) + (long)l * 3 * D * D;
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;  // rows of W (3D), cols of W (D)
+  const ShadowJob jb = jobs.j[blockIdx.z];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  if (r0 >= jb.R || c0 >= jb.C) return;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += 8) {
-    const float v = src[(long)(r0 + i) * D + c0 + tx];
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < jb.R && c < jb.C) {
+      v = jb.src[(long)r * jb.C + c];
+      if (jb.dst) shadow_put(jb.dst, (long)r * jb.C + c, v, jb.prec);
+    }
     tile[i][tx] = v;
-    w16[(long)(r0 + i) * D + c0 + tx] = PrecTraits<PF>::cvt(v);
   }
   __syncthreads();
-  for (int i = ty; i < 32; i += 8) wT16[(long)(c0 + i) * 3 * D + r0 + tx] = PrecTraits<PB>::cvt(tile[tx][i]);
-}
-
-template <int PREC>
-__global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ x, void* out_, long n) {
-  using H = typename PrecTraits<PREC>::h_t;
-  H* out = reinterpret_cast<H*>(out_);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    out[i] = PrecTraits<PREC>::cvt(x[i]);
+  if (jb.dstT)
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;
+      if (r < jb.R && c < jb.C) shadow_put(jb.dstT, (long)c * jb.R + r, tile[tx][i], jb.precT);
+    }
 }
 
 // dynamic LDS above 64 KB must be opted into once per kernel
@@ -148,112 +232,113 @@ static void allow_lds(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-template <int PREC>
-static int launch_fwd_dma(const GruFwdDmaArgs& p, hipStream_t st) {
+int g_fwd_nbuf = 8, g_bwd_nbuf = 8;
+
+template <int PREC, int PRECB, int NBUF>
+static void launch_fwd_nb(const GruFwdDmaArgs& p, hipStream_t st) {
+  using G = DmaTile<PREC, 32, 96, NBUF, 2, 2>;
+  constexpr int LDS = G::LDS_BYTES > 16384 ? G::LDS_BYTES : 16384;
+  static bool once = (allow_lds(gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF>, LDS), true); (void)once;
   const unsigned grid = (unsigned)(((p.B + 31) / 32) * (p.D / 32));
-  if (p.D % 256 == 0) {
-    using G = DmaTile<PREC, 32, 96, 256, 2, 2>;
-    static bool once = (allow_lds(gru_cell_fwd_dma_kernel<PREC, 256>, G::LDS_BYTES), true); (void)once;
-    hipLaunchKernelGGL((gru_cell_fwd_dma_kernel<PREC, 256>), dim3(grid), dim3(256), G::LDS_BYTES, st, p);
-  } else if (p.D % 128 == 0) {
-    using G = DmaTile<PREC, 32, 96, 128, 2, 2>;
-    static bool once = (allow_lds(gru_cell_fwd_dma_kernel<PREC, 128>, G::LDS_BYTES), true); (void)once;
-    hipLaunchKernelGGL((gru_cell_fwd_dma_kernel<PREC, 128>), dim3(grid), dim3(256), G::LDS_BYTES, st, p);
-  } else {
-    using G = DmaTile<PREC, 32, 96, 64, 2, 2>;
-    hipLaunchKernelGGL((gru_cell_fwd_dma_kernel<PREC, 64>), dim3(grid), dim3(256), G::LDS_BYTES, st, p);
-  }
+  hipLaunchKernelGGL((gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF>), dim3(grid), dim3(256), LDS, st, p);
+}
+template <int PREC, int PRECB>
+static int launch_fwd_dma(const GruFwdDmaArgs& p, hipStream_t st) {
+  if (g_fwd_nbuf == 8) launch_fwd_nb<PREC, PRECB, 8>(p, st);
+  else if (g_fwd_nbuf == 4) launch_fwd_nb<PREC, PRECB, 4>(p, st);
+  else launch_fwd_nb<PREC, PRECB, 2>(p, st);
   ARK_LAUNCH_CHECK();
   return 0;
 }
-
+template <int PREC, int NBUF>
+static void launch_bwd_nb(const GruBwdDmaArgs& p, hipStream_t st) {
+  using G = DmaTile<PREC, 32, 64, NBUF, 2, 2>;
+  constexpr int LDS = G::LDS_BYTES > 28672 ? G::LDS_BYTES : 28672;
+  static bool once = (allow_lds(gru_cell_bwd_dma_kernel<PREC, NBUF>, LDS), true); (void)once;
+  const unsigned grid = (unsigned)(((p.B + 31) / 32) * (p.D / 64));
+  hipLaunchKernelGGL((gru_cell_bwd_dma_kernel<PREC, NBUF>), dim3(grid), dim3(256), LDS, st, p);
+}
 template <int PREC>
 static int launch_bwd_dma(const GruBwdDmaArgs& p, hipStream_t st) {
-  const unsigned grid = (unsigned)(((p.B + 31) / 32) * (p.D / 64));
-  if (p.D % 128 == 0) {  // 3D % 384 == 0
-    using G = DmaTile<PREC, 32, 64, 384, 2, 2>;
-    static bool once = (allow_lds(gru_cell_bwd_dma_kernel<PREC, 384>, G::LDS_BYTES), true); (void)once;
-    hipLaunchKernelGGL((gru_cell_bwd_dma_kernel<PREC, 384>), dim3(grid), dim3(256), G::LDS_BYTES, st, p);
-  } else {               // D % 64 == 0 -> 3D % 192 == 0
-    using G = DmaTile<PREC, 32, 64, 192, 2, 2>;
-    static bool once = (allow_lds(gru_cell_bwd_dma_kernel<PREC, 192>, G::LDS_BYTES), true); (void)once;
-    hipLaunchKernelGGL((gru_cell_bwd_dma_kernel<PREC, 192>), dim3(grid), dim3(256), G::LDS_BYTES, st, p);
-  }
+  if (g_bwd_nbuf == 8) launch_bwd_nb<PREC, 8>(p, st);
+  else if (g_bwd_nbuf == 4) launch_bwd_nb<PREC, 4>(p, st);
+  else launch_bwd_nb<PREC, 2>(p, st);
   ARK_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace ark
 
-extern "C" int ark_gru_cell_fwd_dma(int prec, const void* h_prev16, const void* w_hh16, const float* h_prev,
-                                    const float* b_hh, const float* gi, float* h_out, void* h_out16, float* h_drop,
-                                    const float* drop_mask, float* save_r, float* save_z, float* save_n, float* save_hn,
-                                    int B, int D, void* stream) {
-  using namespace ark;
-  if (!h_prev16 || !w_hh16 || !h_prev || !b_hh || !gi || !h_out || !h_out16 || B <= 0 || D <= 0) return ARK_ERR_ARG;
-  if (D % 64 != 0) return ARK_ERR_SHAPE;
-  if (h_drop && !drop_mask) return ARK_ERR_ARG;
-  if (save_r && (!save_z || !save_n || !save_hn)) return ARK_ERR_ARG;
-  GruFwdDmaArgs p{h_prev16, w_hh16, h_prev, b_hh, gi, h_out, h_out16, h_drop, drop_mask, save_r, save_z, save_n, save_hn, B, D};
-  if (prec == PREC_F16) return launch_fwd_dma<PREC_F16>(p, (hipStream_t)stream);
-  if (prec == PREC_BF16) return launch_fwd_dma<PREC_BF16>(p, (hipStream_t)stream);
-  return ARK_ERR_ARG;
-}
-
-extern "C" int ark_gru_cell_bwd_dma(int prec, const void* dgh_next16, const void* w_hhT16, const float* dy, float* carry,
-                                    const float* save_r, const float* save_z, const float* save_n, const float* save_hn,
-                                    const float* h_prev, float* dgi, float* dgh, void* dgh16, int B, int D, int first,
-                                    void* stream) {
-  using namespace ark;
-  if (!w_hhT16 || !carry || !save_r || !save_z || !save_n || !save_hn || !h_prev || !dgi || !dgh || !dgh16 || B <= 0 || D <= 0)
-    return ARK_ERR_ARG;
-  if (!first && !dgh_next16) return ARK_ERR_ARG;
-  if (D % 64 != 0) return ARK_ERR_SHAPE;
-  GruBwdDmaArgs p{dgh_next16 ? dgh_next16 : dgh16, w_hhT16, dy, carry, save_r, save_z, save_n, save_hn, h_prev, dgi, dgh,
-                  dgh16, nullptr, 0, B, D, first ? 1 : 0, 0};
-  if (prec == PREC_F16) return launch_bwd_dma<PREC_F16>(p, (hipStream_t)stream);
-  if (prec == PREC_BF16) return launch_bwd_dma<PREC_BF16>(p, (hipStream_t)stream);
-  return ARK_ERR_ARG;
-}
-
-extern "C" int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_hhT16, const float* carry, float* dh0,
-                                  int accumulate, int B, int D, void* stream) {
-  using namespace ark;
-  if (!dgh0_16 || !w_hhT16 || !carry || !dh0 || B <= 0 || D <= 0) return ARK_ERR_ARG;
-  if (D % 64 != 0) return ARK_ERR_SHAPE;
-  GruBwdDmaArgs p{dgh0_16, w_hhT16, nullptr, const_cast<float*>(carry), nullptr, nullptr, nullptr, nullptr, nullptr,
-                  nullptr, nullptr, nullptr, dh0, accumulate ? 1 : 0, B, D, 0, 1};
-  if (prec == PREC_F16) return launch_bwd_dma<PREC_F16>(p, (hipStream_t)stream);
-  if (prec == PREC_BF16) return launch_bwd_dma<PREC_BF16>(p, (hipStream_t)stream);
-  return ARK_ERR_ARG;
-}
-
-extern "C" int ark_gru_weight_shadows(int prec_fwd, int prec_bwd, const float* w_hh_l0, int64_t layer_stride, void* w16,
-                                      void* wT16, int D, int n_layers, void* stream) {
-  using namespace ark;
-  if (!w_hh_l0 || !w16 || !wT16 || D <= 0 || n_layers <= 0) return ARK_ERR_ARG;
-  if (D % 32 != 0) return ARK_ERR_SHAPE;
-  dim3 grid(D / 32, 3 * D / 32, n_layers);
-  hipStream_t st = (hipStream_t)stream;
-#define ARK_WS(PF, PB) hipLaunchKernelGGL((weight_shadow_kernel<PF, PB>), grid, dim3(256), 0, st, w_hh_l0, (long)layer_stride, w16, wT16, D)
-  if (prec_fwd == PREC_F16 && prec_bwd == PREC_BF16) ARK_WS(PREC_F16, PREC_BF16);
-  else if (prec_fwd == PREC_F16 && prec_bwd == PREC_F16) ARK_WS(PREC_F16, PREC_F16);
-  else if (prec_fwd == PREC_BF16 && prec_bwd == PREC_BF16) ARK_WS(PREC_BF16, PREC_BF16);
-  else if (prec_fwd == PREC_BF16 && prec_bwd == PREC_F16) ARK_WS(PREC_BF16, PREC_F16);
-  else return ARK_ERR_ARG;
-#undef ARK_WS
-  ARK_LAUNCH_CHECK();
+// speed-only knobs: ring depth (2|4|8) of the forward / backward LDS-DMA cell kernels
+extern "C" int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf) {
+  auto ok = [](int v) { return v == 2 || v == 4 || v == 8; };
+  if (!ok(fwd_nbuf) || !ok(bwd_nbuf)) return ARK_ERR_ARG;
+  ark::g_fwd_nbuf = fwd_nbuf;
+  ark::g_bwd_nbuf = bwd_nbuf;
   return 0;
 }
 
-extern "C" int ark_cast16(int prec, const float* x, void* out, int64_t n, void* stream) {
+extern "C" int ark_gru_cell_fwd_dma(int prec, int prec_b, const void* h_prev16, const void* w_hh16, const float* y_prev_t,
+                                    const float* b_hh, const float* gi_t, float* y_out_t, void* y16a, void* y16b,
+                                    void* yd16a, void* yd16b, const float* mask_t, void* save_r, void* save_z,
+                                    void* save_n, void* save_hn, int B, int D, void* stream) {
   using namespace ark;
-  if (!x || !out || n <= 0) return ARK_ERR_ARG;
-  long blocks = (n + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  if (prec == PREC_F16) hipLaunchKernelGGL(cast16_kernel<PREC_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
-  else if (prec == PREC_BF16) hipLaunchKernelGGL(cast16_kernel<PREC_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
-  else return ARK_ERR_ARG;
+  if (!h_prev16 || !w_hh16 || !y_prev_t || !b_hh || !gi_t || !y_out_t || !y16a || B <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (D % 64 != 0 || B % 16 != 0) return ARK_ERR_SHAPE;
+  if (mask_t && !yd16a) return ARK_ERR_ARG;
+  if (save_r && (!save_z || !save_n || !save_hn)) return ARK_ERR_ARG;
+  GruFwdDmaArgs p{h_prev16, w_hh16, y_prev_t, b_hh, gi_t, y_out_t, y16a, y16b, yd16a, yd16b, mask_t,
+                  (_Float16*)save_r, (_Float16*)save_z, (_Float16*)save_n, (_Float16*)save_hn, B, D};
+  hipStream_t st = (hipStream_t)stream;
+  if (prec == PREC_F16 && prec_b == PREC_BF16) return launch_fwd_dma<PREC_F16, PREC_BF16>(p, st);
+  if (prec == PREC_F16 && prec_b == PREC_F16) return launch_fwd_dma<PREC_F16, PREC_F16>(p, st);
+  if (prec == PREC_BF16 && prec_b == PREC_BF16) return launch_fwd_dma<PREC_BF16, PREC_BF16>(p, st);
+  return ARK_ERR_ARG;
+}
+
+extern "C" int ark_gru_cell_bwd_dma(int prec, const void* dgh_next16, const void* w_hhT16, const float* dy_t, float* carry_t,
+                                    const void* save_r, const void* save_z, const void* save_n, const void* save_hn,
+                                    const float* y_prev_t, void* dgi16, void* dgh16, int B, int D, int first, void* stream) {
+  using namespace ark;
+  if (!w_hhT16 || !carry_t || !save_r || !save_z || !save_n || !save_hn || !y_prev_t || !dgi16 || !dgh16 || B <= 0 || D <= 0)
+    return ARK_ERR_ARG;
+  if (!first && !dgh_next16) return ARK_ERR_ARG;
+  if (D % 64 != 0 || B % 16 != 0) return ARK_ERR_SHAPE;
+  GruBwdDmaArgs p{dgh_next16 ? dgh_next16 : dgh16, w_hhT16, dy_t, carry_t, (const _Float16*)save_r, (const _Float16*)save_z,
+                  (const _Float16*)save_n, (const _Float16*)save_hn, y_prev_t, dgi16, dgh16, nullptr, 0, B, D, first ? 1 : 0, 0};
+  if (prec == PREC_F16) return launch_bwd_dma<PREC_F16>(p, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch_bwd_dma<PREC_BF16>(p, (hipStream_t)stream);
+  return ARK_ERR_ARG;
+}
+
+extern "C" int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_hhT16, const float* carry_t, float* dh0,
+                                  int accumulate, int B, int D, void* stream) {
+  using namespace ark;
+  if (!dgh0_16 || !w_hhT16 || !carry_t || !dh0 || B <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (D % 64 != 0 || B % 16 != 0) return ARK_ERR_SHAPE;
+  GruBwdDmaArgs p{dgh0_16, w_hhT16, nullptr, const_cast<float*>(carry_t), nullptr, nullptr, nullptr, nullptr, nullptr,
+                  nullptr, nullptr, dh0, accumulate ? 1 : 0, B, D, 0, 1};
+  if (prec == PREC_F16) return launch_bwd_dma<PREC_F16>(p, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch_bwd_dma<PREC_BF16>(p, (hipStream_t)stream);
+  return ARK_ERR_ARG;
+}
+
+// up to 12 jobs: dst = cast(src [R,C]) in `prec`, dstT = cast(src^T [C,R]) in `precT` (either may be NULL)
+extern "C" int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, void* const* dstT, const int* R,
+                                  const int* C, const int* prec, const int* precT, void* stream) {
+  using namespace ark;
+  if (n_jobs <= 0 || n_jobs > 12 || !src || !dst || !dstT || !R || !C || !prec || !precT) return ARK_ERR_ARG;
+  ShadowJobs jobs;
+  jobs.n = n_jobs;
+  int maxR = 0, maxC = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    if (!src[i] || R[i] <= 0 || C[i] <= 0) return ARK_ERR_ARG;
+    jobs.j[i] = ShadowJob{src[i], dst[i], dstT[i], R[i], C[i], prec[i], precT[i]};
+    if (R[i] > maxR) maxR = R[i];
+    if (C[i] > maxC) maxC = C[i];
+  }
+  hipLaunchKernelGGL(weight_shadow_kernel, dim3((maxC + 31) / 32, (maxR + 31) / 32, n_jobs), dim3(256), 0,
+                     (hipStream_t)stream, jobs);
   ARK_LAUNCH_CHECK();
   return 0;
 }

@@ -145,15 +145,20 @@ class Engine:
         self.training = True
         self.drop_seed = int(cfg.get("dropout_seed", 0x5A11))
         self._graphs = {}
-        # LDS-DMA recurrent kernels: 16-bit shadows of W_hh (forward) and W_hh^T (backward)
+        # 16-bit-operand / LDS-DMA path ("v2"): 16-bit shadows of the decoder weights, refreshed after
+        # every optimiser step: W_ih, W_hh, W_tok in the forward type; W_ih^T, W_hh^T in the backward type
         self.use_dma = (self.prec_fwd != L.PREC_F32 and self.prec_bwd != L.PREC_F32 and self.D % 64 == 0
                         and not cfg.get("ark_no_dma", False))
+        self._v2 = False
         if self.use_dma:
-            D = self.D
-            self.whh16 = torch.empty(self.n, 3 * D, D, device=dev, dtype=torch.int16)
-            self.whhT16 = torch.empty(self.n, D, 3 * D, device=dev, dtype=torch.int16)
-            e = self.layout.entries
-            self._whh_stride = (e["dec.gru.weight_hh_l1"][0] - e["dec.gru.weight_hh_l0"][0]) if self.n > 1 else 0
+            D, V = self.D, self.V
+            i16 = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.int16)
+            self.wih16 = [i16(3 * D, D) for _ in range(self.n)]
+            self.whh16 = [i16(3 * D, D) for _ in range(self.n)]
+            self.wihT16 = [i16(D, 3 * D) for _ in range(self.n)]
+            self.whhT16 = [i16(D, 3 * D) for _ in range(self.n)]
+            self.wtok16 = i16(V, D)
+            self._shadow_jobs = self._build_shadow_jobs()
         self._shadow_ok = False
 
     # ------------------------------------------------------------------ parameters
@@ -169,11 +174,31 @@ class Engine:
         """call after anything other than Engine.adam() changed the parameters"""
         self._shadow_ok = False
 
+    def _build_shadow_jobs(self):
+        import ctypes
+        jobs = []
+        for l in range(self.n):
+            jobs.append((self.p[f"dec.gru.weight_ih_l{l}"], self.wih16[l], self.wihT16[l], 3 * self.D, self.D))
+            jobs.append((self.p[f"dec.gru.weight_hh_l{l}"], self.whh16[l], self.whhT16[l], 3 * self.D, self.D))
+        jobs.append((self.p["dec.out.weight"], self.wtok16, None, self.V, self.D))
+        chunks = []
+        for c0 in range(0, len(jobs), 12):
+            ch = jobs[c0:c0 + 12]
+            n = len(ch)
+            src = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in ch])
+            dst = (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in ch])
+            dstT = (ctypes.c_void_p * n)(*[(j[2].data_ptr() if j[2] is not None else 0) for j in ch])
+            R = (ctypes.c_int * n)(*[j[3] for j in ch])
+            C = (ctypes.c_int * n)(*[j[4] for j in ch])
+            pf = (ctypes.c_int * n)(*[self.prec_fwd] * n)
+            pb = (ctypes.c_int * n)(*[self.prec_bwd] * n)
+            chunks.append((n, src, dst, dstT, R, C, pf, pb))
+        return chunks
+
     def refresh_shadows(self):
         if self.use_dma:
-            _call("ark_gru_weight_shadows", L.i32(self.prec_fwd), L.i32(self.prec_bwd), L.ptr(self.p["dec.gru.weight_hh_l0"]),
-                  L.i64(self._whh_stride), L.ptr(self.whh16), L.ptr(self.whhT16), L.i32(self.D), L.i32(self.n),
-                  L.cur_stream())
+            for (n, src, dst, dstT, R, C, pf, pb) in self._shadow_jobs:
+                _call("ark_weight_shadows", L.i32(n), src, dst, dstT, R, C, pf, pb, L.cur_stream())
         self._shadow_ok = True
 
     def set_hyper(self, lr=None, beta=None, kl_norm=None, ce_count=None, grad_scale=None):
@@ -215,18 +240,38 @@ class Engine:
             w["dz"], w["dhead"] = f(B, Z), f(B, 2 * Z)
             w["dH0"] = f(B, D)
             w["dA"], w["dB"] = f(B, H), f(B, H)
-        w["X0"] = f(R, D)
-        w["GI"] = [f(R, 3 * D) for _ in range(n)]       # gi forward, overwritten by dgi in backward
-        w["dGH"] = [f(R, 3 * D) for _ in range(n)]
-        w["Y"] = [torch.zeros((Lq + 1) * B, D, device=dev) for _ in range(n)]  # slot 0 = h0
-        for nm in ("SR", "SZ", "SN", "SHN"):
-            w[nm] = [f(R, D) for _ in range(n)]
-        if self.use_dma:
-            w["Y16"] = [torch.zeros((Lq + 1) * B, D, device=dev, dtype=torch.int16) for _ in range(n)]
-            w["dGH16"] = [torch.empty(R, 3 * D, device=dev, dtype=torch.int16) for _ in range(n)]
-        if self.p_drop > 0:
-            w["mask"] = [f(R, D) for _ in range(n - 1)]
-            w["Ydrop"] = [f(R, D) for _ in range(n - 1)]
+        v2 = self.use_dma and B % 16 == 0
+        w["v2"] = v2
+        i16 = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.int16)
+        two = self.prec_fwd != self.prec_bwd   # separate backward-type copies of the activations
+        if v2:
+            # "16": row-major 16-bit copies (a: forward type, b: backward type); "_t": tile-native
+            w["X0a"] = i16(R, D)
+            w["X0b"] = i16(R, D) if two else None
+            w["GI"] = [f(R, 3 * D) for _ in range(n)]                       # tile-native fp32
+            w["Y"] = [torch.zeros((Lq + 1) * B, D, device=dev) for _ in range(n)]   # tile-native fp32 state
+            w["Y16a"] = [torch.zeros((Lq + 1) * B, D, device=dev, dtype=torch.int16) for _ in range(n)]
+            w["Y16b"] = [torch.zeros((Lq + 1) * B, D, device=dev, dtype=torch.int16) if two else None for _ in range(n)]
+            for nm in ("SR", "SZ", "SN", "SHN"):
+                w[nm] = [i16(R, D) for _ in range(n)]                        # tile-native fp16 saves
+            w["dGI16"] = [i16(R, 3 * D) for _ in range(n)]
+            w["dGH16"] = [i16(R, 3 * D) for _ in range(n)]
+            w["h0"] = f(B, D)                                                # row-major h0 (z-projection)
+            w["dX0"] = f(R, D)
+            if self.p_drop > 0:
+                w["mask"] = [f(R, D) for _ in range(n - 1)]                  # tile-native interpretation
+                w["Yd16a"] = [i16(R, D) for _ in range(n - 1)]
+                w["Yd16b"] = [i16(R, D) if two else None for _ in range(n - 1)]
+        else:
+            w["X0"] = f(R, D)
+            w["GI"] = [f(R, 3 * D) for _ in range(n)]       # gi forward, overwritten by dgi in backward
+            w["dGH"] = [f(R, 3 * D) for _ in range(n)]
+            w["Y"] = [torch.zeros((Lq + 1) * B, D, device=dev) for _ in range(n)]  # slot 0 = h0
+            for nm in ("SR", "SZ", "SN", "SHN"):
+                w[nm] = [f(R, D) for _ in range(n)]
+            if self.p_drop > 0:
+                w["mask"] = [f(R, D) for _ in range(n - 1)]
+                w["Ydrop"] = [f(R, D) for _ in range(n - 1)]
         self.ldl = _rup(V, 4)
         w["logits"] = torch.zeros(R, self.ldl, device=dev)
         w["row_loss"] = f(R)
@@ -291,8 +336,10 @@ class Engine:
         else:
             for l in range(n):
                 w["Y"][l][:B].zero_()
-                if self.use_dma:
-                    w["Y16"][l][:B].zero_()
+                if w["v2"]:
+                    w["Y16a"][l][:B].zero_()
+                    if w["Y16b"][l] is not None:
+                        w["Y16b"][l][:B].zero_()
         self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop)
         if with_loss:
             if ce_count is None:
@@ -305,15 +352,65 @@ class Engine:
 
     def _decode_h0(self, w, z, B):
         p = self.p
+        st = L.cur_stream()
+        zp = (L.ptr(z), L.ptr(p["dec.z_proj.weight"]), L.ptr(p["dec.z_proj.bias"]))
+        if w["v2"]:
+            D = self.D
+            _call("ark_zproj_fwd", *zp, L.ptr(w["h0"]), L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(D), st)
+            _call("ark_to_tiled", L.ptr(w["h0"]), L.ptr(w["Y"][0]), L.i32(B), L.i32(D), st)
+            _call("ark_cast16", L.i32(self.prec_fwd), L.ptr(w["h0"]), L.ptr(w["Y16a"][0]), L.i64(B * D), st)
+            if w["Y16b"][0] is not None:
+                _call("ark_cast16", L.i32(self.prec_bwd), L.ptr(w["h0"]), L.ptr(w["Y16b"][0]), L.i64(B * D), st)
+            for l in range(1, self.n):   # every layer starts from the same h0 (models.py:140)
+                w["Y"][l][:B].copy_(w["Y"][0][:B])
+                w["Y16a"][l][:B].copy_(w["Y16a"][0][:B])
+                if w["Y16b"][l] is not None:
+                    w["Y16b"][l][:B].copy_(w["Y16b"][0][:B])
+            return
         # layer buffers are separate allocations: write h0 into slot 0 of every layer
         for l in range(self.n):
-            _call("ark_zproj_fwd", L.ptr(z), L.ptr(p["dec.z_proj.weight"]), L.ptr(p["dec.z_proj.bias"]), L.ptr(w["Y"][l]),
-                  L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(self.D), L.cur_stream())
-            if self.use_dma:
-                _call("ark_cast16", L.i32(self.prec_fwd), L.ptr(w["Y"][l]), L.ptr(w["Y16"][l]), L.i64(B * self.D),
-                      L.cur_stream())
+            _call("ark_zproj_fwd", *zp, L.ptr(w["Y"][l]), L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(self.D), st)
+
+    def _decoder_forward_v2(self, w, seq, ld_seq, B, Lq, use_drop, save=True):
+        """16-bit-operand / LDS-DMA decoder forward (see include/ark_amd.h, LDS-DMA section)"""
+        D, n, V = self.D, self.n, self.V
+        R = Lq * B
+        st = L.cur_stream()
+        p = self.p
+        pf, pb = self.prec_fwd, self.prec_bwd
+        _call("ark_tok_gather16", L.i32(pf), L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(p["dec.tok_emb.weight"]),
+              L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0a"]), L.ptr(w["X0b"]), L.i32(B),
+              L.i32(Lq), L.i32(D), st)
+        xin = w["X0a"]
+        for l in range(n):
+            _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(xin), L.i64(D), L.ptr(self.wih16[l]), L.i64(D),
+                  L.ptr(w["GI"][l]), L.i64(3 * D), L.ptr(p[f"dec.gru.bias_ih_l{l}"]), L.ptr(None), L.i32(R), L.i32(3 * D),
+                  L.i32(D), L.i32(1), st)
+            drop = use_drop and l < n - 1
+            if drop:
+                _call("ark_dropout_mask", L.ptr(w["mask"][l]), L.i64(R * D), L.f32(self.p_drop),
+                      L.u64(self.drop_seed + 7919 * l), L.ptr(self.hyper), st)
+            Y, Ya, Yb = w["Y"][l], w["Y16a"][l], w["Y16b"][l]
+            for t in range(Lq):
+                sl = slice(t * B, (t + 1) * B)
+                nx = slice((t + 1) * B, (t + 2) * B)
+                _call("ark_gru_cell_fwd_dma", L.i32(pf), L.i32(pb), L.ptr(Ya[sl]), L.ptr(self.whh16[l]), L.ptr(Y[sl]),
+                      L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l][sl]), L.ptr(Y[nx]), L.ptr(Ya[nx]),
+                      L.ptr(Yb[nx] if Yb is not None else None),
+                      L.ptr(w["Yd16a"][l][sl] if drop else None),
+                      L.ptr(w["Yd16b"][l][sl] if (drop and w["Yd16b"][l] is not None) else None),
+                      L.ptr(w["mask"][l][sl] if drop else None),
+                      L.ptr(w["SR"][l][sl] if save else None), L.ptr(w["SZ"][l][sl] if save else None),
+                      L.ptr(w["SN"][l][sl] if save else None), L.ptr(w["SHN"][l][sl] if save else None),
+                      L.i32(B), L.i32(D), st)
+            xin = w["Yd16a"][l] if drop else Ya[B:]
+        _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(w["Y16a"][n - 1][B:]), L.i64(D), L.ptr(self.wtok16), L.i64(D),
+              L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(p["dec.out.bias"]), L.ptr(None), L.i32(R), L.i32(V), L.i32(D),
+              L.i32(0), st)
 
     def _decoder_forward(self, w, seq, ld_seq, B, Lq, use_drop, save=True):
+        if w["v2"]:
+            return self._decoder_forward_v2(w, seq, ld_seq, B, Lq, use_drop, save)
         D, n, V = self.D, self.n, self.V
         R = Lq * B
         st = L.cur_stream()
@@ -337,13 +434,8 @@ class Engine:
                         L.ptr(w["SR"][l][sl] if save else None), L.ptr(w["SZ"][l][sl] if save else None),
                         L.ptr(w["SN"][l][sl] if save else None), L.ptr(w["SHN"][l][sl] if save else None),
                         L.i32(B), L.i32(D), st)
-                if self.use_dma:
-                    Y16 = w["Y16"][l]
-                    _call("ark_gru_cell_fwd_dma", L.i32(self.prec), L.ptr(Y16[t * B:]), L.ptr(self.whh16[l]), L.ptr(Y[t * B:]),
-                          *common, L.ptr(Y16[(t + 1) * B:]), *tail)
-                else:
-                    _call("ark_gru_cell_fwd", L.i32(self.prec), L.ptr(Y[t * B:]), L.ptr(p[f"dec.gru.weight_hh_l{l}"]),
-                          *common, *tail)
+                _call("ark_gru_cell_fwd", L.i32(self.prec), L.ptr(Y[t * B:]), L.ptr(p[f"dec.gru.weight_hh_l{l}"]),
+                      *common, *tail)
             xin = w["Ydrop"][l] if drop else Y[B:]
         self._xin_top = xin
         self._gemm(KM, KM, L.EPI_BIAS, w["Y"][n - 1][B:], D, p["dec.out.weight"], D, w["logits"], self.ldl, R, V, D,
@@ -362,46 +454,10 @@ class Engine:
         seq = self._seq
         ld_seq = seq.shape[1]
         use_drop = self.training and self.p_drop > 0
-        dlog = w["logits"]
-        ytop = w["Y"][n - 1][B:]
-        # tied vocabulary projection
-        self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
-        self._gemm(MM, MM, L.EPI_NONE, dlog, self.ldl, ytop, D, g["dec.out.weight"], D, V, D, R)
-        self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dYa"], D, R, D, V)
-        dy, dy_other = w["dYa"], w["dYb"]
-        for l in range(n - 1, -1, -1):
-            Y = w["Y"][l]
-            dGI, dGH = w["GI"][l], w["dGH"][l]
-            whh = p[f"dec.gru.weight_hh_l{l}"]
-            for t in range(Lq - 1, -1, -1):
-                sl = slice(t * B, (t + 1) * B)
-                first = (t == Lq - 1)
-                mid = (L.ptr(dy[sl]), L.ptr(w["carry"]), L.ptr(w["SR"][l][sl]), L.ptr(w["SZ"][l][sl]), L.ptr(w["SN"][l][sl]),
-                       L.ptr(w["SHN"][l][sl]), L.ptr(Y[sl]), L.ptr(dGI[sl]), L.ptr(dGH[sl]))
-                if self.use_dma:
-                    d16 = w["dGH16"][l]
-                    _call("ark_gru_cell_bwd_dma", L.i32(self.prec), L.ptr(None if first else d16[(t + 1) * B:]),
-                          L.ptr(self.whhT16[l]), *mid, L.ptr(d16[sl]), L.i32(B), L.i32(D), L.i32(1 if first else 0), st)
-                else:
-                    _call("ark_gru_cell_bwd", L.i32(self.prec), L.ptr(None if first else dGH[(t + 1) * B:]), L.ptr(whh),
-                          *mid, L.i32(B), L.i32(D), L.i32(1 if first else 0), st)
-            if self.mt == "SAIL":
-                if self.use_dma:
-                    _call("ark_gru_h0_bwd_dma", L.i32(self.prec), L.ptr(w["dGH16"][l]), L.ptr(self.whhT16[l]), L.ptr(w["carry"]),
-                          L.ptr(w["dH0"]), L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
-                else:
-                    _call("ark_gru_h0_bwd", L.i32(self.prec), L.ptr(dGH), L.ptr(whh), L.ptr(w["carry"]), L.ptr(w["dH0"]),
-                          L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
-            drop_below = use_drop and l > 0
-            xin = w["X0"] if l == 0 else (w["Ydrop"][l - 1] if drop_below else w["Y"][l - 1][B:])
-            self._gemm(MM, MM, L.EPI_NONE, dGH, 3 * D, Y, D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R)
-            self._gemm(MM, MM, L.EPI_NONE, dGI, 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)
-            self._colsum(dGI, 3 * D, g[f"dec.gru.bias_ih_l{l}"], R, 3 * D)
-            self._colsum(dGH, 3 * D, g[f"dec.gru.bias_hh_l{l}"], R, 3 * D)
-            self._gemm(KM, MM, L.EPI_MUL_AUX if drop_below else L.EPI_NONE, dGI, 3 * D, p[f"dec.gru.weight_ih_l{l}"], D,
-                       dy_other, D, R, D, 3 * D, aux=w["mask"][l - 1] if drop_below else None)
-            dy, dy_other = dy_other, dy
-        dX0 = dy
+        if w["v2"]:
+            dX0 = self._backward_decoder_v2(w, B, Lq, seq, use_drop)
+        else:
+            dX0 = self._backward_decoder_v1(w, B, Lq, seq, use_drop)
         if not self.layout.tied:
             g["dec.tok_emb.weight"].zero_()
         _call("ark_tok_scatter", L.ptr(seq), L.i64(ld_seq), L.ptr(dX0), L.ptr(g["dec.tok_emb.weight"]), L.i32(B), L.i32(Lq),
@@ -414,7 +470,8 @@ class Engine:
             return
         # latent path
         H = 3 * D
-        _call("ark_zproj_bwd", L.ptr(w["dH0"]), L.ptr(w["Y"][0]), L.ptr(w["z"]), L.ptr(p["dec.z_proj.weight"]),
+        h0rm = w["h0"] if w["v2"] else w["Y"][0]   # row-major h0 (the v2 state buffers are tile-native)
+        _call("ark_zproj_bwd", L.ptr(w["dH0"]), L.ptr(h0rm), L.ptr(w["z"]), L.ptr(p["dec.z_proj.weight"]),
               L.ptr(w["dz"]), L.ptr(g["dec.z_proj.weight"]), L.ptr(g["dec.z_proj.bias"]), L.i32(B), L.i32(Z), L.i32(D), st)
         _call("ark_latent_bwd", L.ptr(w["dz"]), L.ptr(w["head"]), L.ptr(self._eps), L.ptr(self.hyper), L.ptr(w["dhead"]),
               L.i32(B), L.i32(Z), st)
@@ -442,6 +499,98 @@ class Engine:
               L.ptr(g["enc.r_emb.weight"]), L.i32(B), L.i32(T), L.i32(D), L.i32(g["enc.e_emb.weight"].shape[0]),
               L.i32(g["enc.r_emb.weight"].shape[0]), L.i64(-1 if self.pad_eid is None else self.pad_eid),
               L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
+
+
+    def _backward_decoder_v1(self, w, B, Lq, seq, use_drop):
+        D, n, V = self.D, self.n, self.V
+        R = Lq * B
+        st = L.cur_stream()
+        KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
+        p, g = self.p, self.g
+        dlog = w["logits"]
+        ytop = w["Y"][n - 1][B:]
+        # tied vocabulary projection
+        self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
+        self._gemm(MM, MM, L.EPI_NONE, dlog, self.ldl, ytop, D, g["dec.out.weight"], D, V, D, R)
+        self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dYa"], D, R, D, V)
+        dy, dy_other = w["dYa"], w["dYb"]
+        for l in range(n - 1, -1, -1):
+            Y = w["Y"][l]
+            dGI, dGH = w["GI"][l], w["dGH"][l]
+            whh = p[f"dec.gru.weight_hh_l{l}"]
+            for t in range(Lq - 1, -1, -1):
+                sl = slice(t * B, (t + 1) * B)
+                first = (t == Lq - 1)
+                mid = (L.ptr(dy[sl]), L.ptr(w["carry"]), L.ptr(w["SR"][l][sl]), L.ptr(w["SZ"][l][sl]), L.ptr(w["SN"][l][sl]),
+                       L.ptr(w["SHN"][l][sl]), L.ptr(Y[sl]), L.ptr(dGI[sl]), L.ptr(dGH[sl]))
+                _call("ark_gru_cell_bwd", L.i32(self.prec), L.ptr(None if first else dGH[(t + 1) * B:]), L.ptr(whh),
+                      *mid, L.i32(B), L.i32(D), L.i32(1 if first else 0), st)
+            if self.mt == "SAIL":
+                _call("ark_gru_h0_bwd", L.i32(self.prec), L.ptr(dGH), L.ptr(whh), L.ptr(w["carry"]), L.ptr(w["dH0"]),
+                      L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
+            drop_below = use_drop and l > 0
+            xin = w["X0"] if l == 0 else (w["Ydrop"][l - 1] if drop_below else w["Y"][l - 1][B:])
+            self._gemm(MM, MM, L.EPI_NONE, dGH, 3 * D, Y, D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R)
+            self._gemm(MM, MM, L.EPI_NONE, dGI, 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)
+            self._colsum(dGI, 3 * D, g[f"dec.gru.bias_ih_l{l}"], R, 3 * D)
+            self._colsum(dGH, 3 * D, g[f"dec.gru.bias_hh_l{l}"], R, 3 * D)
+            self._gemm(KM, MM, L.EPI_MUL_AUX if drop_below else L.EPI_NONE, dGI, 3 * D, p[f"dec.gru.weight_ih_l{l}"], D,
+                       dy_other, D, R, D, 3 * D, aux=w["mask"][l - 1] if drop_below else None)
+            dy, dy_other = dy_other, dy
+        return dy
+
+    def _backward_decoder_v2(self, w, B, Lq, seq, use_drop):
+        """16-bit-operand / LDS-DMA decoder backward: BPTT cells on the DMA engine, weight gradients
+        from the 16-bit gate-gradient panels, input gradients against transposed weight shadows."""
+        D, n, V = self.D, self.n, self.V
+        R = Lq * B
+        st = L.cur_stream()
+        KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
+        p, g = self.p, self.g
+        pb = self.prec_bwd
+        dlog = w["logits"]
+        yb = lambda l: (w["Y16b"][l] if w["Y16b"][l] is not None else w["Y16a"][l])
+        self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
+        _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dlog), L.i32(0), L.i64(self.ldl), L.ptr(yb(n - 1)[B:]), L.i32(1), L.i64(D),
+              L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(V), L.i32(D), L.i32(R), st)
+        # dY of the top layer: K = V is not a multiple of 64 -> register-staged engine, then re-tile
+        self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
+        _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
+        dy, dy_other = w["dYa"], w["dYb"]
+        for l in range(n - 1, -1, -1):
+            Y = w["Y"][l]
+            dGI, dGH = w["dGI16"][l], w["dGH16"][l]
+            for t in range(Lq - 1, -1, -1):
+                sl = slice(t * B, (t + 1) * B)
+                first = (t == Lq - 1)
+                _call("ark_gru_cell_bwd_dma", L.i32(pb), L.ptr(None if first else dGH[(t + 1) * B:]), L.ptr(self.whhT16[l]),
+                      L.ptr(dy[sl]), L.ptr(w["carry"]), L.ptr(w["SR"][l][sl]), L.ptr(w["SZ"][l][sl]), L.ptr(w["SN"][l][sl]),
+                      L.ptr(w["SHN"][l][sl]), L.ptr(Y[sl]), L.ptr(dGI[sl]), L.ptr(dGH[sl]), L.i32(B), L.i32(D),
+                      L.i32(1 if first else 0), st)
+            if self.mt == "SAIL":
+                _call("ark_gru_h0_bwd_dma", L.i32(pb), L.ptr(dGH), L.ptr(self.whhT16[l]), L.ptr(w["carry"]), L.ptr(w["dH0"]),
+                      L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
+            drop_below = use_drop and l > 0
+            if l == 0:
+                xin = w["X0b"] if w["X0b"] is not None else w["X0a"]
+            elif drop_below:
+                xin = w["Yd16b"][l - 1] if w["Yd16b"][l - 1] is not None else w["Yd16a"][l - 1]
+            else:
+                xin = yb(l - 1)[B:]
+            _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGH), L.i32(1), L.i64(3 * D), L.ptr(yb(l)), L.i32(1), L.i64(D),
+                  L.ptr(g[f"dec.gru.weight_hh_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), st)
+            _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGI), L.i32(1), L.i64(3 * D), L.ptr(xin), L.i32(1), L.i64(D),
+                  L.ptr(g[f"dec.gru.weight_ih_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), st)
+            _call("ark_colsum16", L.i32(pb), L.ptr(dGI), L.i64(3 * D), L.ptr(g[f"dec.gru.bias_ih_l{l}"]), L.i32(R), L.i32(3 * D), st)
+            _call("ark_colsum16", L.i32(pb), L.ptr(dGH), L.i64(3 * D), L.ptr(g[f"dec.gru.bias_hh_l{l}"]), L.i32(R), L.i32(3 * D), st)
+            # input gradient: dgi [R,3D] x W_ih^T-shadow [D,3D]; tile-native for the layer below,
+            # row-major for the embedding scatter
+            out = dy_other if l > 0 else w["dX0"]
+            _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_MUL_AUX if drop_below else L.EPI_NONE), L.ptr(dGI), L.i64(3 * D),
+                  L.ptr(self.wihT16[l]), L.i64(3 * D), L.ptr(out), L.i64(D), L.ptr(None),
+                  L.ptr(w["mask"][l - 1] if drop_below else None), L.i32(R), L.i32(D), L.i32(3 * D), L.i32(1 if l > 0 else 0), st)
+            dy, dy_other = dy_other, dy
+        return w["dX0"]
 
     # ------------------------------------------------------------------ optimiser
     def adam(self):
@@ -541,38 +690,44 @@ class Engine:
     @torch.no_grad()
     def greedy_decode(self, z, max_len=None):
         """token sequences of SAIL.decode_latent(z, beam=1) (reference models.py:282-300): the decoder
-        is a causal GRU, so instead of re-running the whole prefix we advance one step per token."""
+        is a causal GRU, so instead of re-running the whole prefix we advance one step per token.
+        Uses the register-staged kernels on private buffers (exact in f32 precision)."""
         assert self.mt == "SAIL"
         self.prec = self.prec_fwd
         B = z.shape[0]
         Lmax = (self.seq_len - 1) if max_len is None else max_len
-        w = self._workspace(B, 0)
-        D, n, V = self.D, self.n, self.V
+        D, n, V, dev = self.D, self.n, self.V, self.device
         st = L.cur_stream()
         p = self.p
         KM = L.LAY_KMAJ
-        z = z.to(self.device, dtype=torch.float32).contiguous()
-        self._decode_h0(w, z, B)
-        toks = torch.full((B, self.seq_len), 2, dtype=torch.int64, device=self.device)
+        f = lambda *sh: torch.zeros(*sh, device=dev, dtype=torch.float32)
+        ldl = _rup(V, 4)
+        x0, gi, logits = f(B, D), f(B, 3 * D), f(B, ldl)
+        Y = [f(2 * B, D) for _ in range(n)]
+        nxt = torch.zeros(B, dtype=torch.int64, device=dev)
+        z = z.to(dev, dtype=torch.float32).contiguous()
+        for l in range(n):
+            _call("ark_zproj_fwd", L.ptr(z), L.ptr(p["dec.z_proj.weight"]), L.ptr(p["dec.z_proj.bias"]), L.ptr(Y[l]),
+                  L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(D), st)
+        toks = torch.full((B, self.seq_len), 2, dtype=torch.int64, device=dev)
         toks[:, 0] = 1
-        cur = torch.full((B, 1), 1, dtype=torch.int64, device=self.device)
+        cur = torch.full((B, 1), 1, dtype=torch.int64, device=dev)
         for t in range(Lmax):
-            _call("ark_tok_gather", L.ptr(cur), L.i64(1), L.ptr(p["dec.tok_emb.weight"]), L.ptr(None), L.ptr(w["X0"]),
+            _call("ark_tok_gather", L.ptr(cur), L.i64(1), L.ptr(p["dec.tok_emb.weight"]), L.ptr(None), L.ptr(x0),
                   L.i32(B), L.i32(1), L.i32(D), st)
-            xin = w["X0"]
+            xin = x0
             for l in range(n):
-                self._gemm(KM, KM, L.EPI_BIAS, xin, D, p[f"dec.gru.weight_ih_l{l}"], D, w["GI"][l], 3 * D, B, 3 * D, D,
+                self._gemm(KM, KM, L.EPI_BIAS, xin, D, p[f"dec.gru.weight_ih_l{l}"], D, gi, 3 * D, B, 3 * D, D,
                            bias=p[f"dec.gru.bias_ih_l{l}"])
-                Y = w["Y"][l]
-                _call("ark_gru_cell_fwd", L.i32(self.prec), L.ptr(Y[(t % 2) * B:]), L.ptr(p[f"dec.gru.weight_hh_l{l}"]),
-                      L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l]), L.ptr(Y[((t + 1) % 2) * B:]), L.ptr(None),
+                a, b = Y[l][(t % 2) * B:], Y[l][((t + 1) % 2) * B:]
+                _call("ark_gru_cell_fwd", L.i32(self.prec), L.ptr(a), L.ptr(p[f"dec.gru.weight_hh_l{l}"]),
+                      L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(gi), L.ptr(b), L.ptr(None),
                       L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), L.i32(B), L.i32(D), st)
-                xin = Y[((t + 1) % 2) * B:]
-            self._gemm(KM, KM, L.EPI_BIAS, xin, D, p["dec.out.weight"], D, w["logits"], self.ldl, B, V, D,
-                       bias=p["dec.out.bias"])
-            _call("ark_argmax_rows", L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(w["tok_next"]), L.i32(B), L.i32(V), st)
-            toks[:, t + 1] = w["tok_next"][:B]
-            cur = w["tok_next"][:B].clone().view(B, 1)
+                xin = b
+            self._gemm(KM, KM, L.EPI_BIAS, xin, D, p["dec.out.weight"], D, logits, ldl, B, V, D, bias=p["dec.out.bias"])
+            _call("ark_argmax_rows", L.ptr(logits), L.i64(ldl), L.ptr(nxt), L.i32(B), L.i32(V), st)
+            toks[:, t + 1] = nxt
+            cur = nxt.clone().view(B, 1)
             if bool((cur == 2).all()):
                 return toks[:, :t + 2]
         return toks[:, :Lmax + 1]

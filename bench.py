@@ -91,27 +91,48 @@ def cpu_baseline(cfg, B, steps=6, warmup=2):
 
 
 def time_dominant_kernel(eng, B, iters=50):
-    """average duration of the dominant kernel (recurrent GRU cell, forward) measured with HIP
-    events on the launch stream, outside the graph."""
+    """average duration of the dominant kernel (the per-timestep forward GRU cell: recurrent MFMA
+    product + fused gate epilogue) measured with HIP events on the launch stream; the launches are
+    captured into one hipGraph so the measurement is GPU-bound, not ctypes-bound."""
     from ark_amd import _lib as L
     w = eng.ws
     D = eng.D
     p = eng.p
-    st = torch.cuda.current_stream()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.Stream()
+    sl, nx = slice(0, B), slice(B, 2 * B)
+
     def launch():
-        L.check(L.lib().ark_gru_cell_fwd(L.i32(eng.prec_fwd), L.ptr(w["Y"][0]), L.ptr(p["dec.gru.weight_hh_l0"]),
-                                         L.ptr(p["dec.gru.bias_hh_l0"]), L.ptr(w["GI"][0]), L.ptr(w["Y"][0][B:]), L.ptr(None),
-                                         L.ptr(None), L.ptr(w["SR"][0]), L.ptr(w["SZ"][0]), L.ptr(w["SN"][0]), L.ptr(w["SHN"][0]),
-                                         L.i32(B), L.i32(D), L.cur_stream()), "ark_gru_cell_fwd")
-    for _ in range(5):
-        launch()
-    e0.record(st)
-    for _ in range(iters):
-        launch()
-    e1.record(st)
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+        if w["v2"]:
+            Yb = w["Y16b"][0]
+            L.check(L.lib().ark_gru_cell_fwd_dma(
+                L.i32(eng.prec_fwd), L.i32(eng.prec_bwd), L.ptr(w["Y16a"][0][sl]), L.ptr(eng.whh16[0]), L.ptr(w["Y"][0][sl]),
+                L.ptr(p["dec.gru.bias_hh_l0"]), L.ptr(w["GI"][0][sl]), L.ptr(w["Y"][0][nx]), L.ptr(w["Y16a"][0][nx]),
+                L.ptr(Yb[nx] if Yb is not None else None), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(w["SR"][0][sl]),
+                L.ptr(w["SZ"][0][sl]), L.ptr(w["SN"][0][sl]), L.ptr(w["SHN"][0][sl]), L.i32(B), L.i32(D), L.cur_stream()),
+                "ark_gru_cell_fwd_dma")
+        else:
+            L.check(L.lib().ark_gru_cell_fwd(
+                L.i32(eng.prec_fwd), L.ptr(w["Y"][0]), L.ptr(p["dec.gru.weight_hh_l0"]), L.ptr(p["dec.gru.bias_hh_l0"]),
+                L.ptr(w["GI"][0]), L.ptr(w["Y"][0][B:]), L.ptr(None), L.ptr(None), L.ptr(w["SR"][0]), L.ptr(w["SZ"][0]),
+                L.ptr(w["SN"][0]), L.ptr(w["SHN"][0]), L.i32(B), L.i32(D), L.cur_stream()), "ark_gru_cell_fwd")
+
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            launch()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                launch()
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            g.replay()
+        e1.record()
+        e1.synchronize()
+    return e0.elapsed_time(e1) / (4 * iters) * 1e-3
 
 
 def main():
@@ -240,7 +261,7 @@ def main():
                        "parallelism": f"dp{world}"},
             "final_loss": loss[0],
             "model_tflops": gps * fl / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gru_cell_fwd_kernel", "achieved": kfl / kt / 1e12, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": "gru_cell_fwd_dma_kernel" if eng.ws["v2"] else "gru_cell_fwd_kernel", "achieved": kfl / kt / 1e12, "peak": peak,
                          "unit": "TFLOP/s", "frac": kfl / kt / 1e12 / peak, "traffic": None,
                          "kernel_avg_us": kt * 1e6, "flops_per_launch": kfl},
         }

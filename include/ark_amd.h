@@ -81,22 +81,34 @@ int ark_gru_cell_bwd(int prec, const float* dgh_next, const float* w_hh, const f
 int ark_gru_h0_bwd(int prec, const float* dgh0, const float* w_hh, const float* carry, float* dh0, int accumulate,
                    int B, int D, void* stream);
 
-/* LDS-DMA editions of the three calls above for 16-bit precisions and d_model % 64 == 0: the
- * recurrent operands are 16-bit copies (h written by the previous cell, W_hh / W_hh^T shadows from
- * ark_gru_weight_shadows); fp32 state, saves and gradients are unchanged. */
-int ark_gru_cell_fwd_dma(int prec, const void* h_prev16, const void* w_hh16, const float* h_prev, const float* b_hh,
-                         const float* gi, float* h_out, void* h_out16, float* h_drop, const float* drop_mask,
-                         float* save_r, float* save_z, float* save_n, float* save_hn, int B, int D, void* stream);
-int ark_gru_cell_bwd_dma(int prec, const void* dgh_next16, const void* w_hhT16, const float* dy, float* carry,
-                         const float* save_r, const float* save_z, const float* save_n, const float* save_hn,
-                         const float* h_prev, float* dgi, float* dgh, void* dgh16, int B, int D, int first,
-                         void* stream);
-int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_hhT16, const float* carry, float* dh0,
+/* ---- LDS-DMA / 16-bit-operand path (precision 16-bit, d_model % 64 == 0, batch % 16 == 0) --------
+ * Layout contract: "16" buffers are row-major 16-bit copies in the named precision's type;
+ * "_t" buffers are fp32 (saves: fp16) in the 16x16 MFMA-tile-native order
+ *   off(row,col,ld) = ((row>>4)*(ld>>4) + (col>>4))*256 + (((row>>2)&3)*16 + (col&15))*4 + (row&3). */
+int ark_gru_cell_fwd_dma(int prec, int prec_b, const void* h_prev16, const void* w_hh16, const float* y_prev_t,
+                         const float* b_hh, const float* gi_t, float* y_out_t, void* y16a, void* y16b, void* yd16a,
+                         void* yd16b, const float* mask_t, void* save_r, void* save_z, void* save_n, void* save_hn,
+                         int B, int D, void* stream);
+int ark_gru_cell_bwd_dma(int prec, const void* dgh_next16, const void* w_hhT16, const float* dy_t, float* carry_t,
+                         const void* save_r, const void* save_z, const void* save_n, const void* save_hn,
+                         const float* y_prev_t, void* dgi16, void* dgh16, int B, int D, int first, void* stream);
+int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_hhT16, const float* carry_t, float* dh0,
                        int accumulate, int B, int D, void* stream);
-/* w16[l] = cast(W_hh_l) [3D,D] in prec_fwd, wT16[l] = cast(W_hh_l^T) [D,3D] in prec_bwd, all layers */
-int ark_gru_weight_shadows(int prec_fwd, int prec_bwd, const float* w_hh_l0, int64_t layer_stride, void* w16,
-                           void* wT16, int D, int n_layers, void* stream);
+int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf);
+/* up to 12 jobs in one launch: dst[i] = cast(src[i] [R,C]) in prec[i]; dstT[i] = cast(src[i]^T) in precT[i] */
+int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, void* const* dstT, const int* R,
+                       const int* C, const int* prec, const int* precT, void* stream);
+/* C[M,N] = A16[M,K] B16[N,K]^T (+bias | *aux), C row-major or tile-native (c_tiled) */
+int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
+               const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* stream);
+/* C[M,N] = sum_k A[k,M] B[k,N]: weight gradients with fp32 or 16-bit stored operands */
+int ark_gemm_wgrad(int prec, const void* A, int a_is16, int64_t lda, const void* B, int b_is16, int64_t ldb, float* C,
+                   int64_t ldc, int M, int N, int K, void* stream);
+int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,
+                     const float* w_pos, void* x16a, void* x16b, int B, int L, int D, void* stream);
+int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, void* stream);
 int ark_cast16(int prec, const float* x, void* out, int64_t n, void* stream);
+int ark_to_tiled(const float* x, float* out, int rows, int ld, void* stream);
 
 /* ---- embeddings (reference: models.py:47-58 encoder gather+concat+masked mean; :138,:343
  *      decoder token / position lookup; autograd embedding_backward) --------------------------- */
