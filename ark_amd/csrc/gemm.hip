@@ -76,7 +76,7 @@ static int launch_gemm(GemmArgs p, hipStream_t st) {
     // Long-K products with few output tiles (weight gradients: K = B*L) are latency-bound at
     // <= 1 workgroup per CU; split K across workgroups until ~4 workgroups per CU are resident,
     // keeping >= 4 K-steps per split, and reduce with fp32 atomics into the zeroed output.
-    if (p.epi == ARK_EPI_NONE && !p.accumulate && g_split_k_enabled) {
+    if (p.epi == ARK_EPI_NONE && g_split_k_enabled) {
       int split = 1;
       while (t64 * split < 1024 && p.K / (split * 2) >= 4 * BK && split < 64) split *= 2;
       if (split > 1) {
@@ -85,7 +85,7 @@ static int launch_gemm(GemmArgs p, hipStream_t st) {
         p.split_k = (p.K + p.k_chunk - 1) / p.k_chunk;
       }
     }
-    if (p.split_k > 1) {
+    if (p.split_k > 1 && !p.accumulate) {
       // rows of C are ldc apart; zero the [M, N] window (dense when ldc == N)
       hipError_t e = (p.ldc == p.N) ? hipMemsetAsync(p.C, 0, sizeof(float) * (size_t)p.M * p.N, st)
                                     : hipMemset2DAsync(p.C, sizeof(float) * p.ldc, 0, sizeof(float) * p.N, p.M, st);
@@ -137,12 +137,12 @@ extern "C" int ark_gemm(int prec, int a_lay, int b_lay, int epi, const float* A,
 // one or both operands are stored in 16 bits (the type `prec` computes in).  Same kernel family as
 // ark_gemm; a_is16 / b_is16 select the storage of each operand (0: fp32, 1: 16-bit).
 extern "C" int ark_gemm_wgrad(int prec, const void* A, int a_is16, int64_t lda, const void* B, int b_is16, int64_t ldb,
-                              float* C, int64_t ldc, int M, int N, int K, void* stream) {
+                              float* C, int64_t ldc, int M, int N, int K, int accumulate, void* stream) {
   using namespace ark;
   if (M <= 0 || N <= 0 || K < 0 || !A || !B || !C) return ARK_ERR_ARG;
   if (prec != PREC_BF16 && prec != PREC_F16) return ARK_ERR_ARG;
   GemmArgs p{reinterpret_cast<const float*>(A), reinterpret_cast<const float*>(B), C, nullptr, nullptr, nullptr,
-             (long)lda, (long)ldb, (long)ldc, M, N, K, ARK_EPI_NONE, 0, 0, 1, K};
+             (long)lda, (long)ldb, (long)ldc, M, N, K, ARK_EPI_NONE, accumulate ? 1 : 0, 0, 1, K};
   hipStream_t st = (hipStream_t)stream;
 #define ARK_WG(P)                                                                                         \
   if (a_is16 && b_is16) return launch_gemm<P, LAY_MMAJ, LAY_MMAJ, 1, 1>(p, st);                          \

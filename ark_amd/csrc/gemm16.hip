@@ -178,12 +178,15 @@ extern "C" int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int6
   return 0;
 }
 
-extern "C" int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, void* stream) {
+extern "C" int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, int accumulate,
+                            void* stream) {
   using namespace ark;
   if (!x16 || !out || M <= 0 || N <= 0) return ARK_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
-  if (e != hipSuccess) return (int)e;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
+    if (e != hipSuccess) return (int)e;
+  }
   int rows_per_wg = 128;
   const int col_tiles = (N + 63) / 64;
   while (rows_per_wg > 16 && (long)col_tiles * ((M + rows_per_wg - 1) / rows_per_wg) < 512) rows_per_wg >>= 1;

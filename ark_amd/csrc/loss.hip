@@ -97,24 +97,48 @@ __global__ __launch_bounds__(256) void zproj_bwd_dz_kernel(const float* __restri
   }
 }
 
-// dWz[d,j] = sum_b dzp[b,d] z[b,j] ; dbz[d] = sum_b dzp[b,d]     thread per d, loop b (coalesced over d)
+// dWz[d,j] += sum_b dzp[b,d] z[b,j] ; dbz[d] += sum_b dzp[b,d]
+// 64 d-columns x 4 row groups per workgroup over a chunk of the batch; z rows are staged in LDS
+// padded to ZT latent columns so the ZT accumulators stay in registers (compile-time indices).
+template <int ZT>
 __global__ __launch_bounds__(256) void zproj_bwd_dw_kernel(const float* __restrict__ dzp, const float* __restrict__ z,
                                                            float* __restrict__ dWz, float* __restrict__ dbz, int B, int Z,
                                                            int D, int b_chunk) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b0 = blockIdx.y * b_chunk, b1 = min(B, b0 + b_chunk);
-  if (d >= D) return;
-  constexpr int ZMAX = 128;
-  float acc[ZMAX];
-  float sb = 0.f;
-  for (int j = 0; j < Z; ++j) acc[j] = 0.f;
-  for (int b = b0; b < b1; ++b) {
-    const float g = dzp[(long)b * D + d];
-    sb += g;
-    for (int j = 0; j < Z; ++j) acc[j] += g * z[(long)b * Z + j];
+  extern __shared__ __attribute__((aligned(16))) char smem_z[];
+  float* zs = reinterpret_cast<float*>(smem_z);            // [b_chunk][ZT]
+  float* red = zs + (size_t)b_chunk * ZT;                  // [4][64] reused per j-block
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + lane;
+  const int b0 = blockIdx.y * b_chunk, nb = min(B, b0 + b_chunk) - b0;
+  for (int i = threadIdx.x; i < b_chunk * ZT; i += 256) {
+    const int bb = i / ZT, j = i % ZT;
+    zs[i] = (bb < nb && j < Z) ? z[(long)(b0 + bb) * Z + j] : 0.f;
   }
-  for (int j = 0; j < Z; ++j) atomicAdd(&dWz[(long)d * Z + j], acc[j]);
-  atomicAdd(&dbz[d], sb);
+  __syncthreads();
+  float acc[ZT];
+#pragma unroll
+  for (int j = 0; j < ZT; ++j) acc[j] = 0.f;
+  float sb = 0.f;
+  if (d < D)
+    for (int bb = rg; bb < nb; bb += 4) {
+      const float g = dzp[(long)(b0 + bb) * D + d];
+      sb += g;
+#pragma unroll
+      for (int j = 0; j < ZT; ++j) acc[j] += g * zs[bb * ZT + j];
+    }
+  // cross row-group reduction through LDS, one latent column at a time
+#pragma unroll
+  for (int j = 0; j <= ZT; ++j) {
+    const float v = (j < ZT) ? acc[j < ZT ? j : 0] : sb;
+    red[rg * 64 + lane] = v;
+    __syncthreads();
+    if (rg == 0 && d < D) {
+      const float t = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+      if (j < ZT) { if (j < Z) atomicAdd(&dWz[(long)d * Z + j], t); }
+      else atomicAdd(&dbz[d], t);
+    }
+    __syncthreads();
+  }
 }
 
 // ---- token cross-entropy over time-major logits rows (t,b); target = seq[b, t+1] ---------------
@@ -235,7 +259,7 @@ extern "C" int ark_zproj_fwd(const float* z, const float* w_z, const float* b_z,
 // dh0 (in: dL/dh0 summed over layers; out: overwritten with dL/d(pre-tanh)), dz / dWz / dbz outputs
 // (dWz, dbz are overwritten).
 extern "C" int ark_zproj_bwd(float* dh0, const float* h0, const float* z, const float* w_z, float* dz, float* d_w_z,
-                             float* d_b_z, int B, int Z, int D, void* stream) {
+                             float* d_b_z, int B, int Z, int D, int accumulate, void* stream) {
   using namespace ark;
   if (!dh0 || !h0 || !z || !w_z || !dz || !d_w_z || !d_b_z || B <= 0 || Z <= 0 || D <= 0) return ARK_ERR_ARG;
   if (Z > 128) return ARK_ERR_SHAPE;
@@ -243,13 +267,20 @@ extern "C" int ark_zproj_bwd(float* dh0, const float* h0, const float* z, const 
   const long n = (long)B * D;
   hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dh0, h0, n);
   hipLaunchKernelGGL(zproj_bwd_dz_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dh0, w_z, dz, B, Z, D);
-  hipError_t e = hipMemsetAsync(d_w_z, 0, sizeof(float) * (size_t)D * Z, st);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(d_b_z, 0, sizeof(float) * (size_t)D, st);
-  if (e != hipSuccess) return (int)e;
-  const int b_chunk = 64;
-  hipLaunchKernelGGL(zproj_bwd_dw_kernel, dim3((D + 255) / 256, (B + b_chunk - 1) / b_chunk), dim3(256), 0, st, dh0, z,
-                     d_w_z, d_b_z, B, Z, D, b_chunk);
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(d_w_z, 0, sizeof(float) * (size_t)D * Z, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(d_b_z, 0, sizeof(float) * (size_t)D, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int b_chunk = 128;
+  dim3 grid((D + 63) / 64, (B + b_chunk - 1) / b_chunk);
+#define ARK_ZDW(ZT) hipLaunchKernelGGL(zproj_bwd_dw_kernel<ZT>, grid, dim3(256), (size_t)(b_chunk * ZT + 256) * sizeof(float), st, dh0, z, d_w_z, d_b_z, B, Z, D, b_chunk)
+  if (Z <= 16) ARK_ZDW(16);
+  else if (Z <= 32) ARK_ZDW(32);
+  else if (Z <= 64) ARK_ZDW(64);
+  else ARK_ZDW(128);
+#undef ARK_ZDW
   ARK_LAUNCH_CHECK();
   return 0;
 }

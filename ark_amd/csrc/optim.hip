@@ -122,10 +122,12 @@ extern "C" int ark_adam_step(float* p, const float* g, float* m, float* v, int64
 }
 
 extern "C" int ark_colsum(const float* x, int64_t ld, int64_t batch_stride_in, float* out, int64_t batch_stride_out,
-                          int M, int N, int n_batch, void* stream) {
+                          int M, int N, int n_batch, int accumulate, void* stream) {
   if (!x || !out || M <= 0 || N <= 0 || n_batch <= 0) return ARK_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (n_batch == 1 || batch_stride_out == N) {
+  if (accumulate) {
+    // out already holds the value to add to (e.g. the zeroed gradient buffer)
+  } else if (n_batch == 1 || batch_stride_out == N) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N * n_batch, st);
     if (e != hipSuccess) return (int)e;
   } else {

@@ -290,8 +290,9 @@ class Engine:
               L.i32(acc), L.cur_stream())
 
     def _colsum(self, X, ld, out, M, N, n_batch=1, bs_in=0, bs_out=0):
+        # gradients accumulate into G, which backward() zeroes once up front
         _call("ark_colsum", L.ptr(X), L.i64(ld), L.i64(bs_in), L.ptr(out), L.i64(bs_out if n_batch > 1 else N), L.i32(M),
-              L.i32(N), L.i32(n_batch), L.cur_stream())
+              L.i32(N), L.i32(n_batch), L.i32(1), L.cur_stream())
 
     # ------------------------------------------------------------------ forward
     def forward(self, triples, seq, eps=None, with_loss=True, with_dlogits=True, L_run=None, ce_count=None):
@@ -454,38 +455,37 @@ class Engine:
         seq = self._seq
         ld_seq = seq.shape[1]
         use_drop = self.training and self.p_drop > 0
+        # ONE fill of the flat gradient buffer; every reduction below (split-K weight gradients, bias
+        # column sums, embedding scatters) then accumulates into it without its own memset launch
+        self.G.zero_()
         if w["v2"]:
             dX0 = self._backward_decoder_v2(w, B, Lq, seq, use_drop)
         else:
             dX0 = self._backward_decoder_v1(w, B, Lq, seq, use_drop)
-        if not self.layout.tied:
-            g["dec.tok_emb.weight"].zero_()
         _call("ark_tok_scatter", L.ptr(seq), L.i64(ld_seq), L.ptr(dX0), L.ptr(g["dec.tok_emb.weight"]), L.i32(B), L.i32(Lq),
               L.i32(D), L.i32(V), st)
         if self.mt == "ARK":
             gp = g["dec.pos_emb.weight"]
-            if Lq < gp.shape[0]:
-                gp[Lq:].zero_()
             self._colsum(dX0, D, gp, B, D, n_batch=Lq, bs_in=B * D, bs_out=D)
             return
         # latent path
         H = 3 * D
         h0rm = w["h0"] if w["v2"] else w["Y"][0]   # row-major h0 (the v2 state buffers are tile-native)
         _call("ark_zproj_bwd", L.ptr(w["dH0"]), L.ptr(h0rm), L.ptr(w["z"]), L.ptr(p["dec.z_proj.weight"]),
-              L.ptr(w["dz"]), L.ptr(g["dec.z_proj.weight"]), L.ptr(g["dec.z_proj.bias"]), L.i32(B), L.i32(Z), L.i32(D), st)
+              L.ptr(w["dz"]), L.ptr(g["dec.z_proj.weight"]), L.ptr(g["dec.z_proj.bias"]), L.i32(B), L.i32(Z), L.i32(D), L.i32(1), st)
         _call("ark_latent_bwd", L.ptr(w["dz"]), L.ptr(w["head"]), L.ptr(self._eps), L.ptr(self.hyper), L.ptr(w["dhead"]),
               L.i32(B), L.i32(Z), st)
         if ext_dhead is not None:
             w["dhead"].add_(ext_dhead)
         self._colsum(w["dhead"], 2 * Z, g["enc.mu.bias"], B, 2 * Z)
-        self._gemm(MM, MM, L.EPI_NONE, w["dhead"], 2 * Z, w["act"][n - 1], H, g["enc.mu.weight"], H, 2 * Z, H, B)
+        self._gemm(MM, MM, L.EPI_NONE, w["dhead"], 2 * Z, w["act"][n - 1], H, g["enc.mu.weight"], H, 2 * Z, H, B, acc=1)
         self._gemm(KM, MM, L.EPI_MUL_DGELU, w["dhead"], 2 * Z, p["enc.mu.weight"], H, w["dA"], H, B, H, 2 * Z,
                    aux=w["pre"][n - 1])
         dpre, other = w["dA"], w["dB"]
         for i in range(n - 1, -1, -1):
             inp = w["act"][i - 1] if i > 0 else w["g"]
             self._colsum(dpre, H, g[f"enc.mlp.{2 * i}.bias"], B, H)
-            self._gemm(MM, MM, L.EPI_NONE, dpre, H, inp, H, g[f"enc.mlp.{2 * i}.weight"], H, H, H, B)
+            self._gemm(MM, MM, L.EPI_NONE, dpre, H, inp, H, g[f"enc.mlp.{2 * i}.weight"], H, H, H, B, acc=1)
             if i > 0:
                 self._gemm(KM, MM, L.EPI_MUL_DGELU, dpre, H, p[f"enc.mlp.{2 * i}.weight"], H, other, H, B, H, H,
                            aux=w["pre"][i - 1])
@@ -493,8 +493,6 @@ class Engine:
                 self._gemm(KM, MM, L.EPI_NONE, dpre, H, p[f"enc.mlp.{2 * i}.weight"], H, other, H, B, H, H)
             dpre, other = other, dpre
         dg = dpre
-        g["enc.e_emb.weight"].zero_()
-        g["enc.r_emb.weight"].zero_()
         _call("ark_enc_pool_bwd", L.ptr(self._triples), L.ptr(dg), L.ptr(w["inv_cnt"]), L.ptr(g["enc.e_emb.weight"]),
               L.ptr(g["enc.r_emb.weight"]), L.i32(B), L.i32(T), L.i32(D), L.i32(g["enc.e_emb.weight"].shape[0]),
               L.i32(g["enc.r_emb.weight"].shape[0]), L.i64(-1 if self.pad_eid is None else self.pad_eid),
@@ -511,7 +509,7 @@ class Engine:
         ytop = w["Y"][n - 1][B:]
         # tied vocabulary projection
         self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
-        self._gemm(MM, MM, L.EPI_NONE, dlog, self.ldl, ytop, D, g["dec.out.weight"], D, V, D, R)
+        self._gemm(MM, MM, L.EPI_NONE, dlog, self.ldl, ytop, D, g["dec.out.weight"], D, V, D, R, acc=1)
         self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dYa"], D, R, D, V)
         dy, dy_other = w["dYa"], w["dYb"]
         for l in range(n - 1, -1, -1):
@@ -530,8 +528,8 @@ class Engine:
                       L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
             drop_below = use_drop and l > 0
             xin = w["X0"] if l == 0 else (w["Ydrop"][l - 1] if drop_below else w["Y"][l - 1][B:])
-            self._gemm(MM, MM, L.EPI_NONE, dGH, 3 * D, Y, D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R)
-            self._gemm(MM, MM, L.EPI_NONE, dGI, 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)
+            self._gemm(MM, MM, L.EPI_NONE, dGH, 3 * D, Y, D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R, acc=1)
+            self._gemm(MM, MM, L.EPI_NONE, dGI, 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R, acc=1)
             self._colsum(dGI, 3 * D, g[f"dec.gru.bias_ih_l{l}"], R, 3 * D)
             self._colsum(dGH, 3 * D, g[f"dec.gru.bias_hh_l{l}"], R, 3 * D)
             self._gemm(KM, MM, L.EPI_MUL_AUX if drop_below else L.EPI_NONE, dGI, 3 * D, p[f"dec.gru.weight_ih_l{l}"], D,
@@ -552,7 +550,7 @@ class Engine:
         yb = lambda l: (w["Y16b"][l] if w["Y16b"][l] is not None else w["Y16a"][l])
         self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
         _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dlog), L.i32(0), L.i64(self.ldl), L.ptr(yb(n - 1)[B:]), L.i32(1), L.i64(D),
-              L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(V), L.i32(D), L.i32(R), st)
+              L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(V), L.i32(D), L.i32(R), L.i32(1), st)
         # dY of the top layer: K = V is not a multiple of 64 -> register-staged engine, then re-tile
         self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
         _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
@@ -578,11 +576,11 @@ class Engine:
             else:
                 xin = yb(l - 1)[B:]
             _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGH), L.i32(1), L.i64(3 * D), L.ptr(yb(l)), L.i32(1), L.i64(D),
-                  L.ptr(g[f"dec.gru.weight_hh_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), st)
+                  L.ptr(g[f"dec.gru.weight_hh_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), L.i32(1), st)
             _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGI), L.i32(1), L.i64(3 * D), L.ptr(xin), L.i32(1), L.i64(D),
-                  L.ptr(g[f"dec.gru.weight_ih_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), st)
-            _call("ark_colsum16", L.i32(pb), L.ptr(dGI), L.i64(3 * D), L.ptr(g[f"dec.gru.bias_ih_l{l}"]), L.i32(R), L.i32(3 * D), st)
-            _call("ark_colsum16", L.i32(pb), L.ptr(dGH), L.i64(3 * D), L.ptr(g[f"dec.gru.bias_hh_l{l}"]), L.i32(R), L.i32(3 * D), st)
+                  L.ptr(g[f"dec.gru.weight_ih_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), L.i32(1), st)
+            _call("ark_colsum16", L.i32(pb), L.ptr(dGI), L.i64(3 * D), L.ptr(g[f"dec.gru.bias_ih_l{l}"]), L.i32(R), L.i32(3 * D), L.i32(1), st)
+            _call("ark_colsum16", L.i32(pb), L.ptr(dGH), L.i64(3 * D), L.ptr(g[f"dec.gru.bias_hh_l{l}"]), L.i32(R), L.i32(3 * D), L.i32(1), st)
             # input gradient: dgi [R,3D] x W_ih^T-shadow [D,3D]; tile-native for the layer below,
             # row-major for the embedding scatter
             out = dy_other if l > 0 else w["dX0"]

@@ -103,10 +103,10 @@ int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16,
                const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* stream);
 /* C[M,N] = sum_k A[k,M] B[k,N]: weight gradients with fp32 or 16-bit stored operands */
 int ark_gemm_wgrad(int prec, const void* A, int a_is16, int64_t lda, const void* B, int b_is16, int64_t ldb, float* C,
-                   int64_t ldc, int M, int N, int K, void* stream);
+                   int64_t ldc, int M, int N, int K, int accumulate, void* stream);
 int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,
                      const float* w_pos, void* x16a, void* x16b, int B, int L, int D, void* stream);
-int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, void* stream);
+int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, int accumulate, void* stream);
 int ark_cast16(int prec, const float* x, void* out, int64_t n, void* stream);
 int ark_to_tiled(const float* x, float* out, int rows, int ld, void* stream);
 
@@ -129,7 +129,7 @@ int ark_latent_bwd(const float* dz, const float* head, const float* eps, const f
 int ark_zproj_fwd(const float* z, const float* w_z, const float* b_z, float* h0, int64_t copy_stride, int n_copies,
                   int B, int Z, int D, void* stream);
 int ark_zproj_bwd(float* dh0, const float* h0, const float* z, const float* w_z, float* dz, float* d_w_z,
-                  float* d_b_z, int B, int Z, int D, void* stream);
+                  float* d_b_z, int B, int Z, int D, int accumulate, void* stream);
 int ark_count_targets(const int64_t* seq, int64_t ld_seq, int B, int L, float* hyper, void* stream);
 /* rows are time-major (t,b); target of row (t,b) is seq[b, t+1]; dlogits may alias logits or be NULL */
 int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int64_t ld_seq, const float* hyper,
@@ -142,8 +142,9 @@ int ark_argmax_rows(const float* x, int64_t ld, int64_t* out, int rows, int V, v
 /* ---- optimiser and reductions (reference: optim.Adam, ablation_study.py:571,76) ---------------- */
 int ark_adam_tick(float* hyper, void* stream);
 int ark_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, void* stream);
+/* accumulate != 0: add into `out` (caller zeroed it, e.g. the whole gradient buffer at once) */
 int ark_colsum(const float* x, int64_t ld, int64_t batch_stride_in, float* out, int64_t batch_stride_out, int M,
-               int N, int n_batch, void* stream);
+               int N, int n_batch, int accumulate, void* stream);
 int ark_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, const float* hyper, void* stream);
 int ark_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
 
