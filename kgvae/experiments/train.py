@@ -1,0 +1,325 @@
+"""Training entry point:  python -m kgvae.experiments.train --config configs/<file>.yaml
+
+Keeps the reference's CLI, flat-YAML schema, vocabulary layout, epoch loop, logging keys and
+checkpoint format (reference kgvae/experiments/train.py:241-624) and -- like the reference's
+ablation_study.py:549-591 -- dispatches on `model_type`, so `model_type: SAIL` trains the VAE with
+`loss = ce + b*kl` and the beta0->beta1 schedule while `model_type: ARK` trains the decoder-only model.
+The step itself (forward, ELBO, backward, Adam) runs on the MI355X engine (ark_amd.engine).
+
+Differences that are deliberate:
+  * `wandb` and `intelligraphs` are optional: without them metrics go to stdout / metrics.jsonl,
+    data falls back to synthetic IntelliGraphs-shaped graphs, semantic verification is skipped;
+  * whole splits are tokenised once per epoch (GraphSeqDataset.tensorize) instead of per item;
+  * launched under torchrun it trains data-parallel (one process per GPU, RCCL all-reduce);
+  * extra optional keys: precision (mixed|bf16|f16|f32), synthetic_sizes, max_steps_per_epoch.
+"""
+import argparse
+import json
+import math
+import os
+import time
+import uuid
+import warnings
+
+import torch
+import yaml
+
+from ark_amd import dp
+from ark_amd.datasets import load_data_as_list
+from kgvae.model.models import ARK, SAIL
+from kgvae.model.utils import GraphSeqDataset, ints_to_labels, seq_to_triples
+from kgvae.model.verification import get_verifier, run_semantic_evaluation
+
+
+class _Tracker:
+    """wandb when installed, else a local stand-in with the same init/log/finish surface"""
+
+    def __init__(self, project, entity, config, name, run_root, enabled=True):
+        self.wandb = None
+        self.config = {}
+        if enabled:
+            try:
+                import wandb
+                kw = dict(project=project, config=config, name=name, anonymous="allow")
+                if entity:
+                    kw["entity"] = entity
+                wandb.init(**kw)
+                self.wandb = wandb
+                self.config = dict(wandb.config)
+                self.run_id = wandb.run.id
+            except Exception:
+                self.wandb = None
+        if self.wandb is None:
+            self.run_id = uuid.uuid4().hex[:8]
+        self._file = None
+        self._root = run_root
+
+    def open_local(self, run_dir):
+        if self.wandb is None:
+            self._file = open(os.path.join(run_dir, "metrics.jsonl"), "a")
+
+    def log(self, d):
+        if self.wandb is not None:
+            self.wandb.log(d)
+        elif self._file is not None:
+            self._file.write(json.dumps(d) + "\n")
+            self._file.flush()
+
+    def finish(self):
+        if self.wandb is not None:
+            self.wandb.finish()
+        elif self._file is not None:
+            self._file.close()
+
+
+def cosine_lr(base_lr, epoch, t_max, eta_min):
+    """closed form of CosineAnnealingLR stepped once per epoch (reference train.py:452-457, 561-563)"""
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * epoch / t_max)) / 2
+
+
+def iterate_batches(tri, seq, batch_size, shuffle, drop_last, generator=None):
+    n = seq.shape[0]
+    order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
+    stop = (n // batch_size) * batch_size if drop_last else n
+    for i in range(0, stop, batch_size):
+        idx = order[i:i + batch_size]
+        yield (tri[idx] if tri is not None else None), seq[idx]
+
+
+def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), max_steps=None):
+    """one pass over the training split; returns epoch means of (loss, recon, kl, 0) over batches,
+    as the reference's train_epoch does (ablation_study.py:31-88)."""
+    model.train()
+    rank, nranks = world
+    tri, seq = dataset.tensorize()   # redraws the per-graph permutations, like a fresh DataLoader pass
+    sums = torch.zeros(4, device=device)
+    nb = 0
+    sync = dp.make_grad_sync(nranks)
+    for tb, sb in iterate_batches(tri, seq, config["batch_size"], config["shuffle_train"], True):
+        ce_count = dp.count_targets(sb, config["special_tokens"]["PAD"])
+        if nranks > 1:
+            tb, sb = dp.shard(tb, rank, nranks), dp.shard(sb, rank, nranks)
+        tb = tb.to(device, non_blocking=True)
+        sb = sb.to(device, non_blocking=True)
+        out4 = model.train_step(tb, sb, beta=b, lr=lr, grad_sync=sync, ce_count=ce_count)
+        sums += out4
+        nb += 1
+        if max_steps and nb >= max_steps:
+            break
+    if nranks > 1:
+        import torch.distributed as dist
+        dist.all_reduce(sums)    # token-loss sums add up; ce/loss are re-derived below
+    s = sums.tolist()
+    if nb == 0:
+        return 0.0, 0.0, 0.0, 0.0
+    if nranks > 1:
+        # every rank divides its token-loss sum by the GLOBAL count, so the per-rank ce values add up
+        # to the global ce; kl_mean is a per-rank mean over equal shards, so the global kl is their mean
+        ce, kl = s[1] / nb, s[2] / nb / nranks
+        return ce + b * kl, ce, kl, 0.0
+    return s[0] / nb, s[1] / nb, s[2] / nb, 0.0
+
+
+@torch.no_grad()
+def validate(model, dataset, config, device, compute_compression=False, b=1.0, special_tokens=None):
+    """mean loss / recon / kl over validation batches (+ compression bits when asked),
+    reference train.py:74-129 / ablation_study.py:92-187"""
+    model.eval()
+    tri, seq = dataset.tensorize()
+    tot = torch.zeros(4, device=device)
+    nb = 0
+    for tb, sb in iterate_batches(tri, seq, config["batch_size"], False, False):
+        tot += model.eval_loss(tb.to(device), sb.to(device), beta=b)
+        nb += 1
+    t = (tot / max(nb, 1)).tolist()
+    res = [t[0], t[1], t[2], 0.0]
+    if compute_compression:
+        bits = model.posterior_bits(dataset, device, pad_id=config["special_tokens"]["PAD"],
+                                    sample_frac=config.get("sample_frac", 0.1))
+        res += [bits["avg_total_bits"], bits["avg_kl_bits"], bits["avg_ar_bits"], 0.0]
+    return tuple(res)
+
+
+def save_checkpoint(path, epoch, model, config, val_loss, vocabs, dataset_meta, lr):
+    """same dict layout and legacy serialisation as the reference (train.py:566-591)"""
+    eng = model.engine()
+    names = [k for k, _ in model.named_parameters()]
+    opt_state = {"state": {i: {"step": torch.tensor(float(eng.adam_steps)),
+                               "exp_avg": eng.M[o:o + n].view(sh).clone(),
+                               "exp_avg_sq": eng.Vv[o:o + n].view(sh).clone()}
+                           for i, (o, sh, n) in enumerate(eng.layout.entries[k] for k in names)},
+                 "param_groups": [{"lr": lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                                   "params": list(range(len(names)))}]}
+    ckpt = {"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+            "optimizer_state_dict": opt_state, "scheduler_state_dict": {"last_epoch": epoch, "_last_lr": [lr]},
+            "val_loss": val_loss, "config": {k: v for k, v in config.items()}, "vocabs": vocabs, "dataset_meta": dataset_meta}
+    torch.save(ckpt, path, _use_new_zipfile_serialization=False)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, required=True, help="Path to config file")
+    ap.add_argument("--wandb-project", type=str, default="submission", help="Weights & Biases project name")
+    ap.add_argument("--wandb-entity", type=str, default=None, help="Weights & Biases entity")
+    ap.add_argument("--checkpoint-dir", type=str, default="checkpoints", help="Directory to save checkpoints")
+    args = ap.parse_args(argv)
+
+    with open(args.config, "r") as f:
+        config = yaml.safe_load(f)
+    rank, local_rank, nranks = dp.init()
+    main_rank = rank == 0
+    model_type = config.get("model_type", "ARK")
+
+    tracker = _Tracker(args.wandb_project, args.wandb_entity or os.getenv("WANDB_ENTITY"), config,
+                       config.get("experiment_name", "ARK_experiment"), args.checkpoint_dir, enabled=main_rank)
+    for k, v in tracker.config.items():   # sweep overrides (reference train.py:252-273)
+        config[k] = v
+    config["learning_rate"] = float(config.get("learning_rate", 1e-3))
+    run_dir = os.path.join(args.checkpoint_dir, tracker.run_id)
+    if main_rank:
+        os.makedirs(run_dir, exist_ok=True)
+        tracker.open_local(run_dir)
+        with open(os.path.join(run_dir, "effective_config.yaml"), "w") as f:
+            yaml.safe_dump(config, f)
+    best_comp_bits = 1e12
+    tracker.log({"objective": best_comp_bits})
+
+    if not torch.cuda.is_available():
+        raise SystemExit("kgvae.experiments.train needs an AMD GPU: the model runs on hand-written gfx950 kernels only")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if config.get("use_test_for_final_eval", False):
+        warnings.warn("Test set evaluation ENABLED! Only use for final evaluation, NOT for hyperparameter tuning!",
+                      UserWarning, stacklevel=2)
+
+    dataset_name = config["dataset"]
+    sizes = config.get("synthetic_sizes") or {}
+    (train_g, val_g, test_g, (e2i, i2e), (r2i, i2r), (min_edges, max_edges), _) = load_data_as_list(dataset_name, **sizes)
+    num_entities, num_relations = len(e2i), len(r2i)
+    use_padding = config.get("use_padding", dataset_name.startswith("wd-"))
+    if use_padding:
+        PAD_EID, PAD_RID = num_entities, num_relations
+        num_entities += 1
+        num_relations += 1
+    else:
+        PAD_EID = PAD_RID = None
+    special_tokens = {"PAD": 0, "BOS": 1, "EOS": 2}
+    ENT_BASE = 3
+    REL_BASE = ENT_BASE + num_entities
+    VOCAB_SIZE = REL_BASE + num_relations
+    seq_len = 1 + max_edges * 3 + 1
+
+    def make_ds(graphs):
+        return GraphSeqDataset(graphs=graphs, i2e=i2e, i2r=i2r, triple_order=config["triple_order"],
+                               permute=config.get("permute_triples", False), use_padding=use_padding, pad_eid=PAD_EID,
+                               pad_rid=PAD_RID, max_triples=max_edges, special_tokens=special_tokens, ent_base=ENT_BASE,
+                               rel_base=REL_BASE, seq_len=seq_len)
+
+    train_ds, val_ds, test_ds = make_ds(train_g), make_ds(val_g), make_ds(test_g)
+    config.update({"n_entities": num_entities, "n_relations": num_relations, "pad_eid": PAD_EID, "pad_rid": PAD_RID,
+                   "seq_len": seq_len, "vocab_size": VOCAB_SIZE, "special_tokens": special_tokens, "ENT_BASE": ENT_BASE,
+                   "REL_BASE": REL_BASE})
+    if main_rank:
+        print(f"Dataset: {dataset_name}")
+        print(f"Entities: {len(e2i)}, Relations: {len(r2i)}")
+        print(f"Train batches: {len(train_ds) // config['batch_size']}, Val batches: {math.ceil(len(val_ds) / config['batch_size'])}")
+    verifier = get_verifier(dataset_name)
+    if verifier is None and main_rank:
+        print(f"Warning: No verifier available for dataset {dataset_name}")
+
+    if model_type == "ARK":
+        model = ARK(config).to(device)
+    elif model_type == "SAIL":
+        model = SAIL(config).to(device)
+    else:
+        raise NotImplementedError(f"Model type '{model_type}' is not implemented. Use one of: 'ARK','SAIL'.")
+    if main_rank:
+        print(f"Using model: {model_type}")
+    eng = model.engine()
+    eng.world_size = nranks
+
+    base_lr = config["learning_rate"]
+    use_sched = bool(config.get("lr_scheduler", False))
+    eta_min = config.get("eta_min", 1e-6)
+    num_epochs = config["num_epochs"]
+    vocabs = {"e2i": e2i, "i2e": i2e, "r2i": r2i, "i2r": i2r}
+    dataset_meta = {"dataset": dataset_name, "n_entities": len(i2e), "n_relations": len(i2r)}
+    best_val_loss = float("inf")
+
+    for epoch in range(num_epochs):
+        if main_rank:
+            print(f"\nEpoch {epoch + 1}/{num_epochs}")
+        b = 1
+        if model_type == "SAIL":
+            b = config["beta0"] + (config["beta1"] - config["beta0"]) * epoch / num_epochs
+        lr = cosine_lr(base_lr, epoch, num_epochs, eta_min) if use_sched else base_lr
+        t0 = time.time()
+        train_loss, train_recon, train_kl, _ = train_epoch(model, train_ds, config, device, b, lr, (rank, nranks),
+                                                           config.get("max_steps_per_epoch"))
+        dt = time.time() - t0
+        do_comp = ((epoch + 1) % int(config.get("compression_log_every", 5)) == 0)
+        if not main_rank:
+            continue
+        val = validate(model, val_ds, config, device, compute_compression=do_comp, b=b, special_tokens=special_tokens)
+        val_loss, val_recon, val_kl = val[:3]
+        if do_comp and len(val) == 8:
+            tracker.log({"val/compression_bits": val[4], "val/compression_kl_bits": val[5],
+                         "val/compression_edge_bits": val[6], "val/compression_entity_bits": val[7]})
+            if math.isfinite(float(val[4])) and float(val[4]) < best_comp_bits:
+                best_comp_bits = float(val[4])
+        tracker.log({"objective": best_comp_bits})
+        log = {"epoch": epoch + 1, "train/loss": train_loss, "train/reconstruction_loss": train_recon,
+               "val/loss": val_loss, "val/reconstruction_loss": val_recon, "learning_rate": lr,
+               "train/graphs_per_sec": (len(train_ds) // config["batch_size"]) * config["batch_size"] / max(dt, 1e-9)}
+        if model_type == "SAIL":
+            log["train/kl_loss"], log["val/kl_loss"] = train_kl, val_kl
+
+        if verifier and (epoch + 1) % config.get("verify_every", 10) == 0:
+            target_n = config.get("num_generated_latent_graphs", 1000)
+            if model_type == "SAIL":
+                zs = torch.randn(target_n, config["d_latent"], device=device)
+                graphs = model.decode_latent(zs, seq_len, special_tokens, seq_to_triples, ENT_BASE, REL_BASE, beam=1)
+            else:
+                chunks = []
+                while sum(c.size(0) for c in chunks) < target_n:
+                    chunks.append(model.generate(seq_len, special_tokens, device=device, batch_size=50, beam=1, sample=True,
+                                                 temperature=config.get("temperature", 1.0), top_p=config.get("top_p", 0.9),
+                                                 top_k=config.get("top_k", 0)).cpu())
+                rows = torch.cat(chunks, 0)[:target_n]
+                graphs = [seq_to_triples(r, special_tokens, ENT_BASE, REL_BASE) for r in rows]
+            labels = ints_to_labels(graphs, i2e, i2r)
+            ev = run_semantic_evaluation(labels, train_g, i2e, i2r, verifier, title=f"{model_type} samples")
+            res = ev.organized_results["results"]
+            tracker.log({"verification/validity_rate": res.get("semantics", 0.0) / 100.0,
+                         "verification/novelty_rate": res.get("novel", 0.0) / 100.0,
+                         "verification/valid_novelty_rate": res.get("novel_semantics", 0.0) / 100.0})
+        tracker.log(log)
+        print(f"Train Loss: {train_loss:.4f} (Recon: {train_recon:.4f})  [{log['train/graphs_per_sec']:.0f} graphs/s]")
+        print(f"Val   Loss: {val_loss:.4f} (Recon: {val_recon:.4f})")
+
+        if val_loss < best_val_loss:
+            best_val_loss = val_loss
+            save_checkpoint(os.path.join(run_dir, f"{dataset_name}_{model_type}_best_model.pt"), epoch + 1, model, config,
+                            val_loss, vocabs, dataset_meta, lr)
+            print(f"Saved best model with validation loss: {val_loss:.4f}")
+        if (epoch + 1) % config.get("save_every", 10) == 0:
+            save_checkpoint(os.path.join(run_dir, f"{dataset_name}_{model_type}_checkpoint_epoch_{epoch + 1}.pt"), epoch + 1,
+                            model, config, val_loss, vocabs, dataset_meta, lr)
+
+    if main_rank:
+        final = {}
+        for split, ds in (("val", val_ds),) + ((("test", test_ds),) if config.get("use_test_for_final_eval", False) else ()):
+            r = validate(model, ds, config, device, compute_compression=True, b=1.0, special_tokens=special_tokens)
+            final.update({f"final_{split}/loss": r[0], f"final_{split}/reconstruction_loss": r[1],
+                          f"final_{split}/kl_loss": r[2], f"final_{split}/compression_bits": r[4]})
+        tracker.log(final)
+        tracker.finish()
+        print("\nTraining and evaluation completed!")
+    if nranks > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

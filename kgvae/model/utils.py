@@ -1,0 +1,133 @@
+"""Data adaptation for the ARK / SAIL training path (drop-in for the reference module of the same
+import path: kgvae/model/utils.py).  Same public names and semantics:
+
+    triples_to_seq      reference kgvae/model/utils.py:102-108
+    seq_to_triples      reference kgvae/model/utils.py:70-78
+    ints_to_labels      reference kgvae/model/utils.py:81-94
+    canonicalize        reference kgvae/model/utils.py:96-99
+    canonical_graph_string  reference kgvae/model/utils.py:66-67
+    GraphSeqDataset     reference kgvae/model/utils.py:112-146
+
+plus `GraphSeqDataset.tensorize()`, which builds the whole split once as two int64 arrays so a
+GPU step measured in milliseconds is not starved by per-item Python.
+Unlike the reference module, importing this file does not require `intelligraphs`.
+"""
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+SPECIAL_TOKENS = {"PAD": 0, "BOS": 1, "EOS": 2}
+
+
+def canonical_graph_string(graph):
+    """order-independent text key of a graph (list of triples)"""
+    return str(sorted(graph))
+
+
+def seq_to_triples(seq, special_tokens, ENT_BASE, REL_BASE):
+    """token sequence -> list of (h, r, t) ids.  Position 0 (BOS) is skipped; triples are read three
+    tokens at a time and reading stops at the first EOS found at a triple boundary, or when fewer
+    than three tokens remain."""
+    toks = seq.tolist() if torch.is_tensor(seq) else list(seq)
+    eos = special_tokens["EOS"]
+    out = []
+    pos = 1
+    while pos + 2 < len(toks):
+        if toks[pos] == eos:
+            break
+        out.append((toks[pos] - ENT_BASE, toks[pos + 1] - REL_BASE, toks[pos + 2] - ENT_BASE))
+        pos += 3
+    return out
+
+
+def ints_to_labels(graphs, i2e, i2r):
+    """id triples -> label triples; triples with an unknown id are dropped (and counted)"""
+    labelled, dropped = [], 0
+    for graph in graphs:
+        keep = []
+        for h, r, t in graph:
+            if (h in i2e) and (r in i2r) and (t in i2e):
+                keep.append((i2e[h], i2r[r], i2e[t]))
+            else:
+                dropped += 1
+        labelled.append(keep)
+    if dropped:
+        print(f"[!] Skipped {dropped} invalid triples")
+    return labelled
+
+
+def canonicalize(triples, i2e=None, i2r=None, mode="keep"):
+    """`keep` leaves the dataset order; any other mode sorts by (head, relation, tail) labels"""
+    if mode == "keep":
+        return triples
+    return sorted(triples, key=lambda tr: (i2e[tr[0]], i2r[tr[1]], i2e[tr[2]]))
+
+
+def triples_to_seq(triples, special_tokens, ENT_BASE, REL_BASE, seq_len):
+    """[BOS, (ENT_BASE+h, REL_BASE+r, ENT_BASE+t) per triple, EOS, PAD ...] as a long tensor"""
+    body = []
+    for h, r, t in triples:
+        body.extend((ENT_BASE + h, REL_BASE + r, ENT_BASE + t))
+    toks = [special_tokens["BOS"], *body, special_tokens["EOS"]]
+    toks.extend([special_tokens["PAD"]] * (seq_len - len(toks)))
+    return torch.tensor(toks, dtype=torch.long)
+
+
+class GraphSeqDataset(Dataset):
+    """items are (triples long[T,3], seq long[seq_len]); same constructor as the reference."""
+
+    def __init__(self, graphs, i2e, i2r, triple_order="keep", permute=False, use_padding=False, pad_eid=None,
+                 pad_rid=None, max_triples=None, special_tokens=None, ent_base=None, rel_base=None, seq_len=None):
+        self.graphs = [canonicalize(g, i2e, i2r, triple_order) for g in graphs]
+        self.permute = permute
+        self.use_padding = use_padding
+        self.pad_eid, self.pad_rid = pad_eid, pad_rid
+        self.max_triples = max_triples
+        self.special_tokens = special_tokens if special_tokens is not None else dict(SPECIAL_TOKENS)
+        self.ent_base, self.rel_base = ent_base, rel_base
+        self.seq_len = seq_len
+
+    def __len__(self):
+        return len(self.graphs)
+
+    def _ordered(self, idx):
+        triples = self.graphs[idx]
+        # the per-item permutation draws from Python's `random` (not torch), and only without padding
+        if self.permute and not self.use_padding:
+            triples = random.sample(triples, k=len(triples))
+        return triples
+
+    def __getitem__(self, idx):
+        triples = self._ordered(idx)
+        if self.use_padding:
+            fill = [(self.pad_eid, self.pad_rid, self.pad_eid)] * (self.max_triples - len(triples))
+            t3 = torch.tensor(list(triples) + fill, dtype=torch.long)
+        else:
+            t3 = torch.tensor(triples, dtype=torch.long)
+        return t3, triples_to_seq(triples, self.special_tokens, self.ent_base, self.rel_base, self.seq_len)
+
+    def tensorize(self, indices=None):
+        """(triples [N,T,3], seq [N,seq_len]) for `indices` (default: all) in one pass.  Draws the same
+        `random.sample` permutations, in the same order, as N successive __getitem__ calls."""
+        idx = range(len(self.graphs)) if indices is None else indices
+        n = len(idx)
+        st = self.special_tokens
+        T = self.max_triples if self.use_padding else (len(self.graphs[idx[0]]) if n else 0)
+        tri = np.empty((n, T, 3), dtype=np.int64)
+        seq = np.full((n, self.seq_len), st["PAD"], dtype=np.int64)
+        seq[:, 0] = st["BOS"]
+        for row, i in enumerate(idx):
+            g = self._ordered(i)
+            k = len(g)
+            if not self.use_padding and k != T:
+                raise ValueError("graphs of different sizes need use_padding=True to be batched")
+            if k:
+                a = np.asarray(g, dtype=np.int64)
+                tri[row, :k] = a
+                seq[row, 1:1 + 3 * k] = (a + np.array([self.ent_base, self.rel_base, self.ent_base])).reshape(-1)
+            if self.use_padding:
+                tri[row, k:] = (self.pad_eid, self.pad_rid, self.pad_eid)
+            seq[row, 1 + 3 * k] = st["EOS"]
+        return torch.from_numpy(tri), torch.from_numpy(seq)

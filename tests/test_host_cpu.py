@@ -1,0 +1,143 @@
+"""CPU-only checks of the host side: C-ABI surface, parameter layout / state-dict compatibility,
+init-order compatibility, data codec, config schema, and loud failure without a GPU."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _golden(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    return z, json.loads(str(z["cfg_json"]))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """every function declared in include/ark_amd.h is exported by the built library"""
+    hdr = open(os.path.join(ROOT, "include", "ark_amd.h")).read()
+    names = sorted(set(re.findall(r"^int\s+(ark_\w+)\s*\(", hdr, flags=re.M)))
+    assert len(names) >= 30
+    lib = ctypes.CDLL(os.path.join(ROOT, "ark_amd", "lib", "libark_amd.so"))
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.ark_version() >= 100
+
+
+def test_argument_errors_are_negative_codes_without_touching_the_gpu():
+    lib = ctypes.CDLL(os.path.join(ROOT, "ark_amd", "lib", "libark_amd.so"))
+    assert lib.ark_set_tuning(99, 0) < 0
+    assert lib.ark_set_dma_ring(3, 3) < 0
+    null = ctypes.c_void_p(0)
+    assert lib.ark_adam_step(null, null, null, null, ctypes.c_int64(0), null, null) < 0
+
+
+@pytest.mark.parametrize("name", ["sail_tiny", "sail_tiny_pad", "ark_tiny"])
+def test_state_dict_keys_order_and_init_match_reference(name):
+    """same keys in the same order as the reference's state_dict, same initial values under the seed"""
+    from kgvae.model.models import ARK, SAIL
+    z, cfg = _golden(name)
+    ref_keys = [k[3:] for k in z.files if k.startswith("w0/")]
+    torch.manual_seed(int(z["seed"]))
+    model = (SAIL if cfg["model_type"] == "SAIL" else ARK)(cfg)
+    sd = model.state_dict()
+    assert list(sd.keys()) == ref_keys
+    for k in ref_keys:
+        assert np.array_equal(sd[k].numpy(), z["w0/" + k]), k
+    assert sd["dec.out.weight"].data_ptr() == sd["dec.tok_emb.weight"].data_ptr()
+
+
+def test_param_layout_is_aligned_and_heads_are_adjacent():
+    from ark_amd.engine import ParamLayout
+    _, cfg = _golden("sail_tiny")
+    lay = ParamLayout(cfg)
+    e = lay.entries
+    for name, (off, shape, numel) in e.items():
+        assert numel == int(np.prod(shape))
+    assert e["enc.logv.weight"][0] == e["enc.mu.weight"][0] + e["enc.mu.weight"][2]   # one [2Z,3D] block
+    assert e["enc.logv.bias"][0] == e["enc.mu.bias"][0] + e["enc.mu.bias"][2]
+    assert e["enc.mu.weight"][0] % 4 == 0 and lay.total % 4 == 0
+    assert "dec.out.weight" not in e   # tied to dec.tok_emb.weight
+    # a constant stride between layers lets one launch refresh every layer's weight shadows
+    assert (e["dec.gru.weight_hh_l2"][0] - e["dec.gru.weight_hh_l1"][0]) == (e["dec.gru.weight_hh_l1"][0] - e["dec.gru.weight_hh_l0"][0])
+
+
+def test_model_refuses_to_run_on_cpu():
+    from ark_amd import ArkError
+    from kgvae.model.models import SAIL
+    _, cfg = _golden("sail_tiny")
+    m = SAIL(cfg)
+    with pytest.raises(ArkError):
+        m(torch.zeros(2, 3, 3, dtype=torch.long), torch.ones(2, 10, dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        SAIL(dict(cfg, model_type="t-SAIL"))
+    with pytest.raises(NotImplementedError):
+        SAIL(dict(cfg, model_type="nope"))
+    with pytest.raises(KeyError):
+        SAIL({"model_type": "SAIL"})
+
+
+def test_codec_and_dataset_match_reference_vectors():
+    from kgvae.model import utils as U
+    st = {"PAD": 0, "BOS": 1, "EOS": 2}
+    for c in json.load(open(os.path.join(GOLD, "codec.json"))):
+        if c["triples"] is not None:
+            assert U.triples_to_seq([tuple(t) for t in c["triples"]], st, 3, 13, len(c["seq"])).tolist() == c["seq"]
+        assert [list(t) for t in U.seq_to_triples(torch.tensor(c["seq"]), st, 3, 13)] == c["decoded"]
+    # golden batches were produced by the reference's GraphSeqDataset: rebuild them from the triples
+    for name in ["sail_tiny", "sail_tiny_pad"]:
+        z, cfg = _golden(name)
+        tri = z["triples"]
+        graphs = []
+        for b in range(tri.shape[0]):
+            graphs.append([tuple(int(x) for x in t) for t in tri[b] if cfg["pad_rid"] is None or t[1] != cfg["pad_rid"]])
+        ds = U.GraphSeqDataset(graphs, None, None, use_padding=cfg["pad_rid"] is not None, pad_eid=cfg["pad_eid"],
+                               pad_rid=cfg["pad_rid"], max_triples=cfg["max_triples"], special_tokens=st,
+                               ent_base=cfg["ENT_BASE"], rel_base=cfg["REL_BASE"], seq_len=cfg["seq_len"])
+        t, s = ds.tensorize()
+        assert np.array_equal(t.numpy(), tri) and np.array_equal(s.numpy(), z["seq"])
+        t0, s0 = ds[0]
+        assert np.array_equal(t0.numpy(), tri[0]) and np.array_equal(s0.numpy(), z["seq"][0])
+    assert U.canonical_graph_string([(2, 0, 1), (1, 0, 2)]) == U.canonical_graph_string([(1, 0, 2), (2, 0, 1)])
+    assert U.ints_to_labels([[(0, 0, 1), (9, 0, 1)]], {0: "a", 1: "b"}, {0: "r"}) == [[("a", "r", "b")]]
+
+
+def test_shipped_configs_carry_the_reference_schema():
+    keys = {"model_type", "d_model", "d_latent", "n_heads", "n_layers", "batch_size", "learning_rate", "num_epochs", "beta0",
+            "beta1", "dataset", "shuffle_train", "use_padding", "triple_order", "permute_triples", "num_diversity_samples",
+            "num_generated_test_graphs", "num_generated_latent_graphs", "sample_frac", "beam_width", "lr_scheduler",
+            "save_every", "resume_from_checkpoint", "checkpoint_path", "verify_every", "experiment_name",
+            "use_test_for_final_eval", "compression_log_every"}
+    cdir = os.path.join(ROOT, "configs")
+    files = [f for f in os.listdir(cdir) if f.endswith(".yaml")]
+    assert len(files) == 5
+    for f in files:
+        cfg = yaml.safe_load(open(os.path.join(cdir, f)))
+        assert keys <= set(cfg), (f, keys - set(cfg))
+        assert cfg["model_type"] in ("SAIL", "ARK")
+
+
+def test_synthetic_dataset_has_the_intelligraphs_tuple_shape():
+    from ark_amd.datasets import synthetic_as_list
+    tr, va, te, (e2i, i2e), (r2i, i2r), (lo, hi), _ = synthetic_as_list("wd-movies", n_train=20, n_val=5, n_test=5)
+    assert len(tr) == 20 and len(va) == 5 and len(te) == 5
+    assert all(lo <= len(g) <= hi for g in tr)
+    assert all(0 <= h < len(e2i) and 0 <= r < len(r2i) and 0 <= t < len(e2i) for g in tr for h, r, t in g)
+    assert i2e[e2i["e3"]] == "e3" and i2r[r2i["r1"]] == "r1"
+
+
+def test_schedules_match_torch():
+    from kgvae.experiments.train import cosine_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10, eta_min=1e-6)
+    for ep in range(10):
+        assert abs(opt.param_groups[0]["lr"] - cosine_lr(1e-3, ep, 10, 1e-6)) < 1e-10
+        opt.step()
+        sch.step()

@@ -1,0 +1,150 @@
+"""GPU tests of the drop-in module API (kgvae.model.models, kgvae.experiments.train)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+import yaml
+
+from tests.parity_util import load_golden, weights_from, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(name, precision="f32"):
+    from kgvae.model.models import ARK, SAIL
+    z, cfg = load_golden(name)
+    cfg = dict(cfg, precision=precision)
+    torch.manual_seed(int(z["seed"]))
+    m = (SAIL if cfg["model_type"] == "SAIL" else ARK)(cfg).to("cuda")
+    return m, z, cfg
+
+
+@pytest.mark.parametrize("name", ["sail_tiny", "sail_small_pad"])
+def test_reference_style_training_loop(name):
+    """the reference's own loop -- model(...), F.cross_entropy, kl_mean, loss.backward(), optim.Adam --
+    runs unchanged on the engine-backed module and reproduces the reference's numbers."""
+    model, z, cfg = _model(name)
+    dev = "cuda"
+    triples, seq = torch.from_numpy(z["triples"]).to(dev), torch.from_numpy(z["seq"]).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=float(z["lr"]))
+    model.train()
+    for s in range(len(z["losses"])):
+        opt.zero_grad()
+        logits, mu, logv = model(triples, seq[:, :-1], eps=torch.from_numpy(z[f"eps{s}"]).to(dev))
+        ce = F.cross_entropy(logits.reshape(-1, logits.size(-1)), seq[:, 1:].reshape(-1), ignore_index=0)
+        kl = model.kl_mean(mu, logv)
+        loss = ce + float(z["betas"][s]) * kl
+        loss.backward()
+        if s == 0:
+            np.testing.assert_allclose(logits.detach().cpu().numpy(), z["logits0"], rtol=2e-4, atol=5e-5)
+            for k, p in model.named_parameters():
+                want = z["g0/" + k]
+                assert np.abs(p.grad.cpu().numpy() - want).max() <= 2e-4 * np.abs(want).max() + 1e-7, k
+        opt.step()
+        assert rel_err(loss.item(), z["losses"][s][0]) < 2e-5, (s, loss.item(), z["losses"][s])
+    assert model.state_dict()["dec.out.weight"].data_ptr() == model.state_dict()["dec.tok_emb.weight"].data_ptr()
+
+
+def test_ark_reference_style_loop():
+    model, z, cfg = _model("ark_tiny")
+    seq = torch.from_numpy(z["seq"]).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=float(z["lr"]))
+    for s in range(len(z["losses"])):
+        opt.zero_grad()
+        logits = model(seq[:, :-1])
+        ce = F.cross_entropy(logits.reshape(-1, logits.size(-1)), seq[:, 1:].reshape(-1), ignore_index=0)
+        ce.backward()
+        opt.step()
+        assert rel_err(ce.item(), z["losses"][s][0]) < 2e-5
+    assert model(torch.zeros(4, 3, 3, dtype=torch.long).cuda(), seq[:, :-1]).shape == (4, cfg["seq_len"] - 1, cfg["vocab_size"])
+
+
+@pytest.mark.parametrize("name", ["sail_small", "ark_tiny"])
+def test_fused_train_step_matches_golden(name):
+    model, z, cfg = _model(name)
+    triples, seq = torch.from_numpy(z["triples"]).cuda(), torch.from_numpy(z["seq"]).cuda()
+    for s in range(len(z["losses"])):
+        eps = torch.from_numpy(z[f"eps{s}"]).cuda() if cfg["model_type"] == "SAIL" else None
+        out4 = model.train_step(triples, seq, beta=float(z["betas"][s]), lr=float(z["lr"]), eps=eps)
+        assert rel_err(float(out4[0]), z["losses"][s][0]) < 2e-5, (s, out4, z["losses"][s])
+    sd = model.state_dict()
+    for k in sd:   # parameters alias the engine buffer, so state_dict() is live
+        want = z[f"w{len(z['losses'])}/" + k]
+        bad = np.abs(sd[k].cpu().numpy() - want) > (1e-4 * np.abs(want) + 5e-6)
+        assert bad.mean() <= 2e-3, k
+
+
+def test_decode_latent_and_beam():
+    from kgvae.model.utils import seq_to_triples
+    model, z, cfg = _model("sail_small")
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in
+                           ((f[3:], z[f]) for f in z.files if f.startswith(f"w{len(z['losses'])}/"))})
+    zs = torch.from_numpy(z["dec_z"])
+    st = cfg["special_tokens"]
+    got = model.decode_latent(zs, cfg["seq_len"], st, seq_to_triples, cfg["ENT_BASE"], cfg["REL_BASE"], beam=1)
+    for i, tr in enumerate(got):
+        n = int(z["dec_ntriples"][i])
+        assert [list(t) for t in tr] == z["dec_triples"][i, :n].tolist()
+    wide = model.decode_latent(zs, cfg["seq_len"], st, seq_to_triples, cfg["ENT_BASE"], cfg["REL_BASE"], beam=3)
+    assert len(wide) == zs.shape[0]
+    uniq = model.count_unique_graphs(cfg["d_latent"], lambda zz, beam: model.decode_latent(
+        zz, cfg["seq_len"], st, seq_to_triples, cfg["ENT_BASE"], cfg["REL_BASE"], beam=beam), num_samples=32, beam=1)
+    assert 1 <= len(uniq) <= 32
+
+
+def test_posterior_bits_is_the_teacher_forced_nll():
+    """ARK.posterior_bits (single pass) equals the oracle's per-sequence token NLL in bits"""
+    from oracle import sail_oracle as O
+    from kgvae.model.utils import GraphSeqDataset
+    model, z, cfg = _model("ark_tiny")
+    seq = torch.from_numpy(z["seq"])
+    graphs = [[tuple(int(x) for x in t) for t in g] for g in z["triples"]]
+    ds = GraphSeqDataset(graphs, None, None, special_tokens=cfg["special_tokens"], ent_base=cfg["ENT_BASE"],
+                         rel_base=cfg["REL_BASE"], seq_len=cfg["seq_len"])
+    stats = model.posterior_bits(ds, "cuda", sample_frac=1.0)
+    P = O.init_params(cfg, int(z["seed"]))
+    with torch.no_grad():
+        logits = O.ark_forward(P, seq[:, :-1], cfg)
+        nll = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), seq[:, 1:].reshape(-1), ignore_index=0,
+                              reduction="none").reshape(seq.shape[0], -1).sum(1) / math.log(2)
+    got = np.array([r["ar_bits"] for r in stats["records"]])
+    np.testing.assert_allclose(got, nll.numpy(), rtol=2e-5)
+    assert stats["avg_kl_bits"] == 0.0
+
+
+def test_ark_generate_shapes_and_sampling():
+    model, z, cfg = _model("ark_tiny")
+    st = cfg["special_tokens"]
+    g = model.generate(cfg["seq_len"], st, batch_size=5)
+    assert g.shape == (5, cfg["seq_len"]) and bool((g[:, 0] == st["BOS"]).all())
+    torch.manual_seed(0)
+    s = model.generate(cfg["seq_len"], st, batch_size=6, sample=True, temperature=0.8, top_p=0.9, top_k=5)
+    assert s.shape == (6, cfg["seq_len"]) and int(s.max()) < cfg["vocab_size"]
+
+
+@pytest.mark.parametrize("model_type", ["SAIL", "ARK"])
+def test_train_entry_point_end_to_end(tmp_path, model_type):
+    """python -m kgvae.experiments.train on synthetic syn-paths-shaped data: 2 epochs, loss goes down,
+    checkpoints are written in the reference's format."""
+    from kgvae.experiments import train as T
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "sail_syn-paths.yaml")))
+    cfg.update(model_type=model_type, d_model=64, num_epochs=2, batch_size=64, save_every=2, compression_log_every=2,
+               learning_rate=1e-3, synthetic_sizes={"n_train": 512, "n_val": 128, "n_test": 64})
+    cpath = tmp_path / "c.yaml"
+    yaml.safe_dump(cfg, open(cpath, "w"))
+    T.main(["--config", str(cpath), "--checkpoint-dir", str(tmp_path / "ck")])
+    run = os.listdir(tmp_path / "ck")[0]
+    files = os.listdir(tmp_path / "ck" / run)
+    assert f"syn-paths_{model_type}_best_model.pt" in files and f"syn-paths_{model_type}_checkpoint_epoch_2.pt" in files
+    assert "effective_config.yaml" in files
+    ck = torch.load(tmp_path / "ck" / run / f"syn-paths_{model_type}_best_model.pt", weights_only=False)
+    assert {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "val_loss", "config", "vocabs",
+            "dataset_meta"} <= set(ck)
+    assert "dec.out.weight" in ck["model_state_dict"] and "dec.gru.weight_hh_l2" in ck["model_state_dict"]
+    import json
+    rows = [json.loads(l) for l in open(tmp_path / "ck" / run / "metrics.jsonl")]
+    ep = [r for r in rows if "train/loss" in r]
+    assert len(ep) == 2 and ep[1]["train/loss"] < ep[0]["train/loss"]
