@@ -39,6 +39,15 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   return cdf + x * pdf;
 }
 
+// XCD-aware workgroup remap (MI355X: 8 XCDs, private 4 MB L2 each; workgroups are dealt round-robin
+// over XCDs, so ids b and b+8 share an L2).  Gives each XCD a CONTIGUOUS range of logical tile ids
+// so neighbouring tiles -- which share an operand panel -- hit the same L2.  Bijective for any grid
+// size; placement is a speed matter only, never correctness.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 }  // namespace ark
 
 // Error plumbing for the C-ABI: 0 = ok, >0 = hipError_t, <0 = argument error.

@@ -22,7 +22,8 @@ template <int PREC, int ALAY, int BLAY, int BM, int BN, int ASRC16 = 0, int BSRC
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   using G = GemmTile<PREC, ALAY, BLAY, BM, BN, 2, 2, ASRC16, BSRC16>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int M = p.M, N = p.N;
   f32x4 acc[G::TM][G::TN];

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
   using G = DmaTile<PREC, BM, BN, NBUF, 2, 2>;
   using h_t = typename G::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int m0 = (blockIdx.x / p.tiles_n) * BM, n0 = (blockIdx.x % p.tiles_n) * BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
   const int M = p.M, N = p.N;
   f32x4 acc[G::TM][G::TN];
   G::run(acc, reinterpret_cast<const h_t*>(p.A), p.lda, [=](int r) -> long { return (long)min(m0 + r, M - 1); },
