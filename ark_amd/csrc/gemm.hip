@@ -8,6 +8,7 @@
 namespace ark {
 
 static int g_split_k_enabled = 1;
+static int g_wgrad_tile128 = 0;  // 1: weight-gradient products use 128x128 tiles + deeper split-K
 
 struct GemmArgs {
   const float* A; const float* B; float* C; float* C2; const float* bias; const float* aux;
@@ -67,10 +68,24 @@ static int launch_gemm(GemmArgs p, hipStream_t st) {
   constexpr int BK = PrecTraits<PREC>::BK;
   p.split_k = 1;
   p.k_chunk = p.K;
-  if (t128 >= 192) {
+  const bool long_k = p.epi == ARK_EPI_NONE && g_split_k_enabled && p.K >= 16 * BK;
+  if (t128 >= 192 || (g_wgrad_tile128 && long_k && t128 >= 16)) {
     p.tiles_n = (p.N + 127) / 128;
+    if (t128 < 192) {
+      int split = 1;
+      while (t128 * split < 768 && p.K / (split * 2) >= 4 * BK && split < 64) split *= 2;
+      if (split > 1) {
+        p.k_chunk = ((p.K + split - 1) / split + BK - 1) / BK * BK;
+        p.split_k = (p.K + p.k_chunk - 1) / p.k_chunk;
+        if (!p.accumulate) {
+          hipError_t e = (p.ldc == p.N) ? hipMemsetAsync(p.C, 0, sizeof(float) * (size_t)p.M * p.N, st)
+                                        : hipMemset2DAsync(p.C, sizeof(float) * p.ldc, 0, sizeof(float) * p.N, p.M, st);
+          if (e != hipSuccess) return (int)e;
+        }
+      }
+    }
     using G = GemmTile<PREC, ALAY, BLAY, 128, 128, 2, 2, ASRC16, BSRC16>;
-    hipLaunchKernelGGL((gemm_kernel<PREC, ALAY, BLAY, 128, 128, ASRC16, BSRC16>), dim3((unsigned)t128), dim3(256), G::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_kernel<PREC, ALAY, BLAY, 128, 128, ASRC16, BSRC16>), dim3((unsigned)t128, (unsigned)p.split_k), dim3(256), G::LDS_BYTES, st, p);
   } else {
     p.tiles_n = (p.N + 63) / 64;
     const long t64 = (long)((p.M + 63) / 64) * p.tiles_n;
@@ -114,6 +129,10 @@ static int dispatch_lay(int a_lay, int b_lay, const GemmArgs& p, hipStream_t st)
 // tuning / test knob: 0 disables split-K (bitwise run-to-run reproducible weight gradients)
 extern "C" int ark_set_split_k(int enabled) {
   ark::g_split_k_enabled = enabled ? 1 : 0;
+  return 0;
+}
+extern "C" int ark_set_wgrad_tile128(int enabled) {
+  ark::g_wgrad_tile128 = enabled ? 1 : 0;
   return 0;
 }
 

@@ -61,20 +61,28 @@ static void allow_lds16(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+int g_g16_nbuf = 2;     // ring depth of the 128x128 tile (2 -> 64 KB LDS, two workgroups per CU)
+int g_g16_force64 = 1;  // 1: always use 64x64 tiles
+
+template <int PREC, int BM, int BN, int NBUF>
+static void launch16_cfg(Gemm16Args p, hipStream_t st) {
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2>;
+  static bool once = (allow_lds16(gemm16_kernel<PREC, BM, BN, NBUF>, G::LDS_BYTES), true); (void)once;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const long tiles = (long)((p.M + BM - 1) / BM) * p.tiles_n;
+  hipLaunchKernelGGL((gemm16_kernel<PREC, BM, BN, NBUF>), dim3((unsigned)tiles), dim3(256), G::LDS_BYTES, st, p);
+}
+
 template <int PREC>
 static int launch16(Gemm16Args p, hipStream_t st) {
   const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  if (t128 >= 192) {
-    using G = DmaTile<PREC, 128, 128, 4, 2, 2>;
-    static bool once = (allow_lds16(gemm16_kernel<PREC, 128, 128, 4>, G::LDS_BYTES), true); (void)once;
-    p.tiles_n = (p.N + 127) / 128;
-    hipLaunchKernelGGL((gemm16_kernel<PREC, 128, 128, 4>), dim3((unsigned)t128), dim3(256), G::LDS_BYTES, st, p);
+  if (t128 >= 192 && !g_g16_force64) {
+    if (g_g16_nbuf == 2) launch16_cfg<PREC, 128, 128, 2>(p, st);
+    else if (g_g16_nbuf == 3) launch16_cfg<PREC, 128, 128, 3>(p, st);
+    else launch16_cfg<PREC, 128, 128, 4>(p, st);
   } else {
-    using G = DmaTile<PREC, 64, 64, 4, 2, 2>;
-    static bool once = (allow_lds16(gemm16_kernel<PREC, 64, 64, 4>, G::LDS_BYTES), true); (void)once;
-    p.tiles_n = (p.N + 63) / 64;
-    const long t64 = (long)((p.M + 63) / 64) * p.tiles_n;
-    hipLaunchKernelGGL((gemm16_kernel<PREC, 64, 64, 4>), dim3((unsigned)t64), dim3(256), G::LDS_BYTES, st, p);
+    if (g_g16_nbuf == 2) launch16_cfg<PREC, 64, 64, 2>(p, st);
+    else launch16_cfg<PREC, 64, 64, 4>(p, st);
   }
   ARK_LAUNCH_CHECK();
   return 0;
@@ -143,6 +151,14 @@ __global__ __launch_bounds__(256) void to_tiled_kernel(const float* __restrict__
 }
 
 }  // namespace ark
+
+// speed-only knobs of the LDS-DMA GEMM: ring depth {2,3,4}; force 64x64 tiles
+extern "C" int ark_set_gemm16_tuning(int nbuf, int force64) {
+  if (nbuf < 2 || nbuf > 4) return ARK_ERR_ARG;
+  ark::g_g16_nbuf = nbuf;
+  ark::g_g16_force64 = force64 ? 1 : 0;
+  return 0;
+}
 
 extern "C" int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
                           int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled,

@@ -232,7 +232,7 @@ static void allow_lds(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int g_fwd_nbuf = 8, g_bwd_nbuf = 8;
+int g_fwd_nbuf = 4, g_bwd_nbuf = 4;
 
 template <int PREC, int PRECB, int NBUF>
 static void launch_fwd_nb(const GruFwdDmaArgs& p, hipStream_t st) {

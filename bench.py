@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--tuning", default="", help="speed-only kernel knobs, e.g. '1=32,2=1' (ark_set_tuning)")
     ap.add_argument("--no-splitk", action="store_true")
+    ap.add_argument("--knobs", default="", help="speed-only knobs: ring=F:B,g16=NBUF:FORCE64,wg128=0|1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,6 +174,11 @@ def main():
         L.check(L.lib().ark_set_tuning(int(k), int(v)), "ark_set_tuning")
     if args.no_splitk:
         L.lib().ark_set_split_k(0)
+    for kv in filter(None, args.knobs.split(",")):   # e.g. ring=8:8,g16=2:0,wg128=1
+        k, v = kv.split("=")
+        vals = [int(x) for x in v.split(":")]
+        fn = {"ring": L.lib().ark_set_dma_ring, "g16": L.lib().ark_set_gemm16_tuning, "wg128": L.lib().ark_set_wgrad_tile128}[k]
+        L.check(fn(*vals), k)
 
     cfg = build_cfg(args.dropout)
     B = args.batch
