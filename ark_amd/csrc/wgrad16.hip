@@ -1,0 +1,255 @@
+// Weight-gradient products on the LDS-DMA ring with hardware-transposed fragment reads:
+//     C[M,N] += sum_k A16[k, M] * B16[k, N]          (K = B*L tokens, both operands reduction-MAJOR)
+// i.e. dW = dgate^T x activation straight from the row-major 16-bit panels the GRU cells wrote.
+// LDS-DMA cannot transpose, so the stage image stays [k][m] (m contiguous, as in memory) and the
+// MFMA fragments are fetched with ds_read_b64_tr_b16, which hands each lane one COLUMN (fixed m)
+// of a 4(k) x 16(m) block -- two of them give the 8 consecutive k an MFMA 16x16x32 lane needs.
+// A 32-byte-slot XOR keyed by k makes the 8 k-rows a half-wave touches land on distinct bank slots;
+// it is applied to the LDS-DMA SOURCE address (the DMA write itself is lane-linear).
+// Split-K over blockIdx.y with fp32 atomics into the (pre-zeroed / accumulating) gradient buffer.
+// Reference op replaced: autograd's weight gradients of nn.GRU / nn.Linear (kgvae/model/models.py:121-128).
+#include "dma_core.h"
+#include "../../include/ark_amd.h"
+
+namespace ark {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int RB>  // RB = bytes per k-row of the image (128 or 256)
+__device__ __forceinline__ int tr_sw(int k) {
+  if constexpr (RB == 128) return ((k >> 1) & 1) | (((k >> 3) & 1) << 1);   // 4 slots of 32 B
+  else return (k & 3) | (((k >> 3) & 1) << 2);                              // 8 slots of 32 B
+}
+
+struct Wgrad16Args {
+  const void* A; const void* B; float* C;
+  long lda, ldb, ldc;
+  int M, N, K, k_chunk, tiles_n, use_atomics;
+};
+// several independent products in ONE launch (e.g. dW_ih / dW_hh of every GRU layer at the end of
+// the backward pass): enough workgroups to fill the chip without deep split-K and its atomics
+constexpr int kMaxGroup = 8;
+struct Wgrad16Group {
+  Wgrad16Args p[kMaxGroup];
+  int tile_start[kMaxGroup + 1];
+  int n;
+};
+
+template <int PREC, int BT, int NBUF>   // square BT x BT output tile, 4 waves in 2x2
+__global__ __launch_bounds__(256) void wgrad16_kernel(Wgrad16Group grp) {
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < grp.n && (int)blockIdx.x >= grp.tile_start[i]) gi = i;
+  const Wgrad16Args p = grp.p[gi];
+  const int bid_raw = blockIdx.x - grp.tile_start[gi];
+  const int ntiles = grp.tile_start[gi + 1] - grp.tile_start[gi];
+  using PT = PrecTraits<PREC>;
+  using h_t = typename PT::h_t;
+  constexpr int RB = BT * 2;                 // bytes per k-row per operand
+  constexpr int LPR = RB / 16;               // lanes (16-B chunks) per k-row
+  constexpr int RPP = 64 / LPR;              // k-rows per 1-KB LDS-DMA piece
+  constexpr int PIECES = 64 / RPP;           // pieces per operand per stage
+  constexpr int PPW = PIECES / 4;            // pieces per wave per operand
+  constexpr int OP_BYTES = 64 * RB;
+  constexpr int STAGE = 2 * OP_BYTES;
+  constexpr int LPS = 2 * PPW;
+  constexpr int WT = BT / 2, T16 = WT / 16;  // wave tile, 16x16 tiles per wave per dim
+  static_assert((NBUF - 1) * LPS <= 63, "vmcnt");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = (grp.n == 1) ? xcd_remap(bid_raw, ntiles) : bid_raw;
+  const int m0 = (bid / p.tiles_n) * BT, n0 = (bid % p.tiles_n) * BT;
+  const int kb = blockIdx.y * p.k_chunk;
+  const int kend = min(p.K, kb + p.k_chunk);
+  const int NS = (kend - kb) / 64;
+
+  const h_t* A = reinterpret_cast<const h_t*>(p.A) + (long)kb * p.lda + m0;
+  const h_t* Bm = reinterpret_cast<const h_t*>(p.B) + (long)kb * p.ldb + n0;
+
+  // per-lane DMA source offsets (elements) for this wave's pieces; LDS image is lane-linear
+  long aoff[PPW], boff[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int piece = wave + 4 * i;
+    const int k = piece * RPP + lane / LPR;            // k-row inside the stage
+    const int pc = lane % LPR;                          // physical 16-B chunk
+    const int c = pc ^ (tr_sw<RB>(k) << 1);             // logical chunk
+    aoff[i] = (long)k * p.lda + 8 * c;
+    boff[i] = (long)k * p.ldb + 8 * c;
+  }
+  auto issue = [&](int s) {
+    char* base = smem + (s % NBUF) * STAGE;
+    const long ka = (long)s * 64 * p.lda, kbb = (long)s * 64 * p.ldb;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + ka + aoff[i]),
+                                       (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bm + kbb + boff[i]),
+                                       (__attribute__((address_space(3))) void*)(base + OP_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[T16][T16];
+#pragma unroll
+  for (int a = 0; a < T16; ++a)
+#pragma unroll
+    for (int b = 0; b < T16; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: lane = 16*g + 4*q + pp  ->  k-row 8g+q (+4), columns 4pp..4pp+3 of the 16-wide block
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  auto frag = [&](const char* op, int s2, int col0) -> typename PT::h8 {
+    const int k1 = 32 * s2 + 8 * g + q, k2 = k1 + 4;
+    const int cb = (col0 * 2) / 16 + (pp >> 1);         // logical 16-B chunk of this lane's 8 bytes
+    const int sub = (pp & 1) * 8;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(op + k1 * RB + ((cb ^ (tr_sw<RB>(k1) << 1)) << 4) + sub));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(op + k2 * RB + ((cb ^ (tr_sw<RB>(k2) << 1)) << 4) + sub));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(typename PT::h8, v);
+  };
+
+  if (NS > 0) {
+    const int pre = NS < NBUF ? NS : NBUF;
+    for (int s = 0; s < pre; ++s) issue(s);
+    for (int s = 0; s < NS; ++s) {
+      const int ahead = (NS - 1 - s) < (NBUF - 1) ? (NS - 1 - s) : (NBUF - 1);
+      switch (ahead) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF > 2 ? 2 : 0) * LPS) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF > 3 ? 3 : 0) * LPS) : "memory"); break;
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const char* opA = smem + (s % NBUF) * STAGE;
+      const char* opB = opA + OP_BYTES;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        typename PT::h8 a[T16], b[T16];
+#pragma unroll
+        for (int t = 0; t < T16; ++t) a[t] = frag(opA, s2, wm * WT + t * 16);
+#pragma unroll
+        for (int t = 0; t < T16; ++t) b[t] = frag(opB, s2, wn * WT + t * 16);
+#pragma unroll
+        for (int ta = 0; ta < T16; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < T16; ++tb) acc[ta][tb] = PT::mfma(a[ta], b[tb], acc[ta][tb]);
+      }
+      if (s + NBUF < NS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue(s + NBUF);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int ta = 0; ta < T16; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < T16; ++tb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wm * WT + ta * 16 + 4 * (lane >> 4) + i;
+        const int col = n0 + wn * WT + tb * 16 + (lane & 15);
+        float* c = p.C + (long)row * p.ldc + col;
+        if (p.use_atomics) atomicAdd(c, acc[ta][tb][i]);
+        else *c += acc[ta][tb][i];
+      }
+}
+
+template <class K>
+static void allow_lds_w(K kernel, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+int g_wg_tile = 128, g_wg_nbuf = 2, g_wg_target = 288;
+
+template <int PREC, int BT, int NBUF>
+static void launch_wg(Wgrad16Group& g, hipStream_t st) {
+  constexpr int LDS = NBUF * 2 * 64 * BT * 2;
+  static bool once = (allow_lds_w(wgrad16_kernel<PREC, BT, NBUF>, LDS), true); (void)once;
+  long tiles = 0;
+  int kmax = 0;
+  for (int i = 0; i < g.n; ++i) {
+    g.p[i].tiles_n = g.p[i].N / BT;
+    g.tile_start[i] = (int)tiles;
+    tiles += (long)(g.p[i].M / BT) * g.p[i].tiles_n;
+    if (g.p[i].K > kmax) kmax = g.p[i].K;
+  }
+  g.tile_start[g.n] = (int)tiles;
+  int split = 1;
+  while (tiles * split < g_wg_target && kmax / (split * 2) >= 256 && split < 64) split *= 2;
+  for (int i = 0; i < g.n; ++i) {
+    g.p[i].k_chunk = ((g.p[i].K + split - 1) / split + 63) / 64 * 64;
+    g.p[i].use_atomics = split > 1;
+  }
+  hipLaunchKernelGGL((wgrad16_kernel<PREC, BT, NBUF>), dim3((unsigned)tiles, (unsigned)split), dim3(256), LDS, st, g);
+}
+
+template <int PREC>
+static int launch_wg_prec(Wgrad16Group& g, hipStream_t st) {
+  bool ok128 = g_wg_tile == 128;
+  for (int i = 0; i < g.n; ++i) ok128 = ok128 && g.p[i].M % 128 == 0 && g.p[i].N % 128 == 0;
+  if (ok128) {
+    if (g_wg_nbuf == 2) launch_wg<PREC, 128, 2>(g, st); else launch_wg<PREC, 128, 3>(g, st);
+  } else {
+    if (g_wg_nbuf == 2) launch_wg<PREC, 64, 2>(g, st); else launch_wg<PREC, 64, 4>(g, st);
+  }
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ark
+
+// speed-only knobs: tile (64|128), ring depth, target workgroup count for the split-K heuristic
+extern "C" int ark_set_wgrad16_tuning(int tile, int nbuf, int target_wgs) {
+  if ((tile != 64 && tile != 128) || nbuf < 2 || nbuf > 4 || target_wgs < 1) return ARK_ERR_ARG;
+  ark::g_wg_tile = tile; ark::g_wg_nbuf = nbuf; ark::g_wg_target = target_wgs;
+  return 0;
+}
+
+static int check_one(const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int M, int N, int K) {
+  if (!A16 || !B16 || !C || M <= 0 || N <= 0 || K <= 0) return ARK_ERR_ARG;
+  if (M % 64 != 0 || N % 64 != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0) return ARK_ERR_SHAPE;
+  if (((uintptr_t)A16 | (uintptr_t)B16) & 15) return ARK_ERR_ALIGN;
+  return 0;
+}
+
+// C[M,N] += A16[K,M]^T B16[K,N]; requires M % 64 == N % 64 == K % 64 == 0, 16-byte aligned rows.
+extern "C" int ark_wgrad16(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
+                           int M, int N, int K, void* stream) {
+  using namespace ark;
+  int rc = check_one(A16, lda, B16, ldb, C, M, N, K);
+  if (rc) return rc;
+  Wgrad16Group g{};
+  g.n = 1;
+  g.p[0] = Wgrad16Args{A16, B16, C, (long)lda, (long)ldb, (long)ldc, M, N, K, K, 1, 0};
+  if (prec == PREC_F16) return launch_wg_prec<PREC_F16>(g, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch_wg_prec<PREC_BF16>(g, (hipStream_t)stream);
+  return ARK_ERR_ARG;
+}
+
+// n (<= 8) independent products of the kind above in ONE launch
+extern "C" int ark_wgrad16_group(int prec, int n, const void* const* A16, const int64_t* lda, const void* const* B16,
+                                 const int64_t* ldb, float* const* C, const int64_t* ldc, const int* M, const int* N,
+                                 const int* K, void* stream) {
+  using namespace ark;
+  if (n <= 0 || n > kMaxGroup || !A16 || !B16 || !C || !lda || !ldb || !ldc || !M || !N || !K) return ARK_ERR_ARG;
+  Wgrad16Group g{};
+  g.n = n;
+  for (int i = 0; i < n; ++i) {
+    int rc = check_one(A16[i], lda[i], B16[i], ldb[i], C[i], M[i], N[i], K[i]);
+    if (rc) return rc;
+    g.p[i] = Wgrad16Args{A16[i], B16[i], C[i], (long)lda[i], (long)ldb[i], (long)ldc[i], M[i], N[i], K[i], K[i], 1, 0};
+  }
+  if (prec == PREC_F16) return launch_wg_prec<PREC_F16>(g, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch_wg_prec<PREC_BF16>(g, (hipStream_t)stream);
+  return ARK_ERR_ARG;
+}

@@ -555,6 +555,7 @@ class Engine:
         self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
         _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
         dy, dy_other = w["dYa"], w["dYb"]
+        group = []
         for l in range(n - 1, -1, -1):
             Y = w["Y"][l]
             dGI, dGH = w["dGI16"][l], w["dGH16"][l]
@@ -575,10 +576,14 @@ class Engine:
                 xin = w["Yd16b"][l - 1] if w["Yd16b"][l - 1] is not None else w["Yd16a"][l - 1]
             else:
                 xin = yb(l - 1)[B:]
-            _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGH), L.i32(1), L.i64(3 * D), L.ptr(yb(l)), L.i32(1), L.i64(D),
-                  L.ptr(g[f"dec.gru.weight_hh_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), L.i32(1), st)
-            _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGI), L.i32(1), L.i64(3 * D), L.ptr(xin), L.i32(1), L.i64(D),
-                  L.ptr(g[f"dec.gru.weight_ih_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), L.i32(1), st)
+            if R % 64 == 0:   # deferred: all layers' weight gradients go out as ONE grouped launch below
+                group.append((dGH, 3 * D, yb(l), D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R))
+                group.append((dGI, 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R))
+            else:
+                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGH), L.i32(1), L.i64(3 * D), L.ptr(yb(l)), L.i32(1), L.i64(D),
+                      L.ptr(g[f"dec.gru.weight_hh_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), L.i32(1), st)
+                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGI), L.i32(1), L.i64(3 * D), L.ptr(xin), L.i32(1), L.i64(D),
+                      L.ptr(g[f"dec.gru.weight_ih_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), L.i32(1), st)
             _call("ark_colsum16", L.i32(pb), L.ptr(dGI), L.i64(3 * D), L.ptr(g[f"dec.gru.bias_ih_l{l}"]), L.i32(R), L.i32(3 * D), L.i32(1), st)
             _call("ark_colsum16", L.i32(pb), L.ptr(dGH), L.i64(3 * D), L.ptr(g[f"dec.gru.bias_hh_l{l}"]), L.i32(R), L.i32(3 * D), L.i32(1), st)
             # input gradient: dgi [R,3D] x W_ih^T-shadow [D,3D]; tile-native for the layer below,
@@ -588,7 +593,18 @@ class Engine:
                   L.ptr(self.wihT16[l]), L.i64(3 * D), L.ptr(out), L.i64(D), L.ptr(None),
                   L.ptr(w["mask"][l - 1] if drop_below else None), L.i32(R), L.i32(D), L.i32(3 * D), L.i32(1 if l > 0 else 0), st)
             dy, dy_other = dy_other, dy
+        for i0 in range(0, len(group), 8):
+            self._wgrad_group(group[i0:i0 + 8])
         return w["dX0"]
+
+    def _wgrad_group(self, items):
+        import ctypes
+        n = len(items)
+        vp = lambda k: (ctypes.c_void_p * n)(*[it[k].data_ptr() for it in items])
+        i64 = lambda k: (ctypes.c_int64 * n)(*[it[k] for it in items])
+        i32 = lambda k: (ctypes.c_int * n)(*[it[k] for it in items])
+        _call("ark_wgrad16_group", L.i32(self.prec_bwd), L.i32(n), vp(0), i64(1), vp(2), i64(3), vp(4), i64(5), i32(6), i32(7),
+              i32(8), L.cur_stream())
 
     # ------------------------------------------------------------------ optimiser
     def adam(self):

@@ -106,6 +106,14 @@ int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16,
 /* C[M,N] = sum_k A[k,M] B[k,N]: weight gradients with fp32 or 16-bit stored operands */
 int ark_gemm_wgrad(int prec, const void* A, int a_is16, int64_t lda, const void* B, int b_is16, int64_t ldb, float* C,
                    int64_t ldc, int M, int N, int K, int accumulate, void* stream);
+/* same product on the LDS-DMA ring with ds_read_b64_tr_b16 fragment reads; C += (accumulates);
+ * needs M, N, K multiples of 64 and both operands 16-bit */
+int ark_wgrad16(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc, int M,
+                int N, int K, void* stream);
+int ark_wgrad16_group(int prec, int n, const void* const* A16, const int64_t* lda, const void* const* B16,
+                      const int64_t* ldb, float* const* C, const int64_t* ldc, const int* M, const int* N, const int* K,
+                      void* stream);
+int ark_set_wgrad16_tuning(int tile, int nbuf, int target_wgs);
 int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,
                      const float* w_pos, void* x16a, void* x16b, int B, int L, int D, void* stream);
 int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, int accumulate, void* stream);

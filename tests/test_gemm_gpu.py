@@ -84,3 +84,26 @@ def test_gemm_bad_args():
                           L.ptr(None), L.i64(1), L.ptr(None), L.ptr(None), L.ptr(None), L.i32(1), L.i32(1), L.i32(1),
                           L.i32(0), L.cur_stream())
     assert rc < 0
+
+
+@pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_F16])
+@pytest.mark.parametrize("tile,nbuf", [(64, 4), (64, 2), (128, 3), (128, 2)])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (192, 128, 640), (1536, 512, 2048), (128, 256, 10240)])
+def test_wgrad16_tr_read_kernel(prec, tile, nbuf, shape):
+    """C += A^T B with both operands reduction-major 16-bit (LDS-DMA + ds_read_b64_tr_b16)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(5)
+    dt = torch.bfloat16 if prec == L.PREC_BF16 else torch.float16
+    A = torch.randn(K, M, generator=g).to(dt)
+    B = torch.randn(K, N, generator=g).to(dt)
+    C0 = torch.randn(M, N, generator=g)
+    dev = torch.device("cuda:0")
+    Ad, Bd, C = A.to(dev), B.to(dev), C0.to(dev).clone()
+    L.check(L.lib().ark_set_wgrad16_tuning(L.i32(tile), L.i32(nbuf), L.i32(512)), "tune")
+    L.check(L.lib().ark_wgrad16(L.i32(prec), L.ptr(Ad), L.i64(M), L.ptr(Bd), L.i64(N), L.ptr(C), L.i64(N), L.i32(M), L.i32(N),
+                                L.i32(K), L.cur_stream()), "ark_wgrad16")
+    torch.cuda.synchronize()
+    L.check(L.lib().ark_set_wgrad16_tuning(L.i32(64), L.i32(4), L.i32(1024)), "tune")
+    ref = C0.double() + A.double().t() @ B.double()
+    err = (C.cpu().double() - ref).abs().max().item()
+    assert err <= 3e-5 * (K ** 0.5) + 1e-4, err
