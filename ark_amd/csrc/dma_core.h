@@ -27,19 +27,21 @@ __device__ __forceinline__ long tile_native_off(int row, int col, int ld) {
   return ((long)(row >> 4) * (ld >> 4) + (col >> 4)) * 256 + ((((row >> 2) & 3) << 4) + (col & 15)) * 4 + (row & 3);
 }
 
-template <int PREC, int BM, int BN, int NBUF, int WGM, int WGN>
+template <int PREC, int BM, int BN, int NBUF, int WGM, int WGN, int KI = 1>
 struct DmaTile {
   static_assert(PREC == PREC_F16 || PREC == PREC_BF16, "LDS-DMA engine takes 16-bit operands");
   static_assert(BM % 32 == 0 && BN % 32 == 0, "tile shape");
   static_assert(WGM * WGN == 4, "4 waves");
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
-  // one pipeline stage = one 64-wide k-image of both operands; NBUF stages ride a ring in LDS
-  static constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;
+  // one pipeline stage = KI 64-wide k-images of both operands; NBUF stages ride a ring in LDS
+  static constexpr int KS = 64 * KI;
+  static constexpr int A_IMG = BM * 128, B_IMG = BN * 128;
+  static constexpr int A_STAGE = A_IMG * KI, B_STAGE = B_IMG * KI;
   static constexpr int STAGE_BYTES = A_STAGE + B_STAGE;
   static constexpr int LDS_BYTES = NBUF * STAGE_BYTES;
-  static constexpr int NPA = BM / 32, NPB = BN / 32;   // 1-KB LDS-DMA pieces per stage per wave
-  static constexpr int LPS = NPA + NPB;                // LDS-DMA instructions per stage per wave
+  static constexpr int NPA = BM / 32, NPB = BN / 32;   // 1-KB LDS-DMA pieces per image per wave
+  static constexpr int LPS = (NPA + NPB) * KI;         // LDS-DMA instructions per stage per wave
   static_assert((NBUF - 1) * LPS <= 63, "in-flight stages must fit the 6-bit vmcnt");
   static_assert(NBUF >= 2 && NBUF <= 8, "ring depth");
   static constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -86,15 +88,18 @@ struct DmaTile {
     }
     auto issue = [&](int s) {
       char* base = lds + (s % NBUF) * STAGE_BYTES;
-      const int k0 = s * 64;
 #pragma unroll
-      for (int i = 0; i < NPA; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap[i] + k0),
-                                         (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024), 16, 0, 0);
+      for (int j = 0; j < KI; ++j) {
+        const int k0 = s * KS + 64 * j;
 #pragma unroll
-      for (int i = 0; i < NPB; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp[i] + k0),
-                                         (__attribute__((address_space(3))) void*)(base + A_STAGE + (wave + 4 * i) * 1024), 16, 0, 0);
+        for (int i = 0; i < NPA; ++i)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap[i] + k0),
+                                           (__attribute__((address_space(3))) void*)(base + j * A_IMG + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NPB; ++i)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp[i] + k0),
+                                           (__attribute__((address_space(3))) void*)(base + A_STAGE + j * B_IMG + (wave + 4 * i) * 1024), 16, 0, 0);
+      }
     };
 
 #pragma unroll
@@ -102,7 +107,7 @@ struct DmaTile {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int NS = K / 64;  // host guarantees K % 64 == 0
+    const int NS = K / KS;  // host guarantees K % KS == 0
     if (NS <= 0) return;
     const int pre = NS < NBUF ? NS : NBUF;
     for (int s = 0; s < pre; ++s) issue(s);
@@ -115,14 +120,16 @@ struct DmaTile {
       const char* bufA = lds + (s % NBUF) * STAGE_BYTES;
       const char* bufB = bufA + A_STAGE;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
+      for (int s2 = 0; s2 < 2 * KI; ++s2) {
         typename PT::h8 a[TM], b[TN];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
-          a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + lds_off(wm * WTM + tm * 16 + lr, 4 * s2 + lq));
+          a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + (s2 >> 1) * A_IMG +
+                                                            lds_off(wm * WTM + tm * 16 + lr, 4 * (s2 & 1) + lq));
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
-          b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + lds_off(wn * WTN + tn * 16 + lr, 4 * s2 + lq));
+          b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + (s2 >> 1) * B_IMG +
+                                                            lds_off(wn * WTN + tn * 16 + lr, 4 * (s2 & 1) + lq));
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll

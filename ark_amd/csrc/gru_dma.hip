@@ -20,6 +20,7 @@ __device__ __forceinline__ f32x4 ld_half4(const _Float16* p) {
   const half4_t h = *reinterpret_cast<const half4_t*>(p);
   return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
+__device__ __forceinline__ f32x4 cv_half4(half4_t h) { return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}; }
 __device__ __forceinline__ void st_half4(_Float16* p, f32x4 v) {
   *reinterpret_cast<half4_t*>(p) = half4_t{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
 }
@@ -34,28 +35,40 @@ struct GruFwdDmaArgs {
   int B, D;
 };
 
-template <int PREC, int PRECB, int NBUF>
+template <int PREC, int PRECB, int NBUF, int KI>
 __global__ __launch_bounds__(256) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) {
   constexpr int BM = 32, BU = 32, BN = 3 * BU;
-  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2>;  // wave tile 16 x 48 (16 units x 3 gates)
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;  // wave tile 16 x 48 (16 units x 3 gates)
   using h_t = typename G::h_t;
   using hb_t = typename PrecTraits<PRECB>::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int units_tiles = p.D / BU;
   const int m0 = (blockIdx.x / units_tiles) * BM, u0 = (blockIdx.x % units_tiles) * BU;
   const int B = p.B, D = p.D;
-  f32x4 acc[G::TM][G::TN];
-  G::run(acc, reinterpret_cast<const h_t*>(p.h_prev16), D, [=](int r) -> long { return (long)min(m0 + r, B - 1); },
-         reinterpret_cast<const h_t*>(p.w_hh16), D,
-         [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); }, D, smem);
-
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ul = wn * 16 + (lane & 15);           // unit within the workgroup tile
   const int u = u0 + ul;
   const int rl = wm * 16 + 4 * (lane >> 4);       // first of this lane's 4 rows within the tile
   const int row0 = m0 + rl;
+  // Epilogue operands are requested BEFORE the recurrent product: they are older than every LDS-DMA
+  // op in the vmcnt queue, so they land underneath the main loop instead of after it.
+  const int rowc = min(row0, B - 4);              // B % 16 == 0: clamped quads stay in bounds
+  const long og = tile_native_off(rowc, u, 3 * D);
+  const long o = tile_native_off(rowc, u, D);
+  const f32x4 gr = *reinterpret_cast<const f32x4*>(p.gi + og);
+  const f32x4 gz = *reinterpret_cast<const f32x4*>(p.gi + og + (long)(D >> 4) * 256);
+  const f32x4 gn = *reinterpret_cast<const f32x4*>(p.gi + og + (long)(D >> 4) * 512);
+  const f32x4 hp = *reinterpret_cast<const f32x4*>(p.y_prev + o);
+  f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+  if (p.mask) mk = *reinterpret_cast<const f32x4*>(p.mask + o);
   const float bhr = p.b_hh[u], bhz = p.b_hh[D + u], bhn = p.b_hh[2 * D + u];
+
+  f32x4 acc[G::TM][G::TN];
+  G::run(acc, reinterpret_cast<const h_t*>(p.h_prev16), D, [=](int r) -> long { return (long)min(m0 + r, B - 1); },
+         reinterpret_cast<const h_t*>(p.w_hh16), D,
+         [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); }, D, smem);
+
   // the LDS ring is free now; reuse it to assemble row-major 16-bit rows [32][32+pad]
   __syncthreads();
   h_t* ta = reinterpret_cast<h_t*>(smem);                 // h        (forward type)
@@ -64,12 +77,6 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) 
   hb_t* tdb = reinterpret_cast<hb_t*>(smem + 12288);
   constexpr int TS = 40;  // row stride in elements (80 B: 16-B aligned rows, spreads banks)
   if (row0 < B) {
-    const long og = tile_native_off(row0, u, 3 * D);
-    const long o = tile_native_off(row0, u, D);
-    const f32x4 gr = *reinterpret_cast<const f32x4*>(p.gi + og);
-    const f32x4 gz = *reinterpret_cast<const f32x4*>(p.gi + og + (long)(D >> 4) * 256);
-    const f32x4 gn = *reinterpret_cast<const f32x4*>(p.gi + og + (long)(D >> 4) * 512);
-    const f32x4 hp = *reinterpret_cast<const f32x4*>(p.y_prev + o);
     f32x4 r, z, n, hn, h;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -81,8 +88,7 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) 
     }
     *reinterpret_cast<f32x4*>(p.y_out + o) = h;
     if (p.sr) { st_half4(p.sr + o, r); st_half4(p.sz + o, z); st_half4(p.sn + o, n); st_half4(p.shn + o, hn); }
-    f32x4 hd = h;
-    if (p.mask) hd = h * *reinterpret_cast<const f32x4*>(p.mask + o);
+    const f32x4 hd = h * mk;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ta[(rl + i) * TS + ul] = G::PT::cvt(h[i]);
@@ -121,24 +127,42 @@ struct GruBwdDmaArgs {
   int B, D, first, final_;
 };
 
-template <int PREC, int NBUF>
+template <int PREC, int NBUF, int KI>
 __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) {
   constexpr int BM = 32, BN = 64;
-  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2>;   // wave tile 16 x 32
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;   // wave tile 16 x 32
   using h_t = typename G::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = p.D / BN;
   const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
   const int B = p.B, D = p.D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int rl = wm * 16 + 4 * (lane >> 4);
+  const int row0 = m0 + rl;
+  // epilogue operands first (older than the LDS-DMA ops -> they land underneath the main loop)
+  const int rowc = min(row0, B - 4);
+  f32x4 pc[G::TN], pdy[G::TN], phy[G::TN];
+  half4_t psr[G::TN], psz[G::TN], psn[G::TN], phn[G::TN];
+#pragma unroll
+  for (int tn = 0; tn < G::TN; ++tn) {
+    const long o = tile_native_off(rowc, n0 + wn * 32 + tn * 16 + (lane & 15), D);
+    pc[tn] = p.first ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(p.carry + o);
+    pdy[tn] = (p.dy && !p.final_) ? *reinterpret_cast<const f32x4*>(p.dy + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!p.final_) {
+      phy[tn] = *reinterpret_cast<const f32x4*>(p.y_prev + o);
+      psr[tn] = *reinterpret_cast<const half4_t*>(p.sr + o);
+      psz[tn] = *reinterpret_cast<const half4_t*>(p.sz + o);
+      psn[tn] = *reinterpret_cast<const half4_t*>(p.sn + o);
+      phn[tn] = *reinterpret_cast<const half4_t*>(p.shn + o);
+    }
+  }
+
   f32x4 acc[G::TM][G::TN];
   G::run(acc, reinterpret_cast<const h_t*>(p.dgh_next16), 3L * D, [=](int r) -> long { return (long)min(m0 + r, B - 1); },
          reinterpret_cast<const h_t*>(p.w_hhT16), 3L * D, [=](int r) -> long { return (long)(n0 + r); },
          p.first ? 0 : 3 * D, smem);
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int rl = wm * 16 + 4 * (lane >> 4);
-  const int row0 = m0 + rl;
   __syncthreads();
   // LDS assembly of the six row-major 16-bit output panels: [gate 0..2][32 rows][64+8] for dgi and dgh
   constexpr int TS = 72;
@@ -150,8 +174,7 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) 
     const int u = n0 + ul;
     if (row0 >= B) continue;
     const long o = tile_native_off(row0, u, D);
-    f32x4 dh = acc[0][tn];
-    if (!p.first) dh += *reinterpret_cast<const f32x4*>(p.carry + o);
+    f32x4 dh = acc[0][tn] + pc[tn];
     if (p.final_) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -160,9 +183,9 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) 
       }
       continue;
     }
-    if (p.dy) dh += *reinterpret_cast<const f32x4*>(p.dy + o);
-    const f32x4 r = ld_half4(p.sr + o), z = ld_half4(p.sz + o), n = ld_half4(p.sn + o), hn = ld_half4(p.shn + o);
-    const f32x4 hp = *reinterpret_cast<const f32x4*>(p.y_prev + o);
+    dh += pdy[tn];
+    const f32x4 r = cv_half4(psr[tn]), z = cv_half4(psz[tn]), n = cv_half4(psn[tn]), hn = cv_half4(phn[tn]);
+    const f32x4 hp = phy[tn];
     f32x4 cz;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -232,37 +255,50 @@ static void allow_lds(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int g_fwd_nbuf = 4, g_bwd_nbuf = 4;
+int g_fwd_nbuf = 2, g_bwd_nbuf = 2;   // ring slots
+int g_fwd_ki = 2, g_bwd_ki = 2;       // 64-wide k-images per stage (1 | 2)
 
-template <int PREC, int PRECB, int NBUF>
+template <int PREC, int PRECB, int NBUF, int KI>
 static void launch_fwd_nb(const GruFwdDmaArgs& p, hipStream_t st) {
-  using G = DmaTile<PREC, 32, 96, NBUF, 2, 2>;
+  using G = DmaTile<PREC, 32, 96, NBUF, 2, 2, KI>;
   constexpr int LDS = G::LDS_BYTES > 16384 ? G::LDS_BYTES : 16384;
-  static bool once = (allow_lds(gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF>, LDS), true); (void)once;
+  static bool once = (allow_lds(gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF, KI>, LDS), true); (void)once;
   const unsigned grid = (unsigned)(((p.B + 31) / 32) * (p.D / 32));
-  hipLaunchKernelGGL((gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF>), dim3(grid), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF, KI>), dim3(grid), dim3(256), LDS, st, p);
 }
 template <int PREC, int PRECB>
 static int launch_fwd_dma(const GruFwdDmaArgs& p, hipStream_t st) {
-  if (g_fwd_nbuf == 8) launch_fwd_nb<PREC, PRECB, 8>(p, st);
-  else if (g_fwd_nbuf == 4) launch_fwd_nb<PREC, PRECB, 4>(p, st);
-  else launch_fwd_nb<PREC, PRECB, 2>(p, st);
+  const bool ki2 = g_fwd_ki == 2 && p.D % 128 == 0;
+  if (ki2) {
+    if (g_fwd_nbuf >= 4) launch_fwd_nb<PREC, PRECB, 4, 2>(p, st);
+    else launch_fwd_nb<PREC, PRECB, 2, 2>(p, st);
+  } else {
+    if (g_fwd_nbuf == 8) launch_fwd_nb<PREC, PRECB, 8, 1>(p, st);
+    else if (g_fwd_nbuf == 4) launch_fwd_nb<PREC, PRECB, 4, 1>(p, st);
+    else launch_fwd_nb<PREC, PRECB, 2, 1>(p, st);
+  }
   ARK_LAUNCH_CHECK();
   return 0;
 }
-template <int PREC, int NBUF>
+template <int PREC, int NBUF, int KI>
 static void launch_bwd_nb(const GruBwdDmaArgs& p, hipStream_t st) {
-  using G = DmaTile<PREC, 32, 64, NBUF, 2, 2>;
+  using G = DmaTile<PREC, 32, 64, NBUF, 2, 2, KI>;
   constexpr int LDS = G::LDS_BYTES > 28672 ? G::LDS_BYTES : 28672;
-  static bool once = (allow_lds(gru_cell_bwd_dma_kernel<PREC, NBUF>, LDS), true); (void)once;
+  static bool once = (allow_lds(gru_cell_bwd_dma_kernel<PREC, NBUF, KI>, LDS), true); (void)once;
   const unsigned grid = (unsigned)(((p.B + 31) / 32) * (p.D / 64));
-  hipLaunchKernelGGL((gru_cell_bwd_dma_kernel<PREC, NBUF>), dim3(grid), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((gru_cell_bwd_dma_kernel<PREC, NBUF, KI>), dim3(grid), dim3(256), LDS, st, p);
 }
 template <int PREC>
 static int launch_bwd_dma(const GruBwdDmaArgs& p, hipStream_t st) {
-  if (g_bwd_nbuf == 8) launch_bwd_nb<PREC, 8>(p, st);
-  else if (g_bwd_nbuf == 4) launch_bwd_nb<PREC, 4>(p, st);
-  else launch_bwd_nb<PREC, 2>(p, st);
+  const bool ki2 = g_bwd_ki == 2 && (3 * p.D) % 128 == 0;
+  if (ki2) {
+    if (g_bwd_nbuf >= 4) launch_bwd_nb<PREC, 4, 2>(p, st);
+    else launch_bwd_nb<PREC, 2, 2>(p, st);
+  } else {
+    if (g_bwd_nbuf == 8) launch_bwd_nb<PREC, 8, 1>(p, st);
+    else if (g_bwd_nbuf == 4) launch_bwd_nb<PREC, 4, 1>(p, st);
+    else launch_bwd_nb<PREC, 2, 1>(p, st);
+  }
   ARK_LAUNCH_CHECK();
   return 0;
 }
@@ -270,6 +306,13 @@ static int launch_bwd_dma(const GruBwdDmaArgs& p, hipStream_t st) {
 }  // namespace ark
 
 // speed-only knobs: ring depth (2|4|8) of the forward / backward LDS-DMA cell kernels
+extern "C" int ark_set_dma_stage(int fwd_ki, int bwd_ki) {
+  if ((fwd_ki != 1 && fwd_ki != 2) || (bwd_ki != 1 && bwd_ki != 2)) return ARK_ERR_ARG;
+  ark::g_fwd_ki = fwd_ki;
+  ark::g_bwd_ki = bwd_ki;
+  return 0;
+}
+
 extern "C" int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf) {
   auto ok = [](int v) { return v == 2 || v == 4 || v == 8; };
   if (!ok(fwd_nbuf) || !ok(bwd_nbuf)) return ARK_ERR_ARG;

@@ -95,6 +95,7 @@ int ark_gru_cell_bwd_dma(int prec, const void* dgh_next16, const void* w_hhT16, 
 int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_hhT16, const float* carry_t, float* dh0,
                        int accumulate, int B, int D, void* stream);
 int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf);
+int ark_set_dma_stage(int fwd_ki, int bwd_ki);
 int ark_set_gemm16_tuning(int nbuf, int force64);
 int ark_set_wgrad_tile128(int enabled);
 /* up to 12 jobs in one launch: dst[i] = cast(src[i] [R,C]) in prec[i]; dstT[i] = cast(src[i]^T) in precT[i] */
