@@ -92,10 +92,21 @@ __global__ __launch_bounds__(256) void scatter_lds_kernel(ScatterArgs p, int n_c
   const int per = (p.n_items + n_chunks - 1) / n_chunks;
   const int i0 = chunk * per, i1 = min(p.n_items, i0 + per);
   const bool col_ok = (c0 + lane) < p.D;
-  for (int i = i0 + wave; i < i1; i += 4) {
-    long id, srow; float sc;
-    if (!scatter_item(p, i, id, srow, sc)) continue;
-    if (col_ok) atomicAdd(&tab[id * 64 + lane], sc * p.src[srow * p.ld_src + p.col_off + c0 + lane]);
+  // 4 items per wave per trip: the id / row / value loads of the four are independent, so their
+  // latencies overlap (a single dependent chain per item made this kernel latency-bound)
+  constexpr int U = 4;
+  for (int i = i0 + wave * U; i < i1; i += 4 * U) {
+    long id[U], srow[U]; float sc[U], v[U]; bool ok[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      id[k] = 0; srow[k] = 0; sc[k] = 0.f;
+      ok[k] = (i + k < i1) && scatter_item(p, i + k, id[k], srow[k], sc[k]) && col_ok;
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) v[k] = ok[k] ? p.src[srow[k] * p.ld_src + p.col_off + c0 + lane] : 0.f;
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (ok[k]) atomicAdd(&tab[id[k] * 64 + lane], sc[k] * v[k]);
   }
   __syncthreads();
   if (col_ok)
@@ -122,7 +133,7 @@ static int launch_scatter(const ScatterArgs& p, hipStream_t st) {
   if (p.n_items <= 0) return 0;
   if ((long)p.n_rows * 64 * 4 <= 48 * 1024) {
     const int slices = (p.D + 63) / 64;
-    int n_chunks = 256 / slices; if (n_chunks < 1) n_chunks = 1;
+    int n_chunks = 512 / slices; if (n_chunks < 1) n_chunks = 1;
     if (n_chunks > (p.n_items + 15) / 16) n_chunks = (p.n_items + 15) / 16;
     hipLaunchKernelGGL(scatter_lds_kernel, dim3(slices * n_chunks), dim3(256), (size_t)p.n_rows * 64 * 4, st, p, n_chunks);
   } else {

@@ -123,6 +123,7 @@ struct GruBwdDmaArgs {
   const _Float16* sr; const _Float16* sz; const _Float16* sn; const _Float16* shn;   // tile-native fp16
   const float* y_prev;                           // tile-native fp32 [B,D]
   void* dgi16; void* dgh16;                      // row-major [B,3D] (prec type)
+  float* db_ih; float* db_hh;                    // [3D] bias gradients, accumulated with atomics (nullable)
   float* dh0; int dh0_accumulate;                // row-major fp32 [B,D] (final_ only)
   int B, D, first, final_;
 };
@@ -214,6 +215,19 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) 
       *reinterpret_cast<uint4*>(gi16 + go) = *reinterpret_cast<const uint4*>(tgi + g * 32 * TS + rr * TS + ch * 8);
       *reinterpret_cast<uint4*>(gh16 + go) = *reinterpret_cast<const uint4*>(tgh + g * 32 * TS + rr * TS + ch * 8);
     }
+  }
+  // bias gradients: column sums of this tile's dgi / dgh panels straight from LDS, one atomic per
+  // (gate, unit) per workgroup -- replaces a separate pass over the [B*L, 3D] panels
+  if (p.db_ih && t < 192) {
+    const int g = t >> 6, ul = t & 63;
+    const int nrows = min(32, B - m0);
+    float si = 0.f, sh = 0.f;
+    for (int r2 = 0; r2 < nrows; ++r2) {
+      si += (float)tgi[g * 32 * TS + r2 * TS + ul];
+      sh += (float)tgh[g * 32 * TS + r2 * TS + ul];
+    }
+    atomicAdd(&p.db_ih[(long)g * D + n0 + ul], si);
+    atomicAdd(&p.db_hh[(long)g * D + n0 + ul], sh);
   }
 }
 
@@ -341,14 +355,17 @@ extern "C" int ark_gru_cell_fwd_dma(int prec, int prec_b, const void* h_prev16, 
 
 extern "C" int ark_gru_cell_bwd_dma(int prec, const void* dgh_next16, const void* w_hhT16, const float* dy_t, float* carry_t,
                                     const void* save_r, const void* save_z, const void* save_n, const void* save_hn,
-                                    const float* y_prev_t, void* dgi16, void* dgh16, int B, int D, int first, void* stream) {
+                                    const float* y_prev_t, void* dgi16, void* dgh16, float* db_ih, float* db_hh, int B,
+                                    int D, int first, void* stream) {
   using namespace ark;
   if (!w_hhT16 || !carry_t || !save_r || !save_z || !save_n || !save_hn || !y_prev_t || !dgi16 || !dgh16 || B <= 0 || D <= 0)
     return ARK_ERR_ARG;
   if (!first && !dgh_next16) return ARK_ERR_ARG;
+  if ((db_ih == nullptr) != (db_hh == nullptr)) return ARK_ERR_ARG;
   if (D % 64 != 0 || B % 16 != 0) return ARK_ERR_SHAPE;
   GruBwdDmaArgs p{dgh_next16 ? dgh_next16 : dgh16, w_hhT16, dy_t, carry_t, (const _Float16*)save_r, (const _Float16*)save_z,
-                  (const _Float16*)save_n, (const _Float16*)save_hn, y_prev_t, dgi16, dgh16, nullptr, 0, B, D, first ? 1 : 0, 0};
+                  (const _Float16*)save_n, (const _Float16*)save_hn, y_prev_t, dgi16, dgh16, db_ih, db_hh, nullptr, 0, B, D,
+                  first ? 1 : 0, 0};
   if (prec == PREC_F16) return launch_bwd_dma<PREC_F16>(p, (hipStream_t)stream);
   if (prec == PREC_BF16) return launch_bwd_dma<PREC_BF16>(p, (hipStream_t)stream);
   return ARK_ERR_ARG;
@@ -360,7 +377,7 @@ extern "C" int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_h
   if (!dgh0_16 || !w_hhT16 || !carry_t || !dh0 || B <= 0 || D <= 0) return ARK_ERR_ARG;
   if (D % 64 != 0 || B % 16 != 0) return ARK_ERR_SHAPE;
   GruBwdDmaArgs p{dgh0_16, w_hhT16, nullptr, const_cast<float*>(carry_t), nullptr, nullptr, nullptr, nullptr, nullptr,
-                  nullptr, nullptr, dh0, accumulate ? 1 : 0, B, D, 0, 1};
+                  nullptr, nullptr, nullptr, nullptr, dh0, accumulate ? 1 : 0, B, D, 0, 1};
   if (prec == PREC_F16) return launch_bwd_dma<PREC_F16>(p, (hipStream_t)stream);
   if (prec == PREC_BF16) return launch_bwd_dma<PREC_BF16>(p, (hipStream_t)stream);
   return ARK_ERR_ARG;

@@ -564,7 +564,8 @@ class Engine:
                 first = (t == Lq - 1)
                 _call("ark_gru_cell_bwd_dma", L.i32(pb), L.ptr(None if first else dGH[(t + 1) * B:]), L.ptr(self.whhT16[l]),
                       L.ptr(dy[sl]), L.ptr(w["carry"]), L.ptr(w["SR"][l][sl]), L.ptr(w["SZ"][l][sl]), L.ptr(w["SN"][l][sl]),
-                      L.ptr(w["SHN"][l][sl]), L.ptr(Y[sl]), L.ptr(dGI[sl]), L.ptr(dGH[sl]), L.i32(B), L.i32(D),
+                      L.ptr(w["SHN"][l][sl]), L.ptr(Y[sl]), L.ptr(dGI[sl]), L.ptr(dGH[sl]),
+                      L.ptr(g[f"dec.gru.bias_ih_l{l}"]), L.ptr(g[f"dec.gru.bias_hh_l{l}"]), L.i32(B), L.i32(D),
                       L.i32(1 if first else 0), st)
             if self.mt == "SAIL":
                 _call("ark_gru_h0_bwd_dma", L.i32(pb), L.ptr(dGH), L.ptr(self.whhT16[l]), L.ptr(w["carry"]), L.ptr(w["dH0"]),
@@ -584,8 +585,7 @@ class Engine:
                       L.ptr(g[f"dec.gru.weight_hh_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), L.i32(1), st)
                 _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGI), L.i32(1), L.i64(3 * D), L.ptr(xin), L.i32(1), L.i64(D),
                       L.ptr(g[f"dec.gru.weight_ih_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), L.i32(1), st)
-            _call("ark_colsum16", L.i32(pb), L.ptr(dGI), L.i64(3 * D), L.ptr(g[f"dec.gru.bias_ih_l{l}"]), L.i32(R), L.i32(3 * D), L.i32(1), st)
-            _call("ark_colsum16", L.i32(pb), L.ptr(dGH), L.i64(3 * D), L.ptr(g[f"dec.gru.bias_hh_l{l}"]), L.i32(R), L.i32(3 * D), L.i32(1), st)
+            # (bias gradients were accumulated by the cell epilogues)
             # input gradient: dgi [R,3D] x W_ih^T-shadow [D,3D]; tile-native for the layer below,
             # row-major for the embedding scatter
             out = dy_other if l > 0 else w["dX0"]

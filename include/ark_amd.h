@@ -91,7 +91,8 @@ int ark_gru_cell_fwd_dma(int prec, int prec_b, const void* h_prev16, const void*
                          int B, int D, void* stream);
 int ark_gru_cell_bwd_dma(int prec, const void* dgh_next16, const void* w_hhT16, const float* dy_t, float* carry_t,
                          const void* save_r, const void* save_z, const void* save_n, const void* save_hn,
-                         const float* y_prev_t, void* dgi16, void* dgh16, int B, int D, int first, void* stream);
+                         const float* y_prev_t, void* dgi16, void* dgh16, float* db_ih /* += colsum(dgi), nullable */,
+                         float* db_hh /* += colsum(dgh) */, int B, int D, int first, void* stream);
 int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_hhT16, const float* carry_t, float* dh0,
                        int accumulate, int B, int D, void* stream);
 int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf);
