@@ -238,3 +238,52 @@ extern "C" int ark_to_tiled(const float* x, float* out, int rows, int ld, void* 
   ARK_LAUNCH_CHECK();
   return 0;
 }
+
+namespace ark {
+// h0 = tanh(z Wz^T + bz) written once for every GRU layer in every layout the LDS-DMA path reads:
+// row-major fp32 (z-projection backward), tile-native fp32 state, row-major 16-bit operand copies
+struct ZprojOut { float* y_t[8]; void* y16a[8]; void* y16b[8]; int n; };
+template <int PA, int PB2>
+__global__ __launch_bounds__(256) void zproj_fwd_v2_kernel(const float* __restrict__ z, const float* __restrict__ Wz,
+                                                           const float* __restrict__ bz, float* __restrict__ h0, ZprojOut o,
+                                                           int B, int Z, int D) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * D) return;
+  const int b = (int)(i / D), d = (int)(i % D);
+  float a = bz[d];
+  for (int j = 0; j < Z; ++j) a += z[(long)b * Z + j] * Wz[(long)d * Z + j];
+  const float h = tanhf(a);
+  h0[i] = h;
+  const long ot = tile_native_off(b, d, D);
+  for (int l = 0; l < o.n; ++l) {
+    o.y_t[l][ot] = h;
+    reinterpret_cast<typename PrecTraits<PA>::h_t*>(o.y16a[l])[i] = PrecTraits<PA>::cvt(h);
+    if (o.y16b[l]) reinterpret_cast<typename PrecTraits<PB2>::h_t*>(o.y16b[l])[i] = PrecTraits<PB2>::cvt(h);
+  }
+}
+}  // namespace ark
+
+extern "C" int ark_zproj_fwd_v2(int prec_a, int prec_b, const float* z, const float* w_z, const float* b_z, float* h0,
+                                int n_layers, float* const* y_t, void* const* y16a, void* const* y16b, int B, int Z, int D,
+                                void* stream) {
+  using namespace ark;
+  if (!z || !w_z || !b_z || !h0 || !y_t || !y16a || n_layers <= 0 || n_layers > 8 || B <= 0 || Z <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (B % 16 != 0 || D % 16 != 0) return ARK_ERR_SHAPE;
+  ZprojOut o{};
+  o.n = n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    if (!y_t[l] || !y16a[l]) return ARK_ERR_ARG;
+    o.y_t[l] = y_t[l]; o.y16a[l] = y16a[l]; o.y16b[l] = y16b ? y16b[l] : nullptr;
+  }
+  const long n = (long)B * D;
+  dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+#define ARK_ZP(PA, PB2) hipLaunchKernelGGL((zproj_fwd_v2_kernel<PA, PB2>), grid, dim3(256), 0, st, z, w_z, b_z, h0, o, B, Z, D)
+  if (prec_a == PREC_F16 && prec_b == PREC_BF16) ARK_ZP(PREC_F16, PREC_BF16);
+  else if (prec_a == PREC_F16 && prec_b == PREC_F16) ARK_ZP(PREC_F16, PREC_F16);
+  else if (prec_a == PREC_BF16 && prec_b == PREC_BF16) ARK_ZP(PREC_BF16, PREC_BF16);
+  else return ARK_ERR_ARG;
+#undef ARK_ZP
+  ARK_LAUNCH_CHECK();
+  return 0;
+}

@@ -356,17 +356,13 @@ class Engine:
         st = L.cur_stream()
         zp = (L.ptr(z), L.ptr(p["dec.z_proj.weight"]), L.ptr(p["dec.z_proj.bias"]))
         if w["v2"]:
-            D = self.D
-            _call("ark_zproj_fwd", *zp, L.ptr(w["h0"]), L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(D), st)
-            _call("ark_to_tiled", L.ptr(w["h0"]), L.ptr(w["Y"][0]), L.i32(B), L.i32(D), st)
-            _call("ark_cast16", L.i32(self.prec_fwd), L.ptr(w["h0"]), L.ptr(w["Y16a"][0]), L.i64(B * D), st)
-            if w["Y16b"][0] is not None:
-                _call("ark_cast16", L.i32(self.prec_bwd), L.ptr(w["h0"]), L.ptr(w["Y16b"][0]), L.i64(B * D), st)
-            for l in range(1, self.n):   # every layer starts from the same h0 (models.py:140)
-                w["Y"][l][:B].copy_(w["Y"][0][:B])
-                w["Y16a"][l][:B].copy_(w["Y16a"][0][:B])
-                if w["Y16b"][l] is not None:
-                    w["Y16b"][l][:B].copy_(w["Y16b"][0][:B])
+            import ctypes
+            n = self.n
+            yt = (ctypes.c_void_p * n)(*[w["Y"][l].data_ptr() for l in range(n)])
+            ya = (ctypes.c_void_p * n)(*[w["Y16a"][l].data_ptr() for l in range(n)])
+            yb = (ctypes.c_void_p * n)(*[(w["Y16b"][l].data_ptr() if w["Y16b"][l] is not None else 0) for l in range(n)])
+            _call("ark_zproj_fwd_v2", L.i32(self.prec_fwd), L.i32(self.prec_bwd), *zp, L.ptr(w["h0"]), L.i32(n), yt, ya, yb,
+                  L.i32(B), L.i32(self.Z), L.i32(self.D), st)
             return
         # layer buffers are separate allocations: write h0 into slot 0 of every layer
         for l in range(self.n):

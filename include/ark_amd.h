@@ -118,6 +118,9 @@ int ark_wgrad16_group(int prec, int n, const void* const* A16, const int64_t* ld
 int ark_set_wgrad16_tuning(int tile, int nbuf, int target_wgs);
 int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,
                      const float* w_pos, void* x16a, void* x16b, int B, int L, int D, void* stream);
+/* h0 = tanh(z_proj(z)) for all layers in every layout of the LDS-DMA path, one launch */
+int ark_zproj_fwd_v2(int prec_a, int prec_b, const float* z, const float* w_z, const float* b_z, float* h0, int n_layers,
+                     float* const* y_t, void* const* y16a, void* const* y16b, int B, int Z, int D, void* stream);
 int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, int accumulate, void* stream);
 int ark_cast16(int prec, const float* x, void* out, int64_t n, void* stream);
 int ark_to_tiled(const float* x, float* out, int rows, int ld, void* stream);
