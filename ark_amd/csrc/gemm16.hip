@@ -14,6 +14,7 @@ struct Gemm16Args {
   const void* A; const void* B; float* C; const float* bias; const float* aux;
   long lda, ldb, ldc;
   int M, N, K, epi, c_tiled, tiles_n;
+  void* c16a; void* c16b; int prec_a, prec_b;   // optional row-major 16-bit copies of the result (ld = ldc)
 };
 
 template <int PREC, int BM, int BN, int NBUF>
@@ -50,7 +51,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
           const long o = (long)(row0 + i) * p.ldc + col;
           float x = v[i];
           if (p.epi == ARK_EPI_MUL_AUX) x *= p.aux[o];
-          p.C[o] = x;
+          if (p.epi == ARK_EPI_MUL_DGELU) x *= dgelu_erf(p.aux[o]);
+          if (p.epi == ARK_EPI_BIAS_GELU) {
+            x += p.bias[col];
+            p.C[o] = x;            // pre-activation (fp32, kept for the backward pass)
+            x = gelu_erf(x);       // the 16-bit copies carry the activation
+          } else {
+            p.C[o] = x;
+          }
+          if (p.c16a) put16(p.c16a, o, x, p.prec_a);
+          if (p.c16b) put16(p.c16b, o, x, p.prec_b);
         }
       }
     }
@@ -160,21 +170,38 @@ extern "C" int ark_set_gemm16_tuning(int nbuf, int force64) {
   return 0;
 }
 
-extern "C" int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
-                          int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled,
-                          void* stream) {
+static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
+                       int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* c16a,
+                       void* c16b, int prec_b, void* stream) {
   using namespace ark;
   if (!A16 || !B16 || !C || M <= 0 || N <= 0 || K <= 0) return ARK_ERR_ARG;
   if (K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0) return ARK_ERR_SHAPE;
   if (((uintptr_t)A16 | (uintptr_t)B16) & 15) return ARK_ERR_ALIGN;
-  if (epi != ARK_EPI_NONE && epi != ARK_EPI_BIAS && epi != ARK_EPI_MUL_AUX) return ARK_ERR_ARG;
-  if (epi == ARK_EPI_BIAS && !bias) return ARK_ERR_ARG;
-  if (epi == ARK_EPI_MUL_AUX && !aux) return ARK_ERR_ARG;
+  if (epi < ARK_EPI_NONE || epi > ARK_EPI_MUL_AUX) return ARK_ERR_ARG;
+  if ((epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU) && !bias) return ARK_ERR_ARG;
+  if ((epi == ARK_EPI_MUL_AUX || epi == ARK_EPI_MUL_DGELU) && !aux) return ARK_ERR_ARG;
   if (c_tiled && (M % 16 != 0 || ldc % 16 != 0 || N > ldc)) return ARK_ERR_SHAPE;
-  Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0};
+  if (c_tiled && (epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_MUL_DGELU || c16a || c16b)) return ARK_ERR_ARG;
+  if (c16b && prec_b != PREC_F16 && prec_b != PREC_BF16) return ARK_ERR_ARG;
+  Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0, c16a, c16b, prec, prec_b};
   if (prec == PREC_F16) return launch16<PREC_F16>(p, (hipStream_t)stream);
   if (prec == PREC_BF16) return launch16<PREC_BF16>(p, (hipStream_t)stream);
   return ARK_ERR_ARG;
+}
+
+extern "C" int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
+                          int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled,
+                          void* stream) {
+  return gemm16_impl(prec, epi, A16, lda, B16, ldb, C, ldc, bias, aux, M, N, K, c_tiled, nullptr, nullptr, 0, stream);
+}
+
+// same product with row-major 16-bit copies of the result written by the epilogue: c16a in `prec`,
+// c16b (nullable) in `prec_b`.  BIAS_GELU: C = pre-activation (fp32), copies = gelu(C);
+// MUL_DGELU: C = acc * gelu'(aux), copies = C.
+extern "C" int ark_gemm16_ex(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
+                             int64_t ldc, const float* bias, const float* aux, void* c16a, void* c16b, int prec_b, int M,
+                             int N, int K, void* stream) {
+  return gemm16_impl(prec, epi, A16, lda, B16, ldb, C, ldc, bias, aux, M, N, K, 0, c16a, c16b, prec_b, stream);
 }
 
 extern "C" int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,

@@ -45,6 +45,12 @@ template <> struct PrecTraits<PREC_F16> {
   static __device__ __forceinline__ f32x4 mfma(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
+// store one value as a 16-bit element whose type is chosen at run time (epilogue side outputs)
+__device__ __forceinline__ void put16(void* base, long idx, float v, int prec) {
+  if (prec == PREC_F16) reinterpret_cast<_Float16*>(base)[idx] = PrecTraits<PREC_F16>::cvt(v);
+  else reinterpret_cast<__bf16*>(base)[idx] = (__bf16)v;
+}
+
 // byte offset of 16-byte chunk `chunk` (0..7) of tile row `row` in the swizzled LDS image
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);

@@ -158,6 +158,11 @@ class Engine:
             self.wihT16 = [i16(D, 3 * D) for _ in range(self.n)]
             self.whhT16 = [i16(D, 3 * D) for _ in range(self.n)]
             self.wtok16 = i16(V, D)
+            if self.mt == "SAIL":
+                H = 3 * D
+                self.wm16 = [i16(H, H) for _ in range(self.n)]      # encoder MLP weights, forward type
+                self.wmT16 = [i16(H, H) for _ in range(self.n)]     # their transposes, backward type
+                self.wh16 = i16(2 * self.Z, H)                      # [mu; logv] head, forward type
             self._shadow_jobs = self._build_shadow_jobs()
         self._shadow_ok = False
 
@@ -181,6 +186,11 @@ class Engine:
             jobs.append((self.p[f"dec.gru.weight_ih_l{l}"], self.wih16[l], self.wihT16[l], 3 * self.D, self.D))
             jobs.append((self.p[f"dec.gru.weight_hh_l{l}"], self.whh16[l], self.whhT16[l], 3 * self.D, self.D))
         jobs.append((self.p["dec.out.weight"], self.wtok16, None, self.V, self.D))
+        if self.mt == "SAIL":
+            H = 3 * self.D
+            for i in range(self.n):
+                jobs.append((self.p[f"enc.mlp.{2 * i}.weight"], self.wm16[i], self.wmT16[i], H, H))
+            jobs.append((self.p["enc.mu.weight"], self.wh16, None, 2 * self.Z, H))
         chunks = []
         for c0 in range(0, len(jobs), 12):
             ch = jobs[c0:c0 + 12]
@@ -244,6 +254,12 @@ class Engine:
         w["v2"] = v2
         i16 = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.int16)
         two = self.prec_fwd != self.prec_bwd   # separate backward-type copies of the activations
+        if v2 and self.mt == "SAIL":
+            H = 3 * D
+            w["g16a"], w["g16b"] = i16(B, H), (i16(B, H) if two else None)
+            w["act16a"] = [i16(B, H) for _ in range(n)]
+            w["act16b"] = [i16(B, H) if two else None for _ in range(n)]
+            w["dpre16"] = [i16(B, H) for _ in range(n)]
         if v2:
             # "16": row-major 16-bit copies (a: forward type, b: backward type); "_t": tile-native
             w["X0a"] = i16(R, D)
@@ -321,13 +337,28 @@ class Engine:
             _call("ark_enc_pool_fwd", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
                   L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.i32(B), L.i32(T), L.i32(D),
                   L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
-            a = w["g"]
-            for i in range(n):
-                self._gemm(KM, KM, L.EPI_BIAS_GELU, a, H, p[f"enc.mlp.{2 * i}.weight"], H, w["pre"][i], H, B, H, H,
-                           C2=w["act"][i], bias=p[f"enc.mlp.{2 * i}.bias"])
-                a = w["act"][i]
-            self._gemm(KM, KM, L.EPI_BIAS, a, H, p["enc.mu.weight"], H, w["head"], 2 * Z, B, 2 * Z, H,
-                       bias=p["enc.mu.bias"])
+            if w["v2"]:
+                pf, pb = self.prec_fwd, self.prec_bwd
+                _call("ark_cast16", L.i32(pf), L.ptr(w["g"]), L.ptr(w["g16a"]), L.i64(B * H), st)
+                if w["g16b"] is not None:
+                    _call("ark_cast16", L.i32(pb), L.ptr(w["g"]), L.ptr(w["g16b"]), L.i64(B * H), st)
+                a16 = w["g16a"]
+                for i in range(n):
+                    _call("ark_gemm16_ex", L.i32(pf), L.i32(L.EPI_BIAS_GELU), L.ptr(a16), L.i64(H), L.ptr(self.wm16[i]), L.i64(H),
+                          L.ptr(w["pre"][i]), L.i64(H), L.ptr(p[f"enc.mlp.{2 * i}.bias"]), L.ptr(None), L.ptr(w["act16a"][i]),
+                          L.ptr(w["act16b"][i]), L.i32(pb), L.i32(B), L.i32(H), L.i32(H), st)
+                    a16 = w["act16a"][i]
+                _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(a16), L.i64(H), L.ptr(self.wh16), L.i64(H),
+                      L.ptr(w["head"]), L.i64(2 * Z), L.ptr(p["enc.mu.bias"]), L.ptr(None), L.i32(B), L.i32(2 * Z), L.i32(H),
+                      L.i32(0), st)
+            else:
+                a = w["g"]
+                for i in range(n):
+                    self._gemm(KM, KM, L.EPI_BIAS_GELU, a, H, p[f"enc.mlp.{2 * i}.weight"], H, w["pre"][i], H, B, H, H,
+                               C2=w["act"][i], bias=p[f"enc.mlp.{2 * i}.bias"])
+                    a = w["act"][i]
+                self._gemm(KM, KM, L.EPI_BIAS, a, H, p["enc.mu.weight"], H, w["head"], 2 * Z, B, 2 * Z, H,
+                           bias=p["enc.mu.bias"])
             if eps is None:
                 eps = w["eps0"]
             self._eps = eps
@@ -474,20 +505,51 @@ class Engine:
         if ext_dhead is not None:
             w["dhead"].add_(ext_dhead)
         self._colsum(w["dhead"], 2 * Z, g["enc.mu.bias"], B, 2 * Z)
-        self._gemm(MM, MM, L.EPI_NONE, w["dhead"], 2 * Z, w["act"][n - 1], H, g["enc.mu.weight"], H, 2 * Z, H, B, acc=1)
-        self._gemm(KM, MM, L.EPI_MUL_DGELU, w["dhead"], 2 * Z, p["enc.mu.weight"], H, w["dA"], H, B, H, 2 * Z,
-                   aux=w["pre"][n - 1])
-        dpre, other = w["dA"], w["dB"]
-        for i in range(n - 1, -1, -1):
-            inp = w["act"][i - 1] if i > 0 else w["g"]
-            self._colsum(dpre, H, g[f"enc.mlp.{2 * i}.bias"], B, H)
-            self._gemm(MM, MM, L.EPI_NONE, dpre, H, inp, H, g[f"enc.mlp.{2 * i}.weight"], H, H, H, B, acc=1)
-            if i > 0:
-                self._gemm(KM, MM, L.EPI_MUL_DGELU, dpre, H, p[f"enc.mlp.{2 * i}.weight"], H, other, H, B, H, H,
-                           aux=w["pre"][i - 1])
-            else:
-                self._gemm(KM, MM, L.EPI_NONE, dpre, H, p[f"enc.mlp.{2 * i}.weight"], H, other, H, B, H, H)
-            dpre, other = other, dpre
+        if w["v2"]:
+            pb = self.prec_bwd
+            a16b = lambda i: (w["act16b"][i] if w["act16b"][i] is not None else w["act16a"][i])
+            g16b = w["g16b"] if w["g16b"] is not None else w["g16a"]
+            _call("ark_gemm_wgrad", L.i32(pb), L.ptr(w["dhead"]), L.i32(0), L.i64(2 * Z), L.ptr(a16b(n - 1)), L.i32(1), L.i64(H),
+                  L.ptr(g["enc.mu.weight"]), L.i64(H), L.i32(2 * Z), L.i32(H), L.i32(B), L.i32(1), st)
+            # K = 2Z is not a multiple of 64 -> register-staged engine for this one product, then a 16-bit copy
+            self._gemm(KM, MM, L.EPI_MUL_DGELU, w["dhead"], 2 * Z, p["enc.mu.weight"], H, w["dA"], H, B, H, 2 * Z,
+                       aux=w["pre"][n - 1])
+            _call("ark_cast16", L.i32(pb), L.ptr(w["dA"]), L.ptr(w["dpre16"][n - 1]), L.i64(B * H), st)
+            dpre, other = w["dA"], w["dB"]
+            group = []
+            for i in range(n - 1, -1, -1):
+                inp16 = a16b(i - 1) if i > 0 else g16b
+                self._colsum(dpre, H, g[f"enc.mlp.{2 * i}.bias"], B, H)
+                if B % 64 == 0:
+                    group.append((w["dpre16"][i], H, inp16, H, g[f"enc.mlp.{2 * i}.weight"], H, H, H, B))
+                else:
+                    _call("ark_gemm_wgrad", L.i32(pb), L.ptr(w["dpre16"][i]), L.i32(1), L.i64(H), L.ptr(inp16), L.i32(1), L.i64(H),
+                          L.ptr(g[f"enc.mlp.{2 * i}.weight"]), L.i64(H), L.i32(H), L.i32(H), L.i32(B), L.i32(1), st)
+                if i > 0:
+                    _call("ark_gemm16_ex", L.i32(pb), L.i32(L.EPI_MUL_DGELU), L.ptr(w["dpre16"][i]), L.i64(H), L.ptr(self.wmT16[i]),
+                          L.i64(H), L.ptr(other), L.i64(H), L.ptr(None), L.ptr(w["pre"][i - 1]), L.ptr(w["dpre16"][i - 1]), L.ptr(None),
+                          L.i32(pb), L.i32(B), L.i32(H), L.i32(H), st)
+                else:
+                    _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dpre16"][0]), L.i64(H), L.ptr(self.wmT16[0]), L.i64(H),
+                          L.ptr(other), L.i64(H), L.ptr(None), L.ptr(None), L.i32(B), L.i32(H), L.i32(H), L.i32(0), st)
+                dpre, other = other, dpre
+            for i0 in range(0, len(group), 8):
+                self._wgrad_group(group[i0:i0 + 8])
+        else:
+            self._gemm(MM, MM, L.EPI_NONE, w["dhead"], 2 * Z, w["act"][n - 1], H, g["enc.mu.weight"], H, 2 * Z, H, B, acc=1)
+            self._gemm(KM, MM, L.EPI_MUL_DGELU, w["dhead"], 2 * Z, p["enc.mu.weight"], H, w["dA"], H, B, H, 2 * Z,
+                       aux=w["pre"][n - 1])
+            dpre, other = w["dA"], w["dB"]
+            for i in range(n - 1, -1, -1):
+                inp = w["act"][i - 1] if i > 0 else w["g"]
+                self._colsum(dpre, H, g[f"enc.mlp.{2 * i}.bias"], B, H)
+                self._gemm(MM, MM, L.EPI_NONE, dpre, H, inp, H, g[f"enc.mlp.{2 * i}.weight"], H, H, H, B, acc=1)
+                if i > 0:
+                    self._gemm(KM, MM, L.EPI_MUL_DGELU, dpre, H, p[f"enc.mlp.{2 * i}.weight"], H, other, H, B, H, H,
+                               aux=w["pre"][i - 1])
+                else:
+                    self._gemm(KM, MM, L.EPI_NONE, dpre, H, p[f"enc.mlp.{2 * i}.weight"], H, other, H, B, H, H)
+                dpre, other = other, dpre
         dg = dpre
         _call("ark_enc_pool_bwd", L.ptr(self._triples), L.ptr(dg), L.ptr(w["inv_cnt"]), L.ptr(g["enc.e_emb.weight"]),
               L.ptr(g["enc.r_emb.weight"]), L.i32(B), L.i32(T), L.i32(D), L.i32(g["enc.e_emb.weight"].shape[0]),

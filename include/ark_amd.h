@@ -105,6 +105,11 @@ int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, vo
 /* C[M,N] = A16[M,K] B16[N,K]^T (+bias | *aux), C row-major or tile-native (c_tiled) */
 int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* stream);
+/* ark_gemm16 with row-major 16-bit copies of the result (c16a in `prec`, c16b nullable in `prec_b`);
+ * BIAS_GELU: C = pre-activation, copies = gelu(C); MUL_DGELU: C = acc * gelu'(aux), copies = C */
+int ark_gemm16_ex(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
+                  const float* bias, const float* aux, void* c16a, void* c16b, int prec_b, int M, int N, int K,
+                  void* stream);
 /* C[M,N] = sum_k A[k,M] B[k,N]: weight gradients with fp32 or 16-bit stored operands */
 int ark_gemm_wgrad(int prec, const void* A, int a_is16, int64_t lda, const void* B, int b_is16, int64_t ldb, float* C,
                    int64_t ldc, int M, int N, int K, int accumulate, void* stream);
