@@ -169,7 +169,7 @@ static void allow_lds_w(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int g_wg_tile = 128, g_wg_nbuf = 2, g_wg_target = 288;
+int g_wg_tile = 128, g_wg_nbuf = 2, g_wg_target = 96;
 
 template <int PREC, int BT, int NBUF>
 static void launch_wg(Wgrad16Group& g, hipStream_t st) {

@@ -58,7 +58,9 @@ class ParamLayout:
                 blocks += [[(f"enc.mlp.{2 * i}.weight", (H, H))], [(f"enc.mlp.{2 * i}.bias", (H,))]]
             blocks += [[("enc.mu.weight", (Z, H)), ("enc.logv.weight", (Z, H))],
                        [("enc.mu.bias", (Z,)), ("enc.logv.bias", (Z,))]]
-            blocks += [[("dec.tok_emb.weight", (V, D))], [("dec.z_proj.weight", (D, Z))], [("dec.z_proj.bias", (D,))]]
+            # z_proj's gradient is produced by the latent/encoder half of the backward pass, so it sits with
+            # the encoder block: everything from dec.tok_emb on is complete once the decoder half is done
+            blocks += [[("dec.z_proj.weight", (D, Z))], [("dec.z_proj.bias", (D,))], [("dec.tok_emb.weight", (V, D))]]
         elif mt == "ARK":
             blocks += [[("dec.tok_emb.weight", (V, D))], [("dec.pos_emb.weight", (cfg["seq_len"], D))]]
         else:
@@ -80,17 +82,9 @@ class ParamLayout:
                 self.entries[name] = (off, tuple(shape), numel)
                 off += numel
         self.total = _rup(off, 4)
-
-    def state_dict_names(self, cfg):
-        """names in the reference's state_dict order (tied weight listed under both keys)"""
-        names = list(self.entries.keys())
-        # reference order: ..., enc.mu.weight, enc.mu.bias, enc.logv.weight, enc.logv.bias, ...
-        if "enc.mu.weight" in self.entries:
-            i = names.index("enc.mu.weight")
-            names[i:i + 4] = ["enc.mu.weight", "enc.mu.bias", "enc.logv.weight", "enc.logv.bias"]
-        if self.tied:
-            names.insert(names.index("dec.out.bias"), "dec.out.weight")
-        return names
+        # gradients in [dec_grad_offset, total) are final after Engine.backward_decoder(): data-parallel
+        # runs all-reduce that bucket while the encoder half is still computing
+        self.dec_grad_offset = self.entries["dec.tok_emb.weight"][0]
 
 
 class Engine:
@@ -165,6 +159,9 @@ class Engine:
                 self.wh16 = i16(2 * self.Z, H)                      # [mu; logv] head, forward type
             self._shadow_jobs = self._build_shadow_jobs()
         self._shadow_ok = False
+        self._side = None
+        self._side_used = False
+        self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
 
     # ------------------------------------------------------------------ parameters
     def load_params(self, named):
@@ -472,6 +469,12 @@ class Engine:
     # ------------------------------------------------------------------ backward
     def backward(self, ext_dhead=None):
         """Launch the backward pass of the last forward (dlogits already sit in ws['logits'])."""
+        if self.backward_decoder():
+            self.backward_encoder(ext_dhead)
+
+    def backward_decoder(self):
+        """decoder half of the backward pass: fills every decoder gradient (the flat buffer from
+        `dec_grad_offset` on); returns True when an encoder half remains (SAIL)."""
         self.prec = self.prec_bwd
         w, B, T, Lq = self.ws, self._B, self._T, self._Lrun
         D, n, V, Z = self.D, self.n, self.V, self.Z
@@ -494,7 +497,19 @@ class Engine:
         if self.mt == "ARK":
             gp = g["dec.pos_emb.weight"]
             self._colsum(dX0, D, gp, B, D, n_batch=Lq, bs_in=B * D, bs_out=D)
-            return
+            self._join_side()
+            return False
+        return True
+
+    def backward_encoder(self, ext_dhead=None):
+        """latent + encoder half of the backward pass (SAIL): fills flat-buffer gradients [0, dec_grad_offset)
+        plus dec.z_proj."""
+        self.prec = self.prec_bwd
+        w, B, T, Lq = self.ws, self._B, self._T, self._Lrun
+        D, n, V, Z = self.D, self.n, self.V, self.Z
+        st = L.cur_stream()
+        KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
+        p, g = self.p, self.g
         # latent path
         H = 3 * D
         h0rm = w["h0"] if w["v2"] else w["Y"][0]   # row-major h0 (the v2 state buffers are tile-native)
@@ -555,7 +570,12 @@ class Engine:
               L.ptr(g["enc.r_emb.weight"]), L.i32(B), L.i32(T), L.i32(D), L.i32(g["enc.e_emb.weight"].shape[0]),
               L.i32(g["enc.r_emb.weight"].shape[0]), L.i64(-1 if self.pad_eid is None else self.pad_eid),
               L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
+        self._join_side()
 
+    def _join_side(self):
+        if self._side_used:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_used = False
 
     def _backward_decoder_v1(self, w, B, Lq, seq, use_drop):
         D, n, V = self.D, self.n, self.V
@@ -635,9 +655,20 @@ class Engine:
                 xin = w["Yd16b"][l - 1] if w["Yd16b"][l - 1] is not None else w["Yd16a"][l - 1]
             else:
                 xin = yb(l - 1)[B:]
-            if R % 64 == 0:   # deferred: all layers' weight gradients go out as ONE grouped launch below
-                group.append((dGH, 3 * D, yb(l), D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R))
-                group.append((dGI, 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R))
+            if R % 64 == 0:
+                # weight gradients of this layer go to the side stream: they only need this layer's
+                # finished gate-gradient panels, so they run underneath the (latency-bound) cell chain
+                # of the layers below and the encoder backward
+                items = [(dGH, 3 * D, yb(l), D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R),
+                         (dGI, 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)]
+                if self.overlap_wgrad:
+                    side = self._side_stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        self._wgrad_group(items)
+                    self._side_used = True
+                else:
+                    group += items
             else:
                 _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGH), L.i32(1), L.i64(3 * D), L.ptr(yb(l)), L.i32(1), L.i64(D),
                       L.ptr(g[f"dec.gru.weight_hh_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), L.i32(1), st)
@@ -654,6 +685,11 @@ class Engine:
         for i0 in range(0, len(group), 8):
             self._wgrad_group(group[i0:i0 + 8])
         return w["dX0"]
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _wgrad_group(self, items):
         import ctypes
@@ -678,14 +714,35 @@ class Engine:
         if self.mt == "SAIL":
             self.set_hyper(kl_norm=1.0 / (B * self.world_size * self.Z))
 
-    def train_step(self, triples, seq, eps=None, grad_sync=None, ce_count=None):
+    def _dp_sync(self, stage, handle=None):
+        """bucketed gradient all-reduce (sum) over torch.distributed (RCCL): stage 0 launches the
+        decoder bucket asynchronously, stage 1 reduces the encoder bucket and waits for both."""
+        import torch.distributed as dist
+        off = self.layout.dec_grad_offset
+        if stage == 0:
+            return dist.all_reduce(self.G[off:], op=dist.ReduceOp.SUM, async_op=True)
+        if off > 0:
+            dist.all_reduce(self.G[:off], op=dist.ReduceOp.SUM)
+        handle.wait()
+        return None
+
+    def train_step(self, triples, seq, eps=None, grad_sync=None, ce_count=None, dp=False):
         """forward + ELBO + backward (+ gradient all-reduce) + Adam.  Returns the device tensor
-        out4 = [loss, ce, kl, token-loss sum] (no host sync)."""
+        out4 = [loss, ce, kl, token-loss sum] (no host sync).  `dp=True`: bucketed all-reduce over the
+        default process group, overlapped with the encoder half of the backward pass; `grad_sync`: a
+        caller-supplied callable(flat_grad) run between backward and Adam."""
         self._default_norms(seq.shape[0])
         if ce_count is not None:
             self.set_hyper(ce_count=ce_count)
         w = self.forward(triples, seq, eps, ce_count=ce_count)
-        self.backward()
+        more = self.backward_decoder()
+        if dp:
+            self._join_side()
+            h = self._dp_sync(0)
+        if more:
+            self.backward_encoder()
+        if dp:
+            self._dp_sync(1, h)
         if grad_sync is not None:
             grad_sync(self.G)
         self.adam()
@@ -702,38 +759,58 @@ class Engine:
         return w["out4"]
 
     # ------------------------------------------------------------------ graph capture
-    def capture_train_step(self, triples, seq, eps=None, ce_count=None, grad_sync=None):
+    def capture_train_step(self, triples, seq, eps=None, ce_count=None, grad_sync=None, dp=False):
         """Capture the train step for fixed-address inputs into hipGraphs; returns replay().
 
-        Without `grad_sync` the whole step (fwd + bwd + Adam) is ONE graph.  With `grad_sync`
-        (data parallel) it is two graphs with the gradient all-reduce launched between them on
-        the same stream.  The caller refreshes the CONTENTS of `triples`, `seq`, `eps` in place
-        between replays; step scalars live in the device `hyper` array."""
+        Single process: ONE graph (fwd + bwd + Adam).  Data parallel (`dp=True`): three graphs --
+        [fwd + decoder bwd] | async all-reduce of the decoder-gradient bucket | [encoder bwd] |
+        all-reduce of the encoder bucket | [Adam] -- so the first collective rides underneath the
+        encoder backward.  `grad_sync` (callable) is the unbucketed alternative: [fwd+bwd] | call | [Adam].
+        The caller refreshes the CONTENTS of `triples`, `seq`, `eps` in place between replays; step
+        scalars live in the device `hyper` array."""
         self._default_norms(seq.shape[0])
         if ce_count is not None:
             self.set_hyper(ce_count=ce_count)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up outside capture (allocates the workspace)
-            self.train_step(triples, seq, eps, ce_count=ce_count, grad_sync=grad_sync)
+            self.train_step(triples, seq, eps, ce_count=ce_count, grad_sync=grad_sync, dp=dp)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g1 = torch.cuda.CUDAGraph()
-        g2 = None
-        if grad_sync is None:
-            with torch.cuda.graph(g1):
+        graphs = []
+
+        def cap(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            graphs.append(g)
+            return g
+
+        steps0 = self.adam_steps
+        if dp:
+            more = [True]
+
+            def a():
+                self.forward(triples, seq, eps, ce_count=ce_count)
+                more[0] = self.backward_decoder()
+                self._join_side()
+            ga = cap(a)
+            gb = cap(self.backward_encoder) if more[0] else None
+            gc = cap(self.adam)
+        elif grad_sync is not None:
+            def a():
                 self.forward(triples, seq, eps, ce_count=ce_count)
                 self.backward()
-                self.adam()
+            ga = cap(a)
+            gb = None
+            gc = cap(self.adam)
         else:
-            with torch.cuda.graph(g1):
+            def a():
                 self.forward(triples, seq, eps, ce_count=ce_count)
                 self.backward()
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
                 self.adam()
-            self.adam_steps -= 1
-        self.adam_steps -= 1  # capture does not execute
+            ga, gb, gc = cap(a), None, None
+        self.adam_steps = steps0  # capture does not execute
         out4 = self.ws["out4"]
         gstream = torch.cuda.Stream(device=self.device)
 
@@ -746,16 +823,22 @@ class Engine:
             if use is not cur:
                 use.wait_stream(cur)
             with torch.cuda.stream(use):
-                g1.replay()
-                if g2 is not None:
+                ga.replay()
+                if dp:
+                    h = self._dp_sync(0)
+                    if gb is not None:
+                        gb.replay()
+                    self._dp_sync(1, h)
+                elif grad_sync is not None:
                     grad_sync(self.G)
-                    g2.replay()
+                if gc is not None:
+                    gc.replay()
             if use is not cur:
                 cur.wait_stream(use)
             self.adam_steps += 1
             return out4
 
-        self._graphs["train"] = (g1, g2)
+        self._graphs["train"] = graphs
         return replay
 
     # ------------------------------------------------------------------ greedy decode (next row of SURVEY 8f)

@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--tuning", default="", help="speed-only kernel knobs, e.g. '1=32,2=1' (ark_set_tuning)")
     ap.add_argument("--no-splitk", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path even with one rank")
     ap.add_argument("--knobs", default="", help="speed-only knobs: ring=F:B,g16=NBUF:FORCE64,wg128=0|1")
     args = ap.parse_args()
 
@@ -160,9 +161,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ark_amd.engine import Engine
@@ -200,10 +202,7 @@ def main():
     ce_count = float(Bg * Lq)  # syn-paths: fixed length, no PAD targets
     tri_in, seq_in, eps_in = (x.clone() for x in ring[0])
 
-    grad_sync = None
-    if world > 1:
-        def grad_sync(G):
-            dist.all_reduce(G, op=dist.ReduceOp.SUM)
+    use_dp = world > 1 or args.force_dist
 
     def feed(i):
         a, b, c = ring[i % NB]
@@ -218,9 +217,9 @@ def main():
     with torch.cuda.stream(run_stream):
         if args.no_graph:
             def step():
-                return eng.train_step(tri_in, seq_in, eps_in, grad_sync=grad_sync, ce_count=ce_count)
+                return eng.train_step(tri_in, seq_in, eps_in, ce_count=ce_count, dp=use_dp)
         else:
-            step = eng.capture_train_step(tri_in, seq_in, eps_in, ce_count=ce_count, grad_sync=grad_sync)
+            step = eng.capture_train_step(tri_in, seq_in, eps_in, ce_count=ce_count, dp=use_dp)
 
         log('captured/ready; warmup')
         for i in range(args.warmup):

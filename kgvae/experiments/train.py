@@ -94,14 +94,13 @@ def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), ma
     tri, seq = dataset.tensorize()   # redraws the per-graph permutations, like a fresh DataLoader pass
     sums = torch.zeros(4, device=device)
     nb = 0
-    sync = dp.make_grad_sync(nranks)
     for tb, sb in iterate_batches(tri, seq, config["batch_size"], config["shuffle_train"], True):
         ce_count = dp.count_targets(sb, config["special_tokens"]["PAD"])
         if nranks > 1:
             tb, sb = dp.shard(tb, rank, nranks), dp.shard(sb, rank, nranks)
         tb = tb.to(device, non_blocking=True)
         sb = sb.to(device, non_blocking=True)
-        out4 = model.train_step(tb, sb, beta=b, lr=lr, grad_sync=sync, ce_count=ce_count)
+        out4 = model.train_step(tb, sb, beta=b, lr=lr, ce_count=ce_count, dp=nranks > 1)
         sums += out4
         nb += 1
         if max_steps and nb >= max_steps:

@@ -85,12 +85,12 @@ class _EngineModel(nn.Module):
         return list(self.named_parameters())
 
     # -- fused training step ----------------------------------------------------------------
-    def train_step(self, triples, seq, beta=1.0, lr=None, eps=None, grad_sync=None, ce_count=None):
+    def train_step(self, triples, seq, beta=1.0, lr=None, eps=None, grad_sync=None, ce_count=None, dp=False):
         """forward + ELBO + backward + Adam on the device; returns the device tensor
         [loss, ce, kl, token-loss sum] without synchronising."""
         eng = self.engine()
         eng.set_hyper(lr=lr, beta=beta)
-        return eng.train_step(self._tri(triples), seq, eps, grad_sync=grad_sync, ce_count=ce_count)
+        return eng.train_step(self._tri(triples), seq, eps, grad_sync=grad_sync, ce_count=ce_count, dp=dp)
 
     @torch.no_grad()
     def eval_loss(self, triples, seq, beta=1.0, eps=None):

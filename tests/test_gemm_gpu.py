@@ -103,7 +103,7 @@ def test_wgrad16_tr_read_kernel(prec, tile, nbuf, shape):
     L.check(L.lib().ark_wgrad16(L.i32(prec), L.ptr(Ad), L.i64(M), L.ptr(Bd), L.i64(N), L.ptr(C), L.i64(N), L.i32(M), L.i32(N),
                                 L.i32(K), L.cur_stream()), "ark_wgrad16")
     torch.cuda.synchronize()
-    L.check(L.lib().ark_set_wgrad16_tuning(L.i32(64), L.i32(4), L.i32(1024)), "tune")
+    L.check(L.lib().ark_set_wgrad16_tuning(L.i32(128), L.i32(2), L.i32(96)), "tune")
     ref = C0.double() + A.double().t() @ B.double()
     err = (C.cpu().double() - ref).abs().max().item()
     assert err <= 3e-5 * (K ** 0.5) + 1e-4, err
