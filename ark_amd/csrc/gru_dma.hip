@@ -33,12 +33,14 @@ struct GruFwdDmaArgs {
   void* yd16a; void* yd16b; const float* mask;   // dropped copies h*mask (mask tile-native fp32), nullable
   _Float16* sr; _Float16* sz; _Float16* sn; _Float16* shn;   // tile-native fp16 saves, nullable
   int B, D;
+  int dbg;   // timing ablations (results invalid when != 0): 1 no main loop, 2 no epilogue stores, 4 no prefetch loads
 };
 
-template <int PREC, int PRECB, int NBUF, int KI>
+template <int PREC, int PRECB, int NBUF, int KI, int BM>
 __global__ __launch_bounds__(256) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) {
-  constexpr int BM = 32, BU = 32, BN = 3 * BU;
-  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;  // wave tile 16 x 48 (16 units x 3 gates)
+  constexpr int BU = 32, BN = 3 * BU;
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;  // wave tile (BM/2) x 48 (16 units x 3 gates)
+  constexpr int TM = G::TM;
   using h_t = typename G::h_t;
   using hb_t = typename PrecTraits<PRECB>::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -49,60 +51,70 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) 
   const int wm = wave >> 1, wn = wave & 1;
   const int ul = wn * 16 + (lane & 15);           // unit within the workgroup tile
   const int u = u0 + ul;
-  const int rl = wm * 16 + 4 * (lane >> 4);       // first of this lane's 4 rows within the tile
-  const int row0 = m0 + rl;
   // Epilogue operands are requested BEFORE the recurrent product: they are older than every LDS-DMA
   // op in the vmcnt queue, so they land underneath the main loop instead of after it.
-  const int rowc = min(row0, B - 4);              // B % 16 == 0: clamped quads stay in bounds
-  const long og = tile_native_off(rowc, u, 3 * D);
-  const long o = tile_native_off(rowc, u, D);
-  const f32x4 gr = *reinterpret_cast<const f32x4*>(p.gi + og);
-  const f32x4 gz = *reinterpret_cast<const f32x4*>(p.gi + og + (long)(D >> 4) * 256);
-  const f32x4 gn = *reinterpret_cast<const f32x4*>(p.gi + og + (long)(D >> 4) * 512);
-  const f32x4 hp = *reinterpret_cast<const f32x4*>(p.y_prev + o);
-  f32x4 mk = {1.f, 1.f, 1.f, 1.f};
-  if (p.mask) mk = *reinterpret_cast<const f32x4*>(p.mask + o);
+  int rl[TM];
+  long o[TM];
+  f32x4 gr[TM], gz[TM], gn[TM], hp[TM], mk[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    rl[tm] = wm * G::WTM + tm * 16 + 4 * (lane >> 4);   // first of this lane's 4 rows within the tile
+    const int rowc = min(m0 + rl[tm], B - 4);            // B % 16 == 0: clamped quads stay in bounds
+    const long og = tile_native_off(rowc, u, 3 * D);
+    o[tm] = tile_native_off(rowc, u, D);
+    gr[tm] = *reinterpret_cast<const f32x4*>(p.gi + og);
+    gz[tm] = *reinterpret_cast<const f32x4*>(p.gi + og + (long)(D >> 4) * 256);
+    gn[tm] = *reinterpret_cast<const f32x4*>(p.gi + og + (long)(D >> 4) * 512);
+    hp[tm] = *reinterpret_cast<const f32x4*>(p.y_prev + o[tm]);
+    mk[tm] = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (p.mask) mk[tm] = *reinterpret_cast<const f32x4*>(p.mask + o[tm]);
+  }
   const float bhr = p.b_hh[u], bhz = p.b_hh[D + u], bhn = p.b_hh[2 * D + u];
 
   f32x4 acc[G::TM][G::TN];
   G::run(acc, reinterpret_cast<const h_t*>(p.h_prev16), D, [=](int r) -> long { return (long)min(m0 + r, B - 1); },
          reinterpret_cast<const h_t*>(p.w_hh16), D,
-         [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); }, D, smem);
+         [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); }, (p.dbg & 1) ? 0 : D, smem);
 
-  // the LDS ring is free now; reuse it to assemble row-major 16-bit rows [32][32+pad]
+  // the LDS ring is free now; reuse it to assemble row-major 16-bit rows [BM][32+pad]
   __syncthreads();
-  h_t* ta = reinterpret_cast<h_t*>(smem);                 // h        (forward type)
-  hb_t* tb = reinterpret_cast<hb_t*>(smem + 4096);        // h        (backward type)
-  h_t* tda = reinterpret_cast<h_t*>(smem + 8192);         // h*mask
-  hb_t* tdb = reinterpret_cast<hb_t*>(smem + 12288);
   constexpr int TS = 40;  // row stride in elements (80 B: 16-B aligned rows, spreads banks)
-  if (row0 < B) {
+  constexpr int ARR = BM * TS * 2;
+  h_t* ta = reinterpret_cast<h_t*>(smem);                 // h        (forward type)
+  hb_t* tb = reinterpret_cast<hb_t*>(smem + ARR);         // h        (backward type)
+  h_t* tda = reinterpret_cast<h_t*>(smem + 2 * ARR);      // h*mask
+  hb_t* tdb = reinterpret_cast<hb_t*>(smem + 3 * ARR);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    if (m0 + rl[tm] >= B) continue;
     f32x4 r, z, n, hn, h;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      r[i] = sigmoidf_(gr[i] + acc[0][0][i] + bhr);
-      z[i] = sigmoidf_(gz[i] + acc[0][1][i] + bhz);
-      hn[i] = acc[0][2][i] + bhn;
-      n[i] = tanhf(gn[i] + r[i] * hn[i]);
-      h[i] = (1.0f - z[i]) * n[i] + z[i] * hp[i];
+      r[i] = sigmoidf_(gr[tm][i] + acc[tm][0][i] + bhr);
+      z[i] = sigmoidf_(gz[tm][i] + acc[tm][1][i] + bhz);
+      hn[i] = acc[tm][2][i] + bhn;
+      n[i] = tanhf(gn[tm][i] + r[i] * hn[i]);
+      h[i] = (1.0f - z[i]) * n[i] + z[i] * hp[tm][i];
     }
-    *reinterpret_cast<f32x4*>(p.y_out + o) = h;
-    if (p.sr) { st_half4(p.sr + o, r); st_half4(p.sz + o, z); st_half4(p.sn + o, n); st_half4(p.shn + o, hn); }
-    const f32x4 hd = h * mk;
+    if (!(p.dbg & 2)) *reinterpret_cast<f32x4*>(p.y_out + o[tm]) = h;
+    if (p.sr && !(p.dbg & 2)) {
+      st_half4(p.sr + o[tm], r); st_half4(p.sz + o[tm], z); st_half4(p.sn + o[tm], n); st_half4(p.shn + o[tm], hn);
+    }
+    const f32x4 hd = h * mk[tm];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ta[(rl + i) * TS + ul] = G::PT::cvt(h[i]);
-      if (p.y16b) tb[(rl + i) * TS + ul] = PrecTraits<PRECB>::cvt(h[i]);
+      ta[(rl[tm] + i) * TS + ul] = G::PT::cvt(h[i]);
+      if (p.y16b) tb[(rl[tm] + i) * TS + ul] = PrecTraits<PRECB>::cvt(h[i]);
       if (p.mask) {
-        tda[(rl + i) * TS + ul] = G::PT::cvt(hd[i]);
-        tdb[(rl + i) * TS + ul] = PrecTraits<PRECB>::cvt(hd[i]);
+        tda[(rl[tm] + i) * TS + ul] = G::PT::cvt(hd[i]);
+        tdb[(rl[tm] + i) * TS + ul] = PrecTraits<PRECB>::cvt(hd[i]);
       }
     }
   }
   __syncthreads();
-  // 32 rows x 64 B per array: thread t -> row t/4 (0..31 for t<128), 16-byte chunk t%4
+  // BM rows x 64 B per array: thread t -> row t/4, 16-byte chunk t%4
   const int t = threadIdx.x;
-  if (t < 128) {
+  if (t < BM * 4 && !(p.dbg & 2)) {
     const int rr = t >> 2, ch = t & 3;
     const int row = m0 + rr;
     if (row < B) {
@@ -269,28 +281,37 @@ static void allow_lds(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+int g_dma_dbg = 0;
 int g_fwd_nbuf = 2, g_bwd_nbuf = 2;   // ring slots
 int g_fwd_ki = 2, g_bwd_ki = 2;       // 64-wide k-images per stage (1 | 2)
 
-template <int PREC, int PRECB, int NBUF, int KI>
+int g_fwd_bm = 32;   // rows per forward-cell workgroup (32 | 64)
+
+template <int PREC, int PRECB, int NBUF, int KI, int BM>
 static void launch_fwd_nb(const GruFwdDmaArgs& p, hipStream_t st) {
-  using G = DmaTile<PREC, 32, 96, NBUF, 2, 2, KI>;
-  constexpr int LDS = G::LDS_BYTES > 16384 ? G::LDS_BYTES : 16384;
-  static bool once = (allow_lds(gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF, KI>, LDS), true); (void)once;
-  const unsigned grid = (unsigned)(((p.B + 31) / 32) * (p.D / 32));
-  hipLaunchKernelGGL((gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF, KI>), dim3(grid), dim3(256), LDS, st, p);
+  using G = DmaTile<PREC, BM, 96, NBUF, 2, 2, KI>;
+  constexpr int MINL = 4 * BM * 40 * 2;
+  constexpr int LDS = G::LDS_BYTES > MINL ? G::LDS_BYTES : MINL;
+  static bool once = (allow_lds(gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF, KI, BM>, LDS), true); (void)once;
+  const unsigned grid = (unsigned)(((p.B + BM - 1) / BM) * (p.D / 32));
+  hipLaunchKernelGGL((gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF, KI, BM>), dim3(grid), dim3(256), LDS, st, p);
+}
+template <int PREC, int PRECB, int BM>
+static void launch_fwd_bm(const GruFwdDmaArgs& p, hipStream_t st) {
+  const bool ki2 = g_fwd_ki == 2 && p.D % 128 == 0;
+  if (ki2) {
+    if (g_fwd_nbuf >= 4 && BM == 32) launch_fwd_nb<PREC, PRECB, (BM == 32 ? 4 : 2), 2, BM>(p, st);
+    else launch_fwd_nb<PREC, PRECB, 2, 2, BM>(p, st);
+  } else {
+    if (g_fwd_nbuf == 8 && BM == 32) launch_fwd_nb<PREC, PRECB, (BM == 32 ? 8 : 4), 1, BM>(p, st);
+    else if (g_fwd_nbuf >= 4) launch_fwd_nb<PREC, PRECB, 4, 1, BM>(p, st);
+    else launch_fwd_nb<PREC, PRECB, 2, 1, BM>(p, st);
+  }
 }
 template <int PREC, int PRECB>
 static int launch_fwd_dma(const GruFwdDmaArgs& p, hipStream_t st) {
-  const bool ki2 = g_fwd_ki == 2 && p.D % 128 == 0;
-  if (ki2) {
-    if (g_fwd_nbuf >= 4) launch_fwd_nb<PREC, PRECB, 4, 2>(p, st);
-    else launch_fwd_nb<PREC, PRECB, 2, 2>(p, st);
-  } else {
-    if (g_fwd_nbuf == 8) launch_fwd_nb<PREC, PRECB, 8, 1>(p, st);
-    else if (g_fwd_nbuf == 4) launch_fwd_nb<PREC, PRECB, 4, 1>(p, st);
-    else launch_fwd_nb<PREC, PRECB, 2, 1>(p, st);
-  }
+  if (g_fwd_bm == 64) launch_fwd_bm<PREC, PRECB, 64>(p, st);
+  else launch_fwd_bm<PREC, PRECB, 32>(p, st);
   ARK_LAUNCH_CHECK();
   return 0;
 }
@@ -320,6 +341,12 @@ static int launch_bwd_dma(const GruBwdDmaArgs& p, hipStream_t st) {
 }  // namespace ark
 
 // speed-only knobs: ring depth (2|4|8) of the forward / backward LDS-DMA cell kernels
+extern "C" int ark_set_dma_fwd_rows(int bm) {
+  if (bm != 32 && bm != 64) return ARK_ERR_ARG;
+  ark::g_fwd_bm = bm;
+  return 0;
+}
+
 extern "C" int ark_set_dma_stage(int fwd_ki, int bwd_ki) {
   if ((fwd_ki != 1 && fwd_ki != 2) || (bwd_ki != 1 && bwd_ki != 2)) return ARK_ERR_ARG;
   ark::g_fwd_ki = fwd_ki;
@@ -345,7 +372,7 @@ extern "C" int ark_gru_cell_fwd_dma(int prec, int prec_b, const void* h_prev16, 
   if (mask_t && !yd16a) return ARK_ERR_ARG;
   if (save_r && (!save_z || !save_n || !save_hn)) return ARK_ERR_ARG;
   GruFwdDmaArgs p{h_prev16, w_hh16, y_prev_t, b_hh, gi_t, y_out_t, y16a, y16b, yd16a, yd16b, mask_t,
-                  (_Float16*)save_r, (_Float16*)save_z, (_Float16*)save_n, (_Float16*)save_hn, B, D};
+                  (_Float16*)save_r, (_Float16*)save_z, (_Float16*)save_n, (_Float16*)save_hn, B, D, g_dma_dbg};
   hipStream_t st = (hipStream_t)stream;
   if (prec == PREC_F16 && prec_b == PREC_BF16) return launch_fwd_dma<PREC_F16, PREC_BF16>(p, st);
   if (prec == PREC_F16 && prec_b == PREC_F16) return launch_fwd_dma<PREC_F16, PREC_F16>(p, st);
@@ -402,3 +429,6 @@ extern "C" int ark_weight_shadows(int n_jobs, const float* const* src, void* con
   ARK_LAUNCH_CHECK();
   return 0;
 }
+
+// timing ablations of the forward cell (results invalid while != 0); see tools/cell_timing.py
+extern "C" int ark_set_dma_debug(int mask) { ark::g_dma_dbg = mask; return 0; }

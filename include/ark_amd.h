@@ -97,6 +97,8 @@ int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_hhT16, const
                        int accumulate, int B, int D, void* stream);
 int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf);
 int ark_set_dma_stage(int fwd_ki, int bwd_ki);
+int ark_set_dma_fwd_rows(int bm);
+int ark_set_dma_debug(int mask); /* timing ablations only: results are invalid while mask != 0 */
 int ark_set_gemm16_tuning(int nbuf, int force64);
 int ark_set_wgrad_tile128(int enabled);
 /* up to 12 jobs in one launch: dst[i] = cast(src[i] [R,C]) in prec[i]; dstT[i] = cast(src[i]^T) in precT[i] */
