@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) 
 }
 
 // ---- 16-bit shadows (plain and transposed) of a list of fp32 matrices, one launch ------------
-struct ShadowJob { const float* src; void* dst; void* dstT; int R, C, prec, precT; };
+struct ShadowJob { const float* src; void* dst; void* dstT; int R, C, prec, precT, ldT; };   // dstT[c*ldT + r]
 struct ShadowJobs { ShadowJob j[12]; int n; };
 
 __device__ __forceinline__ void shadow_put(void* base, long idx, float v, int prec) {
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void weight_shadow_kernel(ShadowJobs jobs) {
   if (jb.dstT)
     for (int i = ty; i < 32; i += 8) {
       const int c = c0 + i, r = r0 + tx;
-      if (r < jb.R && c < jb.C) shadow_put(jb.dstT, (long)c * jb.R + r, tile[tx][i], jb.precT);
+      if (r < jb.R && c < jb.C) shadow_put(jb.dstT, (long)c * jb.ldT + r, tile[tx][i], jb.precT);
     }
 }
 
@@ -412,7 +412,7 @@ extern "C" int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_h
 
 // up to 12 jobs: dst = cast(src [R,C]) in `prec`, dstT = cast(src^T [C,R]) in `precT` (either may be NULL)
 extern "C" int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, void* const* dstT, const int* R,
-                                  const int* C, const int* prec, const int* precT, void* stream) {
+                                  const int* C, const int* prec, const int* precT, const int* ldT, void* stream) {
   using namespace ark;
   if (n_jobs <= 0 || n_jobs > 12 || !src || !dst || !dstT || !R || !C || !prec || !precT) return ARK_ERR_ARG;
   ShadowJobs jobs;
@@ -420,7 +420,9 @@ extern "C" int ark_weight_shadows(int n_jobs, const float* const* src, void* con
   int maxR = 0, maxC = 0;
   for (int i = 0; i < n_jobs; ++i) {
     if (!src[i] || R[i] <= 0 || C[i] <= 0) return ARK_ERR_ARG;
-    jobs.j[i] = ShadowJob{src[i], dst[i], dstT[i], R[i], C[i], prec[i], precT[i]};
+    const int ld = (ldT && ldT[i] > 0) ? ldT[i] : R[i];
+    if (ld < R[i]) return ARK_ERR_ARG;
+    jobs.j[i] = ShadowJob{src[i], dst[i], dstT[i], R[i], C[i], prec[i], precT[i], ld};
     if (R[i] > maxR) maxR = R[i];
     if (C[i] > maxC) maxC = C[i];
   }

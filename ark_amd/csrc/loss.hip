@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void zproj_bwd_dw_kernel(const float* __restri
 // Writes the per-row loss and (optionally, in place) dlogits = (softmax - onehot) * inv_count.
 __global__ __launch_bounds__(256) void ce_kernel(float* logits, long ld, const int64_t* __restrict__ seq,
                                                  long ld_seq, const float* __restrict__ hyper, float* __restrict__ row_loss,
-                                                 float* dlogits, int B, int L, int V) {
+                                                 float* dlogits, __bf16* d16bf, _Float16* d16h, long ld16, int B, int L, int V) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= B * L) return;
   const int t = row / B, b = row % B;
@@ -164,10 +164,16 @@ __global__ __launch_bounds__(256) void ce_kernel(float* logits, long ld, const i
   if (dlogits) {
     const float s = live ? hyper[ARK_HP_CE_INV_COUNT] : 0.f;
     float* d = dlogits + (long)row * ld;
-    for (int c = lane; c < ld; c += 64) {
+    const long nc = (d16bf || d16h) ? (ld16 > ld ? ld16 : ld) : ld;
+    for (int c = lane; c < nc; c += 64) {
       float g = 0.f;
       if (c < V) g = (expf(x[c] - lse) - ((long)c == tgt ? 1.0f : 0.f)) * s;
-      d[c] = g;
+      if (c < ld) d[c] = g;
+      // K-padded 16-bit copy (zeros beyond V) for the input-gradient product on the LDS-DMA engine
+      if (c < ld16) {
+        if (d16bf) d16bf[(long)row * ld16 + c] = (__bf16)g;
+        if (d16h) d16h[(long)row * ld16 + c] = (_Float16)fminf(fmaxf(g, -65504.f), 65504.f);
+      }
     }
   }
 }
@@ -294,11 +300,14 @@ extern "C" int ark_count_targets(const int64_t* seq, int64_t ld_seq, int B, int 
 }
 
 extern "C" int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int64_t ld_seq, const float* hyper,
-                              float* row_loss, float* dlogits, int B, int L, int V, void* stream) {
+                              float* row_loss, float* dlogits, void* dlogits16, int prec16, int64_t ld16, int B, int L, int V,
+                              void* stream) {
   using namespace ark;
   if (!logits || !seq || !hyper || !row_loss || B <= 0 || L <= 0 || V <= 0 || ld < V) return ARK_ERR_ARG;
+  if (dlogits16 && (!dlogits || ld16 < V || (prec16 != 1 && prec16 != 2))) return ARK_ERR_ARG;
   hipLaunchKernelGGL(ce_kernel, dim3((B * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, seq, (long)ld_seq,
-                     hyper, row_loss, dlogits, B, L, V);
+                     hyper, row_loss, dlogits, prec16 == 1 ? (__bf16*)dlogits16 : nullptr,
+                     prec16 == 2 ? (_Float16*)dlogits16 : nullptr, (long)ld16, B, L, V);
   ARK_LAUNCH_CHECK();
   return 0;
 }

@@ -152,6 +152,8 @@ class Engine:
             self.wihT16 = [i16(D, 3 * D) for _ in range(self.n)]
             self.whhT16 = [i16(D, 3 * D) for _ in range(self.n)]
             self.wtok16 = i16(V, D)
+            self.Vp = _rup(V, 64)                                    # K-padded vocabulary for the dY product
+            self.wtokT16 = torch.zeros(D, self.Vp, device=dev, dtype=torch.int16)   # W_tok^T, backward type, zero pad
             if self.mt == "SAIL":
                 H = 3 * D
                 self.wm16 = [i16(H, H) for _ in range(self.n)]      # encoder MLP weights, forward type
@@ -162,6 +164,8 @@ class Engine:
         self._side = None
         self._side_used = False
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
+        self._layer_streams = []
+        self.pipeline_layers = bool(cfg.get("ark_pipeline_layers", False))   # measured slower on MI355X
 
     # ------------------------------------------------------------------ parameters
     def load_params(self, named):
@@ -182,7 +186,7 @@ class Engine:
         for l in range(self.n):
             jobs.append((self.p[f"dec.gru.weight_ih_l{l}"], self.wih16[l], self.wihT16[l], 3 * self.D, self.D))
             jobs.append((self.p[f"dec.gru.weight_hh_l{l}"], self.whh16[l], self.whhT16[l], 3 * self.D, self.D))
-        jobs.append((self.p["dec.out.weight"], self.wtok16, None, self.V, self.D))
+        jobs.append((self.p["dec.out.weight"], self.wtok16, self.wtokT16, self.V, self.D, self.Vp))
         if self.mt == "SAIL":
             H = 3 * self.D
             for i in range(self.n):
@@ -199,13 +203,14 @@ class Engine:
             C = (ctypes.c_int * n)(*[j[4] for j in ch])
             pf = (ctypes.c_int * n)(*[self.prec_fwd] * n)
             pb = (ctypes.c_int * n)(*[self.prec_bwd] * n)
-            chunks.append((n, src, dst, dstT, R, C, pf, pb))
+            ldT = (ctypes.c_int * n)(*[(j[5] if len(j) > 5 else 0) for j in ch])
+            chunks.append((n, src, dst, dstT, R, C, pf, pb, ldT))
         return chunks
 
     def refresh_shadows(self):
         if self.use_dma:
-            for (n, src, dst, dstT, R, C, pf, pb) in self._shadow_jobs:
-                _call("ark_weight_shadows", L.i32(n), src, dst, dstT, R, C, pf, pb, L.cur_stream())
+            for (n, src, dst, dstT, R, C, pf, pb, ldT) in self._shadow_jobs:
+                _call("ark_weight_shadows", L.i32(n), src, dst, dstT, R, C, pf, pb, ldT, L.cur_stream())
         self._shadow_ok = True
 
     def set_hyper(self, lr=None, beta=None, kl_norm=None, ce_count=None, grad_scale=None):
@@ -269,6 +274,7 @@ class Engine:
                 w[nm] = [i16(R, D) for _ in range(n)]                        # tile-native fp16 saves
             w["dGI16"] = [i16(R, 3 * D) for _ in range(n)]
             w["dGH16"] = [i16(R, 3 * D) for _ in range(n)]
+            w["dlog16"] = torch.zeros(R, self.Vp, device=dev, dtype=torch.int16)   # K-padded 16-bit dlogits
             w["h0"] = f(B, D)                                                # row-major h0 (z-projection)
             w["dX0"] = f(R, D)
             if self.p_drop > 0:
@@ -312,6 +318,7 @@ class Engine:
         """Launch the forward pass.  triples [B,T,3] int64 (SAIL), seq [B,seq_len] int64 (device).
         Results stay on the device in the workspace (out4 = loss, ce, kl, token-loss sum)."""
         self.prec = self.prec_fwd
+        self._dlog16_valid = False
         if not self._shadow_ok:
             self.refresh_shadows()
         B = seq.shape[0]
@@ -373,8 +380,12 @@ class Engine:
         if with_loss:
             if ce_count is None:
                 _call("ark_count_targets", L.ptr(seq), L.i64(ld_seq), L.i32(B), L.i32(Lq), L.ptr(self.hyper), st)
+            d16 = w["dlog16"] if (with_dlogits and w["v2"]) else None
             _call("ark_ce_fwd_bwd", L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper),
-                  L.ptr(w["row_loss"]), L.ptr(w["logits"] if with_dlogits else None), L.i32(B), L.i32(Lq), L.i32(V), st)
+                  L.ptr(w["row_loss"]), L.ptr(w["logits"] if with_dlogits else None), L.ptr(d16),
+                  L.i32(self.prec_bwd if d16 is not None else 0), L.i64(self.Vp if d16 is not None else 0), L.i32(B), L.i32(Lq),
+                  L.i32(V), st)
+            self._dlog16_valid = d16 is not None
             _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R), L.ptr(w["kl"] if self.mt == "SAIL" else None),
                   L.ptr(self.hyper), L.ptr(w["out4"]), st)
         return w
@@ -406,29 +417,73 @@ class Engine:
         _call("ark_tok_gather16", L.i32(pf), L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(p["dec.tok_emb.weight"]),
               L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0a"]), L.ptr(w["X0b"]), L.i32(B),
               L.i32(Lq), L.i32(D), st)
-        xin = w["X0a"]
-        for l in range(n):
+        def in_gemm(l, xin, rows, row0):
+            # gi[l][row0 : row0+rows] = xin x W_ih^T + b_ih   (tile-native; B % 16 == 0 keeps slices tile-aligned)
             _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(xin), L.i64(D), L.ptr(self.wih16[l]), L.i64(D),
-                  L.ptr(w["GI"][l]), L.i64(3 * D), L.ptr(p[f"dec.gru.bias_ih_l{l}"]), L.ptr(None), L.i32(R), L.i32(3 * D),
-                  L.i32(D), L.i32(1), st)
-            drop = use_drop and l < n - 1
-            if drop:
-                _call("ark_dropout_mask", L.ptr(w["mask"][l]), L.i64(R * D), L.f32(self.p_drop),
-                      L.u64(self.drop_seed + 7919 * l), L.ptr(self.hyper), st)
+                  L.ptr(w["GI"][l][row0:]), L.i64(3 * D), L.ptr(p[f"dec.gru.bias_ih_l{l}"]), L.ptr(None), L.i32(rows),
+                  L.i32(3 * D), L.i32(D), L.i32(1), L.cur_stream())
+
+        def cell(l, t, drop):
             Y, Ya, Yb = w["Y"][l], w["Y16a"][l], w["Y16b"][l]
-            for t in range(Lq):
-                sl = slice(t * B, (t + 1) * B)
-                nx = slice((t + 1) * B, (t + 2) * B)
-                _call("ark_gru_cell_fwd_dma", L.i32(pf), L.i32(pb), L.ptr(Ya[sl]), L.ptr(self.whh16[l]), L.ptr(Y[sl]),
-                      L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l][sl]), L.ptr(Y[nx]), L.ptr(Ya[nx]),
-                      L.ptr(Yb[nx] if Yb is not None else None),
-                      L.ptr(w["Yd16a"][l][sl] if drop else None),
-                      L.ptr(w["Yd16b"][l][sl] if (drop and w["Yd16b"][l] is not None) else None),
-                      L.ptr(w["mask"][l][sl] if drop else None),
-                      L.ptr(w["SR"][l][sl] if save else None), L.ptr(w["SZ"][l][sl] if save else None),
-                      L.ptr(w["SN"][l][sl] if save else None), L.ptr(w["SHN"][l][sl] if save else None),
-                      L.i32(B), L.i32(D), st)
-            xin = w["Yd16a"][l] if drop else Ya[B:]
+            sl = slice(t * B, (t + 1) * B)
+            nx = slice((t + 1) * B, (t + 2) * B)
+            _call("ark_gru_cell_fwd_dma", L.i32(pf), L.i32(pb), L.ptr(Ya[sl]), L.ptr(self.whh16[l]), L.ptr(Y[sl]),
+                  L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l][sl]), L.ptr(Y[nx]), L.ptr(Ya[nx]),
+                  L.ptr(Yb[nx] if Yb is not None else None),
+                  L.ptr(w["Yd16a"][l][sl] if drop else None),
+                  L.ptr(w["Yd16b"][l][sl] if (drop and w["Yd16b"][l] is not None) else None),
+                  L.ptr(w["mask"][l][sl] if drop else None),
+                  L.ptr(w["SR"][l][sl] if save else None), L.ptr(w["SZ"][l][sl] if save else None),
+                  L.ptr(w["SN"][l][sl] if save else None), L.ptr(w["SHN"][l][sl] if save else None),
+                  L.i32(B), L.i32(D), L.cur_stream())
+
+        def mask_gen(l):
+            _call("ark_dropout_mask", L.ptr(w["mask"][l]), L.i64(R * D), L.f32(self.p_drop),
+                  L.u64(self.drop_seed + 7919 * l), L.ptr(self.hyper), L.cur_stream())
+
+        if self.pipeline_layers and n > 1:
+            # Layer wavefront: layer l runs on its own stream, one step behind layer l-1.  cell(l,t) needs
+            # gi[l][t] (a [B,D]x[D,3D] product of the layer below's step-t output) and cell(l,t-1); cells of
+            # different layers overlap, so the dependent chain is L+n-1 steps long instead of n*L.
+            main = torch.cuda.current_stream()
+            streams = [main] + [self._layer_stream(l) for l in range(1, n)]
+            ev = [[None] * Lq for _ in range(n)]
+            in_gemm(0, w["X0a"], R, 0)
+            start = torch.cuda.Event()
+            start.record(main)
+            for l in range(1, n):
+                streams[l].wait_event(start)
+            # issue in diagonal order so every wait refers to an event already recorded
+            for d in range(Lq + n - 1):
+                for l in range(n):
+                    t = d - l
+                    if t < 0 or t >= Lq:
+                        continue
+                    drop = use_drop and l < n - 1
+                    with torch.cuda.stream(streams[l]):
+                        if t == 0 and drop:
+                            mask_gen(l)
+                        if l > 0:
+                            streams[l].wait_event(ev[l - 1][t])
+                            below_drop = use_drop
+                            src = w["Yd16a"][l - 1][t * B:] if below_drop else w["Y16a"][l - 1][(t + 1) * B:]
+                            in_gemm(l, src, B, t * B)
+                        cell(l, t, drop)
+                        if l < n - 1:
+                            ev[l][t] = torch.cuda.Event()
+                            ev[l][t].record(streams[l])
+            for l in range(1, n):
+                main.wait_stream(streams[l])
+        else:
+            xin = w["X0a"]
+            for l in range(n):
+                in_gemm(l, xin, R, 0)
+                drop = use_drop and l < n - 1
+                if drop:
+                    mask_gen(l)
+                for t in range(Lq):
+                    cell(l, t, drop)
+                xin = w["Yd16a"][l] if drop else w["Y16a"][l][B:]
         _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(w["Y16a"][n - 1][B:]), L.i64(D), L.ptr(self.wtok16), L.i64(D),
               L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(p["dec.out.bias"]), L.ptr(None), L.i32(R), L.i32(V), L.i32(D),
               L.i32(0), st)
@@ -629,9 +684,15 @@ class Engine:
         self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
         _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dlog), L.i32(0), L.i64(self.ldl), L.ptr(yb(n - 1)[B:]), L.i32(1), L.i64(D),
               L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(V), L.i32(D), L.i32(R), L.i32(1), st)
-        # dY of the top layer: K = V is not a multiple of 64 -> register-staged engine, then re-tile
-        self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
-        _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
+        if getattr(self, "_dlog16_valid", False):
+            # dY of the top layer on the LDS-DMA engine: K-padded 16-bit dlogits x K-padded W_tok^T shadow
+            _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(self.wtokT16),
+                  L.i64(self.Vp), L.ptr(w["dYa"]), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(self.Vp),
+                  L.i32(1), st)
+        else:
+            # external dlogits (autograd path): register-staged engine on the fp32 buffer, then re-tile
+            self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
+            _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
         dy, dy_other = w["dYa"], w["dYb"]
         group = []
         for l in range(n - 1, -1, -1):
@@ -685,6 +746,11 @@ class Engine:
         for i0 in range(0, len(group), 8):
             self._wgrad_group(group[i0:i0 + 8])
         return w["dX0"]
+
+    def _layer_stream(self, l):
+        while len(self._layer_streams) <= l:
+            self._layer_streams.append(torch.cuda.Stream(device=self.device))
+        return self._layer_streams[l]
 
     def _side_stream(self):
         if self._side is None:

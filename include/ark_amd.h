@@ -101,9 +101,10 @@ int ark_set_dma_fwd_rows(int bm);
 int ark_set_dma_debug(int mask); /* timing ablations only: results are invalid while mask != 0 */
 int ark_set_gemm16_tuning(int nbuf, int force64);
 int ark_set_wgrad_tile128(int enabled);
-/* up to 12 jobs in one launch: dst[i] = cast(src[i] [R,C]) in prec[i]; dstT[i] = cast(src[i]^T) in precT[i] */
+/* up to 12 jobs in one launch: dst[i] = cast(src[i] [R,C]) in prec[i]; dstT[i] = cast(src[i]^T) in precT[i],
+ * rows of dstT ldT[i] apart (ldT NULL or 0: dense, = R) */
 int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, void* const* dstT, const int* R,
-                       const int* C, const int* prec, const int* precT, void* stream);
+                       const int* C, const int* prec, const int* precT, const int* ldT, void* stream);
 /* C[M,N] = A16[M,K] B16[N,K]^T (+bias | *aux), C row-major or tile-native (c_tiled) */
 int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* stream);
@@ -154,8 +155,10 @@ int ark_zproj_bwd(float* dh0, const float* h0, const float* z, const float* w_z,
                   float* d_b_z, int B, int Z, int D, int accumulate, void* stream);
 int ark_count_targets(const int64_t* seq, int64_t ld_seq, int B, int L, float* hyper, void* stream);
 /* rows are time-major (t,b); target of row (t,b) is seq[b, t+1]; dlogits may alias logits or be NULL */
+/* dlogits16 (nullable): additional [B*L, ld16] copy of dlogits in 16 bits (prec16), zero beyond V */
 int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int64_t ld_seq, const float* hyper,
-                   float* row_loss, float* dlogits, int B, int L, int V, void* stream);
+                   float* row_loss, float* dlogits, void* dlogits16, int prec16, int64_t ld16, int B, int L, int V,
+                   void* stream);
 /* out4 = {loss = ce + beta*kl, ce, kl, sum of token losses}; kl nullable (ARK) */
 int ark_loss_finalize(const float* row_loss, int n_rows, const float* kl, const float* hyper, float* out4,
                       void* stream);
