@@ -129,12 +129,17 @@ __global__ __launch_bounds__(256) void scatter_global_kernel(ScatterArgs p) {
   }
 }
 
+int g_scatter_chunk_items = 48;
+
 static int launch_scatter(const ScatterArgs& p, hipStream_t st) {
   if (p.n_items <= 0) return 0;
   if ((long)p.n_rows * 64 * 4 <= 48 * 1024) {
     const int slices = (p.D + 63) / 64;
-    int n_chunks = 512 / slices; if (n_chunks < 1) n_chunks = 1;
-    if (n_chunks > (p.n_items + 15) / 16) n_chunks = (p.n_items + 15) / 16;
+    // chunks trade item-loop length against the fixed per-workgroup cost (LDS table zero + flush of
+    // n_rows x 64 global atomics): ~chunk_items items per workgroup, at most ~512 workgroups
+    int n_chunks = (p.n_items + g_scatter_chunk_items - 1) / g_scatter_chunk_items;
+    if (n_chunks > 2048 / slices) n_chunks = 2048 / slices;
+    if (n_chunks < 1) n_chunks = 1;
     hipLaunchKernelGGL(scatter_lds_kernel, dim3(slices * n_chunks), dim3(256), (size_t)p.n_rows * 64 * 4, st, p, n_chunks);
   } else {
     int grid = (p.n_items + 3) / 4; if (grid > 2048) grid = 2048;
@@ -145,6 +150,12 @@ static int launch_scatter(const ScatterArgs& p, hipStream_t st) {
 }
 
 }  // namespace ark
+
+extern "C" int ark_set_scatter_chunk(int items) {
+  if (items < 16) return ARK_ERR_ARG;
+  ark::g_scatter_chunk_items = items;
+  return 0;
+}
 
 extern "C" int ark_enc_pool_fwd(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt,
                                 int B, int T, int D, int64_t pad_rid, void* stream) {
