@@ -17,6 +17,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required for RCCL on this pool
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -90,49 +92,53 @@ def cpu_baseline(cfg, B, steps=6, warmup=2):
                       f"{dt * 1e3:.1f} ms/step"}
 
 
-def time_dominant_kernel(eng, B, iters=50):
+def time_dominant_kernel(eng, B, reps=8):
     """average duration of the dominant kernel (the per-timestep forward GRU cell: recurrent MFMA
-    product + fused gate epilogue) measured with HIP events on the launch stream; the launches are
-    captured into one hipGraph so the measurement is GPU-bound, not ctypes-bound."""
+    product + fused gate epilogue), measured live with HIP events on the launch stream.  The launches
+    replay the real forward's cell sequence (every layer and timestep, its own gi / state / save
+    buffers, so cache residency matches the train step) from one hipGraph, so the figure is GPU-bound."""
     from ark_amd import _lib as L
     w = eng.ws
-    D = eng.D
+    D, n, Lq = eng.D, eng.n, eng.L
     p = eng.p
     st = torch.cuda.Stream()
-    sl, nx = slice(0, B), slice(B, 2 * B)
 
-    def launch():
+    def launch(l, t):
+        sl, nx = slice(t * B, (t + 1) * B), slice((t + 1) * B, (t + 2) * B)
         if w["v2"]:
-            Yb = w["Y16b"][0]
+            Yb = w["Y16b"][l]
             L.check(L.lib().ark_gru_cell_fwd_dma(
-                L.i32(eng.prec_fwd), L.i32(eng.prec_bwd), L.ptr(w["Y16a"][0][sl]), L.ptr(eng.whh16[0]), L.ptr(w["Y"][0][sl]),
-                L.ptr(p["dec.gru.bias_hh_l0"]), L.ptr(w["GI"][0][sl]), L.ptr(w["Y"][0][nx]), L.ptr(w["Y16a"][0][nx]),
-                L.ptr(Yb[nx] if Yb is not None else None), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(w["SR"][0][sl]),
-                L.ptr(w["SZ"][0][sl]), L.ptr(w["SN"][0][sl]), L.ptr(w["SHN"][0][sl]), L.i32(B), L.i32(D), L.cur_stream()),
+                L.i32(eng.prec_fwd), L.i32(eng.prec_bwd), L.ptr(w["Y16a"][l][sl]), L.ptr(eng.whh16[l]), L.ptr(w["Y"][l][sl]),
+                L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l][sl]), L.ptr(w["Y"][l][nx]), L.ptr(w["Y16a"][l][nx]),
+                L.ptr(Yb[nx] if Yb is not None else None), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(w["SR"][l][sl]),
+                L.ptr(w["SZ"][l][sl]), L.ptr(w["SN"][l][sl]), L.ptr(w["SHN"][l][sl]), L.i32(B), L.i32(D), L.cur_stream()),
                 "ark_gru_cell_fwd_dma")
         else:
             L.check(L.lib().ark_gru_cell_fwd(
-                L.i32(eng.prec_fwd), L.ptr(w["Y"][0]), L.ptr(p["dec.gru.weight_hh_l0"]), L.ptr(p["dec.gru.bias_hh_l0"]),
-                L.ptr(w["GI"][0]), L.ptr(w["Y"][0][B:]), L.ptr(None), L.ptr(None), L.ptr(w["SR"][0]), L.ptr(w["SZ"][0]),
-                L.ptr(w["SN"][0]), L.ptr(w["SHN"][0]), L.i32(B), L.i32(D), L.cur_stream()), "ark_gru_cell_fwd")
+                L.i32(eng.prec_fwd), L.ptr(w["Y"][l][sl]), L.ptr(p[f"dec.gru.weight_hh_l{l}"]), L.ptr(p[f"dec.gru.bias_hh_l{l}"]),
+                L.ptr(w["GI"][l][sl]), L.ptr(w["Y"][l][nx]), L.ptr(None), L.ptr(None), L.ptr(w["SR"][l][sl]), L.ptr(w["SZ"][l][sl]),
+                L.ptr(w["SN"][l][sl]), L.ptr(w["SHN"][l][sl]), L.i32(B), L.i32(D), L.cur_stream()), "ark_gru_cell_fwd")
+
+    def sweep():
+        for l in range(n):
+            for t in range(Lq):
+                launch(l, t)
 
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
-        for _ in range(3):
-            launch()
+        sweep()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            for _ in range(iters):
-                launch()
+            sweep()
         g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(4):
+        for _ in range(reps):
             g.replay()
         e1.record()
         e1.synchronize()
-    return e0.elapsed_time(e1) / (4 * iters) * 1e-3
+    return e0.elapsed_time(e1) / (reps * n * Lq) * 1e-3
 
 
 def main():
@@ -255,8 +261,30 @@ def main():
         # dominant kernel: the per-timestep recurrent GRU cell (MFMA + fused gate epilogue)
         kt = time_dominant_kernel(eng, B)
         log(f'kernel avg {kt*1e6:.2f} us; cpu baseline next')
-        kfl = 2.0 * B * cfg["d_model"] * 3 * cfg["d_model"]  # [B,D]x[D,3D] product per launch
-        peak = 2500.0 if args.precision != "f32" else 157.3
+        D = cfg["d_model"]
+        kfl = 2.0 * B * D * 3 * D  # [B,D]x[D,3D] recurrent product per launch
+        mfma_peak = 2500.0 if args.precision != "f32" else 157.3
+        if eng.ws["v2"]:
+            # per graph the forward cell reads gi (3D f32), h (D f32 + D 16-bit) and writes
+            # h (D f32 + 2 x D 16-bit) + 4 fp16 gate saves; per launch it also reads the 16-bit W_hh and b_hh.
+            # 87 FLOP/B is below the chip's ~310 FLOP/B balance point, so the HBM roofline bounds it.
+            two = eng.prec_fwd != eng.prec_bwd
+            per_graph = 3 * D * 4 + D * 4 + D * 2 + D * 4 + D * 2 * (2 if two else 1) + 4 * D * 2
+            kbytes = B * per_graph + 3 * D * D * 2 + 3 * D * 4
+            traffic = None
+            try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+                traffic = [v["hbm_bytes_corrected"] for k, v in pm.items() if "gru_cell_fwd_dma_kernel" in k][0]
+            except Exception:
+                pass
+            roof = {"bound": "hbm", "kernel": "gru_cell_fwd_dma_kernel", "achieved": kbytes / kt / 1e9, "peak": 8000.0,
+                    "unit": "GB/s", "frac": kbytes / kt / 1e9 / 8000.0, "traffic": traffic, "kernel_avg_us": kt * 1e6,
+                    "bytes_per_launch": kbytes, "flops_per_launch": kfl,
+                    "mfma": {"achieved": kfl / kt / 1e12, "peak": mfma_peak, "unit": "TFLOP/s", "frac": kfl / kt / 1e12 / mfma_peak}}
+        else:
+            roof = {"bound": "mfma", "kernel": "gru_cell_fwd_kernel", "achieved": kfl / kt / 1e12, "peak": mfma_peak,
+                    "unit": "TFLOP/s", "frac": kfl / kt / 1e12 / mfma_peak, "traffic": None, "kernel_avg_us": kt * 1e6,
+                    "flops_per_launch": kfl}
         res = {
             "metric": "training graphs/sec", "value": gps, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -270,9 +298,8 @@ def main():
                        "parallelism": f"dp{world}"},
             "final_loss": loss[0],
             "model_tflops": gps * fl / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gru_cell_fwd_dma_kernel" if eng.ws["v2"] else "gru_cell_fwd_kernel", "achieved": kfl / kt / 1e12, "peak": peak,
-                         "unit": "TFLOP/s", "frac": kfl / kt / 1e12 / peak, "traffic": None,
-                         "kernel_avg_us": kt * 1e6, "flops_per_launch": kfl},
+            "model_mfma_frac": gps * fl / 1e12 / mfma_peak,
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(dict(cfg, dec_dropout=0.0), B, steps=args.cpu_steps)
