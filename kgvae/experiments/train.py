@@ -11,7 +11,8 @@ Differences that are deliberate:
     data falls back to synthetic IntelliGraphs-shaped graphs, semantic verification is skipped;
   * whole splits are tokenised once per epoch (GraphSeqDataset.tensorize) instead of per item;
   * launched under torchrun it trains data-parallel (one process per GPU, RCCL all-reduce);
-  * extra optional keys: precision (mixed|bf16|f16|f32), synthetic_sizes, max_steps_per_epoch.
+  * extra optional keys: precision (mixed|bf16|f16|f32), synthetic_sizes, max_steps_per_epoch,
+    permute_rng (python|numpy), seed.
 """
 import argparse
 import json
@@ -215,6 +216,9 @@ def main(argv=None):
                                rel_base=REL_BASE, seq_len=seq_len)
 
     train_ds, val_ds, test_ds = make_ds(train_g), make_ds(val_g), make_ds(test_g)
+    if config.get("permute_rng", "python") == "numpy":   # extension: vectorised per-epoch permutations
+        import numpy as np
+        train_ds.fast_rng = np.random.default_rng(int(config.get("seed", 0)))
     config.update({"n_entities": num_entities, "n_relations": num_relations, "pad_eid": PAD_EID, "pad_rid": PAD_RID,
                    "seq_len": seq_len, "vocab_size": VOCAB_SIZE, "special_tokens": special_tokens, "ENT_BASE": ENT_BASE,
                    "REL_BASE": REL_BASE})

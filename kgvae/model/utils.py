@@ -88,6 +88,7 @@ class GraphSeqDataset(Dataset):
         self.special_tokens = special_tokens if special_tokens is not None else dict(SPECIAL_TOKENS)
         self.ent_base, self.rel_base = ent_base, rel_base
         self.seq_len = seq_len
+        self.fast_rng = None   # set to np.random.default_rng(seed) for vectorised permutations in tensorize()
 
     def __len__(self):
         return len(self.graphs)
@@ -108,26 +109,48 @@ class GraphSeqDataset(Dataset):
             t3 = torch.tensor(triples, dtype=torch.long)
         return t3, triples_to_seq(triples, self.special_tokens, self.ent_base, self.rel_base, self.seq_len)
 
+    def _base_arrays(self):
+        """one-time numpy image of the split: triples [N,Tmax,3] (padded), lengths [N]"""
+        if getattr(self, "_base", None) is None:
+            n = len(self.graphs)
+            lens = np.fromiter((len(g) for g in self.graphs), dtype=np.int64, count=n)
+            tmax = int(self.max_triples) if self.use_padding else (int(lens.max()) if n else 0)
+            base = np.zeros((n, tmax, 3), dtype=np.int64)
+            if self.use_padding:
+                base[:] = (self.pad_eid, self.pad_rid, self.pad_eid)
+            for i, g in enumerate(self.graphs):
+                if len(g):
+                    base[i, :len(g)] = np.asarray(g, dtype=np.int64)
+            self._base = (base, lens)
+        return self._base
+
     def tensorize(self, indices=None):
-        """(triples [N,T,3], seq [N,seq_len]) for `indices` (default: all) in one pass.  Draws the same
-        `random.sample` permutations, in the same order, as N successive __getitem__ calls."""
-        idx = range(len(self.graphs)) if indices is None else indices
+        """(triples [N,T,3], seq [N,seq_len]) for `indices` (default: all) in one vectorised pass.
+        Draws the same `random.sample` permutations, in the same order, as N successive __getitem__
+        calls (random.sample picks POSITIONS, so sampling range(k) consumes the generator identically)."""
+        base, lens = self._base_arrays()
+        idx = np.arange(len(self.graphs)) if indices is None else np.asarray(list(indices), dtype=np.int64)
         n = len(idx)
         st = self.special_tokens
-        T = self.max_triples if self.use_padding else (len(self.graphs[idx[0]]) if n else 0)
-        tri = np.empty((n, T, 3), dtype=np.int64)
+        tri = base[idx]
+        ln = lens[idx]
+        if not self.use_padding:
+            if n and not (ln == ln[0]).all():
+                raise ValueError("graphs of different sizes need use_padding=True to be batched")
+            T = int(ln[0]) if n else 0
+            tri = tri[:, :T]
+            if self.permute and T > 1:
+                if self.fast_rng is not None:   # opt-in: numpy generator, one vectorised draw (not Python-RNG identical)
+                    perm = self.fast_rng.permuted(np.tile(np.arange(T), (n, 1)), axis=1)
+                else:
+                    rng = range(T)
+                    perm = np.array([random.sample(rng, T) for _ in range(n)], dtype=np.int64)
+                tri = np.take_along_axis(tri, perm[:, :, None], axis=1)
+        T = tri.shape[1]
         seq = np.full((n, self.seq_len), st["PAD"], dtype=np.int64)
         seq[:, 0] = st["BOS"]
-        for row, i in enumerate(idx):
-            g = self._ordered(i)
-            k = len(g)
-            if not self.use_padding and k != T:
-                raise ValueError("graphs of different sizes need use_padding=True to be batched")
-            if k:
-                a = np.asarray(g, dtype=np.int64)
-                tri[row, :k] = a
-                seq[row, 1:1 + 3 * k] = (a + np.array([self.ent_base, self.rel_base, self.ent_base])).reshape(-1)
-            if self.use_padding:
-                tri[row, k:] = (self.pad_eid, self.pad_rid, self.pad_eid)
-            seq[row, 1 + 3 * k] = st["EOS"]
-        return torch.from_numpy(tri), torch.from_numpy(seq)
+        body = (tri + np.array([self.ent_base, self.rel_base, self.ent_base], dtype=np.int64)).reshape(n, 3 * T)
+        valid = np.arange(3 * T)[None, :] < (3 * ln)[:, None]
+        seq[:, 1:1 + 3 * T] = np.where(valid, body, st["PAD"])
+        seq[np.arange(n), 1 + 3 * ln] = st["EOS"]
+        return torch.from_numpy(np.ascontiguousarray(tri)), torch.from_numpy(seq)
