@@ -72,7 +72,7 @@ static void allow_lds16(K kernel, int bytes) {
 }
 
 int g_g16_nbuf = 2;     // ring depth of the 128x128 tile (2 -> 64 KB LDS, two workgroups per CU)
-int g_g16_force64 = 1;  // 1: always use 64x64 tiles
+int g_g16_force64 = 0;  // 1: always use 64x64 tiles
 
 template <int PREC, int BM, int BN, int NBUF>
 static void launch16_cfg(Gemm16Args p, hipStream_t st) {
@@ -83,16 +83,25 @@ static void launch16_cfg(Gemm16Args p, hipStream_t st) {
   hipLaunchKernelGGL((gemm16_kernel<PREC, BM, BN, NBUF>), dim3((unsigned)tiles), dim3(256), G::LDS_BYTES, st, p);
 }
 
+int g_g16_tile = 1;   // 0: heuristic below, 1: 64x64, 2: 128x64, 3: 128x128
+
 template <int PREC>
 static int launch16(Gemm16Args p, hipStream_t st) {
-  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  if (t128 >= 192 && !g_g16_force64) {
-    if (g_g16_nbuf == 2) launch16_cfg<PREC, 128, 128, 2>(p, st);
-    else if (g_g16_nbuf == 3) launch16_cfg<PREC, 128, 128, 3>(p, st);
-    else launch16_cfg<PREC, 128, 128, 4>(p, st);
+  int tile = g_g16_tile;
+  if (tile == 0) {
+    // 128x64 tiles halve the per-CU L2->LDS traffic of the A panel (these products are bound by the
+    // ~75 GB/s per-CU LDS-DMA rate, not by MFMA issue) while still giving >= 4 workgroups per CU
+    const long t128x64 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+    tile = (g_g16_force64 || t128x64 < 1024) ? 1 : 2;
+  }
+  if (tile == 3) {
+    if (g_g16_nbuf == 3) launch16_cfg<PREC, 128, 128, 3>(p, st); else launch16_cfg<PREC, 128, 128, 2>(p, st);
+  } else if (tile == 2) {
+    if (g_g16_nbuf == 4) launch16_cfg<PREC, 128, 64, 4>(p, st);
+    else if (g_g16_nbuf == 3) launch16_cfg<PREC, 128, 64, 3>(p, st);
+    else launch16_cfg<PREC, 128, 64, 2>(p, st);
   } else {
-    if (g_g16_nbuf == 2) launch16_cfg<PREC, 64, 64, 2>(p, st);
-    else launch16_cfg<PREC, 64, 64, 4>(p, st);
+    if (g_g16_nbuf == 4) launch16_cfg<PREC, 64, 64, 4>(p, st); else launch16_cfg<PREC, 64, 64, 2>(p, st);
   }
   ARK_LAUNCH_CHECK();
   return 0;
@@ -162,11 +171,11 @@ __global__ __launch_bounds__(256) void to_tiled_kernel(const float* __restrict__
 
 }  // namespace ark
 
-// speed-only knobs of the LDS-DMA GEMM: ring depth {2,3,4}; force 64x64 tiles
-extern "C" int ark_set_gemm16_tuning(int nbuf, int force64) {
-  if (nbuf < 2 || nbuf > 4) return ARK_ERR_ARG;
+// speed-only knobs of the LDS-DMA GEMM: ring depth {2,3,4}; tile 0 auto | 1 64x64 | 2 128x64 | 3 128x128
+extern "C" int ark_set_gemm16_tuning(int nbuf, int tile) {
+  if (nbuf < 2 || nbuf > 4 || tile < 0 || tile > 3) return ARK_ERR_ARG;
   ark::g_g16_nbuf = nbuf;
-  ark::g_g16_force64 = force64 ? 1 : 0;
+  ark::g_g16_tile = tile;
   return 0;
 }
 

@@ -100,7 +100,7 @@ int ark_set_dma_stage(int fwd_ki, int bwd_ki);
 int ark_set_dma_fwd_rows(int bm);
 int ark_set_scatter_chunk(int items_per_workgroup);
 int ark_set_dma_debug(int mask); /* timing ablations only: results are invalid while mask != 0 */
-int ark_set_gemm16_tuning(int nbuf, int force64);
+int ark_set_gemm16_tuning(int nbuf, int tile);
 int ark_set_wgrad_tile128(int enabled);
 /* up to 12 jobs in one launch: dst[i] = cast(src[i] [R,C]) in prec[i]; dstT[i] = cast(src[i]^T) in precT[i],
  * rows of dstT ldT[i] apart (ldT NULL or 0: dense, = R) */
