@@ -9,9 +9,21 @@ namespace ark {
 // ---- encoder: g[b, :] = (1/max(1,cnt_b)) * sum_t m[b,t] * [E[h] | R[r] | E[t]] -----------------
 // One workgroup per graph; each thread owns float4 columns of the 3D-wide row, so every table row
 // read is a coalesced 16 B/lane stream (tables of the syn-* sets are L2-resident).
+__device__ __forceinline__ void put16x4(void* base, long idx4, f32x4 v, int prec) {
+  if (prec == PREC_F16) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    auto c = [](float x) { return (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f); };
+    reinterpret_cast<h4*>(base)[idx4] = h4{c(v[0]), c(v[1]), c(v[2]), c(v[3])};
+  } else {
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    reinterpret_cast<b4*>(base)[idx4] = b4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  }
+}
+
 __global__ __launch_bounds__(256) void enc_pool_fwd_kernel(const int64_t* __restrict__ triples, const float* __restrict__ E,
                                                            const float* __restrict__ R, float* __restrict__ g,
-                                                           float* __restrict__ inv_cnt, int T, int D, long pad_rid) {
+                                                           float* __restrict__ inv_cnt, int T, int D, long pad_rid,
+                                                           void* g16a, int prec_a, void* g16b, int prec_b) {
   const int b = blockIdx.x;
   const int64_t* tr = triples + (long)b * T * 3;
   int cnt = 0;
@@ -29,7 +41,10 @@ __global__ __launch_bounds__(256) void enc_pool_fwd_kernel(const int64_t* __rest
       const float* tab = (part == 1) ? R : E;
       s += *reinterpret_cast<const f32x4*>(tab + id * D + 4 * d4);
     }
-    *reinterpret_cast<f32x4*>(g + (long)b * 3 * D + 4 * c) = s * w;
+    const f32x4 r = s * w;
+    *reinterpret_cast<f32x4*>(g + (long)b * 3 * D + 4 * c) = r;
+    if (g16a) put16x4(g16a, (long)b * 3 * D4 + c, r, prec_a);   // 16-bit operand copies for the MLP products
+    if (g16b) put16x4(g16b, (long)b * 3 * D4 + c, r, prec_b);
   }
 }
 
@@ -129,6 +144,62 @@ __global__ __launch_bounds__(256) void scatter_global_kernel(ScatterArgs p) {
   }
 }
 
+// all three encoder scatters (head -> E, relation -> R, tail -> E) of one column slice in one pass:
+// both tables are privatised in LDS; item = (graph b, triple t)
+__global__ __launch_bounds__(256) void enc_scatter_fused_kernel(const int64_t* __restrict__ triples, const float* __restrict__ dg,
+                                                                const float* __restrict__ inv_cnt, float* __restrict__ dE,
+                                                                float* __restrict__ dR, int B, int T, int D, int n_ent, int n_rel,
+                                                                long pad_eid, long pad_rid, int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* te = reinterpret_cast<float*>(smem);        // [n_ent][64]
+  float* tr = te + (size_t)n_ent * 64;               // [n_rel][64]
+  const int slice = blockIdx.x / n_chunks, chunk = blockIdx.x % n_chunks;
+  const int c0 = slice * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < (n_ent + n_rel) * 64; i += 256) te[i] = 0.f;
+  __syncthreads();
+  const int n_items = B * T;
+  const int per = (n_items + n_chunks - 1) / n_chunks;
+  const int i0 = chunk * per, i1 = min(n_items, i0 + per);
+  const bool col_ok = (c0 + lane) < D;
+  constexpr int U = 4;
+  for (int i = i0 + wave * U; i < i1; i += 4 * U) {
+    long h[U], r[U], t[U]; float sc[U], vh[U], vr[U], vt[U]; bool ok[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int it = min(i + k, i1 - 1);
+      const int64_t* p3 = triples + (long)it * 3;
+      h[k] = p3[0]; r[k] = p3[1]; t[k] = p3[2];
+      ok[k] = (i + k < i1) && col_ok && !(pad_rid >= 0 && r[k] == pad_rid);
+      sc[k] = inv_cnt[it / T];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int it = min(i + k, i1 - 1);
+      const float* src = dg + (long)(it / T) * 3 * D + c0 + lane;
+      vh[k] = ok[k] ? src[0] : 0.f; vr[k] = ok[k] ? src[D] : 0.f; vt[k] = ok[k] ? src[2 * D] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (ok[k]) {
+        if (h[k] != pad_eid) atomicAdd(&te[h[k] * 64 + lane], sc[k] * vh[k]);
+        if (r[k] != pad_rid) atomicAdd(&tr[r[k] * 64 + lane], sc[k] * vr[k]);
+        if (t[k] != pad_eid) atomicAdd(&te[t[k] * 64 + lane], sc[k] * vt[k]);
+      }
+  }
+  __syncthreads();
+  if (col_ok) {
+    for (int row = wave; row < n_ent; row += 4) {
+      const float v = te[row * 64 + lane];
+      if (v != 0.f) atomicAdd(&dE[(long)row * D + c0 + lane], v);
+    }
+    for (int row = wave; row < n_rel; row += 4) {
+      const float v = tr[row * 64 + lane];
+      if (v != 0.f) atomicAdd(&dR[(long)row * D + c0 + lane], v);
+    }
+  }
+}
+
 int g_scatter_chunk_items = 48;
 
 static int launch_scatter(const ScatterArgs& p, hipStream_t st) {
@@ -163,7 +234,21 @@ extern "C" int ark_enc_pool_fwd(const int64_t* triples, const float* E, const fl
   if (!triples || !E || !R || !g || B <= 0 || T <= 0 || D <= 0) return ARK_ERR_ARG;
   if (D % 4 != 0) return ARK_ERR_SHAPE;
   hipLaunchKernelGGL(enc_pool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, triples, E, R, g, inv_cnt, T, D,
-                     (long)pad_rid);
+                     (long)pad_rid, (void*)nullptr, 0, (void*)nullptr, 0);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// same, additionally writing 16-bit copies of g (g16a in prec_a, g16b nullable in prec_b)
+extern "C" int ark_enc_pool_fwd16(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt,
+                                  void* g16a, int prec_a, void* g16b, int prec_b, int B, int T, int D, int64_t pad_rid,
+                                  void* stream) {
+  using namespace ark;
+  if (!triples || !E || !R || !g || !g16a || B <= 0 || T <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (D % 4 != 0) return ARK_ERR_SHAPE;
+  if ((prec_a != PREC_F16 && prec_a != PREC_BF16) || (g16b && prec_b != PREC_F16 && prec_b != PREC_BF16)) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(enc_pool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, triples, E, R, g, inv_cnt, T, D,
+                     (long)pad_rid, g16a, prec_a, g16b, prec_b);
   ARK_LAUNCH_CHECK();
   return 0;
 }
@@ -175,6 +260,16 @@ extern "C" int ark_enc_pool_bwd(const int64_t* triples, const float* dg, const f
   using namespace ark;
   if (!triples || !dg || !inv_cnt || !dE || !dR || B <= 0 || T <= 0 || D <= 0) return ARK_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if ((long)(n_ent + n_rel) * 64 * 4 <= 48 * 1024) {   // both tables fit LDS: one fused launch
+    const int slices = (D + 63) / 64;
+    int n_chunks = (B * T + g_scatter_chunk_items - 1) / g_scatter_chunk_items;
+    if (n_chunks > 2048 / slices) n_chunks = 2048 / slices;
+    if (n_chunks < 1) n_chunks = 1;
+    hipLaunchKernelGGL(enc_scatter_fused_kernel, dim3(slices * n_chunks), dim3(256), (size_t)(n_ent + n_rel) * 64 * 4, st,
+                       triples, dg, inv_cnt, dE, dR, B, T, D, n_ent, n_rel, (long)pad_eid, (long)pad_rid, n_chunks);
+    ARK_LAUNCH_CHECK();
+    return 0;
+  }
   for (int part = 0; part < 3; ++part) {
     ScatterArgs p{};
     p.dst = (part == 1) ? dR : dE; p.src = dg; p.ld_src = 3L * D; p.col_off = part * D;

@@ -338,14 +338,16 @@ class Engine:
         if self.mt == "SAIL":
             assert triples.dtype == torch.int64 and triples.is_contiguous() and triples.device == self.device
             H = 3 * D
-            _call("ark_enc_pool_fwd", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
-                  L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.i32(B), L.i32(T), L.i32(D),
-                  L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
             if w["v2"]:
                 pf, pb = self.prec_fwd, self.prec_bwd
-                _call("ark_cast16", L.i32(pf), L.ptr(w["g"]), L.ptr(w["g16a"]), L.i64(B * H), st)
-                if w["g16b"] is not None:
-                    _call("ark_cast16", L.i32(pb), L.ptr(w["g"]), L.ptr(w["g16b"]), L.i64(B * H), st)
+                _call("ark_enc_pool_fwd16", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
+                      L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.ptr(w["g16a"]), L.i32(pf), L.ptr(w["g16b"]), L.i32(pb), L.i32(B),
+                      L.i32(T), L.i32(D), L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
+            else:
+                _call("ark_enc_pool_fwd", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
+                      L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.i32(B), L.i32(T), L.i32(D),
+                      L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
+            if w["v2"]:
                 a16 = w["g16a"]
                 for i in range(n):
                     _call("ark_gemm16_ex", L.i32(pf), L.i32(L.EPI_BIAS_GELU), L.ptr(a16), L.i64(H), L.ptr(self.wm16[i]), L.i64(H),

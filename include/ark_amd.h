@@ -138,6 +138,9 @@ int ark_to_tiled(const float* x, float* out, int rows, int ld, void* stream);
  *      decoder token / position lookup; autograd embedding_backward) --------------------------- */
 int ark_enc_pool_fwd(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt, int B, int T,
                      int D, int64_t pad_rid /* -1: none */, void* stream);
+/* ark_enc_pool_fwd that also writes 16-bit copies of g for the MLP products */
+int ark_enc_pool_fwd16(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt, void* g16a,
+                       int prec_a, void* g16b, int prec_b, int B, int T, int D, int64_t pad_rid, void* stream);
 int ark_enc_pool_bwd(const int64_t* triples, const float* dg, const float* inv_cnt, float* dE, float* dR, int B,
                      int T, int D, int n_ent, int n_rel, int64_t pad_eid, int64_t pad_rid, void* stream);
 int ark_tok_gather(const int64_t* seq, int64_t ld_seq, const float* w_tok, const float* w_pos /* nullable */,
