@@ -39,6 +39,21 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   return cdf + x * pdf;
 }
 
+// counter-based dropout: keep-scale of element i of a layer's [B*L, D] output at optimiser step `step`.
+// One definition shared by the mask kernel (register-staged path) and the in-kernel use of the
+// LDS-DMA path (forward cell epilogue and the input-gradient product), so both directions agree.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ float dropout_keep_scale(uint64_t seed, uint64_t step, uint64_t i, float p, float keep_scale) {
+  const uint64_t h = splitmix64(seed ^ splitmix64(step * 0x100000001B3ull + i));
+  const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+  return (u >= p) ? keep_scale : 0.f;
+}
+
 // XCD-aware workgroup remap (MI355X: 8 XCDs, private 4 MB L2 each; workgroups are dealt round-robin
 // over XCDs, so ids b and b+8 share an L2).  Gives each XCD a CONTIGUOUS range of logical tile ids
 // so neighbouring tiles -- which share an operand panel -- hit the same L2.  Bijective for any grid

@@ -15,6 +15,7 @@ struct Gemm16Args {
   long lda, ldb, ldc;
   int M, N, K, epi, c_tiled, tiles_n;
   void* c16a; void* c16b; int prec_a, prec_b;   // optional row-major 16-bit copies of the result (ld = ldc)
+  float drop_p; uint64_t drop_seed; const float* hyper;   // ARK_EPI_DROPOUT (tile-native C only)
 };
 
 template <int PREC, int BM, int BN, int NBUF>
@@ -43,6 +44,12 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
       if (p.c_tiled) {  // M % 16 == 0 and ldc % 16 == 0 (checked on the host): the quad is whole
         const long o = tile_native_off(row0, col, (int)p.ldc);
         if (p.epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
+        if (p.epi == ARK_EPI_DROPOUT) {   // the mask the forward cell applied to this element (same hash, same index)
+          const uint64_t step = (uint64_t)p.hyper[ARK_HP_ADAM_STEP];
+          const float ks = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] *= dropout_keep_scale(p.drop_seed, step, (uint64_t)(o + i), p.drop_p, ks);
+        }
         *reinterpret_cast<f32x4*>(p.C + o) = v;
       } else {
 #pragma unroll
@@ -179,6 +186,8 @@ extern "C" int ark_set_gemm16_tuning(int nbuf, int tile) {
   return 0;
 }
 
+static float g16_drop_p = 0.f; static uint64_t g16_drop_seed = 0; static const float* g16_hyper = nullptr;
+
 static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
                        int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* c16a,
                        void* c16b, int prec_b, void* stream) {
@@ -186,16 +195,29 @@ static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const vo
   if (!A16 || !B16 || !C || M <= 0 || N <= 0 || K <= 0) return ARK_ERR_ARG;
   if (K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0) return ARK_ERR_SHAPE;
   if (((uintptr_t)A16 | (uintptr_t)B16) & 15) return ARK_ERR_ALIGN;
-  if (epi < ARK_EPI_NONE || epi > ARK_EPI_MUL_AUX) return ARK_ERR_ARG;
+  if (epi < ARK_EPI_NONE || epi > ARK_EPI_DROPOUT) return ARK_ERR_ARG;
+  if (epi == ARK_EPI_DROPOUT && (!c_tiled || !g16_hyper || g16_drop_p <= 0.f || g16_drop_p >= 1.f)) return ARK_ERR_ARG;
   if ((epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU) && !bias) return ARK_ERR_ARG;
   if ((epi == ARK_EPI_MUL_AUX || epi == ARK_EPI_MUL_DGELU) && !aux) return ARK_ERR_ARG;
   if (c_tiled && (M % 16 != 0 || ldc % 16 != 0 || N > ldc)) return ARK_ERR_SHAPE;
   if (c_tiled && (epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_MUL_DGELU || c16a || c16b)) return ARK_ERR_ARG;
   if (c16b && prec_b != PREC_F16 && prec_b != PREC_BF16) return ARK_ERR_ARG;
-  Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0, c16a, c16b, prec, prec_b};
+  Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0, c16a, c16b, prec, prec_b,
+               g16_drop_p, g16_drop_seed, g16_hyper};
   if (prec == PREC_F16) return launch16<PREC_F16>(p, (hipStream_t)stream);
   if (prec == PREC_BF16) return launch16<PREC_BF16>(p, (hipStream_t)stream);
   return ARK_ERR_ARG;
+}
+
+// C (tile-native) = (A16 B16^T) * dropout_keep_scale(seed, step, element index): the input gradient of a
+// dropped layer output, with the mask regenerated from the same counter-based hash the forward cell used
+extern "C" int ark_gemm16_dropout(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
+                                  int M, int N, int K, float drop_p, uint64_t drop_seed, const float* hyper, void* stream) {
+  g16_drop_p = drop_p; g16_drop_seed = drop_seed; g16_hyper = hyper;
+  const int rc = gemm16_impl(prec, ARK_EPI_DROPOUT, A16, lda, B16, ldb, C, ldc, nullptr, nullptr, M, N, K, 1, nullptr, nullptr, 0,
+                             stream);
+  g16_hyper = nullptr;
+  return rc;
 }
 
 extern "C" int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,

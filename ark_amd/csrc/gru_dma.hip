@@ -30,7 +30,8 @@ struct GruFwdDmaArgs {
   const float* y_prev; const float* b_hh; const float* gi;   // tile-native fp32 [B,D], [3D], tile-native [B,3D]
   float* y_out;                                  // tile-native fp32 [B,D]
   void* y16a; void* y16b;                        // row-major 16-bit copies of h: forward type / backward type (nullable)
-  void* yd16a; void* yd16b; const float* mask;   // dropped copies h*mask (mask tile-native fp32), nullable
+  void* yd16a; void* yd16b;                      // dropped copies h*mask of the layer output, nullable
+  float drop_p; uint64_t drop_seed; long drop_base; const float* hyper;   // in-kernel dropout (drop_p > 0)
   _Float16* sr; _Float16* sz; _Float16* sn; _Float16* shn;   // tile-native fp16 saves, nullable
   int B, D;
   int dbg;   // timing ablations (results invalid when != 0): 1 no main loop, 2 no epilogue stores, 4 no prefetch loads
@@ -67,7 +68,16 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) 
     gn[tm] = *reinterpret_cast<const f32x4*>(p.gi + og + (long)(D >> 4) * 512);
     hp[tm] = *reinterpret_cast<const f32x4*>(p.y_prev + o[tm]);
     mk[tm] = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (p.mask) mk[tm] = *reinterpret_cast<const f32x4*>(p.mask + o[tm]);
+  }
+  const bool drop = p.drop_p > 0.f;
+  if (drop) {   // same hash stream as ark_dropout_mask over the layer's tile-native [B*L, D] index space
+    const uint64_t step = (uint64_t)p.hyper[ARK_HP_ADAM_STEP];
+    const float ks = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        mk[tm][i] = dropout_keep_scale(p.drop_seed, step, (uint64_t)(p.drop_base + o[tm] + i), p.drop_p, ks);
   }
   const float bhr = p.b_hh[u], bhz = p.b_hh[D + u], bhn = p.b_hh[2 * D + u];
 
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) 
     for (int i = 0; i < 4; ++i) {
       ta[(rl[tm] + i) * TS + ul] = G::PT::cvt(h[i]);
       if (p.y16b) tb[(rl[tm] + i) * TS + ul] = PrecTraits<PRECB>::cvt(h[i]);
-      if (p.mask) {
+      if (drop) {
         tda[(rl[tm] + i) * TS + ul] = G::PT::cvt(hd[i]);
         tdb[(rl[tm] + i) * TS + ul] = PrecTraits<PRECB>::cvt(hd[i]);
       }
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) 
       const long go = (long)row * D + u0 + ch * 8;
       *reinterpret_cast<uint4*>(reinterpret_cast<h_t*>(p.y16a) + go) = *reinterpret_cast<const uint4*>(ta + rr * TS + ch * 8);
       if (p.y16b) *reinterpret_cast<uint4*>(reinterpret_cast<hb_t*>(p.y16b) + go) = *reinterpret_cast<const uint4*>(tb + rr * TS + ch * 8);
-      if (p.mask) {
+      if (drop) {
         *reinterpret_cast<uint4*>(reinterpret_cast<h_t*>(p.yd16a) + go) = *reinterpret_cast<const uint4*>(tda + rr * TS + ch * 8);
         if (p.yd16b) *reinterpret_cast<uint4*>(reinterpret_cast<hb_t*>(p.yd16b) + go) = *reinterpret_cast<const uint4*>(tdb + rr * TS + ch * 8);
       }
@@ -364,14 +374,15 @@ extern "C" int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf) {
 
 extern "C" int ark_gru_cell_fwd_dma(int prec, int prec_b, const void* h_prev16, const void* w_hh16, const float* y_prev_t,
                                     const float* b_hh, const float* gi_t, float* y_out_t, void* y16a, void* y16b,
-                                    void* yd16a, void* yd16b, const float* mask_t, void* save_r, void* save_z,
-                                    void* save_n, void* save_hn, int B, int D, void* stream) {
+                                    void* yd16a, void* yd16b, float drop_p, uint64_t drop_seed, int64_t drop_base,
+                                    const float* hyper, void* save_r, void* save_z, void* save_n, void* save_hn, int B,
+                                    int D, void* stream) {
   using namespace ark;
   if (!h_prev16 || !w_hh16 || !y_prev_t || !b_hh || !gi_t || !y_out_t || !y16a || B <= 0 || D <= 0) return ARK_ERR_ARG;
   if (D % 64 != 0 || B % 16 != 0) return ARK_ERR_SHAPE;
-  if (mask_t && !yd16a) return ARK_ERR_ARG;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!yd16a || !hyper))) return ARK_ERR_ARG;
   if (save_r && (!save_z || !save_n || !save_hn)) return ARK_ERR_ARG;
-  GruFwdDmaArgs p{h_prev16, w_hh16, y_prev_t, b_hh, gi_t, y_out_t, y16a, y16b, yd16a, yd16b, mask_t,
+  GruFwdDmaArgs p{h_prev16, w_hh16, y_prev_t, b_hh, gi_t, y_out_t, y16a, y16b, yd16a, yd16b, drop_p, drop_seed, (long)drop_base, hyper,
                   (_Float16*)save_r, (_Float16*)save_z, (_Float16*)save_n, (_Float16*)save_hn, B, D, g_dma_dbg};
   hipStream_t st = (hipStream_t)stream;
   if (prec == PREC_F16 && prec_b == PREC_BF16) return launch_fwd_dma<PREC_F16, PREC_BF16>(p, st);

@@ -75,21 +75,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 // counter-based dropout mask: mask[i] = keep ? 1/(1-p) : 0, keep ~ Bernoulli(1-p) from a
 // splitmix64 hash of (seed, offset + i).  Statistically equivalent to torch's inter-layer GRU
 // dropout, not bit-identical (the reference draws from the CPU/cuRAND generator).
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, long n, float p, uint64_t seed,
                                                            const float* __restrict__ hyper) {
   // the optimiser step counter is folded into the stream so a replayed graph draws fresh masks
   const uint64_t step = (uint64_t)hyper[ARK_HP_ADAM_STEP];
   const float keep_scale = 1.0f / (1.0f - p);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const uint64_t h = splitmix64(seed ^ splitmix64(step * 0x100000001B3ull + (uint64_t)i));
-    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
-    mask[i] = (u >= p) ? keep_scale : 0.f;
+    mask[i] = dropout_keep_scale(seed, step, (uint64_t)i, p, keep_scale);
   }
 }
 

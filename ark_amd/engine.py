@@ -277,8 +277,7 @@ class Engine:
             w["dlog16"] = torch.zeros(R, self.Vp, device=dev, dtype=torch.int16)   # K-padded 16-bit dlogits
             w["h0"] = f(B, D)                                                # row-major h0 (z-projection)
             w["dX0"] = f(R, D)
-            if self.p_drop > 0:
-                w["mask"] = [f(R, D) for _ in range(n - 1)]                  # tile-native interpretation
+            if self.p_drop > 0:   # the dropout mask itself is regenerated in-kernel from a counter hash
                 w["Yd16a"] = [i16(R, D) for _ in range(n - 1)]
                 w["Yd16b"] = [i16(R, D) if two else None for _ in range(n - 1)]
         else:
@@ -434,14 +433,14 @@ class Engine:
                   L.ptr(Yb[nx] if Yb is not None else None),
                   L.ptr(w["Yd16a"][l][sl] if drop else None),
                   L.ptr(w["Yd16b"][l][sl] if (drop and w["Yd16b"][l] is not None) else None),
-                  L.ptr(w["mask"][l][sl] if drop else None),
+                  L.f32(self.p_drop if drop else 0.0), L.u64(self.drop_seed + 7919 * l), L.i64(t * B * D),
+                  L.ptr(self.hyper),
                   L.ptr(w["SR"][l][sl] if save else None), L.ptr(w["SZ"][l][sl] if save else None),
                   L.ptr(w["SN"][l][sl] if save else None), L.ptr(w["SHN"][l][sl] if save else None),
                   L.i32(B), L.i32(D), L.cur_stream())
 
         def mask_gen(l):
-            _call("ark_dropout_mask", L.ptr(w["mask"][l]), L.i64(R * D), L.f32(self.p_drop),
-                  L.u64(self.drop_seed + 7919 * l), L.ptr(self.hyper), L.cur_stream())
+            pass   # nothing to materialise: cells and the input-gradient product hash the mask in-kernel
 
         if self.pipeline_layers and n > 1:
             # Layer wavefront: layer l runs on its own stream, one step behind layer l-1.  cell(l,t) needs
@@ -741,9 +740,14 @@ class Engine:
             # input gradient: dgi [R,3D] x W_ih^T-shadow [D,3D]; tile-native for the layer below,
             # row-major for the embedding scatter
             out = dy_other if l > 0 else w["dX0"]
-            _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_MUL_AUX if drop_below else L.EPI_NONE), L.ptr(dGI), L.i64(3 * D),
-                  L.ptr(self.wihT16[l]), L.i64(3 * D), L.ptr(out), L.i64(D), L.ptr(None),
-                  L.ptr(w["mask"][l - 1] if drop_below else None), L.i32(R), L.i32(D), L.i32(3 * D), L.i32(1 if l > 0 else 0), st)
+            if drop_below:
+                _call("ark_gemm16_dropout", L.i32(pb), L.ptr(dGI), L.i64(3 * D), L.ptr(self.wihT16[l]), L.i64(3 * D), L.ptr(out),
+                      L.i64(D), L.i32(R), L.i32(D), L.i32(3 * D), L.f32(self.p_drop), L.u64(self.drop_seed + 7919 * (l - 1)),
+                      L.ptr(self.hyper), st)
+            else:
+                _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(dGI), L.i64(3 * D), L.ptr(self.wihT16[l]), L.i64(3 * D),
+                      L.ptr(out), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(3 * D),
+                      L.i32(1 if l > 0 else 0), st)
             dy, dy_other = dy_other, dy
         for i0 in range(0, len(group), 8):
             self._wgrad_group(group[i0:i0 + 8])

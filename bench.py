@@ -110,7 +110,8 @@ def time_dominant_kernel(eng, B, reps=8):
             L.check(L.lib().ark_gru_cell_fwd_dma(
                 L.i32(eng.prec_fwd), L.i32(eng.prec_bwd), L.ptr(w["Y16a"][l][sl]), L.ptr(eng.whh16[l]), L.ptr(w["Y"][l][sl]),
                 L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l][sl]), L.ptr(w["Y"][l][nx]), L.ptr(w["Y16a"][l][nx]),
-                L.ptr(Yb[nx] if Yb is not None else None), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(w["SR"][l][sl]),
+                L.ptr(Yb[nx] if Yb is not None else None), L.ptr(None), L.ptr(None), L.f32(0.0), L.u64(0), L.i64(0), L.ptr(None),
+                L.ptr(w["SR"][l][sl]),
                 L.ptr(w["SZ"][l][sl]), L.ptr(w["SN"][l][sl]), L.ptr(w["SHN"][l][sl]), L.i32(B), L.i32(D), L.cur_stream()),
                 "ark_gru_cell_fwd_dma")
         else:

@@ -30,6 +30,7 @@ extern "C" {
 #define ARK_EPI_BIAS_GELU 2 /* C = acc + bias (pre-act), C2 = gelu_erf(C) */
 #define ARK_EPI_MUL_DGELU 3 /* C = acc * gelu_erf'(aux[row,col])         */
 #define ARK_EPI_MUL_AUX 4   /* C = acc * aux[row,col]                    */
+#define ARK_EPI_DROPOUT 5   /* C = acc * counter-hash dropout scale (ark_gemm16_dropout only) */
 
 int ark_version(void);
 
@@ -87,8 +88,9 @@ int ark_gru_h0_bwd(int prec, const float* dgh0, const float* w_hh, const float* 
  *   off(row,col,ld) = ((row>>4)*(ld>>4) + (col>>4))*256 + (((row>>2)&3)*16 + (col&15))*4 + (row&3). */
 int ark_gru_cell_fwd_dma(int prec, int prec_b, const void* h_prev16, const void* w_hh16, const float* y_prev_t,
                          const float* b_hh, const float* gi_t, float* y_out_t, void* y16a, void* y16b, void* yd16a,
-                         void* yd16b, const float* mask_t, void* save_r, void* save_z, void* save_n, void* save_hn,
-                         int B, int D, void* stream);
+                         void* yd16b, float drop_p /* 0: none */, uint64_t drop_seed, int64_t drop_base /* element index of
+                         this timestep in the layer's [B*L, D] space */, const float* hyper, void* save_r, void* save_z,
+                         void* save_n, void* save_hn, int B, int D, void* stream);
 int ark_gru_cell_bwd_dma(int prec, const void* dgh_next16, const void* w_hhT16, const float* dy_t, float* carry_t,
                          const void* save_r, const void* save_z, const void* save_n, const void* save_hn,
                          const float* y_prev_t, void* dgi16, void* dgh16, float* db_ih /* += colsum(dgi), nullable */,
@@ -109,6 +111,9 @@ int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, vo
 /* C[M,N] = A16[M,K] B16[N,K]^T (+bias | *aux), C row-major or tile-native (c_tiled) */
 int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* stream);
+/* tile-native C = (A16 B16^T) * dropout scale regenerated from (seed, optimiser step, element index) */
+int ark_gemm16_dropout(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc, int M,
+                       int N, int K, float drop_p, uint64_t drop_seed, const float* hyper, void* stream);
 /* ark_gemm16 with row-major 16-bit copies of the result (c16a in `prec`, c16b nullable in `prec_b`);
  * BIAS_GELU: C = pre-activation, copies = gelu(C); MUL_DGELU: C = acc * gelu'(aux), copies = C */
 int ark_gemm16_ex(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,

@@ -179,3 +179,48 @@ def test_graph_replay_matches_eager():
     lb = [la[0]] + [float(replay()[0]) for _ in range(3)]
     assert np.allclose(la, lb, rtol=1e-5), (la, lb)
     assert la[-1] < la[0]
+
+
+def _tile_native_index(rows, D):
+    """row-major (row, col) -> offset in the MFMA-tile-native order (include/ark_amd.h)"""
+    r = torch.arange(rows).view(-1, 1)
+    c = torch.arange(D).view(1, -1)
+    return ((r >> 4) * (D >> 4) + (c >> 4)) * 256 + ((((r >> 2) & 3) << 4) + (c & 15)) * 4 + (r & 3)
+
+
+def test_in_kernel_dropout_is_consistent_forward_and_backward():
+    """LDS-DMA path: the forward cell and the input-gradient product regenerate the SAME mask from the
+    counter hash that ark_dropout_mask materialises (seed, optimiser step, element index)."""
+    from ark_amd import _lib as L
+    from oracle import sail_oracle as O
+    cfg = dict(_big_cfg(), dec_dropout=0.5)
+    P = O.init_params(cfg, 0)
+    B = 64
+    triples, seq = synth_batch(cfg, B, seed=4)
+    eng = make_engine(cfg, P, "mixed")
+    dev = eng.device
+    eng.training = True
+    eng._default_norms(B)
+    w = eng.forward(triples.to(dev), seq.to(dev), torch.randn(B, cfg["d_latent"]).to(dev))
+    assert w["v2"]
+    D, R = eng.D, eng.L * B
+    idx = _tile_native_index(R, D).to(dev)
+    for l in range(eng.n - 1):
+        y = w["Y16a"][l][B:].view(torch.float16).float()
+        yd = w["Yd16a"][l].view(torch.float16).float()
+        ref = torch.empty(R * D, device=dev)
+        L.check(L.lib().ark_dropout_mask(L.ptr(ref), L.i64(R * D), L.f32(0.5), L.u64(eng.drop_seed + 7919 * l), L.ptr(eng.hyper),
+                                         L.cur_stream()), "mask")
+        m = ref[idx]                                   # row-major view of the tile-native mask
+        assert set(m.unique().tolist()) == {0.0, 2.0} and 0.45 < (m == 0).float().mean().item() < 0.55
+        assert torch.allclose(yd, y * m, rtol=2e-3, atol=1e-4)
+        # backward: dropout-scaled input gradient == plain product * the same mask (buffer order)
+        A = (torch.randn(R, 3 * D, device=dev) * 0.1).to(torch.bfloat16)
+        plain, dropped = torch.empty(R * D, device=dev), torch.empty(R * D, device=dev)
+        L.check(L.lib().ark_gemm16(L.i32(L.PREC_BF16), L.i32(L.EPI_NONE), L.ptr(A), L.i64(3 * D), L.ptr(eng.wihT16[l + 1]),
+                                   L.i64(3 * D), L.ptr(plain), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D),
+                                   L.i32(3 * D), L.i32(1), L.cur_stream()), "gemm16")
+        L.check(L.lib().ark_gemm16_dropout(L.i32(L.PREC_BF16), L.ptr(A), L.i64(3 * D), L.ptr(eng.wihT16[l + 1]), L.i64(3 * D),
+                                           L.ptr(dropped), L.i64(D), L.i32(R), L.i32(D), L.i32(3 * D), L.f32(0.5),
+                                           L.u64(eng.drop_seed + 7919 * l), L.ptr(eng.hyper), L.cur_stream()), "gemm16_dropout")
+        assert torch.allclose(dropped, plain * ref, rtol=1e-6, atol=1e-7)

@@ -18,7 +18,7 @@ st = torch.cuda.Stream()
 def launch(i):
     i %= NB
     L.check(L.lib().ark_gru_cell_fwd_dma(L.i32(2), L.i32(1), L.ptr(h16[i]), L.ptr(w16), L.ptr(yp[i]), L.ptr(bh), L.ptr(gi[i]), L.ptr(yo[i]),
-            L.ptr(o16a[i]), L.ptr(o16b[i]), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(sv[i][0]), L.ptr(sv[i][1]), L.ptr(sv[i][2]),
+            L.ptr(o16a[i]), L.ptr(o16b[i]), L.ptr(None), L.ptr(None), L.f32(0.0), L.u64(0), L.i64(0), L.ptr(None), L.ptr(sv[i][0]), L.ptr(sv[i][1]), L.ptr(sv[i][2]),
             L.ptr(sv[i][3]), L.i32(B), L.i32(D), L.cur_stream()), "cell")
 with torch.cuda.stream(st):
     for mask in (0, 1, 2, 4, 3, 5, 6, 7):
