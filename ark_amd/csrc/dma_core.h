@@ -1,17 +1,19 @@
-// Second-generation tile engine for the latency-critical recurrent products: 16-bit operands
-// are streamed HBM/L2 -> LDS by LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging), a whole
-// K-stage (KS reduction elements, up to 2 stages = the full panel for d_model 512) in flight per
-// workgroup, counted `s_waitcnt vmcnt(N)` + raw `s_barrier` so the next stage keeps flying
-// underneath the MFMA block.
+// LDS-DMA ring engine for products whose operands are both 16-bit and K-contiguous (GRU cells,
+// input / input-gradient products against plain or transposed weight shadows).  Operands stream
+// HBM/L2 -> LDS with `global_load_lds_dwordx4` (no VGPR staging, no conversions); NBUF ring slots of
+// KI 64-wide k-images each are kept in flight per workgroup with counted `s_waitcnt vmcnt(N)` and raw
+// `s_barrier`s, so the next stages keep flying underneath the MFMA block.
 //
 // Why: the register-staged engine (gemm_core.h) holds at most ~32 KB in flight per CU, and a GRU
 // timestep is one short dependent launch -- Little's law capped it at ~8 TB/s of L2->CU traffic
-// (profiles/r01_*).  LDS-DMA keeps 64-128 KB in flight per CU without spending registers.
+// (profiles/r01_first_path_*).  Measured on MI355X: SMALL rings win (2 slots x 128 k for the cells,
+// 2 x 64 k for the GEMMs): what matters is how many workgroups are resident per CU, not ring depth;
+// a single-barrier variant with one more slot was slower for the same reason.
 //
-// LDS image per stage and operand: KS/64 "k-images" of R rows x 128 B, same XOR swizzle and the
-// same ds_read_b128 fragment reads as gemm_core.h.  LDS-DMA writes are lane-linear (wave-uniform
-// base + lane*16), so the swizzle is applied to the per-lane SOURCE address instead: lane i of
-// the wave-instruction that fills rows 8p..8p+7 of an image supplies row 8p + i/8, logical chunk
+// LDS image per slot and operand: KI "k-images" of R rows x 128 B, same XOR swizzle and the same
+// ds_read_b128 fragment reads as gemm_core.h.  LDS-DMA writes are lane-linear (wave-uniform base +
+// lane*16), so the swizzle is applied to the per-lane SOURCE address instead: lane i of the
+// wave-instruction that fills rows 8p..8p+7 of an image supplies row 8p + i/8, logical chunk
 // (i%8) ^ ((row>>1)&7).
 #pragma once
 #include "gemm_core.h"
