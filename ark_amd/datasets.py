@@ -50,3 +50,29 @@ def load_data_as_list(name, allow_synthetic=True, **synthetic_kwargs):
             raise
         print(f"[data] intelligraphs unavailable ({type(exc).__name__}); using synthetic '{name}'-shaped graphs")
         return synthetic_as_list(name, **synthetic_kwargs)
+
+
+def synthetic_batch(n_ent, n_rel, max_triples, batch, seed, padded=False, min_triples=None):
+    """One IntelliGraphs-shaped batch as the tensors GraphSeqDataset would yield (vectorised):
+    triples [B,T,3] and seq [B, 2+3T] int64 with uniform random ids; with `padded`, per-graph edge
+    counts are uniform in [min_triples, max_triples] and the tail is filled with the pad ids
+    (n_ent, n_rel), exactly as kgvae/model/utils.py does for use_padding datasets."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    T = max_triples
+    ne2, nr2 = (n_ent + 1, n_rel + 1) if padded else (n_ent, n_rel)
+    ent_base, rel_base = 3, 3 + ne2
+    h = torch.randint(0, n_ent, (batch, T), generator=g)
+    r = torch.randint(0, n_rel, (batch, T), generator=g)
+    t = torch.randint(0, n_ent, (batch, T), generator=g)
+    k = torch.randint(min_triples or 1, T + 1, (batch,), generator=g) if padded else torch.full((batch,), T)
+    live = torch.arange(T).view(1, -1) < k.view(-1, 1)
+    triples = torch.stack([h, r, t], -1)
+    if padded:
+        triples = torch.where(live.unsqueeze(-1), triples, torch.tensor([n_ent, n_rel, n_ent]))
+    seq = torch.zeros(batch, 2 + 3 * T, dtype=torch.long)
+    seq[:, 0] = 1
+    body = torch.stack([ent_base + h, rel_base + r, ent_base + t], -1).reshape(batch, 3 * T)
+    seq[:, 1:1 + 3 * T] = torch.where(live.repeat_interleave(3, dim=1), body, torch.zeros_like(body))
+    seq[torch.arange(batch), 1 + 3 * k] = 2
+    return triples, seq
