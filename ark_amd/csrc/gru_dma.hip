@@ -150,10 +150,11 @@ struct GruBwdDmaArgs {
   int B, D, first, final_;
 };
 
-template <int PREC, int NBUF, int KI>
+template <int PREC, int NBUF, int KI, int BN>
 __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) {
-  constexpr int BM = 32, BN = 64;
-  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;   // wave tile 16 x 32
+  constexpr int BM = 32;
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;   // wave tile 16 x (BN/2)
+  constexpr int WN = BN / 2;
   using h_t = typename G::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = p.D / BN;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) 
   half4_t psr[G::TN], psz[G::TN], psn[G::TN], phn[G::TN];
 #pragma unroll
   for (int tn = 0; tn < G::TN; ++tn) {
-    const long o = tile_native_off(rowc, n0 + wn * 32 + tn * 16 + (lane & 15), D);
+    const long o = tile_native_off(rowc, n0 + wn * WN + tn * 16 + (lane & 15), D);
     pc[tn] = p.first ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(p.carry + o);
     pdy[tn] = (p.dy && !p.final_) ? *reinterpret_cast<const f32x4*>(p.dy + o) : f32x4{0.f, 0.f, 0.f, 0.f};
     if (!p.final_) {
@@ -187,13 +188,13 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) 
          p.first ? 0 : 3 * D, smem);
 
   __syncthreads();
-  // LDS assembly of the six row-major 16-bit output panels: [gate 0..2][32 rows][64+8] for dgi and dgh
-  constexpr int TS = 72;
+  // LDS assembly of the six row-major 16-bit output panels: [gate 0..2][32 rows][BN+8] for dgi and dgh
+  constexpr int TS = BN + 8;
   h_t* tgi = reinterpret_cast<h_t*>(smem);
   h_t* tgh = tgi + 3 * 32 * TS;
 #pragma unroll
   for (int tn = 0; tn < G::TN; ++tn) {
-    const int ul = wn * 32 + tn * 16 + (lane & 15);
+    const int ul = wn * WN + tn * 16 + (lane & 15);
     const int u = n0 + ul;
     if (row0 >= B) continue;
     const long o = tile_native_off(row0, u, D);
@@ -224,11 +225,12 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) 
   }
   if (p.final_) return;
   __syncthreads();
-  // 3 gates x 32 rows x 128 B per array: thread t -> (row t/8, chunk t%8) for each gate
+  // 3 gates x 32 rows x (2*BN) B per array: thread t -> (row, 16-byte chunk) for each gate
   const int t = threadIdx.x;
-  const int rr = t >> 3, ch = t & 7;
+  constexpr int CPR = BN / 8;
+  const int rr = t / CPR, ch = t % CPR;
   const int row = m0 + rr;
-  if (row < B) {
+  if (rr < 32 && row < B) {
     h_t* gi16 = reinterpret_cast<h_t*>(p.dgi16);
     h_t* gh16 = reinterpret_cast<h_t*>(p.dgh16);
 #pragma unroll
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_dma_kernel(GruBwdDmaArgs p) 
   }
   // bias gradients: column sums of this tile's dgi / dgh panels straight from LDS, one atomic per
   // (gate, unit) per workgroup -- replaces a separate pass over the [B*L, 3D] panels
-  if (p.db_ih && t < 192) {
-    const int g = t >> 6, ul = t & 63;
+  if (p.db_ih && t < 3 * BN) {
+    const int g = t / BN, ul = t % BN;
     const int nrows = min(32, B - m0);
     float si = 0.f, sh = 0.f;
     for (int r2 = 0; r2 < nrows; ++r2) {
@@ -325,25 +327,32 @@ static int launch_fwd_dma(const GruFwdDmaArgs& p, hipStream_t st) {
   ARK_LAUNCH_CHECK();
   return 0;
 }
-template <int PREC, int NBUF, int KI>
+int g_bwd_bn = 64;   // hidden units per backward-cell workgroup (64 | 32)
+
+template <int PREC, int NBUF, int KI, int BN>
 static void launch_bwd_nb(const GruBwdDmaArgs& p, hipStream_t st) {
-  using G = DmaTile<PREC, 32, 64, NBUF, 2, 2, KI>;
-  constexpr int LDS = G::LDS_BYTES > 28672 ? G::LDS_BYTES : 28672;
-  static bool once = (allow_lds(gru_cell_bwd_dma_kernel<PREC, NBUF, KI>, LDS), true); (void)once;
-  const unsigned grid = (unsigned)(((p.B + 31) / 32) * (p.D / 64));
-  hipLaunchKernelGGL((gru_cell_bwd_dma_kernel<PREC, NBUF, KI>), dim3(grid), dim3(256), LDS, st, p);
+  using G = DmaTile<PREC, 32, BN, NBUF, 2, 2, KI>;
+  constexpr int MINL = 2 * 3 * 32 * (BN + 8) * 2;
+  constexpr int LDS = G::LDS_BYTES > MINL ? G::LDS_BYTES : MINL;
+  static bool once = (allow_lds(gru_cell_bwd_dma_kernel<PREC, NBUF, KI, BN>, LDS), true); (void)once;
+  const unsigned grid = (unsigned)(((p.B + 31) / 32) * (p.D / BN));
+  hipLaunchKernelGGL((gru_cell_bwd_dma_kernel<PREC, NBUF, KI, BN>), dim3(grid), dim3(256), LDS, st, p);
+}
+template <int PREC, int BN>
+static void launch_bwd_bn(const GruBwdDmaArgs& p, hipStream_t st) {
+  const bool ki2 = g_bwd_ki == 2 && (3 * p.D) % 128 == 0;
+  if (ki2) {
+    if (g_bwd_nbuf >= 4) launch_bwd_nb<PREC, 4, 2, BN>(p, st);
+    else launch_bwd_nb<PREC, 2, 2, BN>(p, st);
+  } else {
+    if (g_bwd_nbuf >= 4) launch_bwd_nb<PREC, 4, 1, BN>(p, st);
+    else launch_bwd_nb<PREC, 2, 1, BN>(p, st);
+  }
 }
 template <int PREC>
 static int launch_bwd_dma(const GruBwdDmaArgs& p, hipStream_t st) {
-  const bool ki2 = g_bwd_ki == 2 && (3 * p.D) % 128 == 0;
-  if (ki2) {
-    if (g_bwd_nbuf >= 4) launch_bwd_nb<PREC, 4, 2>(p, st);
-    else launch_bwd_nb<PREC, 2, 2>(p, st);
-  } else {
-    if (g_bwd_nbuf == 8) launch_bwd_nb<PREC, 8, 1>(p, st);
-    else if (g_bwd_nbuf == 4) launch_bwd_nb<PREC, 4, 1>(p, st);
-    else launch_bwd_nb<PREC, 2, 1>(p, st);
-  }
+  if (g_bwd_bn == 32) launch_bwd_bn<PREC, 32>(p, st);
+  else launch_bwd_bn<PREC, 64>(p, st);
   ARK_LAUNCH_CHECK();
   return 0;
 }
@@ -351,6 +360,12 @@ static int launch_bwd_dma(const GruBwdDmaArgs& p, hipStream_t st) {
 }  // namespace ark
 
 // speed-only knobs: ring depth (2|4|8) of the forward / backward LDS-DMA cell kernels
+extern "C" int ark_set_dma_bwd_units(int bn) {
+  if (bn != 32 && bn != 64) return ARK_ERR_ARG;
+  ark::g_bwd_bn = bn;
+  return 0;
+}
+
 extern "C" int ark_set_dma_fwd_rows(int bm) {
   if (bm != 32 && bm != 64) return ARK_ERR_ARG;
   ark::g_fwd_bm = bm;
@@ -365,7 +380,7 @@ extern "C" int ark_set_dma_stage(int fwd_ki, int bwd_ki) {
 }
 
 extern "C" int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf) {
-  auto ok = [](int v) { return v == 2 || v == 4 || v == 8; };
+  auto ok = [](int v) { return v == 2 || v == 4 || v == 8; };   // 8 applies to the forward cell only
   if (!ok(fwd_nbuf) || !ok(bwd_nbuf)) return ARK_ERR_ARG;
   ark::g_fwd_nbuf = fwd_nbuf;
   ark::g_bwd_nbuf = bwd_nbuf;

@@ -100,6 +100,7 @@ int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_hhT16, const
 int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf);
 int ark_set_dma_stage(int fwd_ki, int bwd_ki);
 int ark_set_dma_fwd_rows(int bm);
+int ark_set_dma_bwd_units(int bn);
 int ark_set_scatter_chunk(int items_per_workgroup);
 int ark_set_dma_debug(int mask); /* timing ablations only: results are invalid while mask != 0 */
 int ark_set_gemm16_tuning(int nbuf, int tile);
