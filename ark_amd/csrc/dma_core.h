@@ -33,7 +33,8 @@ template <int PREC, int BM, int BN, int NBUF, int WGM, int WGN, int KI = 1>
 struct DmaTile {
   static_assert(PREC == PREC_F16 || PREC == PREC_BF16, "LDS-DMA engine takes 16-bit operands");
   static_assert(BM % 32 == 0 && BN % 32 == 0, "tile shape");
-  static_assert(WGM * WGN == 4, "4 waves");
+  static constexpr int NW = WGM * WGN;   // waves per workgroup (4, or 8 for 512-thread workgroups)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
   // one pipeline stage = KI 64-wide k-images of both operands; NBUF stages ride a ring in LDS
@@ -42,8 +43,11 @@ struct DmaTile {
   static constexpr int A_STAGE = A_IMG * KI, B_STAGE = B_IMG * KI;
   static constexpr int STAGE_BYTES = A_STAGE + B_STAGE;
   static constexpr int LDS_BYTES = NBUF * STAGE_BYTES;
-  static constexpr int NPA = BM / 32, NPB = BN / 32;   // 1-KB LDS-DMA pieces per image per wave
-  static constexpr int LPS = (NPA + NPB) * KI;         // LDS-DMA instructions per stage per wave
+  // a stage of one operand is KI * R/8 one-KB pieces (8 rows x 128 B each), dealt round-robin to the waves
+  static constexpr int PA = KI * BM / 8, PB = KI * BN / 8;
+  static_assert(PA % NW == 0 && PB % NW == 0, "pieces per stage must divide evenly over the waves");
+  static constexpr int NPA = PA / NW, NPB = PB / NW;   // pieces per stage per wave
+  static constexpr int LPS = NPA + NPB;                // LDS-DMA instructions per stage per wave
   static_assert((NBUF - 1) * LPS <= 63, "in-flight stages must fit the 6-bit vmcnt");
   static_assert(NBUF >= 2 && NBUF <= 8, "ring depth");
   static constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -76,32 +80,32 @@ struct DmaTile {
     const int wm = wave / WGN, wn = wave % WGN;
     const int lr = lane & 15, lq = lane >> 4;
 
+    // piece q of an operand's stage: image j = q / (R/8), rows 8p..8p+7 with p = q % (R/8)
     const h_t* ap[NPA];
     const h_t* bp[NPB];
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
-      const int row = 8 * (wave + 4 * i) + (lane >> 3);
-      ap[i] = A + rma(row) * lda + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+      const int q = wave + NW * i, j = q / (BM / 8), pr = q % (BM / 8);
+      const int row = 8 * pr + (lane >> 3);
+      ap[i] = A + rma(row) * lda + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
-      const int row = 8 * (wave + 4 * i) + (lane >> 3);
-      bp[i] = B + rmb(row) * ldb + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+      const int q = wave + NW * i, j = q / (BN / 8), pr = q % (BN / 8);
+      const int row = 8 * pr + (lane >> 3);
+      bp[i] = B + rmb(row) * ldb + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
     }
     auto issue = [&](int s) {
       char* base = lds + (s % NBUF) * STAGE_BYTES;
+      const int k0 = s * KS;
 #pragma unroll
-      for (int j = 0; j < KI; ++j) {
-        const int k0 = s * KS + 64 * j;
+      for (int i = 0; i < NPA; ++i)   // piece q lands at byte q*1024 of the operand's stage (images are contiguous)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NPA; ++i)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap[i] + k0),
-                                           (__attribute__((address_space(3))) void*)(base + j * A_IMG + (wave + 4 * i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NPB; ++i)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp[i] + k0),
-                                           (__attribute__((address_space(3))) void*)(base + A_STAGE + j * B_IMG + (wave + 4 * i) * 1024), 16, 0, 0);
-      }
+      for (int i = 0; i < NPB; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(base + A_STAGE + (wave + NW * i) * 1024), 16, 0, 0);
     };
 
 #pragma unroll

@@ -37,10 +37,10 @@ struct GruFwdDmaArgs {
   int dbg;   // timing ablations (results invalid when != 0): 1 no main loop, 2 no epilogue stores, 4 no prefetch loads
 };
 
-template <int PREC, int PRECB, int NBUF, int KI, int BM>
-__global__ __launch_bounds__(256) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) {
+template <int PREC, int PRECB, int NBUF, int KI, int BM, int NW>
+__global__ __launch_bounds__(64 * NW) void gru_cell_fwd_dma_kernel(GruFwdDmaArgs p) {
   constexpr int BU = 32, BN = 3 * BU;
-  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;  // wave tile (BM/2) x 48 (16 units x 3 gates)
+  using G = DmaTile<PREC, BM, BN, NBUF, NW / 2, 2, KI>;  // wave tile (2*BM/NW) x 48 (16 units x 3 gates)
   constexpr int TM = G::TM;
   using h_t = typename G::h_t;
   using hb_t = typename PrecTraits<PRECB>::h_t;
@@ -297,32 +297,35 @@ int g_dma_dbg = 0;
 int g_fwd_nbuf = 2, g_bwd_nbuf = 2;   // ring slots
 int g_fwd_ki = 2, g_bwd_ki = 2;       // 64-wide k-images per stage (1 | 2)
 
-int g_fwd_bm = 32;   // rows per forward-cell workgroup (32 | 64)
+int g_fwd_bm = 32;   // rows per forward-cell workgroup: 32 | 64 (4 waves) | 128 = 64 rows with 8 waves
 
-template <int PREC, int PRECB, int NBUF, int KI, int BM>
+template <int PREC, int PRECB, int NBUF, int KI, int BM, int NW>
 static void launch_fwd_nb(const GruFwdDmaArgs& p, hipStream_t st) {
-  using G = DmaTile<PREC, BM, 96, NBUF, 2, 2, KI>;
+  using G = DmaTile<PREC, BM, 96, NBUF, NW / 2, 2, KI>;
   constexpr int MINL = 4 * BM * 40 * 2;
   constexpr int LDS = G::LDS_BYTES > MINL ? G::LDS_BYTES : MINL;
-  static bool once = (allow_lds(gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF, KI, BM>, LDS), true); (void)once;
+  static bool once = (allow_lds(gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF, KI, BM, NW>, LDS), true); (void)once;
   const unsigned grid = (unsigned)(((p.B + BM - 1) / BM) * (p.D / 32));
-  hipLaunchKernelGGL((gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF, KI, BM>), dim3(grid), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((gru_cell_fwd_dma_kernel<PREC, PRECB, NBUF, KI, BM, NW>), dim3(grid), dim3(64 * NW), LDS, st, p);
 }
 template <int PREC, int PRECB, int BM>
 static void launch_fwd_bm(const GruFwdDmaArgs& p, hipStream_t st) {
   const bool ki2 = g_fwd_ki == 2 && p.D % 128 == 0;
   if (ki2) {
-    if (g_fwd_nbuf >= 4 && BM == 32) launch_fwd_nb<PREC, PRECB, (BM == 32 ? 4 : 2), 2, BM>(p, st);
-    else launch_fwd_nb<PREC, PRECB, 2, 2, BM>(p, st);
+    if (g_fwd_nbuf >= 4 && BM == 32) launch_fwd_nb<PREC, PRECB, (BM == 32 ? 4 : 2), 2, BM, 4>(p, st);
+    else launch_fwd_nb<PREC, PRECB, 2, 2, BM, 4>(p, st);
   } else {
-    if (g_fwd_nbuf == 8 && BM == 32) launch_fwd_nb<PREC, PRECB, (BM == 32 ? 8 : 4), 1, BM>(p, st);
-    else if (g_fwd_nbuf >= 4) launch_fwd_nb<PREC, PRECB, 4, 1, BM>(p, st);
-    else launch_fwd_nb<PREC, PRECB, 2, 1, BM>(p, st);
+    if (g_fwd_nbuf == 8 && BM == 32) launch_fwd_nb<PREC, PRECB, (BM == 32 ? 8 : 4), 1, BM, 4>(p, st);
+    else if (g_fwd_nbuf >= 4) launch_fwd_nb<PREC, PRECB, 4, 1, BM, 4>(p, st);
+    else launch_fwd_nb<PREC, PRECB, 2, 1, BM, 4>(p, st);
   }
 }
 template <int PREC, int PRECB>
 static int launch_fwd_dma(const GruFwdDmaArgs& p, hipStream_t st) {
-  if (g_fwd_bm == 64) launch_fwd_bm<PREC, PRECB, 64>(p, st);
+  if (g_fwd_bm == 128 && p.D % 128 == 0) {   // 64 rows, 8 waves: W_hh panel loaded once per 64 rows, same waves per CU
+    if (g_fwd_nbuf >= 4) launch_fwd_nb<PREC, PRECB, 3, 2, 64, 8>(p, st);   // 3 x 40 KB slots
+    else launch_fwd_nb<PREC, PRECB, 2, 2, 64, 8>(p, st);                  // 2 x 40 KB slots
+  } else if (g_fwd_bm == 64) launch_fwd_bm<PREC, PRECB, 64>(p, st);
   else launch_fwd_bm<PREC, PRECB, 32>(p, st);
   ARK_LAUNCH_CHECK();
   return 0;
@@ -367,7 +370,7 @@ extern "C" int ark_set_dma_bwd_units(int bn) {
 }
 
 extern "C" int ark_set_dma_fwd_rows(int bm) {
-  if (bm != 32 && bm != 64) return ARK_ERR_ARG;
+  if (bm != 32 && bm != 64 && bm != 128) return ARK_ERR_ARG;
   ark::g_fwd_bm = bm;
   return 0;
 }
