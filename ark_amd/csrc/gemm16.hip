@@ -186,24 +186,24 @@ extern "C" int ark_set_gemm16_tuning(int nbuf, int tile) {
   return 0;
 }
 
-static float g16_drop_p = 0.f; static uint64_t g16_drop_seed = 0; static const float* g16_hyper = nullptr;
+struct Gemm16Dropout { float p; uint64_t seed; const float* hyper; };
 
 static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
                        int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* c16a,
-                       void* c16b, int prec_b, void* stream) {
+                       void* c16b, int prec_b, void* stream, Gemm16Dropout drop = Gemm16Dropout{0.f, 0, nullptr}) {
   using namespace ark;
   if (!A16 || !B16 || !C || M <= 0 || N <= 0 || K <= 0) return ARK_ERR_ARG;
   if (K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0) return ARK_ERR_SHAPE;
   if (((uintptr_t)A16 | (uintptr_t)B16) & 15) return ARK_ERR_ALIGN;
   if (epi < ARK_EPI_NONE || epi > ARK_EPI_DROPOUT) return ARK_ERR_ARG;
-  if (epi == ARK_EPI_DROPOUT && (!c_tiled || !g16_hyper || g16_drop_p <= 0.f || g16_drop_p >= 1.f)) return ARK_ERR_ARG;
+  if (epi == ARK_EPI_DROPOUT && (!c_tiled || !drop.hyper || drop.p <= 0.f || drop.p >= 1.f)) return ARK_ERR_ARG;
   if ((epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU) && !bias) return ARK_ERR_ARG;
   if ((epi == ARK_EPI_MUL_AUX || epi == ARK_EPI_MUL_DGELU) && !aux) return ARK_ERR_ARG;
   if (c_tiled && (M % 16 != 0 || ldc % 16 != 0 || N > ldc)) return ARK_ERR_SHAPE;
   if (c_tiled && (epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_MUL_DGELU || c16a || c16b)) return ARK_ERR_ARG;
   if (c16b && prec_b != PREC_F16 && prec_b != PREC_BF16) return ARK_ERR_ARG;
   Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0, c16a, c16b, prec, prec_b,
-               g16_drop_p, g16_drop_seed, g16_hyper};
+               drop.p, drop.seed, drop.hyper};
   if (prec == PREC_F16) return launch16<PREC_F16>(p, (hipStream_t)stream);
   if (prec == PREC_BF16) return launch16<PREC_BF16>(p, (hipStream_t)stream);
   return ARK_ERR_ARG;
@@ -213,11 +213,8 @@ static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const vo
 // dropped layer output, with the mask regenerated from the same counter-based hash the forward cell used
 extern "C" int ark_gemm16_dropout(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                                   int M, int N, int K, float drop_p, uint64_t drop_seed, const float* hyper, void* stream) {
-  g16_drop_p = drop_p; g16_drop_seed = drop_seed; g16_hyper = hyper;
-  const int rc = gemm16_impl(prec, ARK_EPI_DROPOUT, A16, lda, B16, ldb, C, ldc, nullptr, nullptr, M, N, K, 1, nullptr, nullptr, 0,
-                             stream);
-  g16_hyper = nullptr;
-  return rc;
+  return gemm16_impl(prec, ARK_EPI_DROPOUT, A16, lda, B16, ldb, C, ldc, nullptr, nullptr, M, N, K, 1, nullptr, nullptr, 0,
+                     stream, Gemm16Dropout{drop_p, drop_seed, hyper});
 }
 
 extern "C" int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,

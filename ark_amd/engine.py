@@ -123,16 +123,12 @@ class Engine:
         if self.layout.tied:
             self.p["dec.out.weight"] = self.p["dec.tok_emb.weight"]
             self.g["dec.out.weight"] = self.g["dec.tok_emb.weight"]
-        self.hyper_host = torch.zeros(HP["COUNT"], dtype=torch.float32)
-        self.hyper = torch.zeros(HP["COUNT"], device=dev, dtype=torch.float32)
-        self.hyper_host[HP["ADAM_B1"]] = 0.9
-        self.hyper_host[HP["ADAM_B2"]] = 0.999
-        self.hyper_host[HP["ADAM_EPS"]] = 1e-8
-        self.hyper_host[HP["GRAD_SCALE"]] = 1.0
-        self.hyper_host[HP["BETA"]] = 1.0
-        self.hyper_host[HP["LR"]] = float(cfg.get("learning_rate", 1e-3))
-        self.hyper.copy_(self.hyper_host)
-        self._hp = {"LR": float(self.hyper_host[HP["LR"]]), "BETA": 1.0, "GRAD_SCALE": 1.0}
+        init = torch.zeros(HP["COUNT"], dtype=torch.float32)
+        init[HP["ADAM_B1"]], init[HP["ADAM_B2"]], init[HP["ADAM_EPS"]] = 0.9, 0.999, 1e-8
+        init[HP["GRAD_SCALE"]], init[HP["BETA"]] = 1.0, 1.0
+        init[HP["LR"]] = float(cfg.get("learning_rate", 1e-3))
+        self.hyper = init.to(dev)   # device-resident step scalars (include/ark_amd.h ARK_HP_*)
+        self._hp = {"LR": float(cfg.get("learning_rate", 1e-3)), "BETA": 1.0, "GRAD_SCALE": 1.0}   # host mirror of host-owned slots
         self.adam_steps = 0
         self.ws = None
         self.ws_key = None
