@@ -135,6 +135,9 @@ class Engine:
         self.training = True
         self.drop_seed = int(cfg.get("dropout_seed", 0x5A11))
         self._graphs = {}
+        self._ws_cache = {}
+        self._pinned_B = set()
+        self._graph_steps = {}
         # 16-bit-operand / LDS-DMA path ("v2"): 16-bit shadows of the decoder weights, refreshed after
         # every optimiser step: W_ih, W_hh, W_tok in the forward type; W_ih^T, W_hh^T in the backward type
         self.use_dma = (self.prec_fwd != L.PREC_F32 and self.prec_bwd != L.PREC_F32 and self.D % 64 == 0
@@ -231,6 +234,9 @@ class Engine:
         key = B
         if self.ws_key == key:
             return self.ws
+        if key in self._ws_cache:   # captured graphs hold raw workspace addresses: never free a live one
+            self.ws, self.ws_key = self._ws_cache[key], key
+            return self.ws
         dev, D, n, Lq, V, Z = self.device, self.D, self.n, self.L, self.V, self.Z
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         w = {}
@@ -293,8 +299,11 @@ class Engine:
         w["dYa"], w["dYb"] = f(R, D), f(R, D)
         w["carry"] = f(B, D)
         w["tok_next"] = torch.zeros(B, dtype=torch.int64, device=dev)
+        if len(self._ws_cache) >= 6:   # bound the cache; batch sizes with captured graphs stay pinned
+            for k in [k for k in self._ws_cache if k not in self._pinned_B][:1]:
+                del self._ws_cache[k]
+        self._ws_cache[key] = w
         self.ws, self.ws_key = w, key
-        self._graphs = {}
         return w
 
     # ------------------------------------------------------------------ kernel wrappers
@@ -360,8 +369,8 @@ class Engine:
                     a = w["act"][i]
                 self._gemm(KM, KM, L.EPI_BIAS, a, H, p["enc.mu.weight"], H, w["head"], 2 * Z, B, 2 * Z, H,
                            bias=p["enc.mu.bias"])
-            if eps is None:
-                eps = w["eps0"]
+            if eps is None:   # z = mu + N(0,1) * std, drawn on the device (reference models.py:63)
+                eps = w["eps0"].normal_()
             self._eps = eps
             _call("ark_latent_fwd", L.ptr(w["head"]), L.ptr(eps), L.ptr(w["mu"]), L.ptr(w["logv"]), L.ptr(w["z"]),
                   L.ptr(w["kl"]), L.i32(B), L.i32(Z), st)
@@ -906,8 +915,34 @@ class Engine:
             self.adam_steps += 1
             return out4
 
-        self._graphs["train"] = graphs
+        self._graphs[("train", seq.shape[0], dp)] = graphs
+        self._pinned_B.add(seq.shape[0])
         return replay
+
+    def graphed_train_step(self, triples, seq, ce_count=None, dp=False):
+        """train_step() through a cached hipGraph: the first call for a batch shape runs the step eagerly
+        (that IS the step for this batch) and captures it on private input buffers; later calls copy the
+        batch into those buffers and replay.  The latent noise is drawn inside the graph."""
+        assert self.training, "graphed_train_step is a training-mode step"
+        key = (None if triples is None else tuple(triples.shape), tuple(seq.shape), bool(dp), ce_count is None)
+        ent = self._graph_steps.get(key)
+        if ent is None:
+            tri_s = None if triples is None else triples.clone()
+            seq_s = seq.clone()
+            replay = self.capture_train_step(tri_s, seq_s, None, ce_count=ce_count, dp=dp)
+            self._graph_steps[key] = (tri_s, seq_s, replay)
+            return self.ws["out4"]
+        tri_s, seq_s, replay = ent
+        if tri_s is not None:
+            tri_s.copy_(triples, non_blocking=True)
+        seq_s.copy_(seq, non_blocking=True)
+        self._default_norms(seq.shape[0])
+        if ce_count is not None:
+            self.set_hyper(ce_count=ce_count)
+        self._workspace(seq.shape[0], 0)
+        if not self._shadow_ok:   # parameters were written from outside since the last step
+            self.refresh_shadows()
+        return replay()
 
     # ------------------------------------------------------------------ greedy decode (next row of SURVEY 8f)
     @torch.no_grad()

@@ -89,19 +89,35 @@ def iterate_batches(tri, seq, batch_size, shuffle, drop_last, generator=None):
 
 def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), max_steps=None):
     """one pass over the training split; returns epoch means of (loss, recon, kl, 0) over batches,
-    as the reference's train_epoch does (ablation_study.py:31-88)."""
+    as the reference's train_epoch does (ablation_study.py:31-88).
+
+    The epoch's index tensors go to the device in one copy and every step is a hipGraph replay
+    (`use_hip_graph: false` in the config falls back to eager launches), so the host only slices."""
     model.train()
     rank, nranks = world
     tri, seq = dataset.tensorize()   # redraws the per-graph permutations, like a fresh DataLoader pass
+    B = config["batch_size"]
+    nb_all = seq.shape[0] // B       # drop_last
+    if config["shuffle_train"]:
+        order = torch.randperm(seq.shape[0])
+        seq = seq[order]
+        tri = tri[order] if tri is not None else None
+    seq = seq[:nb_all * B].view(nb_all, B, -1)
+    tri = tri[:nb_all * B].view(nb_all, B, *tri.shape[1:]) if tri is not None else None
+    # CE is a mean over the GLOBAL batch's target tokens; counting on the host keeps ranks collective-free
+    counts = (seq[:, :, 1:] != config["special_tokens"]["PAD"]).sum(dim=(1, 2)).tolist()
+    if nranks > 1:
+        Bl = B // nranks
+        seq = seq[:, rank * Bl:(rank + 1) * Bl]
+        tri = tri[:, rank * Bl:(rank + 1) * Bl] if tri is not None else None
+    seq = seq.contiguous().to(device, non_blocking=True)
+    tri = tri.contiguous().to(device, non_blocking=True) if tri is not None else None
+    graph = bool(config.get("use_hip_graph", True))
     sums = torch.zeros(4, device=device)
     nb = 0
-    for tb, sb in iterate_batches(tri, seq, config["batch_size"], config["shuffle_train"], True):
-        ce_count = dp.count_targets(sb, config["special_tokens"]["PAD"])
-        if nranks > 1:
-            tb, sb = dp.shard(tb, rank, nranks), dp.shard(sb, rank, nranks)
-        tb = tb.to(device, non_blocking=True)
-        sb = sb.to(device, non_blocking=True)
-        out4 = model.train_step(tb, sb, beta=b, lr=lr, ce_count=ce_count, dp=nranks > 1)
+    for i in range(nb_all):
+        out4 = model.train_step(tri[i] if tri is not None else None, seq[i], beta=b, lr=lr, ce_count=counts[i],
+                                dp=nranks > 1, graph=graph)
         sums += out4
         nb += 1
         if max_steps and nb >= max_steps:

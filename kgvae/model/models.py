@@ -85,11 +85,14 @@ class _EngineModel(nn.Module):
         return list(self.named_parameters())
 
     # -- fused training step ----------------------------------------------------------------
-    def train_step(self, triples, seq, beta=1.0, lr=None, eps=None, grad_sync=None, ce_count=None, dp=False):
+    def train_step(self, triples, seq, beta=1.0, lr=None, eps=None, grad_sync=None, ce_count=None, dp=False, graph=False):
         """forward + ELBO + backward + Adam on the device; returns the device tensor
-        [loss, ce, kl, token-loss sum] without synchronising."""
+        [loss, ce, kl, token-loss sum] without synchronising.  `graph=True` replays the step from a
+        cached hipGraph (captured on the first batch of each shape; needs eps and grad_sync unset)."""
         eng = self.engine()
         eng.set_hyper(lr=lr, beta=beta)
+        if graph and eps is None and grad_sync is None:
+            return eng.graphed_train_step(self._tri(triples), seq, ce_count=ce_count, dp=dp)
         return eng.train_step(self._tri(triples), seq, eps, grad_sync=grad_sync, ce_count=ce_count, dp=dp)
 
     @torch.no_grad()
