@@ -87,6 +87,28 @@ def iterate_batches(tri, seq, batch_size, shuffle, drop_last, generator=None):
         yield (tri[idx] if tri is not None else None), seq[idx]
 
 
+def epoch_batches(tri, seq, batch_size, shuffle, pad, rank=0, nranks=1):
+    """Host side of one epoch: (optionally shuffled) full batches only (drop_last), stacked as
+    [n_batches, B_local, ...] with this rank's contiguous row shard of every global batch, plus the
+    GLOBAL target-token count of every batch (CE is a mean over the global batch's non-PAD targets;
+    counting here keeps the ranks free of a per-step collective)."""
+    B = batch_size
+    nb = seq.shape[0] // B
+    if shuffle:
+        order = torch.randperm(seq.shape[0])
+        seq = seq[order]
+        tri = tri[order] if tri is not None else None
+    seq = seq[:nb * B].view(nb, B, -1)
+    tri = tri[:nb * B].view(nb, B, *tri.shape[1:]) if tri is not None else None
+    counts = (seq[:, :, 1:] != pad).sum(dim=(1, 2)).tolist()
+    if nranks > 1:
+        assert B % nranks == 0, "batch_size must divide evenly over the ranks"
+        Bl = B // nranks
+        seq = seq[:, rank * Bl:(rank + 1) * Bl]
+        tri = tri[:, rank * Bl:(rank + 1) * Bl] if tri is not None else None
+    return tri, seq, counts
+
+
 def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), max_steps=None):
     """one pass over the training split; returns epoch means of (loss, recon, kl, 0) over batches,
     as the reference's train_epoch does (ablation_study.py:31-88).
@@ -96,20 +118,9 @@ def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), ma
     model.train()
     rank, nranks = world
     tri, seq = dataset.tensorize()   # redraws the per-graph permutations, like a fresh DataLoader pass
-    B = config["batch_size"]
-    nb_all = seq.shape[0] // B       # drop_last
-    if config["shuffle_train"]:
-        order = torch.randperm(seq.shape[0])
-        seq = seq[order]
-        tri = tri[order] if tri is not None else None
-    seq = seq[:nb_all * B].view(nb_all, B, -1)
-    tri = tri[:nb_all * B].view(nb_all, B, *tri.shape[1:]) if tri is not None else None
-    # CE is a mean over the GLOBAL batch's target tokens; counting on the host keeps ranks collective-free
-    counts = (seq[:, :, 1:] != config["special_tokens"]["PAD"]).sum(dim=(1, 2)).tolist()
-    if nranks > 1:
-        Bl = B // nranks
-        seq = seq[:, rank * Bl:(rank + 1) * Bl]
-        tri = tri[:, rank * Bl:(rank + 1) * Bl] if tri is not None else None
+    tri, seq, counts = epoch_batches(tri, seq, config["batch_size"], config["shuffle_train"],
+                                     config["special_tokens"]["PAD"], rank, nranks)
+    nb_all = seq.shape[0]
     seq = seq.contiguous().to(device, non_blocking=True)
     tri = tri.contiguous().to(device, non_blocking=True) if tri is not None else None
     graph = bool(config.get("use_hip_graph", True))

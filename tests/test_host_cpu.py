@@ -141,3 +141,25 @@ def test_schedules_match_torch():
         assert abs(opt.param_groups[0]["lr"] - cosine_lr(1e-3, ep, 10, 1e-6)) < 1e-10
         opt.step()
         sch.step()
+
+
+def test_epoch_batches_shards_and_counts():
+    """train.py's host-side epoch preparation agrees with dp.shard / dp.count_targets batch by batch"""
+    import torch
+    from ark_amd import dp
+    from kgvae.experiments.train import epoch_batches
+    g = torch.Generator().manual_seed(0)
+    n, B, L, T = 37, 8, 7, 3
+    seq = torch.randint(0, 9, (n, L), generator=g)
+    tri = torch.randint(0, 5, (n, T, 3), generator=g)
+    full_t, full_s, counts = epoch_batches(tri, seq, B, False, 0)
+    assert full_s.shape == (n // B, B, L) and full_t.shape == (n // B, B, T, 3) and len(counts) == n // B
+    for r in range(4):
+        t_r, s_r, c_r = epoch_batches(tri, seq, B, False, 0, rank=r, nranks=4)
+        assert c_r == counts
+        for i in range(n // B):
+            assert torch.equal(s_r[i], dp.shard(seq[i * B:(i + 1) * B], r, 4))
+            assert torch.equal(t_r[i], dp.shard(tri[i * B:(i + 1) * B], r, 4))
+            assert counts[i] == dp.count_targets(seq[i * B:(i + 1) * B], 0)
+    t_n, s_n, c_n = epoch_batches(None, seq, B, True, 0)
+    assert t_n is None and s_n.shape == full_s.shape and sum(c_n) <= int((seq[:, 1:] != 0).sum())
