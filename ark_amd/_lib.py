@@ -64,3 +64,19 @@ def f32(x):
 
 def u64(x):
     return ctypes.c_uint64(int(x) & 0xFFFFFFFFFFFFFFFF)
+
+
+DIAG_MAX_ROLES = 4
+
+
+class GruDiagRole(ctypes.Structure):
+    """ArkGruDiagRole of include/ark_amd.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in (
+        "x16", "h_prev16", "w_ih16", "w_hh16", "b_ih", "b_hh", "y_prev_t", "y_out_t", "y16a", "y16b", "yd16a", "yd16b",
+        "save_r", "save_z", "save_n", "save_hn")] + [
+        ("drop_seed", ctypes.c_uint64), ("drop_base", ctypes.c_int64), ("drop_p", ctypes.c_float), ("pad_", ctypes.c_int)]
+
+
+def dptr(t):
+    """raw device address (0 for None) for struct fields"""
+    return 0 if t is None else t.data_ptr()

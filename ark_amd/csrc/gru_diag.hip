@@ -1,0 +1,216 @@
+// Layer-diagonal GRU forward (engine: dma_core.h, DmaTile::run2).
+//
+// In a stacked GRU cell (l, t) depends on (l, t-1) and (l-1, t) only, so the cells of one
+// anti-diagonal d = l + t are independent.  One launch runs them all: workgroup -> (role = layer,
+// row tile, unit tile).  Each role forms BOTH products itself -- x_t W_ih^T and h_{t-1} W_hh^T stream
+// through one LDS-DMA ring back to back -- so the per-layer input GEMM, its [B*L,3D] fp32 `gi`
+// round trip and 2 of every 3 dependent launches disappear.  Everything else (tile-native fp32
+// state, fp16 gate saves, row-major 16-bit copies assembled in LDS, in-kernel counter-hash dropout)
+// is the forward cell of gru_dma.hip.  Reference op replaced: torch.nn.GRU (kgvae/model/models.py:121-127).
+#include "dma_core.h"
+#include "../../include/ark_amd.h"
+
+namespace ark {
+
+typedef _Float16 dhalf4_t __attribute__((ext_vector_type(4)));
+
+struct GruDiagArgs {
+  ArkGruDiagRole role[ARK_DIAG_MAX_ROLES];
+  const float* hyper;
+  int n_roles, B, D, xcd_map;
+};
+
+template <int PREC, int PRECB, int NBUF, int KI, int BM>
+__global__ __launch_bounds__(256) void gru_diag_fwd_kernel(GruDiagArgs p) {
+  constexpr int BU = 32, BN = 3 * BU;
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;   // wave tile (BM/2) x 48 (16 units x 3 gates)
+  constexpr int TM = G::TM;
+  using h_t = typename G::h_t;
+  using hb_t = typename PrecTraits<PRECB>::h_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int B = p.B, D = p.D;
+  const int UT = D / BU, MT = (B + BM - 1) / BM;
+  int role, mt, ut;
+  if (p.xcd_map) {
+    // consecutive workgroup ids go to consecutive XCDs (8 private L2s).  Give XCD x the unit tiles
+    // = x (mod 4) and row tiles = x/4 (mod 2) of every role, so an L2 holds a quarter of the weight
+    // panels and half of the activation rows instead of everything.  (host checks UT%4==0, MT%2==0)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int per_role = (UT / 4) * (MT / 2);
+    role = j / per_role;
+    const int k = j % per_role;
+    ut = (k % (UT / 4)) * 4 + (xcd & 3);
+    mt = (k / (UT / 4)) * 2 + (xcd >> 2);
+  } else {
+    role = blockIdx.x / (UT * MT);
+    const int k = blockIdx.x % (UT * MT);
+    mt = k / UT;
+    ut = k % UT;
+  }
+  const ArkGruDiagRole& R = p.role[role];
+  const int m0 = mt * BM, u0 = ut * BU;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ul = wn * 16 + (lane & 15);
+  const int u = u0 + ul;
+  // epilogue operands first: older than every LDS-DMA op in the vmcnt queue -> they land underneath the products
+  int rl[TM];
+  long o[TM];
+  f32x4 hp[TM], mk[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    rl[tm] = wm * G::WTM + tm * 16 + 4 * (lane >> 4);
+    const int rowc = min(m0 + rl[tm], B - 4);   // B % 16 == 0: clamped quads stay in bounds
+    o[tm] = tile_native_off(rowc, u, D);
+    hp[tm] = *reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]);
+    mk[tm] = f32x4{1.f, 1.f, 1.f, 1.f};
+  }
+  const bool drop = R.drop_p > 0.f;
+  if (drop) {
+    const uint64_t step = (uint64_t)p.hyper[ARK_HP_ADAM_STEP];
+    const float ks = 1.0f / (1.0f - R.drop_p);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        mk[tm][i] = dropout_keep_scale(R.drop_seed, step, (uint64_t)(R.drop_base + o[tm] + i), R.drop_p, ks);
+  }
+  const float br = R.b_ih[u] + R.b_hh[u], bz = R.b_ih[D + u] + R.b_hh[D + u];
+  const float bin = R.b_ih[2 * D + u], bhn = R.b_hh[2 * D + u];
+
+  f32x4 ai[TM][G::TN], ah[TM][G::TN];
+  G::run2(ai, ah, reinterpret_cast<const h_t*>(R.x16), reinterpret_cast<const h_t*>(R.w_ih16), D,
+          reinterpret_cast<const h_t*>(R.h_prev16), reinterpret_cast<const h_t*>(R.w_hh16), D, (long)D, (long)D,
+          [=](int r) -> long { return (long)min(m0 + r, B - 1); },
+          [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); }, smem);
+
+  __syncthreads();   // ring is free: reuse it to assemble row-major 16-bit rows [BM][32+pad]
+  constexpr int TS = 40;
+  constexpr int ARR = BM * TS * 2;
+  h_t* ta = reinterpret_cast<h_t*>(smem);
+  hb_t* tb = reinterpret_cast<hb_t*>(smem + ARR);
+  h_t* tda = reinterpret_cast<h_t*>(smem + 2 * ARR);
+  hb_t* tdb = reinterpret_cast<hb_t*>(smem + 3 * ARR);
+  _Float16* sr = reinterpret_cast<_Float16*>(R.save_r);
+  _Float16* sz = reinterpret_cast<_Float16*>(R.save_z);
+  _Float16* sn = reinterpret_cast<_Float16*>(R.save_n);
+  _Float16* shn = reinterpret_cast<_Float16*>(R.save_hn);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    if (m0 + rl[tm] >= B) continue;
+    f32x4 r, z, n, hn, h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r[i] = sigmoidf_(ai[tm][0][i] + ah[tm][0][i] + br);
+      z[i] = sigmoidf_(ai[tm][1][i] + ah[tm][1][i] + bz);
+      hn[i] = ah[tm][2][i] + bhn;
+      n[i] = tanhf(ai[tm][2][i] + bin + r[i] * hn[i]);
+      h[i] = (1.0f - z[i]) * n[i] + z[i] * hp[tm][i];
+    }
+    *reinterpret_cast<f32x4*>(R.y_out_t + o[tm]) = h;
+    if (sr) {
+      *reinterpret_cast<dhalf4_t*>(sr + o[tm]) = dhalf4_t{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
+      *reinterpret_cast<dhalf4_t*>(sz + o[tm]) = dhalf4_t{(_Float16)z[0], (_Float16)z[1], (_Float16)z[2], (_Float16)z[3]};
+      *reinterpret_cast<dhalf4_t*>(sn + o[tm]) = dhalf4_t{(_Float16)n[0], (_Float16)n[1], (_Float16)n[2], (_Float16)n[3]};
+      *reinterpret_cast<dhalf4_t*>(shn + o[tm]) = dhalf4_t{(_Float16)hn[0], (_Float16)hn[1], (_Float16)hn[2], (_Float16)hn[3]};
+    }
+    const f32x4 hd = h * mk[tm];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ta[(rl[tm] + i) * TS + ul] = G::PT::cvt(h[i]);
+      if (R.y16b) tb[(rl[tm] + i) * TS + ul] = PrecTraits<PRECB>::cvt(h[i]);
+      if (drop) {
+        tda[(rl[tm] + i) * TS + ul] = G::PT::cvt(hd[i]);
+        tdb[(rl[tm] + i) * TS + ul] = PrecTraits<PRECB>::cvt(hd[i]);
+      }
+    }
+  }
+  __syncthreads();
+  // BM rows x 64 B per array: thread t -> row t/4, 16-byte chunk t%4 (BM=64: exactly the 256 threads)
+  const int t = threadIdx.x;
+  if (t < BM * 4) {
+    const int rr = t >> 2, ch = t & 3;
+    const int row = m0 + rr;
+    if (row < B) {
+      const long go = (long)row * D + u0 + ch * 8;
+      *reinterpret_cast<uint4*>(reinterpret_cast<h_t*>(R.y16a) + go) = *reinterpret_cast<const uint4*>(ta + rr * TS + ch * 8);
+      if (R.y16b) *reinterpret_cast<uint4*>(reinterpret_cast<hb_t*>(R.y16b) + go) = *reinterpret_cast<const uint4*>(tb + rr * TS + ch * 8);
+      if (drop) {
+        *reinterpret_cast<uint4*>(reinterpret_cast<h_t*>(R.yd16a) + go) = *reinterpret_cast<const uint4*>(tda + rr * TS + ch * 8);
+        if (R.yd16b) *reinterpret_cast<uint4*>(reinterpret_cast<hb_t*>(R.yd16b) + go) = *reinterpret_cast<const uint4*>(tdb + rr * TS + ch * 8);
+      }
+    }
+  }
+}
+
+// measured on MI355X (syn-paths, B=1024): 64 rows x 2 k-images x 2 slots with the XCD map is fastest
+static int g_diag_rows = 64, g_diag_ki = 2, g_diag_nbuf = 2, g_diag_xcd = 1;
+
+template <int PREC, int PRECB, int NBUF, int KI, int BM>
+static void launch_diag(const GruDiagArgs& p, hipStream_t st) {
+  using G = DmaTile<PREC, BM, 96, NBUF, 2, 2, KI>;
+  constexpr int MINL = 4 * BM * 40 * 2;
+  constexpr int LDS = G::LDS_BYTES > MINL ? G::LDS_BYTES : MINL;
+  auto kern = gru_diag_fwd_kernel<PREC, PRECB, NBUF, KI, BM>;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+  (void)once;
+  const unsigned grid = (unsigned)(p.n_roles * ((p.B + BM - 1) / BM) * (p.D / 32));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, p);
+}
+
+template <int PREC, int PRECB>
+static int launch_diag_cfg(GruDiagArgs& p, hipStream_t st) {
+  const bool ki2 = g_diag_ki == 2 && p.D % 128 == 0;
+  const int rows = g_diag_rows;
+  const int MT = (p.B + rows - 1) / rows, UT = p.D / 32;
+  p.xcd_map = (g_diag_xcd && UT % 4 == 0 && MT % 2 == 0) ? 1 : 0;
+  if (rows == 64) {
+    if (ki2) launch_diag<PREC, PRECB, 2, 2, 64>(p, st);
+    else if (g_diag_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 64>(p, st);
+    else launch_diag<PREC, PRECB, 2, 1, 64>(p, st);
+  } else {
+    if (ki2) launch_diag<PREC, PRECB, 2, 2, 32>(p, st);
+    else if (g_diag_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 32>(p, st);
+    else launch_diag<PREC, PRECB, 2, 1, 32>(p, st);
+  }
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ark
+
+extern "C" int ark_set_diag_tuning(int rows, int ki, int nbuf, int xcd_map) {
+  if ((rows != 32 && rows != 64) || (ki != 1 && ki != 2) || (nbuf != 2 && nbuf != 4)) return ARK_ERR_ARG;
+  ark::g_diag_rows = rows;
+  ark::g_diag_ki = ki;
+  ark::g_diag_nbuf = nbuf;
+  ark::g_diag_xcd = xcd_map ? 1 : 0;
+  return 0;
+}
+
+extern "C" int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruDiagRole* roles, const float* hyper, int B, int D,
+                                void* stream) {
+  using namespace ark;
+  if (!roles || n_roles <= 0 || n_roles > ARK_DIAG_MAX_ROLES || B <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (D % 64 != 0 || B % 16 != 0) return ARK_ERR_SHAPE;
+  GruDiagArgs p;
+  for (int i = 0; i < n_roles; ++i) {
+    const ArkGruDiagRole& r = roles[i];
+    if (!r.x16 || !r.h_prev16 || !r.w_ih16 || !r.w_hh16 || !r.b_ih || !r.b_hh || !r.y_prev_t || !r.y_out_t || !r.y16a)
+      return ARK_ERR_ARG;
+    if (r.drop_p < 0.f || r.drop_p >= 1.f || (r.drop_p > 0.f && (!r.yd16a || !hyper))) return ARK_ERR_ARG;
+    if (r.save_r && (!r.save_z || !r.save_n || !r.save_hn)) return ARK_ERR_ARG;
+    p.role[i] = r;
+  }
+  for (int i = n_roles; i < ARK_DIAG_MAX_ROLES; ++i) p.role[i] = roles[0];
+  p.hyper = hyper;
+  p.n_roles = n_roles;
+  p.B = B;
+  p.D = D;
+  p.xcd_map = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (prec == PREC_F16 && prec_b == PREC_BF16) return launch_diag_cfg<PREC_F16, PREC_BF16>(p, st);
+  if (prec == PREC_F16 && prec_b == PREC_F16) return launch_diag_cfg<PREC_F16, PREC_F16>(p, st);
+  if (prec == PREC_BF16 && prec_b == PREC_BF16) return launch_diag_cfg<PREC_BF16, PREC_BF16>(p, st);
+  return ARK_ERR_ARG;
+}

@@ -164,6 +164,7 @@ class Engine:
         self._side_used = False
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
         self._layer_streams = []
+        self.diag_cells = bool(cfg.get("ark_diag_cells", True))   # one launch per (layer, time) anti-diagonal
         self.pipeline_layers = bool(cfg.get("ark_pipeline_layers", False))   # measured slower on MI355X
 
     # ------------------------------------------------------------------ parameters
@@ -268,7 +269,9 @@ class Engine:
             # "16": row-major 16-bit copies (a: forward type, b: backward type); "_t": tile-native
             w["X0a"] = i16(R, D)
             w["X0b"] = i16(R, D) if two else None
-            w["GI"] = [f(R, 3 * D) for _ in range(n)]                       # tile-native fp32
+            w["diag"] = self.diag_cells and n <= L.DIAG_MAX_ROLES
+            if not w["diag"]:   # the diagonal cells project their inputs themselves: no gi buffers
+                w["GI"] = [f(R, 3 * D) for _ in range(n)]                   # tile-native fp32
             w["Y"] = [torch.zeros((Lq + 1) * B, D, device=dev) for _ in range(n)]   # tile-native fp32 state
             w["Y16a"] = [torch.zeros((Lq + 1) * B, D, device=dev, dtype=torch.int16) for _ in range(n)]
             w["Y16b"] = [torch.zeros((Lq + 1) * B, D, device=dev, dtype=torch.int16) if two else None for _ in range(n)]
@@ -447,7 +450,9 @@ class Engine:
         def mask_gen(l):
             pass   # nothing to materialise: cells and the input-gradient product hash the mask in-kernel
 
-        if self.pipeline_layers and n > 1:
+        if w["diag"]:
+            self._diag_sweep(w, B, Lq, use_drop, save)
+        elif self.pipeline_layers and n > 1:
             # Layer wavefront: layer l runs on its own stream, one step behind layer l-1.  cell(l,t) needs
             # gi[l][t] (a [B,D]x[D,3D] product of the layer below's step-t output) and cell(l,t-1); cells of
             # different layers overlap, so the dependent chain is L+n-1 steps long instead of n*L.
@@ -493,6 +498,45 @@ class Engine:
         _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(w["Y16a"][n - 1][B:]), L.i64(D), L.ptr(self.wtok16), L.i64(D),
               L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(p["dec.out.bias"]), L.ptr(None), L.i32(R), L.i32(V), L.i32(D),
               L.i32(0), st)
+
+    def _diag_sweep(self, w, B, Lq, use_drop, save=True):
+        """Layer-diagonal forward recurrence: cells (l, d-l) of one anti-diagonal are independent -> ONE
+        launch per diagonal, each role doing its own input projection (no gi buffers, no per-layer
+        input GEMM): L+n-1 dependent launches instead of n*L + n."""
+        D, n, p = self.D, self.n, self.p
+        pf, pb = self.prec_fwd, self.prec_bwd
+        for d in range(Lq + n - 1):
+            roles = (L.GruDiagRole * L.DIAG_MAX_ROLES)()
+            k = 0
+            for l in range(n):
+                t = d - l
+                if t < 0 or t >= Lq:
+                    continue
+                drop = use_drop and l < n - 1
+                Y, Ya, Yb = w["Y"][l], w["Y16a"][l], w["Y16b"][l]
+                sl = slice(t * B, (t + 1) * B)
+                nx = slice((t + 1) * B, (t + 2) * B)
+                if l == 0:
+                    x = w["X0a"][sl]
+                else:
+                    x = w["Yd16a"][l - 1][sl] if use_drop else w["Y16a"][l - 1][nx]
+                r = roles[k]
+                r.x16, r.h_prev16 = L.dptr(x), L.dptr(Ya[sl])
+                r.w_ih16, r.w_hh16 = L.dptr(self.wih16[l]), L.dptr(self.whh16[l])
+                r.b_ih, r.b_hh = L.dptr(p[f"dec.gru.bias_ih_l{l}"]), L.dptr(p[f"dec.gru.bias_hh_l{l}"])
+                r.y_prev_t, r.y_out_t = L.dptr(Y[sl]), L.dptr(Y[nx])
+                r.y16a, r.y16b = L.dptr(Ya[nx]), L.dptr(Yb[nx] if Yb is not None else None)
+                r.yd16a = L.dptr(w["Yd16a"][l][sl] if drop else None)
+                r.yd16b = L.dptr(w["Yd16b"][l][sl] if (drop and w["Yd16b"][l] is not None) else None)
+                if save:
+                    r.save_r, r.save_z = L.dptr(w["SR"][l][sl]), L.dptr(w["SZ"][l][sl])
+                    r.save_n, r.save_hn = L.dptr(w["SN"][l][sl]), L.dptr(w["SHN"][l][sl])
+                r.drop_seed = (self.drop_seed + 7919 * l) & 0xFFFFFFFFFFFFFFFF
+                r.drop_base = t * B * D
+                r.drop_p = self.p_drop if drop else 0.0
+                k += 1
+            _call("ark_gru_diag_fwd", L.i32(pf), L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(B), L.i32(D),
+                  L.cur_stream())
 
     def _decoder_forward(self, w, seq, ld_seq, B, Lq, use_drop, save=True):
         if w["v2"]:

@@ -120,7 +120,13 @@ def time_dominant_kernel(eng, B, reps=8):
                 L.ptr(w["GI"][l][sl]), L.ptr(w["Y"][l][nx]), L.ptr(None), L.ptr(None), L.ptr(w["SR"][l][sl]), L.ptr(w["SZ"][l][sl]),
                 L.ptr(w["SN"][l][sl]), L.ptr(w["SHN"][l][sl]), L.i32(B), L.i32(D), L.cur_stream()), "ark_gru_cell_fwd")
 
+    diag = bool(w.get("diag"))
+    launches = (Lq + n - 1) if diag else n * Lq
+
     def sweep():
+        if diag:   # the real forward recurrence: one launch per (layer, time) anti-diagonal
+            eng._diag_sweep(w, B, Lq, eng.training and eng.p_drop > 0, True)
+            return
         for l in range(n):
             for t in range(Lq):
                 launch(l, t)
@@ -139,7 +145,7 @@ def time_dominant_kernel(eng, B, reps=8):
             g.replay()
         e1.record()
         e1.synchronize()
-    return e0.elapsed_time(e1) / (reps * n * Lq) * 1e-3
+    return e0.elapsed_time(e1) / (reps * launches) * 1e-3, launches
 
 
 def main():
@@ -188,7 +194,7 @@ def main():
     for kv in filter(None, args.knobs.split(",")):   # e.g. ring=8:8,g16=2:0,wg128=1
         k, v = kv.split("=")
         vals = [int(x) for x in v.split(":")]
-        fn = {"ring": L.lib().ark_set_dma_ring, "g16": L.lib().ark_set_gemm16_tuning, "wg128": L.lib().ark_set_wgrad_tile128, "wg16": L.lib().ark_set_wgrad16_tuning, "ki": L.lib().ark_set_dma_stage, "fbm": L.lib().ark_set_dma_fwd_rows, "sc": L.lib().ark_set_scatter_chunk, "bbn": L.lib().ark_set_dma_bwd_units}[k]
+        fn = {"ring": L.lib().ark_set_dma_ring, "g16": L.lib().ark_set_gemm16_tuning, "wg128": L.lib().ark_set_wgrad_tile128, "wg16": L.lib().ark_set_wgrad16_tuning, "ki": L.lib().ark_set_dma_stage, "fbm": L.lib().ark_set_dma_fwd_rows, "sc": L.lib().ark_set_scatter_chunk, "bbn": L.lib().ark_set_dma_bwd_units, "diag": L.lib().ark_set_diag_tuning}[k]
         L.check(fn(*vals), k)
 
     cfg = build_cfg(args.dropout, args.workload)
@@ -264,27 +270,41 @@ def main():
         gps = Bg * args.steps / dt
         fl = flops_per_graph(cfg)
         # dominant kernel: the per-timestep recurrent GRU cell (MFMA + fused gate epilogue)
-        kt = time_dominant_kernel(eng, B)
+        kt, launches = time_dominant_kernel(eng, B)
         log(f'kernel avg {kt*1e6:.2f} us; cpu baseline next')
         D = cfg["d_model"]
-        kfl = 2.0 * B * D * 3 * D  # [B,D]x[D,3D] recurrent product per launch
+        n_l, Lq = eng.n, eng.L
         mfma_peak = 2500.0 if args.precision != "f32" else 157.3
+        kfl = 2.0 * B * D * 3 * D  # [B,D]x[D,3D] recurrent product per launch
         if eng.ws["v2"]:
-            # per graph the forward cell reads gi (3D f32), h (D f32 + D 16-bit) and writes
-            # h (D f32 + 2 x D 16-bit) + 4 fp16 gate saves; per launch it also reads the 16-bit W_hh and b_hh.
-            # 87 FLOP/B is below the chip's ~310 FLOP/B balance point, so the HBM roofline bounds it.
             two = eng.prec_fwd != eng.prec_bwd
-            per_graph = 3 * D * 4 + D * 4 + D * 2 + D * 4 + D * 2 * (2 if two else 1) + 4 * D * 2
-            kbytes = B * per_graph + 3 * D * D * 2 + 3 * D * 4
+            if eng.ws.get("diag"):
+                # one launch = the cells of one (layer, time) anti-diagonal.  Per cell and graph:
+                # read x and h (16-bit) + h (f32); write h (f32 + 16-bit fwd/bwd copies) + 4 fp16 gate saves
+                # (+ the two dropped 16-bit copies below the top layer); per cell: 16-bit W_ih, W_hh and both biases.
+                kname = "gru_diag_fwd_kernel"
+                cells = n_l * Lq
+                drop_cells = (n_l - 1) * Lq if (eng.training and eng.p_drop > 0) else 0
+                per_graph = 2 * D * 2 + D * 4 + D * 4 + D * 2 * (2 if two else 1) + 4 * D * 2
+                tot = cells * (B * per_graph + 2 * 3 * D * D * 2 + 2 * 3 * D * 4) + drop_cells * B * D * 2 * (2 if two else 1)
+                kbytes = tot / launches
+                kfl = cells * 2.0 * B * D * 6 * D / launches   # x W_ih^T and h W_hh^T per cell
+            else:
+                # per graph the forward cell reads gi (3D f32), h (D f32 + D 16-bit) and writes h (D f32 + 2 x D 16-bit)
+                # + 4 fp16 gate saves; per launch it also reads the 16-bit W_hh and b_hh.
+                kname = "gru_cell_fwd_dma_kernel"
+                per_graph = 3 * D * 4 + D * 4 + D * 2 + D * 4 + D * 2 * (2 if two else 1) + 4 * D * 2
+                kbytes = B * per_graph + 3 * D * D * 2 + 3 * D * 4
             traffic = None
             try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-                traffic = [v["hbm_bytes_corrected"] for k, v in pm.items() if "gru_cell_fwd_dma_kernel" in k][0]
+                traffic = [v["hbm_bytes_corrected"] for k, v in pm.items() if kname in k][0]
             except Exception:
                 pass
-            roof = {"bound": "hbm", "kernel": "gru_cell_fwd_dma_kernel", "achieved": kbytes / kt / 1e9, "peak": 8000.0,
+            # both editions sit below the chip's ~310 FLOP/B balance point, so the HBM roofline bounds them
+            roof = {"bound": "hbm", "kernel": kname, "achieved": kbytes / kt / 1e9, "peak": 8000.0,
                     "unit": "GB/s", "frac": kbytes / kt / 1e9 / 8000.0, "traffic": traffic, "kernel_avg_us": kt * 1e6,
-                    "bytes_per_launch": kbytes, "flops_per_launch": kfl,
+                    "launches_per_step": launches, "bytes_per_launch": kbytes, "flops_per_launch": kfl,
                     "mfma": {"achieved": kfl / kt / 1e12, "peak": mfma_peak, "unit": "TFLOP/s", "frac": kfl / kt / 1e12 / mfma_peak}}
         else:
             roof = {"bound": "mfma", "kernel": "gru_cell_fwd_kernel", "achieved": kfl / kt / 1e12, "peak": mfma_peak,

@@ -97,6 +97,37 @@ int ark_gru_cell_bwd_dma(int prec, const void* dgh_next16, const void* w_hhT16, 
                          float* db_hh /* += colsum(dgh) */, int B, int D, int first, void* stream);
 int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_hhT16, const float* carry_t, float* dh0,
                        int accumulate, int B, int D, void* stream);
+/* Layer-diagonal forward step: up to ARK_DIAG_MAX_ROLES independent GRU cells -- cell (layer l, step
+ * d-l) for every layer of one anti-diagonal d of the (layer, time) grid -- in ONE launch.  Each role
+ * computes its input projection itself (x W_ih^T + b_ih; no gi buffer, no per-layer input GEMM), so
+ * a stacked GRU of n layers over L steps is L+n-1 dependent launches instead of n*L + n.
+ * Same math and outputs as ark_gru_cell_fwd_dma (reference: nn.GRU, kgvae/model/models.py:121-127). */
+#define ARK_DIAG_MAX_ROLES 4
+typedef struct {
+  const void* x16;       /* [B,D] row-major, forward type: this step's layer input                   */
+  const void* h_prev16;  /* [B,D] row-major, forward type                                            */
+  const void* w_ih16;    /* [3D,D] shadows, forward type                                             */
+  const void* w_hh16;
+  const float* b_ih;     /* [3D]                                                                     */
+  const float* b_hh;
+  const float* y_prev_t; /* tile-native fp32 [B,D]                                                   */
+  float* y_out_t;
+  void* y16a;            /* row-major 16-bit copies of h: forward type / backward type (nullable)    */
+  void* y16b;
+  void* yd16a;           /* h * dropout mask (drop_p > 0 only)                                       */
+  void* yd16b;
+  void* save_r;          /* tile-native fp16 saves, nullable together                                */
+  void* save_z;
+  void* save_n;
+  void* save_hn;
+  uint64_t drop_seed;
+  int64_t drop_base;
+  float drop_p;
+  int pad_;
+} ArkGruDiagRole;
+int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruDiagRole* roles, const float* hyper, int B, int D,
+                     void* stream);
+int ark_set_diag_tuning(int rows /* 32 | 64 */, int ki /* 1 | 2 */, int nbuf /* 2 | 4 */, int xcd_map /* 0 | 1 */);
 int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf);
 int ark_set_dma_stage(int fwd_ki, int bwd_ki);
 int ark_set_dma_fwd_rows(int bm);

@@ -224,3 +224,46 @@ def test_in_kernel_dropout_is_consistent_forward_and_backward():
                                            L.ptr(dropped), L.i64(D), L.i32(R), L.i32(D), L.i32(3 * D), L.f32(0.5),
                                            L.u64(eng.drop_seed + 7919 * l), L.ptr(eng.hyper), L.cur_stream()), "gemm16_dropout")
         assert torch.allclose(dropped, plain * ref, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("rows,ki,nbuf,xcd", [(32, 2, 2, 0), (64, 1, 2, 0), (64, 2, 2, 1), (32, 1, 4, 1)])
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_diagonal_cells_match_layer_order(rows, ki, nbuf, xcd, drop):
+    """the layer-diagonal forward (one launch per anti-diagonal, in-cell input projection) computes the
+    same states, saves, losses and gradients as the layer-by-layer LDS-DMA path, and the same ELBO as
+    the CPU oracle within north_star's tolerance"""
+    from ark_amd import _lib as L
+    from oracle import sail_oracle as O
+    cfg = dict(_big_cfg(), dec_dropout=drop)
+    P = O.init_params(cfg, 0)
+    B = 256
+    triples, seq = synth_batch(cfg, B, seed=3)
+    torch.manual_seed(5)
+    eps = torch.randn(B, cfg["d_latent"])
+    a = make_engine(dict(cfg, ark_diag_cells=False), P, "mixed")
+    b = make_engine(dict(cfg, ark_diag_cells=True), P, "mixed")
+    L.check(L.lib().ark_set_diag_tuning(rows, ki, nbuf, xcd), "ark_set_diag_tuning")
+    try:
+        dev = a.device
+        args = (triples.to(dev), seq.to(dev), eps.to(dev))
+        for eng in (a, b):
+            eng.set_hyper(beta=0.1)
+        a.drop_seed = b.drop_seed = 1234
+        if drop == 0.0:   # before any optimiser step: the oracle sees the same weights
+            with torch.no_grad():
+                loss, *_ = O.sail_elbo(P, triples, seq, eps, 0.1, cfg)
+            out = b.eval_loss(*args).cpu().numpy()
+            assert rel_err(float(out[0]), float(loss)) < 1e-4, (out, float(loss))
+        oa = a.train_step(*args).cpu().numpy()
+        ob = b.train_step(*args).cpu().numpy()
+        torch.cuda.synchronize()
+        assert rel_err(float(ob[0]), float(oa[0])) < 2e-5, (oa, ob)
+        n = cfg["n_layers"]
+        for l in range(n):
+            ya, yb = a.ws["Y"][l], b.ws["Y"][l]
+            assert (ya - yb).abs().max().item() < 2e-3, l
+            assert torch.equal(a.ws["Y16a"][l][:B], b.ws["Y16a"][l][:B])
+        ga, gb = a.G, b.G
+        assert (ga - gb).norm().item() < 2e-3 * ga.norm().item()
+    finally:
+        L.check(L.lib().ark_set_diag_tuning(64, 2, 2, 1), "ark_set_diag_tuning")
