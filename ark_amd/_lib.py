@@ -80,3 +80,11 @@ class GruDiagRole(ctypes.Structure):
 def dptr(t):
     """raw device address (0 for None) for struct fields"""
     return 0 if t is None else t.data_ptr()
+
+
+class GruDiagBwdRole(ctypes.Structure):
+    """ArkGruDiagBwdRole of include/ark_amd.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in (
+        "dgi_up16", "w_ihT_up16", "dgh_next16", "w_hhT16", "dy_t", "carry_t", "save_r", "save_z", "save_n", "save_hn",
+        "y_prev_t", "dgi16", "dgh16", "db_ih", "db_hh")] + [
+        ("drop_seed", ctypes.c_uint64), ("drop_base", ctypes.c_int64), ("drop_p", ctypes.c_float), ("first", ctypes.c_int)]

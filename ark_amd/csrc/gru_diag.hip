@@ -214,3 +214,207 @@ extern "C" int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruD
   if (prec == PREC_BF16 && prec_b == PREC_BF16) return launch_diag_cfg<PREC_BF16, PREC_BF16>(p, st);
   return ARK_ERR_ARG;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Layer-diagonal BPTT.  Cell (l, t) needs (l, t+1) [dgh, carry] and (l+1, t) [dgi]; the cells of one
+// backward anti-diagonal are independent.  A role streams [dgi_up | dgh_next] against
+// [W_ih(l+1)^T | W_hh(l)^T] through one ring (two accumulators: the part arriving from the layer above
+// passes through this layer's output-dropout mask), then runs the gate-derivative epilogue of
+// gru_dma.hip: row-major 16-bit dgi / dgh panels assembled in LDS, bias gradients as column sums.
+namespace ark {
+
+struct GruDiagBwdArgs {
+  ArkGruDiagBwdRole role[ARK_DIAG_MAX_ROLES];
+  const float* hyper;
+  int n_roles, B, D;
+};
+
+template <int PREC, int NBUF, int KI, int BM>
+__global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
+  constexpr int BN = 64;
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;   // wave tile (BM/2) x 32
+  constexpr int TM = G::TM, TN = G::TN, WN = BN / 2;
+  using h_t = typename G::h_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int B = p.B, D = p.D;
+  const int NT = D / BN, MT = (B + BM - 1) / BM;
+  const int role = blockIdx.x / (NT * MT);
+  const int kk = blockIdx.x % (NT * MT);
+  const int m0 = (kk / NT) * BM, n0 = (kk % NT) * BN;
+  const ArkGruDiagBwdRole& R = p.role[role];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool top = R.dgi_up16 == nullptr;
+  const bool drop = R.drop_p > 0.f && !top;
+  const _Float16* sr = reinterpret_cast<const _Float16*>(R.save_r);
+  const _Float16* sz = reinterpret_cast<const _Float16*>(R.save_z);
+  const _Float16* sn = reinterpret_cast<const _Float16*>(R.save_n);
+  const _Float16* shn = reinterpret_cast<const _Float16*>(R.save_hn);
+  // epilogue operands first (older than the LDS-DMA ops -> they land underneath the products)
+  int rl[TM];
+  f32x4 pc[TM][TN], pdy[TM][TN], phy[TM][TN], mk[TM][TN];
+  dhalf4_t psr[TM][TN], psz[TM][TN], psn[TM][TN], phn[TM][TN];
+  uint64_t step = 0;
+  float ks = 1.f;
+  if (drop) {
+    step = (uint64_t)p.hyper[ARK_HP_ADAM_STEP];
+    ks = 1.0f / (1.0f - R.drop_p);
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    rl[tm] = wm * G::WTM + tm * 16 + 4 * (lane >> 4);
+    const int rowc = min(m0 + rl[tm], B - 4);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const long o = tile_native_off(rowc, n0 + wn * WN + tn * 16 + (lane & 15), D);
+      pc[tm][tn] = R.first ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(R.carry_t + o);
+      pdy[tm][tn] = R.dy_t ? *reinterpret_cast<const f32x4*>(R.dy_t + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+      phy[tm][tn] = *reinterpret_cast<const f32x4*>(R.y_prev_t + o);
+      psr[tm][tn] = *reinterpret_cast<const dhalf4_t*>(sr + o);
+      psz[tm][tn] = *reinterpret_cast<const dhalf4_t*>(sz + o);
+      psn[tm][tn] = *reinterpret_cast<const dhalf4_t*>(sn + o);
+      phn[tm][tn] = *reinterpret_cast<const dhalf4_t*>(shn + o);
+      mk[tm][tn] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (drop) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          mk[tm][tn][i] = dropout_keep_scale(R.drop_seed, step, (uint64_t)(R.drop_base + o + i), R.drop_p, ks);
+      }
+    }
+  }
+
+  f32x4 ax[TM][TN], ah[TM][TN];
+  G::run2(ax, ah, reinterpret_cast<const h_t*>(R.dgi_up16), reinterpret_cast<const h_t*>(R.w_ihT_up16), top ? 0 : 3 * D,
+          reinterpret_cast<const h_t*>(R.dgh_next16), reinterpret_cast<const h_t*>(R.w_hhT16), R.first ? 0 : 3 * D,
+          3L * D, 3L * D, [=](int r) -> long { return (long)min(m0 + r, B - 1); },
+          [=](int r) -> long { return (long)(n0 + r); }, smem);
+
+  __syncthreads();
+  // LDS assembly of the six row-major 16-bit output panels: [gate 0..2][BM rows][BN+8] for dgi and dgh
+  constexpr int TS = BN + 8;
+  h_t* tgi = reinterpret_cast<h_t*>(smem);
+  h_t* tgh = tgi + 3 * BM * TS;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row0 = m0 + rl[tm];
+    if (row0 >= B) continue;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int ul = wn * WN + tn * 16 + (lane & 15);
+      const long o = tile_native_off(row0, n0 + ul, D);
+      const f32x4 dh = ah[tm][tn] + pc[tm][tn] + pdy[tm][tn] + ax[tm][tn] * mk[tm][tn];
+      const f32x4 hp = phy[tm][tn];
+      f32x4 cz;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float r = (float)psr[tm][tn][i], z = (float)psz[tm][tn][i], n = (float)psn[tm][tn][i], hn = (float)phn[tm][tn][i];
+        const float dn_pre = dh[i] * (1.0f - z) * (1.0f - n * n);
+        const float dz_pre = dh[i] * (hp[i] - n) * z * (1.0f - z);
+        const float dr_pre = dn_pre * hn * r * (1.0f - r);
+        cz[i] = dh[i] * z;
+        const int ro = (rl[tm] + i) * TS + ul;
+        tgi[ro] = G::PT::cvt(dr_pre); tgi[BM * TS + ro] = G::PT::cvt(dz_pre); tgi[2 * BM * TS + ro] = G::PT::cvt(dn_pre);
+        tgh[ro] = G::PT::cvt(dr_pre); tgh[BM * TS + ro] = G::PT::cvt(dz_pre); tgh[2 * BM * TS + ro] = G::PT::cvt(dn_pre * r);
+      }
+      *reinterpret_cast<f32x4*>(R.carry_t + o) = cz;
+    }
+  }
+  __syncthreads();
+  // 3 gates x BM rows x 128 B per array: thread t -> (row, 16-byte chunk) for each gate, 32 rows per pass
+  const int t = threadIdx.x;
+  constexpr int CPR = BN / 8;   // 8 chunks per row -> 32 rows per 256 threads
+  h_t* gi16 = reinterpret_cast<h_t*>(R.dgi16);
+  h_t* gh16 = reinterpret_cast<h_t*>(R.dgh16);
+#pragma unroll
+  for (int r0 = 0; r0 < BM; r0 += 32) {
+    const int rr = r0 + t / CPR, ch = t % CPR;
+    const int row = m0 + rr;
+    if (row < B) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const long go = (long)row * 3 * D + (long)g * D + n0 + ch * 8;
+        *reinterpret_cast<uint4*>(gi16 + go) = *reinterpret_cast<const uint4*>(tgi + g * BM * TS + rr * TS + ch * 8);
+        *reinterpret_cast<uint4*>(gh16 + go) = *reinterpret_cast<const uint4*>(tgh + g * BM * TS + rr * TS + ch * 8);
+      }
+    }
+  }
+  // bias gradients: column sums of this tile's panels straight from LDS, one atomic per (gate, unit)
+  if (R.db_ih && t < 3 * BN) {
+    const int g = t / BN, ul = t % BN;
+    const int nrows = min(BM, B - m0);
+    float si = 0.f, sh = 0.f;
+    for (int r2 = 0; r2 < nrows; ++r2) {
+      si += (float)tgi[g * BM * TS + r2 * TS + ul];
+      sh += (float)tgh[g * BM * TS + r2 * TS + ul];
+    }
+    atomicAdd(&R.db_ih[(long)g * D + n0 + ul], si);
+    atomicAdd(&R.db_hh[(long)g * D + n0 + ul], sh);
+  }
+}
+
+static int g_dbwd_rows = 32, g_dbwd_ki = 2, g_dbwd_nbuf = 2;
+
+template <int PREC, int NBUF, int KI, int BM>
+static void launch_diag_bwd(const GruDiagBwdArgs& p, hipStream_t st) {
+  using G = DmaTile<PREC, BM, 64, NBUF, 2, 2, KI>;
+  constexpr int MINL = 2 * 3 * BM * (64 + 8) * 2;
+  constexpr int LDS = G::LDS_BYTES > MINL ? G::LDS_BYTES : MINL;
+  auto kern = gru_diag_bwd_kernel<PREC, NBUF, KI, BM>;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+  (void)once;
+  const unsigned grid = (unsigned)(p.n_roles * ((p.B + BM - 1) / BM) * (p.D / 64));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, p);
+}
+
+template <int PREC>
+static int launch_diag_bwd_cfg(const GruDiagBwdArgs& p, hipStream_t st) {
+  const bool ki2 = g_dbwd_ki == 2 && (3 * p.D) % 128 == 0;
+  if (g_dbwd_rows == 64) {
+    if (ki2) launch_diag_bwd<PREC, 2, 2, 64>(p, st);
+    else if (g_dbwd_nbuf >= 4) launch_diag_bwd<PREC, 4, 1, 64>(p, st);
+    else launch_diag_bwd<PREC, 2, 1, 64>(p, st);
+  } else {
+    if (ki2) launch_diag_bwd<PREC, 2, 2, 32>(p, st);
+    else if (g_dbwd_nbuf >= 4) launch_diag_bwd<PREC, 4, 1, 32>(p, st);
+    else launch_diag_bwd<PREC, 2, 1, 32>(p, st);
+  }
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ark
+
+extern "C" int ark_set_diag_bwd_tuning(int rows, int ki, int nbuf) {
+  if ((rows != 32 && rows != 64) || (ki != 1 && ki != 2) || (nbuf != 2 && nbuf != 4)) return ARK_ERR_ARG;
+  ark::g_dbwd_rows = rows;
+  ark::g_dbwd_ki = ki;
+  ark::g_dbwd_nbuf = nbuf;
+  return 0;
+}
+
+extern "C" int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* roles, const float* hyper, int B, int D,
+                                void* stream) {
+  using namespace ark;
+  if (!roles || n_roles <= 0 || n_roles > ARK_DIAG_MAX_ROLES || B <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (D % 64 != 0 || B % 16 != 0) return ARK_ERR_SHAPE;
+  GruDiagBwdArgs p;
+  for (int i = 0; i < n_roles; ++i) {
+    const ArkGruDiagBwdRole& r = roles[i];
+    if (!r.w_hhT16 || !r.carry_t || !r.save_r || !r.save_z || !r.save_n || !r.save_hn || !r.y_prev_t || !r.dgi16 || !r.dgh16)
+      return ARK_ERR_ARG;
+    if (!r.first && !r.dgh_next16) return ARK_ERR_ARG;
+    if ((r.dgi_up16 == nullptr) != (r.w_ihT_up16 == nullptr)) return ARK_ERR_ARG;
+    if ((r.dgi_up16 == nullptr) == (r.dy_t == nullptr)) return ARK_ERR_ARG;   // exactly one source of dy
+    if ((r.db_ih == nullptr) != (r.db_hh == nullptr)) return ARK_ERR_ARG;
+    if (r.drop_p < 0.f || r.drop_p >= 1.f || (r.drop_p > 0.f && !hyper)) return ARK_ERR_ARG;
+    p.role[i] = r;
+  }
+  for (int i = n_roles; i < ARK_DIAG_MAX_ROLES; ++i) p.role[i] = roles[0];
+  p.hyper = hyper;
+  p.n_roles = n_roles;
+  p.B = B;
+  p.D = D;
+  if (prec == PREC_F16) return launch_diag_bwd_cfg<PREC_F16>(p, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch_diag_bwd_cfg<PREC_BF16>(p, (hipStream_t)stream);
+  return ARK_ERR_ARG;
+}

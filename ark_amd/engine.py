@@ -164,7 +164,8 @@ class Engine:
         self._side_used = False
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
         self._layer_streams = []
-        self.diag_cells = bool(cfg.get("ark_diag_cells", True))   # one launch per (layer, time) anti-diagonal
+        self.diag_cells = bool(cfg.get("ark_diag_cells", True))
+        self.diag_bwd = bool(cfg.get("ark_diag_bwd", True))   # one launch per (layer, time) anti-diagonal
         self.pipeline_layers = bool(cfg.get("ark_pipeline_layers", False))   # measured slower on MI355X
 
     # ------------------------------------------------------------------ parameters
@@ -301,6 +302,8 @@ class Engine:
         w["out4"] = torch.zeros(4, device=dev)
         w["dYa"], w["dYb"] = f(R, D), f(R, D)
         w["carry"] = f(B, D)
+        if v2 and w.get("diag"):
+            w["carry_l"] = [f(B, D) for _ in range(n)]   # the diagonal BPTT keeps one carry per layer
         w["tok_next"] = torch.zeros(B, dtype=torch.int64, device=dev)
         if len(self._ws_cache) >= 6:   # bound the cache; batch sizes with captured graphs stay pinned
             for k in [k for k in self._ws_cache if k not in self._pinned_B][:1]:
@@ -743,6 +746,8 @@ class Engine:
             # external dlogits (autograd path): register-staged engine on the fp32 buffer, then re-tile
             self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
             _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
+        if w.get("diag") and self.diag_bwd:
+            return self._backward_decoder_diag(w, B, Lq, use_drop)
         dy, dy_other = w["dYa"], w["dYb"]
         group = []
         for l in range(n - 1, -1, -1):
@@ -800,6 +805,79 @@ class Engine:
             dy, dy_other = dy_other, dy
         for i0 in range(0, len(group), 8):
             self._wgrad_group(group[i0:i0 + 8])
+        return w["dX0"]
+
+    def _backward_decoder_diag(self, w, B, Lq, use_drop):
+        """BPTT in layer-diagonal order (after dY of the top layer is formed): one launch per backward
+        anti-diagonal; the gradient arriving from the layer above is formed inside the cell
+        (dgi_above x W_ih_above, through this layer's dropout mask), so only layer 0's input gradient
+        remains a separate product.  Weight gradients of all layers go out as one grouped launch."""
+        D, n = self.D, self.n
+        R = Lq * B
+        st = L.cur_stream()
+        p, g = self.p, self.g
+        pb = self.prec_bwd
+        yb = lambda l: (w["Y16b"][l] if w["Y16b"][l] is not None else w["Y16a"][l])
+        for e in range(Lq + n - 1):
+            roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
+            k = 0
+            for l in range(n - 1, -1, -1):
+                t = Lq - 1 - (e - (n - 1 - l))
+                if t < 0 or t >= Lq:
+                    continue
+                sl = slice(t * B, (t + 1) * B)
+                r = roles[k]
+                top = l == n - 1
+                if top:
+                    r.dy_t = L.dptr(w["dYa"][sl])
+                else:
+                    r.dgi_up16, r.w_ihT_up16 = L.dptr(w["dGI16"][l + 1][sl]), L.dptr(self.wihT16[l + 1])
+                r.first = 1 if t == Lq - 1 else 0
+                r.dgh_next16 = 0 if r.first else L.dptr(w["dGH16"][l][(t + 1) * B:])
+                r.w_hhT16 = L.dptr(self.whhT16[l])
+                r.carry_t = L.dptr(w["carry_l"][l])
+                r.save_r, r.save_z = L.dptr(w["SR"][l][sl]), L.dptr(w["SZ"][l][sl])
+                r.save_n, r.save_hn = L.dptr(w["SN"][l][sl]), L.dptr(w["SHN"][l][sl])
+                r.y_prev_t = L.dptr(w["Y"][l][sl])
+                r.dgi16, r.dgh16 = L.dptr(w["dGI16"][l][sl]), L.dptr(w["dGH16"][l][sl])
+                r.db_ih, r.db_hh = L.dptr(g[f"dec.gru.bias_ih_l{l}"]), L.dptr(g[f"dec.gru.bias_hh_l{l}"])
+                drop = use_drop and not top
+                r.drop_seed = (self.drop_seed + 7919 * l) & 0xFFFFFFFFFFFFFFFF
+                r.drop_base = t * B * D
+                r.drop_p = self.p_drop if drop else 0.0
+                k += 1
+            _call("ark_gru_diag_bwd", L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
+        if self.mt == "SAIL":
+            for l in range(n - 1, -1, -1):
+                _call("ark_gru_h0_bwd_dma", L.i32(pb), L.ptr(w["dGH16"][l]), L.ptr(self.whhT16[l]), L.ptr(w["carry_l"][l]),
+                      L.ptr(w["dH0"]), L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
+        items = []
+        for l in range(n):
+            if l == 0:
+                xin = w["X0b"] if w["X0b"] is not None else w["X0a"]
+            elif use_drop:
+                xin = w["Yd16b"][l - 1] if w["Yd16b"][l - 1] is not None else w["Yd16a"][l - 1]
+            else:
+                xin = yb(l - 1)[B:]
+            items += [(w["dGH16"][l], 3 * D, yb(l), D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R),
+                      (w["dGI16"][l], 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)]
+        if R % 64 == 0:
+            if self.overlap_wgrad:   # underneath layer 0's input gradient, the scatter and the encoder backward
+                side = self._side_stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for i0 in range(0, len(items), 8):
+                        self._wgrad_group(items[i0:i0 + 8])
+                self._side_used = True
+            else:
+                for i0 in range(0, len(items), 8):
+                    self._wgrad_group(items[i0:i0 + 8])
+        else:
+            for (a, lda, x, ldx, out, ldo, M, N, K) in items:
+                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(a), L.i32(1), L.i64(lda), L.ptr(x), L.i32(1), L.i64(ldx), L.ptr(out),
+                      L.i64(ldo), L.i32(M), L.i32(N), L.i32(K), L.i32(1), st)
+        _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dGI16"][0]), L.i64(3 * D), L.ptr(self.wihT16[0]), L.i64(3 * D),
+              L.ptr(w["dX0"]), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(3 * D), L.i32(0), st)
         return w["dX0"]
 
     def _layer_stream(self, l):

@@ -127,6 +127,34 @@ typedef struct {
 } ArkGruDiagRole;
 int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruDiagRole* roles, const float* hyper, int B, int D,
                      void* stream);
+/* Layer-diagonal BPTT step: cells (layer l, step t) of one anti-diagonal of the backward order in ONE
+ * launch.  A role forms dh_t = carry + dgh_{t+1} W_hh (its own layer) + dy_t, where dy_t is given
+ * (top layer: gradient of the vocabulary projection) or computed in place as
+ * dropout_mask(l,t) * (dgi_t of the layer above) W_ih(above) -- so the per-layer input-gradient GEMM
+ * disappears.  Outputs as ark_gru_cell_bwd_dma; `carry_t` is per layer here. */
+typedef struct {
+  const void* dgi_up16;    /* [B,3D] backward type: gate-input gradients of layer l+1 at step t (NULL: top layer) */
+  const void* w_ihT_up16;  /* [D,3D] W_ih^T shadow of layer l+1 (NULL: top layer)                             */
+  const void* dgh_next16;  /* [B,3D] this layer's dgh at step t+1 (ignored when first != 0)                   */
+  const void* w_hhT16;     /* [D,3D] W_hh^T shadow                                                            */
+  const float* dy_t;       /* tile-native fp32 [B,D], top layer only (NULL otherwise)                         */
+  float* carry_t;          /* tile-native fp32 [B,D], this layer's dh_t * z_t carry (in/out)                  */
+  const void* save_r;      /* tile-native fp16 saves of the forward pass                                      */
+  const void* save_z;
+  const void* save_n;
+  const void* save_hn;
+  const float* y_prev_t;   /* tile-native fp32 h_{t-1}                                                        */
+  void* dgi16;             /* row-major [B,3D] outputs, backward type                                         */
+  void* dgh16;
+  float* db_ih;            /* [3D] += column sums (nullable together)                                         */
+  float* db_hh;
+  uint64_t drop_seed;      /* dropout of THIS layer's output (applied to the gradient arriving from above)    */
+  int64_t drop_base;
+  float drop_p;
+  int first;               /* last timestep: no successor                                                     */
+} ArkGruDiagBwdRole;
+int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* roles, const float* hyper, int B, int D, void* stream);
+int ark_set_diag_bwd_tuning(int rows /* 32 | 64 */, int ki /* 1 | 2 */, int nbuf /* 2 | 4 */);
 int ark_set_diag_tuning(int rows /* 32 | 64 */, int ki /* 1 | 2 */, int nbuf /* 2 | 4 */, int xcd_map /* 0 | 1 */);
 int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf);
 int ark_set_dma_stage(int fwd_ki, int bwd_ki);
