@@ -137,6 +137,29 @@ __global__ __launch_bounds__(256) void tok_gather16_kernel(const int64_t* __rest
   }
 }
 
+// ---- one-hot rows of the decoder's input tokens: out[(t,b), v] = (v == seq[b,t]), v < Vp -------
+// Turns the embedding-gradient scatter into a product on the matrix cores:
+//   dW_tok = onehot^T x dX0 = (onehot^T x dgi_0) x W_ih_0     (0/1 are exact in every 16-bit type)
+template <int PREC>
+__global__ __launch_bounds__(256) void onehot16_kernel(const int64_t* __restrict__ seq, long ld_seq, void* out_, int B, int L,
+                                                       int Vp) {
+  using H = typename PrecTraits<PREC>::h_t;
+  typedef H h8v __attribute__((ext_vector_type(8)));
+  const int C8 = Vp >> 3;
+  const long total = (long)B * L * C8;
+  const H one = PrecTraits<PREC>::cvt(1.0f), zero = PrecTraits<PREC>::cvt(0.0f);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    const long row = i / C8;
+    const int t = (int)(row / B), b = (int)(row % B);
+    const int tok = (int)seq[(long)b * ld_seq + t];
+    h8v v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (8 * c + j == tok) ? one : zero;
+    reinterpret_cast<h8v*>(out_)[i] = v;
+  }
+}
+
 // out[n] = sum_m X16[m, n]   (bias gradients from the 16-bit gate-gradient panels)
 template <int PREC>
 __global__ __launch_bounds__(256) void colsum16_kernel(const void* X_, long ld, float* __restrict__ out, int M, int N, int rows_per_wg) {
@@ -246,6 +269,20 @@ extern "C" int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int6
   else if (prec_a == PREC_BF16 && prec_b == PREC_BF16) ARK_TG(PREC_BF16, PREC_BF16);
   else return ARK_ERR_ARG;
 #undef ARK_TG
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_onehot16(int prec, const int64_t* seq, int64_t ld_seq, void* out16, int B, int L, int Vp, void* stream) {
+  using namespace ark;
+  if (!seq || !out16 || B <= 0 || L <= 0 || Vp <= 0) return ARK_ERR_ARG;
+  if (Vp % 8 != 0) return ARK_ERR_SHAPE;
+  const long total = (long)B * L * (Vp / 8);
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (prec == PREC_F16) hipLaunchKernelGGL(onehot16_kernel<PREC_F16>, dim3(grid), dim3(256), 0, st, seq, (long)ld_seq, out16, B, L, Vp);
+  else if (prec == PREC_BF16) hipLaunchKernelGGL(onehot16_kernel<PREC_BF16>, dim3(grid), dim3(256), 0, st, seq, (long)ld_seq, out16, B, L, Vp);
+  else return ARK_ERR_ARG;
   ARK_LAUNCH_CHECK();
   return 0;
 }

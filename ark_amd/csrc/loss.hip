@@ -78,23 +78,34 @@ __global__ __launch_bounds__(256) void zproj_fwd_kernel(const float* __restrict_
   for (int c = 0; c < n_copies; ++c) h0[c * copy_stride + i] = h;
 }
 
-// dzp = dh0 * (1 - h0^2)  (in place)
-__global__ __launch_bounds__(256) void tanh_bwd_kernel(float* __restrict__ dh0, const float* __restrict__ h0, long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const float h = h0[i]; dh0[i] *= (1.0f - h * h); }
-}
-
-// dz[b,j] = sum_d dzp[b,d] Wz[d,j]      one wave per (b), lanes over d, then wave reduction per j
-__global__ __launch_bounds__(256) void zproj_bwd_dz_kernel(const float* __restrict__ dzp, const float* __restrict__ Wz,
-                                                           float* __restrict__ dz, int B, int Z, int D) {
+// dzp = dh0 * (1 - h0^2) (written back in place for the dWz kernel) and dz[b,j] = sum_d dzp[b,d] Wz[d,j].
+// One wave per row b, lanes over d; all ZT >= Z latent accumulators stay in registers, so every
+// dzp element and every Wz row (Z contiguous floats) is read exactly once.
+template <int ZT>
+__global__ __launch_bounds__(256) void zproj_bwd_dz_kernel(float* __restrict__ dh0, const float* __restrict__ h0,
+                                                           const float* __restrict__ Wz, float* __restrict__ dz, int B, int Z,
+                                                           int D) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;
-  for (int j = 0; j < Z; ++j) {
-    float a = 0.f;
-    for (int d = lane; d < D; d += 64) a += dzp[(long)b * D + d] * Wz[(long)d * Z + j];
-    a = wave_sum(a);
-    if (lane == 0) dz[(long)b * Z + j] = a;
+  float acc[ZT];
+#pragma unroll
+  for (int j = 0; j < ZT; ++j) acc[j] = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const long i = (long)b * D + d;
+    const float h = h0[i];
+    const float g = dh0[i] * (1.0f - h * h);
+    dh0[i] = g;
+    const float* wr = Wz + (long)d * Z;
+#pragma unroll
+    for (int j = 0; j < ZT; ++j)
+      if (j < Z) acc[j] += g * wr[j];
   }
+#pragma unroll
+  for (int j = 0; j < ZT; ++j)
+    if (j < Z) {
+      const float a = wave_sum(acc[j]);
+      if (lane == 0) dz[(long)b * Z + j] = a;
+    }
 }
 
 // dWz[d,j] += sum_b dzp[b,d] z[b,j] ; dbz[d] += sum_b dzp[b,d]
@@ -271,15 +282,20 @@ extern "C" int ark_zproj_bwd(float* dh0, const float* h0, const float* z, const 
   if (Z > 128) return ARK_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const long n = (long)B * D;
-  hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dh0, h0, n);
-  hipLaunchKernelGGL(zproj_bwd_dz_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dh0, w_z, dz, B, Z, D);
+  (void)n;
+#define ARK_ZDZ(ZT) hipLaunchKernelGGL(zproj_bwd_dz_kernel<ZT>, dim3((B + 3) / 4), dim3(256), 0, st, dh0, h0, w_z, dz, B, Z, D)
+  if (Z <= 16) ARK_ZDZ(16);
+  else if (Z <= 32) ARK_ZDZ(32);
+  else if (Z <= 64) ARK_ZDZ(64);
+  else ARK_ZDZ(128);
+#undef ARK_ZDZ
   if (!accumulate) {
     hipError_t e = hipMemsetAsync(d_w_z, 0, sizeof(float) * (size_t)D * Z, st);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(d_b_z, 0, sizeof(float) * (size_t)D, st);
     if (e != hipSuccess) return (int)e;
   }
-  const int b_chunk = 128;
+  const int b_chunk = 32;   // 256 workgroups at B=1024, D=512: the reduction over the batch is atomic anyway
   dim3 grid((D + 63) / 64, (B + b_chunk - 1) / b_chunk);
 #define ARK_ZDW(ZT) hipLaunchKernelGGL(zproj_bwd_dw_kernel<ZT>, grid, dim3(256), (size_t)(b_chunk * ZT + 256) * sizeof(float), st, dh0, z, d_w_z, d_b_z, B, Z, D, b_chunk)
   if (Z <= 16) ARK_ZDW(16);

@@ -165,7 +165,8 @@ class Engine:
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
         self._layer_streams = []
         self.diag_cells = bool(cfg.get("ark_diag_cells", True))
-        self.diag_bwd = bool(cfg.get("ark_diag_bwd", True))   # one launch per (layer, time) anti-diagonal
+        self.diag_bwd = bool(cfg.get("ark_diag_bwd", True))
+        self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))   # one launch per (layer, time) anti-diagonal
         self.pipeline_layers = bool(cfg.get("ark_pipeline_layers", False))   # measured slower on MI355X
 
     # ------------------------------------------------------------------ parameters
@@ -281,6 +282,12 @@ class Engine:
             w["dGI16"] = [i16(R, 3 * D) for _ in range(n)]
             w["dGH16"] = [i16(R, 3 * D) for _ in range(n)]
             w["dlog16"] = torch.zeros(R, self.Vp, device=dev, dtype=torch.int16)   # K-padded 16-bit dlogits
+            # small vocabularies: the token-embedding gradient as (onehot^T x dgi_0) x W_ih_0 instead of
+            # input-gradient GEMM + scatter (SAIL; ARK also needs dX0 for the position embedding)
+            w["emb_gemm"] = bool(w["diag"] and self.mt == "SAIL" and self.Vp <= 256 and R % 64 == 0 and self.emb_gemm)
+            if w["emb_gemm"]:
+                w["onehot16"] = i16(R, self.Vp)
+                w["S_tok"] = f(self.Vp, 3 * D)
             w["h0"] = f(B, D)                                                # row-major h0 (z-projection)
             w["dX0"] = f(R, D)
             if self.p_drop > 0:   # the dropout mask itself is regenerated in-kernel from a counter hash
@@ -595,6 +602,12 @@ class Engine:
         use_drop = self.training and self.p_drop > 0
         # ONE fill of the flat gradient buffer; every reduction below (split-K weight gradients, bias
         # column sums, embedding scatters) then accumulates into it without its own memset launch
+        if w["v2"] and w.get("diag") and self.diag_bwd:
+            self._backward_decoder_diag(w, B, Lq, seq, use_drop)   # fills, scatters and forks streams itself
+            if self.mt == "ARK":
+                self._join_side()
+                return False
+            return True
         self.G.zero_()
         if w["v2"]:
             dX0 = self._backward_decoder_v2(w, B, Lq, seq, use_drop)
@@ -746,8 +759,6 @@ class Engine:
             # external dlogits (autograd path): register-staged engine on the fp32 buffer, then re-tile
             self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
             _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
-        if w.get("diag") and self.diag_bwd:
-            return self._backward_decoder_diag(w, B, Lq, use_drop)
         dy, dy_other = w["dYa"], w["dYb"]
         group = []
         for l in range(n - 1, -1, -1):
@@ -807,17 +818,42 @@ class Engine:
             self._wgrad_group(group[i0:i0 + 8])
         return w["dX0"]
 
-    def _backward_decoder_diag(self, w, B, Lq, use_drop):
-        """BPTT in layer-diagonal order (after dY of the top layer is formed): one launch per backward
-        anti-diagonal; the gradient arriving from the layer above is formed inside the cell
-        (dgi_above x W_ih_above, through this layer's dropout mask), so only layer 0's input gradient
-        remains a separate product.  Weight gradients of all layers go out as one grouped launch."""
-        D, n = self.D, self.n
+    def _backward_decoder_diag(self, w, B, Lq, seq, use_drop):
+        """Decoder backward in layer-diagonal order.  Main stream = the dependent chain only
+        (dY of the top layer -> one launch per backward anti-diagonal -> h0 gradients); everything that
+        merely accumulates into the flat gradient buffer runs on the side stream underneath it:
+        the buffer fill, db_out / dW_tok, then -- once the gate-gradient panels are complete -- all GRU
+        weight gradients as one grouped launch, layer 0's input gradient and the embedding scatter.
+        The gradient arriving from the layer above is formed inside the cell (dgi_above x W_ih_above,
+        through this layer's dropout mask), so no per-layer input-gradient GEMM remains."""
+        D, n, V = self.D, self.n, self.V
         R = Lq * B
-        st = L.cur_stream()
         p, g = self.p, self.g
         pb = self.prec_bwd
+        KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
+        ld_seq = seq.shape[1]
+        dlog = w["logits"]
         yb = lambda l: (w["Y16b"][l] if w["Y16b"][l] is not None else w["Y16a"][l])
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_wgrad else main   # ark_overlap_wgrad=0: everything in one queue
+        side.wait_stream(main)
+        filled = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            self.G.zero_()   # ONE fill; every reduction of the step accumulates into it
+            filled.record(side)
+            self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
+            _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dlog), L.i32(0), L.i64(self.ldl), L.ptr(yb(n - 1)[B:]), L.i32(1), L.i64(D),
+                  L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(V), L.i32(D), L.i32(R), L.i32(1), L.cur_stream())
+        self._side_used = side is not main
+        st = L.cur_stream()
+        if getattr(self, "_dlog16_valid", False):
+            _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(self.wtokT16),
+                  L.i64(self.Vp), L.ptr(w["dYa"]), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(self.Vp),
+                  L.i32(1), st)
+        else:   # external dlogits (autograd path): register-staged engine on the fp32 buffer, then re-tile
+            self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
+            _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
+        main.wait_event(filled)   # the cells accumulate bias gradients into the flat buffer
         for e in range(Lq + n - 1):
             roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
             k = 0
@@ -847,10 +883,6 @@ class Engine:
                 r.drop_p = self.p_drop if drop else 0.0
                 k += 1
             _call("ark_gru_diag_bwd", L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
-        if self.mt == "SAIL":
-            for l in range(n - 1, -1, -1):
-                _call("ark_gru_h0_bwd_dma", L.i32(pb), L.ptr(w["dGH16"][l]), L.ptr(self.whhT16[l]), L.ptr(w["carry_l"][l]),
-                      L.ptr(w["dH0"]), L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
         items = []
         for l in range(n):
             if l == 0:
@@ -861,24 +893,40 @@ class Engine:
                 xin = yb(l - 1)[B:]
             items += [(w["dGH16"][l], 3 * D, yb(l), D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R),
                       (w["dGI16"][l], 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)]
-        if R % 64 == 0:
-            if self.overlap_wgrad:   # underneath layer 0's input gradient, the scatter and the encoder backward
-                side = self._side_stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for i0 in range(0, len(items), 8):
-                        self._wgrad_group(items[i0:i0 + 8])
-                self._side_used = True
-            else:
+        side.wait_stream(main)   # gate-gradient panels complete
+        with torch.cuda.stream(side):
+            ss = L.cur_stream()
+            if R % 64 == 0:
                 for i0 in range(0, len(items), 8):
                     self._wgrad_group(items[i0:i0 + 8])
-        else:
-            for (a, lda, x, ldx, out, ldo, M, N, K) in items:
-                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(a), L.i32(1), L.i64(lda), L.ptr(x), L.i32(1), L.i64(ldx), L.ptr(out),
-                      L.i64(ldo), L.i32(M), L.i32(N), L.i32(K), L.i32(1), st)
-        _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dGI16"][0]), L.i64(3 * D), L.ptr(self.wihT16[0]), L.i64(3 * D),
-              L.ptr(w["dX0"]), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(3 * D), L.i32(0), st)
-        return w["dX0"]
+            else:
+                for (a, lda, x, ldx, out, ldo, M, N, K) in items:
+                    _call("ark_gemm_wgrad", L.i32(pb), L.ptr(a), L.i32(1), L.i64(lda), L.ptr(x), L.i32(1), L.i64(ldx), L.ptr(out),
+                          L.i64(ldo), L.i32(M), L.i32(N), L.i32(K), L.i32(1), ss)
+            if w["emb_gemm"]:
+                # dW_tok += onehot^T dX0 = (onehot^T dgi_0) W_ih_0: a [Vp,3D] reduction over the tokens on the
+                # matrix cores, then one small exact-fp32 product -- no [R,D] input gradient, no scatter
+                w["S_tok"].zero_()
+                _call("ark_onehot16", L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(w["onehot16"]), L.i32(B), L.i32(Lq),
+                      L.i32(self.Vp), ss)
+                _call("ark_wgrad16", L.i32(pb), L.ptr(w["onehot16"]), L.i64(self.Vp), L.ptr(w["dGI16"][0]), L.i64(3 * D),
+                      L.ptr(w["S_tok"]), L.i64(3 * D), L.i32(self.Vp), L.i32(3 * D), L.i32(R), ss)
+                _call("ark_gemm", L.i32(L.PREC_F32), L.i32(KM), L.i32(MM), L.i32(L.EPI_NONE), L.ptr(w["S_tok"]), L.i64(3 * D),
+                      L.ptr(p["dec.gru.weight_ih_l0"]), L.i64(D), L.ptr(g["dec.tok_emb.weight"]), L.i64(D), L.ptr(None),
+                      L.ptr(None), L.ptr(None), L.i32(V), L.i32(D), L.i32(3 * D), L.i32(1), ss)
+            else:
+                _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dGI16"][0]), L.i64(3 * D), L.ptr(self.wihT16[0]),
+                      L.i64(3 * D), L.ptr(w["dX0"]), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(3 * D),
+                      L.i32(0), ss)
+                _call("ark_tok_scatter", L.ptr(seq), L.i64(ld_seq), L.ptr(w["dX0"]), L.ptr(g["dec.tok_emb.weight"]), L.i32(B),
+                      L.i32(Lq), L.i32(D), L.i32(V), ss)
+                if self.mt == "ARK":
+                    self._colsum(w["dX0"], D, g["dec.pos_emb.weight"], B, D, n_batch=Lq, bs_in=B * D, bs_out=D)
+        self._side_used = side is not main
+        if self.mt == "SAIL":   # continues on the main stream into the encoder half
+            for l in range(n - 1, -1, -1):
+                _call("ark_gru_h0_bwd_dma", L.i32(pb), L.ptr(w["dGH16"][l]), L.ptr(self.whhT16[l]), L.ptr(w["carry_l"][l]),
+                      L.ptr(w["dH0"]), L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
 
     def _layer_stream(self, l):
         while len(self._layer_streams) <= l:

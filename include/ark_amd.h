@@ -195,6 +195,10 @@ int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq,
 /* h0 = tanh(z_proj(z)) for all layers in every layout of the LDS-DMA path, one launch */
 int ark_zproj_fwd_v2(int prec_a, int prec_b, const float* z, const float* w_z, const float* b_z, float* h0, int n_layers,
                      float* const* y_t, void* const* y16a, void* const* y16b, int B, int Z, int D, void* stream);
+/* one-hot rows of the decoder input tokens, time-major: out16[(t*B+b), v] = (v == seq[b,t]) for v < Vp
+ * (Vp % 8 == 0).  With it the embedding-gradient scatter (autograd embedding_backward of
+ * models.py:138) becomes dW_tok += (onehot^T x dgi_0) x W_ih_0 on the matrix cores. */
+int ark_onehot16(int prec, const int64_t* seq, int64_t ld_seq, void* out16, int B, int L, int Vp, void* stream);
 int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, int accumulate, void* stream);
 int ark_cast16(int prec, const float* x, void* out, int64_t n, void* stream);
 int ark_to_tiled(const float* x, float* out, int rows, int ld, void* stream);
