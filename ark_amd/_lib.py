@@ -86,5 +86,5 @@ class GruDiagBwdRole(ctypes.Structure):
     """ArkGruDiagBwdRole of include/ark_amd.h"""
     _fields_ = [(k, ctypes.c_void_p) for k in (
         "dgi_up16", "w_ihT_up16", "dgh_next16", "w_hhT16", "dy_t", "carry_t", "save_r", "save_z", "save_n", "save_hn",
-        "y_prev_t", "dgi16", "dgh16", "db_ih", "db_hh")] + [
+        "y_prev_t", "dgi16", "dgh16", "db_ih", "db_hh", "dh0")] + [
         ("drop_seed", ctypes.c_uint64), ("drop_base", ctypes.c_int64), ("drop_p", ctypes.c_float), ("first", ctypes.c_int)]

@@ -244,8 +244,9 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
   const ArkGruDiagBwdRole& R = p.role[role];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  const bool fin = R.dh0 != nullptr;   // initial-state role: dh0 += carry + dgh_0 W_hh, nothing else
   const bool top = R.dgi_up16 == nullptr;
-  const bool drop = R.drop_p > 0.f && !top;
+  const bool drop = R.drop_p > 0.f && !top && !fin;
   const _Float16* sr = reinterpret_cast<const _Float16*>(R.save_r);
   const _Float16* sz = reinterpret_cast<const _Float16*>(R.save_z);
   const _Float16* sn = reinterpret_cast<const _Float16*>(R.save_n);
@@ -269,12 +270,13 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
       const long o = tile_native_off(rowc, n0 + wn * WN + tn * 16 + (lane & 15), D);
       pc[tm][tn] = R.first ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(R.carry_t + o);
       pdy[tm][tn] = R.dy_t ? *reinterpret_cast<const f32x4*>(R.dy_t + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+      mk[tm][tn] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (fin) continue;
       phy[tm][tn] = *reinterpret_cast<const f32x4*>(R.y_prev_t + o);
       psr[tm][tn] = *reinterpret_cast<const dhalf4_t*>(sr + o);
       psz[tm][tn] = *reinterpret_cast<const dhalf4_t*>(sz + o);
       psn[tm][tn] = *reinterpret_cast<const dhalf4_t*>(sn + o);
       phn[tm][tn] = *reinterpret_cast<const dhalf4_t*>(shn + o);
-      mk[tm][tn] = f32x4{1.f, 1.f, 1.f, 1.f};
       if (drop) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -289,6 +291,21 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
           3L * D, 3L * D, [=](int r) -> long { return (long)min(m0 + r, B - 1); },
           [=](int r) -> long { return (long)(n0 + r); }, smem);
 
+  if (fin) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row0 = m0 + rl[tm];
+      if (row0 >= B) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int u = n0 + wn * WN + tn * 16 + (lane & 15);
+        const f32x4 dh = ah[tm][tn] + pc[tm][tn];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&R.dh0[(long)(row0 + i) * D + u], dh[i]);
+      }
+    }
+    return;   // block-uniform: every wave of this workgroup serves the same role
+  }
   __syncthreads();
   // LDS assembly of the six row-major 16-bit output panels: [gate 0..2][BM rows][BN+8] for dgi and dgh
   constexpr int TS = BN + 8;
@@ -400,8 +417,13 @@ extern "C" int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* 
   GruDiagBwdArgs p;
   for (int i = 0; i < n_roles; ++i) {
     const ArkGruDiagBwdRole& r = roles[i];
-    if (!r.w_hhT16 || !r.carry_t || !r.save_r || !r.save_z || !r.save_n || !r.save_hn || !r.y_prev_t || !r.dgi16 || !r.dgh16)
-      return ARK_ERR_ARG;
+    if (!r.w_hhT16 || !r.carry_t) return ARK_ERR_ARG;
+    if (r.dh0) {   // initial-state role
+      if (!r.dgh_next16 || r.first || r.dgi_up16 || r.w_ihT_up16 || r.dy_t) return ARK_ERR_ARG;
+      p.role[i] = r;
+      continue;
+    }
+    if (!r.save_r || !r.save_z || !r.save_n || !r.save_hn || !r.y_prev_t || !r.dgi16 || !r.dgh16) return ARK_ERR_ARG;
     if (!r.first && !r.dgh_next16) return ARK_ERR_ARG;
     if ((r.dgi_up16 == nullptr) != (r.w_ihT_up16 == nullptr)) return ARK_ERR_ARG;
     if ((r.dgi_up16 == nullptr) == (r.dy_t == nullptr)) return ARK_ERR_ARG;   // exactly one source of dy

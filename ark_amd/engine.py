@@ -840,6 +840,8 @@ class Engine:
         filled = torch.cuda.Event()
         with torch.cuda.stream(side):
             self.G.zero_()   # ONE fill; every reduction of the step accumulates into it
+            if self.mt == "SAIL":
+                w["dH0"].zero_()   # the initial-state roles add into it
             filled.record(side)
             self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
             _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dlog), L.i32(0), L.i64(self.ldl), L.ptr(yb(n - 1)[B:]), L.i32(1), L.i64(D),
@@ -924,9 +926,13 @@ class Engine:
                     self._colsum(w["dX0"], D, g["dec.pos_emb.weight"], B, D, n_batch=Lq, bs_in=B * D, bs_out=D)
         self._side_used = side is not main
         if self.mt == "SAIL":   # continues on the main stream into the encoder half
-            for l in range(n - 1, -1, -1):
-                _call("ark_gru_h0_bwd_dma", L.i32(pb), L.ptr(w["dGH16"][l]), L.ptr(self.whhT16[l]), L.ptr(w["carry_l"][l]),
-                      L.ptr(w["dH0"]), L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
+            # dH0 = sum over layers of (carry + dgh_0 W_hh): all layers as roles of ONE more launch
+            roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
+            for l in range(n):
+                r = roles[l]
+                r.dgh_next16, r.w_hhT16 = L.dptr(w["dGH16"][l]), L.dptr(self.whhT16[l])
+                r.carry_t, r.dh0 = L.dptr(w["carry_l"][l]), L.dptr(w["dH0"])
+            _call("ark_gru_diag_bwd", L.i32(pb), L.i32(n), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
 
     def _layer_stream(self, l):
         while len(self._layer_streams) <= l:

@@ -148,6 +148,8 @@ typedef struct {
   void* dgh16;
   float* db_ih;            /* [3D] += column sums (nullable together)                                         */
   float* db_hh;
+  float* dh0;              /* non-NULL: "initial state" role -- only dh0[B,D] (row-major, pre-zeroed) +=      */
+                           /* carry + dgh_next W_hh (dgh_next = the layer's step-0 panel); saves etc. unused  */
   uint64_t drop_seed;      /* dropout of THIS layer's output (applied to the gradient arriving from above)    */
   int64_t drop_base;
   float drop_p;
