@@ -34,16 +34,27 @@ struct Wgrad16Group {
   Wgrad16Args p[kMaxGroup];
   int tile_start[kMaxGroup + 1];
   int n;
+  // Balanced mode (n_long > 0; 1-D grid): the first n_long tiles are whole-K workgroups, one per CU; every
+  // remaining tile is cut into s_short k-slices (fp32 atomics).  288 tiles on 256 CUs would otherwise leave
+  // 32 CUs with two whole tiles and everyone else waiting: 256 whole + 32 x 8 slices gives every CU 1.125 tiles.
+  int n_long, s_short;
 };
 
 template <int PREC, int BT, int NBUF>   // square BT x BT output tile; 8 waves as 2 (m) x 4 (n), wave tile BT/2 x BT/4
 __global__ __launch_bounds__(512) void wgrad16_kernel(Wgrad16Group grp) {
+  int gtile = blockIdx.x, slice = blockIdx.y, nslice = gridDim.y;
+  if (grp.n_long > 0 && (int)blockIdx.x >= grp.n_long) {
+    const int j = blockIdx.x - grp.n_long;
+    gtile = grp.n_long + j / grp.s_short;
+    slice = j % grp.s_short;
+    nslice = grp.s_short;
+  }
   int gi = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
-    if (i < grp.n && (int)blockIdx.x >= grp.tile_start[i]) gi = i;
+    if (i < grp.n && gtile >= grp.tile_start[i]) gi = i;
   const Wgrad16Args p = grp.p[gi];
-  const int bid_raw = blockIdx.x - grp.tile_start[gi];
+  const int bid_raw = gtile - grp.tile_start[gi];
   const int ntiles = grp.tile_start[gi + 1] - grp.tile_start[gi];
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
@@ -69,8 +80,10 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(Wgrad16Group grp) {
   const int wm = wave >> 2, wn = wave & 3;
   const int bid = (grp.n == 1) ? xcd_remap(bid_raw, ntiles) : bid_raw;
   const int m0 = (bid / p.tiles_n) * BT, n0 = (bid % p.tiles_n) * BT;
-  const int kb = blockIdx.y * p.k_chunk;
-  const int kend = min(p.K, kb + p.k_chunk);
+  const int k_chunk = (grp.n_long > 0) ? ((p.K + nslice - 1) / nslice + 63) / 64 * 64 : p.k_chunk;
+  const int kb = slice * k_chunk;
+  const int kend = min(p.K, kb + k_chunk);
+  const bool atomics = (grp.n_long > 0) ? nslice > 1 : p.use_atomics != 0;
   const int NS = (kend - kb) / 64;
 
   const h_t* A = reinterpret_cast<const h_t*>(p.A) + (long)kb * p.lda + m0;
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(Wgrad16Group grp) {
         const int row = m0 + wm * WTM + ta * 16 + 4 * (lane >> 4) + i;
         const int col = n0 + wn * WTN + tb * 16 + (lane & 15);
         float* c = p.C + (long)row * p.ldc + col;
-        if (p.use_atomics) atomicAdd(c, acc[ta][tb][i]);
+        if (atomics) atomicAdd(c, acc[ta][tb][i]);
         else *c += acc[ta][tb][i];
       }
 }
@@ -174,7 +187,7 @@ static void allow_lds_w(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int g_wg_tile = 128, g_wg_nbuf = 2, g_wg_target = 96;
+int g_wg_tile = 128, g_wg_nbuf = 2, g_wg_target = 96, g_wg_balance = 1;
 
 template <int PREC, int BT, int NBUF>
 static void launch_wg(Wgrad16Group& g, hipStream_t st) {
@@ -195,6 +208,19 @@ static void launch_wg(Wgrad16Group& g, hipStream_t st) {
     g.p[i].k_chunk = ((g.p[i].K + split - 1) / split + 63) / 64 * 64;
     g.p[i].use_atomics = split > 1;
   }
+  g.n_long = 0;
+  g.s_short = 1;
+  constexpr int kCUs = 256;
+  if (g_wg_balance && split == 1 && tiles > kCUs && tiles < 2 * kCUs) {
+    const int rest = (int)tiles - kCUs;
+    const int s = kCUs / rest;   // slices per remaining tile: rest * s <= 256 short workgroups
+    if (s >= 2 && kmax / s >= 256) {
+      g.n_long = kCUs;
+      g.s_short = s;
+      hipLaunchKernelGGL((wgrad16_kernel<PREC, BT, NBUF>), dim3((unsigned)(kCUs + rest * s), 1), dim3(512), LDS, st, g);
+      return;
+    }
+  }
   hipLaunchKernelGGL((wgrad16_kernel<PREC, BT, NBUF>), dim3((unsigned)tiles, (unsigned)split), dim3(512), LDS, st, g);
 }
 
@@ -214,6 +240,8 @@ static int launch_wg_prec(Wgrad16Group& g, hipStream_t st) {
 }  // namespace ark
 
 // speed-only knobs: tile (64|128), ring depth, target workgroup count for the split-K heuristic
+extern "C" int ark_set_wgrad16_balance(int enabled) { ark::g_wg_balance = enabled ? 1 : 0; return 0; }
+
 extern "C" int ark_set_wgrad16_tuning(int tile, int nbuf, int target_wgs) {
   if ((tile != 64 && tile != 128) || nbuf < 2 || nbuf > 4 || target_wgs < 1) return ARK_ERR_ARG;
   ark::g_wg_tile = tile; ark::g_wg_nbuf = nbuf; ark::g_wg_target = target_wgs;

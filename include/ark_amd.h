@@ -192,6 +192,7 @@ int ark_wgrad16_group(int prec, int n, const void* const* A16, const int64_t* ld
                       const int64_t* ldb, float* const* C, const int64_t* ldc, const int* M, const int* N, const int* K,
                       void* stream);
 int ark_set_wgrad16_tuning(int tile, int nbuf, int target_wgs);
+int ark_set_wgrad16_balance(int enabled);   /* whole tiles on every CU + k-slices of the remainder (default on) */
 int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,
                      const float* w_pos, void* x16a, void* x16b, int B, int L, int D, void* stream);
 /* h0 = tanh(z_proj(z)) for all layers in every layout of the LDS-DMA path, one launch */
