@@ -226,7 +226,7 @@ namespace ark {
 struct GruDiagBwdArgs {
   ArkGruDiagBwdRole role[ARK_DIAG_MAX_ROLES];
   const float* hyper;
-  int n_roles, B, D;
+  int n_roles, B, D, xcd_m;
 };
 
 template <int PREC, int NBUF, int KI, int BM>
@@ -238,9 +238,26 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int B = p.B, D = p.D;
   const int NT = D / BN, MT = (B + BM - 1) / BM;
-  const int role = blockIdx.x / (NT * MT);
-  const int kk = blockIdx.x % (NT * MT);
-  const int m0 = (kk / NT) * BM, n0 = (kk % NT) * BN;
+  int role, mt, nt;
+  if (p.xcd_m > 1) {
+    // consecutive workgroup ids land on consecutive XCDs (8 private L2s).  XCD x serves the row tiles
+    // = x % xcd_m (mod xcd_m) and the unit tiles = x / xcd_m (mod 8/xcd_m) of every role: its L2 then
+    // fetches 1/xcd_m of the gate-gradient rows and xcd_m/8 of the transposed weight panels instead of
+    // all rows (PMC: the plain order fetched the [B,3D] panels once per XCD, 124 MB per launch).
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xm = p.xcd_m, xn = 8 / p.xcd_m;
+    const int per_role = (MT / xm) * (NT / xn);
+    role = j / per_role;
+    const int k = j % per_role;
+    nt = (k % (NT / xn)) * xn + xcd / xm;
+    mt = (k / (NT / xn)) * xm + xcd % xm;
+  } else {
+    role = blockIdx.x / (NT * MT);
+    const int kk = blockIdx.x % (NT * MT);
+    mt = kk / NT;
+    nt = kk % NT;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
   const ArkGruDiagBwdRole& R = p.role[role];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -369,7 +386,7 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
   }
 }
 
-static int g_dbwd_rows = 32, g_dbwd_ki = 2, g_dbwd_nbuf = 2;
+static int g_dbwd_rows = 32, g_dbwd_ki = 2, g_dbwd_nbuf = 2, g_dbwd_xcd_m = 4;
 
 template <int PREC, int NBUF, int KI, int BM>
 static void launch_diag_bwd(const GruDiagBwdArgs& p, hipStream_t st) {
@@ -384,8 +401,13 @@ static void launch_diag_bwd(const GruDiagBwdArgs& p, hipStream_t st) {
 }
 
 template <int PREC>
-static int launch_diag_bwd_cfg(const GruDiagBwdArgs& p, hipStream_t st) {
+static int launch_diag_bwd_cfg(GruDiagBwdArgs& p, hipStream_t st) {
   const bool ki2 = g_dbwd_ki == 2 && (3 * p.D) % 128 == 0;
+  {
+    const int MT = (p.B + g_dbwd_rows - 1) / g_dbwd_rows, NT = p.D / 64;
+    const int xm = g_dbwd_xcd_m;
+    p.xcd_m = (xm > 1 && MT % xm == 0 && NT % (8 / xm) == 0) ? xm : 1;
+  }
   if (g_dbwd_rows == 64) {
     if (ki2) launch_diag_bwd<PREC, 2, 2, 64>(p, st);
     else if (g_dbwd_nbuf >= 4) launch_diag_bwd<PREC, 4, 1, 64>(p, st);
@@ -400,6 +422,12 @@ static int launch_diag_bwd_cfg(const GruDiagBwdArgs& p, hipStream_t st) {
 }
 
 }  // namespace ark
+
+extern "C" int ark_set_diag_bwd_xcd(int row_classes) {
+  if (row_classes != 1 && row_classes != 2 && row_classes != 4 && row_classes != 8) return ARK_ERR_ARG;
+  ark::g_dbwd_xcd_m = row_classes;
+  return 0;
+}
 
 extern "C" int ark_set_diag_bwd_tuning(int rows, int ki, int nbuf) {
   if ((rows != 32 && rows != 64) || (ki != 1 && ki != 2) || (nbuf != 2 && nbuf != 4)) return ARK_ERR_ARG;
@@ -436,6 +464,7 @@ extern "C" int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* 
   p.n_roles = n_roles;
   p.B = B;
   p.D = D;
+  p.xcd_m = 1;
   if (prec == PREC_F16) return launch_diag_bwd_cfg<PREC_F16>(p, (hipStream_t)stream);
   if (prec == PREC_BF16) return launch_diag_bwd_cfg<PREC_BF16>(p, (hipStream_t)stream);
   return ARK_ERR_ARG;
