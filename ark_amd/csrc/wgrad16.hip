@@ -43,6 +43,11 @@ struct Wgrad16Group {
 template <int PREC, int BT, int NBUF>   // square BT x BT output tile; 8 waves as 2 (m) x 4 (n), wave tile BT/2 x BT/4
 __global__ __launch_bounds__(512) void wgrad16_kernel(Wgrad16Group grp) {
   int gtile = blockIdx.x, slice = blockIdx.y, nslice = gridDim.y;
+  if (grp.n_long > 0 && (int)blockIdx.x < grp.n_long) {
+    gtile = xcd_remap(blockIdx.x, grp.n_long);   // consecutive tiles share operand panels: keep them on one XCD
+  } else if (grp.n_long == 0 && grp.n > 1) {
+    gtile = xcd_remap(blockIdx.x, gridDim.x);
+  }
   if (grp.n_long > 0 && (int)blockIdx.x >= grp.n_long) {
     const int j = blockIdx.x - grp.n_long;
     gtile = grp.n_long + j / grp.s_short;
