@@ -16,6 +16,7 @@
 // wave-instruction that fills rows 8p..8p+7 of an image supplies row 8p + i/8, logical chunk
 // (i%8) ^ ((row>>1)&7).
 #pragma once
+#include <type_traits>
 #include "gemm_core.h"
 
 namespace ark {
@@ -226,6 +227,94 @@ struct DmaTile {
       __builtin_amdgcn_sched_barrier(0);
       if (s < NS1) consume(acc1, s);
       else consume(acc2, s);
+      if (s + NBUF < NS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue(s + NBUF);
+      }
+    }
+  }
+
+  // run2 with SHARED accumulators for all but the last 16-column block of the wave tile: segment 1 adds
+  // into acc[.][0..TN-1], segment 2 into acc[.][0..TN-2] and acc[.][TN].  The GRU forward cell needs
+  // x W_ih^T and h W_hh^T apart for the candidate gate only (last block of the r|z|n wave tile), so
+  // it carries 4 instead of 6 accumulator tiles per 16 rows.
+  template <class RMA, class RMB>
+  static __device__ __forceinline__ void run2_shared(f32x4 (&acc)[TM][TN + 1], const h_t* A1, const h_t* B1,
+                                              int K1, const h_t* A2, const h_t* B2, int K2, long lda, long ldb, RMA rma,
+                                              RMB rmb, char* lds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lr = lane & 15, lq = lane >> 4;
+    long ao[NPA], bo[NPB];   // element offsets of this lane's piece rows (same in both segments)
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int q = wave + NW * i, j = q / (BM / 8), pr = q % (BM / 8);
+      const int row = 8 * pr + (lane >> 3);
+      ao[i] = rma(row) * lda + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      const int q = wave + NW * i, j = q / (BN / 8), pr = q % (BN / 8);
+      const int row = 8 * pr + (lane >> 3);
+      bo[i] = rmb(row) * ldb + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+    }
+    const int NS1 = K1 / KS, NS = NS1 + K2 / KS;   // host guarantees K1 % KS == 0 && K2 % KS == 0
+    auto issue = [&](int s) {
+      char* base = lds + (s % NBUF) * STAGE_BYTES;
+      const bool first = s < NS1;
+      const h_t* A = first ? A1 : A2;
+      const h_t* B = first ? B1 : B2;
+      const int k0 = (first ? s : s - NS1) * KS;
+#pragma unroll
+      for (int i = 0; i < NPA; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + ao[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NPB; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + bo[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(base + A_STAGE + (wave + NW * i) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn <= TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (NS <= 0) return;
+    const int pre = NS < NBUF ? NS : NBUF;
+    for (int s = 0; s < pre; ++s) issue(s);
+    auto consume = [&](auto last_col, int s) {   // last_col: accumulator column of the wave tile's last block
+      const char* bufA = lds + (s % NBUF) * STAGE_BYTES;
+      const char* bufB = bufA + A_STAGE;
+#pragma unroll
+      for (int s2 = 0; s2 < 2 * KI; ++s2) {
+        typename PT::h8 a[TM], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + (s2 >> 1) * A_IMG +
+                                                            lds_off(wm * WTM + tm * 16 + lr, 4 * (s2 & 1) + lq));
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + (s2 >> 1) * B_IMG +
+                                                            lds_off(wn * WTN + tn * 16 + lr, 4 * (s2 & 1) + lq));
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            constexpr int LC = decltype(last_col)::value;
+            const int c = (tn == TN - 1) ? LC : tn;
+            acc[tm][c] = PT::mfma(a[tm], b[tn], acc[tm][c]);
+          }
+      }
+    };
+    for (int s = 0; s < NS; ++s) {
+      const int ahead = (NS - 1 - s) < (NBUF - 1) ? (NS - 1 - s) : (NBUF - 1);
+      wait_stages(ahead);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (s < NS1) consume(std::integral_constant<int, TN - 1>{}, s);
+      else consume(std::integral_constant<int, TN>{}, s);
       if (s + NBUF < NS) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();

@@ -20,10 +20,13 @@ struct GruDiagArgs {
   int n_roles, B, D, xcd_map;
 };
 
-template <int PREC, int PRECB, int NBUF, int KI, int BM>
-__global__ __launch_bounds__(256) void gru_diag_fwd_kernel(GruDiagArgs p) {
-  constexpr int BU = 32, BN = 3 * BU;
-  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;   // wave tile (BM/2) x 48 (16 units x 3 gates)
+// BM rows x BU hidden units (x 3 gates) per workgroup, 2 x (BU/16) waves; wave tile (BM/2) x 48 = 16 units x 3 gates.
+// The per-CU LDS-DMA rate (~72 GB/s) bounds a launch, so what counts is the operand rows a CU streams:
+// 768 tiles of 64 x 32u are 3 x (64+96) rows per CU, 192 tiles of 128 x 64u are 128+192 on 3/4 of the CUs.
+template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU>
+__global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagArgs p) {
+  constexpr int BN = 3 * BU, WGN = BU / 16, NTHR = 128 * WGN;
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, WGN, KI>;
   constexpr int TM = G::TM;
   using h_t = typename G::h_t;
   using hb_t = typename PrecTraits<PRECB>::h_t;
@@ -50,42 +53,51 @@ __global__ __launch_bounds__(256) void gru_diag_fwd_kernel(GruDiagArgs p) {
   const ArkGruDiagRole& R = p.role[role];
   const int m0 = mt * BM, u0 = ut * BU;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int ul = wn * 16 + (lane & 15);
   const int u = u0 + ul;
-  // epilogue operands first: older than every LDS-DMA op in the vmcnt queue -> they land underneath the products
+  // epilogue operands first: older than every LDS-DMA op in the vmcnt queue -> they land underneath the
+  // products.  (Tall tiles keep only the addresses: 4 x 16 rows of prefetched state would spill.)
+  constexpr bool PRE = TM <= 2;
   int rl[TM];
   long o[TM];
-  f32x4 hp[TM], mk[TM];
+  f32x4 hp[PRE ? TM : 1], mk[PRE ? TM : 1];
+  const bool drop = R.drop_p > 0.f;
+  uint64_t step = 0;
+  float ks = 1.f;
+  if (drop) {
+    step = (uint64_t)p.hyper[ARK_HP_ADAM_STEP];
+    ks = 1.0f / (1.0f - R.drop_p);
+  }
+  auto mask_of = [&](long off) -> f32x4 {
+    f32x4 m = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (drop) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) m[i] = dropout_keep_scale(R.drop_seed, step, (uint64_t)(R.drop_base + off + i), R.drop_p, ks);
+    }
+    return m;
+  };
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     rl[tm] = wm * G::WTM + tm * 16 + 4 * (lane >> 4);
     const int rowc = min(m0 + rl[tm], B - 4);   // B % 16 == 0: clamped quads stay in bounds
     o[tm] = tile_native_off(rowc, u, D);
-    hp[tm] = *reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]);
-    mk[tm] = f32x4{1.f, 1.f, 1.f, 1.f};
-  }
-  const bool drop = R.drop_p > 0.f;
-  if (drop) {
-    const uint64_t step = (uint64_t)p.hyper[ARK_HP_ADAM_STEP];
-    const float ks = 1.0f / (1.0f - R.drop_p);
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        mk[tm][i] = dropout_keep_scale(R.drop_seed, step, (uint64_t)(R.drop_base + o[tm] + i), R.drop_p, ks);
+    if constexpr (PRE) {
+      hp[tm] = *reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]);
+      mk[tm] = mask_of(o[tm]);
+    }
   }
   const float br = R.b_ih[u] + R.b_hh[u], bz = R.b_ih[D + u] + R.b_hh[D + u];
   const float bin = R.b_ih[2 * D + u], bhn = R.b_hh[2 * D + u];
 
-  f32x4 ai[TM][G::TN], ah[TM][G::TN];
-  G::run2(ai, ah, reinterpret_cast<const h_t*>(R.x16), reinterpret_cast<const h_t*>(R.w_ih16), D,
-          reinterpret_cast<const h_t*>(R.h_prev16), reinterpret_cast<const h_t*>(R.w_hh16), D, (long)D, (long)D,
-          [=](int r) -> long { return (long)min(m0 + r, B - 1); },
-          [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); }, smem);
+  f32x4 acc[TM][G::TN + 1];   // r, z (input + recurrent parts summed), W_in x, W_hn h
+  G::run2_shared(acc, reinterpret_cast<const h_t*>(R.x16), reinterpret_cast<const h_t*>(R.w_ih16), D,
+                 reinterpret_cast<const h_t*>(R.h_prev16), reinterpret_cast<const h_t*>(R.w_hh16), D, (long)D, (long)D,
+                 [=](int r) -> long { return (long)min(m0 + r, B - 1); },
+                 [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); }, smem);
 
   __syncthreads();   // ring is free: reuse it to assemble row-major 16-bit rows [BM][32+pad]
-  constexpr int TS = 40;
+  constexpr int TS = BU + 8;   // row stride in elements: 16-B aligned rows, spreads banks
   constexpr int ARR = BM * TS * 2;
   h_t* ta = reinterpret_cast<h_t*>(smem);
   hb_t* tb = reinterpret_cast<hb_t*>(smem + ARR);
@@ -98,14 +110,17 @@ __global__ __launch_bounds__(256) void gru_diag_fwd_kernel(GruDiagArgs p) {
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     if (m0 + rl[tm] >= B) continue;
+    f32x4 hpv, mkv;
+    if constexpr (PRE) { hpv = hp[tm]; mkv = mk[tm]; }
+    else { hpv = *reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]); mkv = mask_of(o[tm]); }
     f32x4 r, z, n, hn, h;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      r[i] = sigmoidf_(ai[tm][0][i] + ah[tm][0][i] + br);
-      z[i] = sigmoidf_(ai[tm][1][i] + ah[tm][1][i] + bz);
-      hn[i] = ah[tm][2][i] + bhn;
-      n[i] = tanhf(ai[tm][2][i] + bin + r[i] * hn[i]);
-      h[i] = (1.0f - z[i]) * n[i] + z[i] * hp[tm][i];
+      r[i] = sigmoidf_(acc[tm][0][i] + br);
+      z[i] = sigmoidf_(acc[tm][1][i] + bz);
+      hn[i] = acc[tm][3][i] + bhn;
+      n[i] = tanhf(acc[tm][2][i] + bin + r[i] * hn[i]);
+      h[i] = (1.0f - z[i]) * n[i] + z[i] * hpv[i];
     }
     *reinterpret_cast<f32x4*>(R.y_out_t + o[tm]) = h;
     if (sr) {
@@ -114,7 +129,7 @@ __global__ __launch_bounds__(256) void gru_diag_fwd_kernel(GruDiagArgs p) {
       *reinterpret_cast<dhalf4_t*>(sn + o[tm]) = dhalf4_t{(_Float16)n[0], (_Float16)n[1], (_Float16)n[2], (_Float16)n[3]};
       *reinterpret_cast<dhalf4_t*>(shn + o[tm]) = dhalf4_t{(_Float16)hn[0], (_Float16)hn[1], (_Float16)hn[2], (_Float16)hn[3]};
     }
-    const f32x4 hd = h * mk[tm];
+    const f32x4 hd = h * mkv;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ta[(rl[tm] + i) * TS + ul] = G::PT::cvt(h[i]);
@@ -126,12 +141,14 @@ __global__ __launch_bounds__(256) void gru_diag_fwd_kernel(GruDiagArgs p) {
     }
   }
   __syncthreads();
-  // BM rows x 64 B per array: thread t -> row t/4, 16-byte chunk t%4 (BM=64: exactly the 256 threads)
+  // BM rows x (2*BU) B per array: thread t -> row t / CPR, 16-byte chunk t % CPR, NTHR / CPR rows per pass
   const int t = threadIdx.x;
-  if (t < BM * 4) {
-    const int rr = t >> 2, ch = t & 3;
+  constexpr int CPR = BU / 8, RPP = NTHR / CPR;
+#pragma unroll
+  for (int r0 = 0; r0 < BM; r0 += RPP) {
+    const int rr = r0 + t / CPR, ch = t % CPR;
     const int row = m0 + rr;
-    if (row < B) {
+    if (rr < BM && row < B) {
       const long go = (long)row * D + u0 + ch * 8;
       *reinterpret_cast<uint4*>(reinterpret_cast<h_t*>(R.y16a) + go) = *reinterpret_cast<const uint4*>(ta + rr * TS + ch * 8);
       if (R.y16b) *reinterpret_cast<uint4*>(reinterpret_cast<hb_t*>(R.y16b) + go) = *reinterpret_cast<const uint4*>(tb + rr * TS + ch * 8);
@@ -143,35 +160,45 @@ __global__ __launch_bounds__(256) void gru_diag_fwd_kernel(GruDiagArgs p) {
   }
 }
 
-// measured on MI355X (syn-paths, B=1024): 64 rows x 2 k-images x 2 slots with the XCD map is fastest
-static int g_diag_rows = 64, g_diag_ki = 2, g_diag_nbuf = 2, g_diag_xcd = 1;
+// measured on MI355X (syn-paths, B=1024): see DESIGN.md section 6
+static int g_diag_rows = 64, g_diag_ki = 2, g_diag_nbuf = 2, g_diag_xcd = 1, g_diag_units = 32;
 
-template <int PREC, int PRECB, int NBUF, int KI, int BM>
+template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU>
 static void launch_diag(const GruDiagArgs& p, hipStream_t st) {
-  using G = DmaTile<PREC, BM, 96, NBUF, 2, 2, KI>;
-  constexpr int MINL = 4 * BM * 40 * 2;
+  using G = DmaTile<PREC, BM, 3 * BU, NBUF, 2, BU / 16, KI>;
+  constexpr int MINL = 4 * BM * (BU + 8) * 2;
   constexpr int LDS = G::LDS_BYTES > MINL ? G::LDS_BYTES : MINL;
-  auto kern = gru_diag_fwd_kernel<PREC, PRECB, NBUF, KI, BM>;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  auto kern = gru_diag_fwd_kernel<PREC, PRECB, NBUF, KI, BM, BU>;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
   (void)once;
-  const unsigned grid = (unsigned)(p.n_roles * ((p.B + BM - 1) / BM) * (p.D / 32));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, p);
+  const unsigned grid = (unsigned)(p.n_roles * ((p.B + BM - 1) / BM) * (p.D / BU));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * (BU / 16)), LDS, st, p);
 }
 
 template <int PREC, int PRECB>
 static int launch_diag_cfg(GruDiagArgs& p, hipStream_t st) {
   const bool ki2 = g_diag_ki == 2 && p.D % 128 == 0;
   const int rows = g_diag_rows;
-  const int MT = (p.B + rows - 1) / rows, UT = p.D / 32;
+  const int units = (g_diag_units == 64 && p.D % 64 == 0) ? 64 : 32;
+  const int MT = (p.B + rows - 1) / rows, UT = p.D / units;
   p.xcd_map = (g_diag_xcd && UT % 4 == 0 && MT % 2 == 0) ? 1 : 0;
-  if (rows == 64) {
-    if (ki2) launch_diag<PREC, PRECB, 2, 2, 64>(p, st);
-    else if (g_diag_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 64>(p, st);
-    else launch_diag<PREC, PRECB, 2, 1, 64>(p, st);
+  if (units == 64) {   // 8 waves
+    if (rows == 128) {
+      if (g_diag_nbuf >= 4) launch_diag<PREC, PRECB, 3, 1, 128, 64>(p, st);   // 3 x 40 KB
+      else launch_diag<PREC, PRECB, 2, 1, 128, 64>(p, st);
+    } else {
+      if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 64>(p, st);
+      else launch_diag<PREC, PRECB, 2, 1, 64, 64>(p, st);
+    }
+  } else if (rows == 64) {
+    if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 32>(p, st);
+    else if (g_diag_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 64, 32>(p, st);
+    else launch_diag<PREC, PRECB, 2, 1, 64, 32>(p, st);
   } else {
-    if (ki2) launch_diag<PREC, PRECB, 2, 2, 32>(p, st);
-    else if (g_diag_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 32>(p, st);
-    else launch_diag<PREC, PRECB, 2, 1, 32>(p, st);
+    if (ki2) launch_diag<PREC, PRECB, 2, 2, 32, 32>(p, st);
+    else if (g_diag_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 32, 32>(p, st);
+    else launch_diag<PREC, PRECB, 2, 1, 32, 32>(p, st);
   }
   ARK_LAUNCH_CHECK();
   return 0;
@@ -180,11 +207,19 @@ static int launch_diag_cfg(GruDiagArgs& p, hipStream_t st) {
 }  // namespace ark
 
 extern "C" int ark_set_diag_tuning(int rows, int ki, int nbuf, int xcd_map) {
-  if ((rows != 32 && rows != 64) || (ki != 1 && ki != 2) || (nbuf != 2 && nbuf != 4)) return ARK_ERR_ARG;
+  if ((rows != 32 && rows != 64 && rows != 128) || (ki != 1 && ki != 2) || (nbuf != 2 && nbuf != 4)) return ARK_ERR_ARG;
+  if (rows == 128 && ark::g_diag_units != 64) return ARK_ERR_ARG;   // 128-row tiles exist for 64-unit tiles only
   ark::g_diag_rows = rows;
   ark::g_diag_ki = ki;
   ark::g_diag_nbuf = nbuf;
   ark::g_diag_xcd = xcd_map ? 1 : 0;
+  return 0;
+}
+
+extern "C" int ark_set_diag_units(int units) {
+  if (units != 32 && units != 64) return ARK_ERR_ARG;
+  ark::g_diag_units = units;
+  if (units == 32 && ark::g_diag_rows == 128) ark::g_diag_rows = 64;
   return 0;
 }
 

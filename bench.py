@@ -194,7 +194,7 @@ def main():
     for kv in filter(None, args.knobs.split(",")):   # e.g. ring=8:8,g16=2:0,wg128=1
         k, v = kv.split("=")
         vals = [int(x) for x in v.split(":")]
-        fn = {"ring": L.lib().ark_set_dma_ring, "g16": L.lib().ark_set_gemm16_tuning, "wg128": L.lib().ark_set_wgrad_tile128, "wg16": L.lib().ark_set_wgrad16_tuning, "ki": L.lib().ark_set_dma_stage, "fbm": L.lib().ark_set_dma_fwd_rows, "sc": L.lib().ark_set_scatter_chunk, "bbn": L.lib().ark_set_dma_bwd_units, "diag": L.lib().ark_set_diag_tuning, "dbwd": L.lib().ark_set_diag_bwd_tuning, "wgbal": L.lib().ark_set_wgrad16_balance, "dbx": L.lib().ark_set_diag_bwd_xcd}[k]
+        fn = {"ring": L.lib().ark_set_dma_ring, "g16": L.lib().ark_set_gemm16_tuning, "wg128": L.lib().ark_set_wgrad_tile128, "wg16": L.lib().ark_set_wgrad16_tuning, "ki": L.lib().ark_set_dma_stage, "fbm": L.lib().ark_set_dma_fwd_rows, "sc": L.lib().ark_set_scatter_chunk, "bbn": L.lib().ark_set_dma_bwd_units, "diag": L.lib().ark_set_diag_tuning, "dbwd": L.lib().ark_set_diag_bwd_tuning, "wgbal": L.lib().ark_set_wgrad16_balance, "dbx": L.lib().ark_set_diag_bwd_xcd, "du": L.lib().ark_set_diag_units}[k]
         L.check(fn(*vals), k)
 
     cfg = build_cfg(args.dropout, args.workload)

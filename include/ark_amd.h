@@ -158,7 +158,8 @@ typedef struct {
 int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* roles, const float* hyper, int B, int D, void* stream);
 int ark_set_diag_bwd_tuning(int rows /* 32 | 64 */, int ki /* 1 | 2 */, int nbuf /* 2 | 4 */);
 int ark_set_diag_bwd_xcd(int row_classes /* 1 (plain order) | 2 | 4 | 8: row-tile classes per XCD octet */);
-int ark_set_diag_tuning(int rows /* 32 | 64 */, int ki /* 1 | 2 */, int nbuf /* 2 | 4 */, int xcd_map /* 0 | 1 */);
+int ark_set_diag_tuning(int rows /* 32 | 64 | 128 (64-unit tiles only) */, int ki /* 1 | 2 */, int nbuf /* 2 | 4 */, int xcd_map /* 0 | 1 */);
+int ark_set_diag_units(int units /* hidden units per forward workgroup: 32 (4 waves) | 64 (8 waves) */);
 int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf);
 int ark_set_dma_stage(int fwd_ki, int bwd_ki);
 int ark_set_dma_fwd_rows(int bm);

@@ -226,9 +226,13 @@ def test_in_kernel_dropout_is_consistent_forward_and_backward():
         assert torch.allclose(dropped, plain * ref, rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("rows,ki,nbuf,xcd", [(32, 2, 2, 0), (64, 1, 2, 0), (64, 2, 2, 1), (32, 1, 4, 1)])
+DIAG_DEFAULT = (64, 2, 2, 1, 32)   # library defaults (rows, ki, nbuf, xcd_map, units) of the forward diagonal kernel
+
+
+@pytest.mark.parametrize("rows,ki,nbuf,xcd,units", [(32, 2, 2, 0, 32), (64, 1, 2, 0, 32), (64, 2, 2, 1, 32), (32, 1, 4, 1, 32),
+                                                   (128, 1, 2, 1, 64), (128, 1, 4, 0, 64), (64, 2, 2, 1, 64)])
 @pytest.mark.parametrize("drop", [0.0, 0.1])
-def test_diagonal_cells_match_layer_order(rows, ki, nbuf, xcd, drop):
+def test_diagonal_cells_match_layer_order(rows, ki, nbuf, xcd, units, drop):
     """the layer-diagonal forward (one launch per anti-diagonal, in-cell input projection) computes the
     same states, saves, losses and gradients as the layer-by-layer LDS-DMA path, and the same ELBO as
     the CPU oracle within north_star's tolerance"""
@@ -242,8 +246,9 @@ def test_diagonal_cells_match_layer_order(rows, ki, nbuf, xcd, drop):
     eps = torch.randn(B, cfg["d_latent"])
     a = make_engine(dict(cfg, ark_diag_cells=False), P, "mixed")
     b = make_engine(dict(cfg, ark_diag_cells=True, ark_diag_bwd=True), P, "mixed")
+    L.check(L.lib().ark_set_diag_units(units), "ark_set_diag_units")
     L.check(L.lib().ark_set_diag_tuning(rows, ki, nbuf, xcd), "ark_set_diag_tuning")
-    L.check(L.lib().ark_set_diag_bwd_tuning(rows, ki, nbuf), "ark_set_diag_bwd_tuning")
+    L.check(L.lib().ark_set_diag_bwd_tuning(min(rows, 64), ki, nbuf), "ark_set_diag_bwd_tuning")
     try:
         dev = a.device
         args = (triples.to(dev), seq.to(dev), eps.to(dev))
@@ -268,5 +273,6 @@ def test_diagonal_cells_match_layer_order(rows, ki, nbuf, xcd, drop):
             da, db = a.g[k].float(), b.g[k].float()
             assert (da - db).norm().item() <= 3e-3 * da.norm().item() + 1e-9, k
     finally:
-        L.check(L.lib().ark_set_diag_tuning(64, 2, 2, 1), "ark_set_diag_tuning")
+        L.check(L.lib().ark_set_diag_units(DIAG_DEFAULT[4]), "ark_set_diag_units")
+        L.check(L.lib().ark_set_diag_tuning(*DIAG_DEFAULT[:4]), "ark_set_diag_tuning")
         L.check(L.lib().ark_set_diag_bwd_tuning(32, 2, 2), "ark_set_diag_bwd_tuning")
