@@ -108,6 +108,88 @@ __global__ __launch_bounds__(256) void zproj_bwd_dz_kernel(float* __restrict__ d
     }
 }
 
+// The whole per-row part of the latent backward in ONE launch (it sits on the dependent chain between
+// the GRU's initial-state gradient and the encoder MLP backward), one wave per batch row:
+//   dzp = dh0 * (1 - h0^2)              (in place, for the batch reductions that follow off-chain)
+//   dz  = dzp Wz                        (z-projection, models.py:139)
+//   dhead = d(beta*kl)/d(mu,logv) + dz through the reparameterisation (+ external dmu/dlogv)
+//   dA  = (dhead W_head) * gelu'(pre)   (heads models.py:43-44, last MLP activation models.py:32-41)
+// The reductions over the batch (dWz, dbz, db_head, dW_head) only need dzp / dhead and run elsewhere.
+template <int ZT>
+__global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict__ dh0, const float* __restrict__ h0,
+                                                               const float* __restrict__ Wz, const float* __restrict__ head,
+                                                               const float* __restrict__ eps, const float* __restrict__ hyper,
+                                                               const float* __restrict__ ext_dhead,
+                                                               const float* __restrict__ Whead, const float* __restrict__ pre,
+                                                               float* __restrict__ dhead, float* __restrict__ dA, void* dA16,
+                                                               int prec16, int B, int Z, int D, int H) {
+  __shared__ float sh[4][2 * ZT];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  const bool valid = b < B;
+  const int bb = valid ? b : B - 1;
+  float acc[ZT];
+#pragma unroll
+  for (int j = 0; j < ZT; ++j) acc[j] = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const long i = (long)bb * D + d;
+    const float h = h0[i];
+    const float g = dh0[i] * (1.0f - h * h);
+    if (valid) dh0[i] = g;
+    const float* wr = Wz + (long)d * Z;
+#pragma unroll
+    for (int j = 0; j < ZT; ++j)
+      if (j < Z) acc[j] += g * wr[j];
+  }
+  float mydz = 0.f;
+#pragma unroll
+  for (int j = 0; j < ZT; ++j)
+    if (j < Z) {
+      const float a = wave_sum(acc[j]);
+      if (lane == j) mydz = a;
+    }
+  if (lane < Z) {
+    const float ks = hyper[ARK_HP_BETA] * hyper[ARK_HP_KL_NORM];  // beta / (B_global * Z)
+    const float m = head[(long)bb * 2 * Z + lane];
+    const float raw = head[(long)bb * 2 * Z + Z + lane];
+    const float lv = fminf(fmaxf(raw, -10.0f), 10.0f);
+    float dmu = mydz + ks * m;
+    float dlv = mydz * (eps ? eps[(long)bb * Z + lane] : 0.f) * 0.5f * expf(0.5f * lv) + ks * 0.5f * (expf(lv) - 1.0f);
+    if (raw < -10.0f || raw > 10.0f) dlv = 0.f;
+    if (ext_dhead) {
+      dmu += ext_dhead[(long)bb * 2 * Z + lane];
+      dlv += ext_dhead[(long)bb * 2 * Z + Z + lane];
+    }
+    sh[wave][lane] = dmu;
+    sh[wave][Z + lane] = dlv;
+    if (valid) {
+      dhead[(long)bb * 2 * Z + lane] = dmu;
+      dhead[(long)bb * 2 * Z + Z + lane] = dlv;
+    }
+  }
+  __syncthreads();
+  // dA for the workgroup's 4 rows: thread -> column (every W_head element is loaded once per workgroup
+  // and used for all 4 rows; dhead rows are LDS broadcasts)
+  const int row0 = blockIdx.x * 4;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int j = 0; j < 2 * Z; ++j) {
+      const float wv = Whead[(long)j * H + c];
+      s0 += sh[0][j] * wv; s1 += sh[1][j] * wv; s2 += sh[2][j] * wv; s3 += sh[3][j] * wv;
+    }
+    const float sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (row0 + r >= B) break;
+      const long o = (long)(row0 + r) * H + c;
+      const float v = sv[r] * dgelu_erf(pre[o]);
+      dA[o] = v;
+      if (prec16 == 2) reinterpret_cast<_Float16*>(dA16)[o] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+      else reinterpret_cast<__bf16*>(dA16)[o] = (__bf16)v;
+    }
+  }
+}
+
 // dWz[d,j] += sum_b dzp[b,d] z[b,j] ; dbz[d] += sum_b dzp[b,d]
 // 64 d-columns x 4 row groups per workgroup over a chunk of the batch; z rows are staged in LDS
 // padded to ZT latent columns so the ZT accumulators stay in registers (compile-time indices).
@@ -303,6 +385,49 @@ extern "C" int ark_zproj_bwd(float* dh0, const float* h0, const float* z, const 
   else if (Z <= 64) ARK_ZDW(64);
   else ARK_ZDW(128);
 #undef ARK_ZDW
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// batch reductions of the z-projection backward alone: dWz (+)= dzp^T z, dbz (+)= colsum(dzp)
+extern "C" int ark_zproj_bwd_dw(const float* dzp, const float* z, float* d_w_z, float* d_b_z, int B, int Z, int D,
+                                int accumulate, void* stream) {
+  using namespace ark;
+  if (!dzp || !z || !d_w_z || !d_b_z || B <= 0 || Z <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (Z > 128) return ARK_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(d_w_z, 0, sizeof(float) * (size_t)D * Z, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(d_b_z, 0, sizeof(float) * (size_t)D, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int b_chunk = 32;
+  dim3 grid((D + 63) / 64, (B + b_chunk - 1) / b_chunk);
+#define ARK_ZDW(ZT) hipLaunchKernelGGL(zproj_bwd_dw_kernel<ZT>, grid, dim3(256), (size_t)(b_chunk * ZT + 256) * sizeof(float), st, dzp, z, d_w_z, d_b_z, B, Z, D, b_chunk)
+  if (Z <= 16) ARK_ZDW(16);
+  else if (Z <= 32) ARK_ZDW(32);
+  else if (Z <= 64) ARK_ZDW(64);
+  else ARK_ZDW(128);
+#undef ARK_ZDW
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_z, const float* head, const float* eps,
+                                    const float* hyper, const float* ext_dhead, const float* w_head, const float* pre,
+                                    float* dhead, float* dA, void* dA16, int prec16, int B, int Z, int D, int H, void* stream) {
+  using namespace ark;
+  if (!dh0 || !h0 || !w_z || !head || !hyper || !w_head || !pre || !dhead || !dA || !dA16 || B <= 0 || Z <= 0 || D <= 0 || H <= 0)
+    return ARK_ERR_ARG;
+  if (Z > 64) return ARK_ERR_SHAPE;
+  if (prec16 != 1 && prec16 != 2) return ARK_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+#define ARK_LC(ZT) hipLaunchKernelGGL(latent_chain_bwd_kernel<ZT>, dim3((B + 3) / 4), dim3(256), 0, st, dh0, h0, w_z, head, eps, hyper, ext_dhead, w_head, pre, dhead, dA, dA16, prec16, B, Z, D, H)
+  if (Z <= 16) ARK_LC(16);
+  else if (Z <= 32) ARK_LC(32);
+  else ARK_LC(64);
+#undef ARK_LC
   ARK_LAUNCH_CHECK();
   return 0;
 }

@@ -634,23 +634,48 @@ class Engine:
         # latent path
         H = 3 * D
         h0rm = w["h0"] if w["v2"] else w["Y"][0]   # row-major h0 (the v2 state buffers are tile-native)
-        _call("ark_zproj_bwd", L.ptr(w["dH0"]), L.ptr(h0rm), L.ptr(w["z"]), L.ptr(p["dec.z_proj.weight"]),
-              L.ptr(w["dz"]), L.ptr(g["dec.z_proj.weight"]), L.ptr(g["dec.z_proj.bias"]), L.i32(B), L.i32(Z), L.i32(D), L.i32(1), st)
-        _call("ark_latent_bwd", L.ptr(w["dz"]), L.ptr(w["head"]), L.ptr(self._eps), L.ptr(self.hyper), L.ptr(w["dhead"]),
-              L.i32(B), L.i32(Z), st)
-        if ext_dhead is not None:
-            w["dhead"].add_(ext_dhead)
-        self._colsum(w["dhead"], 2 * Z, g["enc.mu.bias"], B, 2 * Z)
+        fused = w["v2"] and Z <= 64
+        if fused:
+            # ONE launch for the per-row chain dh0 -> dz -> dhead -> dA (it sits on the dependent chain);
+            # the reductions over the batch it feeds go to the side queue
+            pb = self.prec_bwd
+            a16b = lambda i: (w["act16b"][i] if w["act16b"][i] is not None else w["act16a"][i])
+            g16b = w["g16b"] if w["g16b"] is not None else w["g16a"]
+            ext = ext_dhead.contiguous() if ext_dhead is not None else None
+            _call("ark_latent_chain_bwd", L.ptr(w["dH0"]), L.ptr(h0rm), L.ptr(p["dec.z_proj.weight"]), L.ptr(w["head"]),
+                  L.ptr(self._eps), L.ptr(self.hyper), L.ptr(ext), L.ptr(p["enc.mu.weight"]), L.ptr(w["pre"][n - 1]),
+                  L.ptr(w["dhead"]), L.ptr(w["dA"]), L.ptr(w["dpre16"][n - 1]), L.i32(pb), L.i32(B), L.i32(Z), L.i32(D),
+                  L.i32(H), st)
+            main = torch.cuda.current_stream()
+            side = self._side_stream() if self.overlap_wgrad else main
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ss = L.cur_stream()
+                _call("ark_zproj_bwd_dw", L.ptr(w["dH0"]), L.ptr(w["z"]), L.ptr(g["dec.z_proj.weight"]),
+                      L.ptr(g["dec.z_proj.bias"]), L.i32(B), L.i32(Z), L.i32(D), L.i32(1), ss)
+                self._colsum(w["dhead"], 2 * Z, g["enc.mu.bias"], B, 2 * Z)
+                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(w["dhead"]), L.i32(0), L.i64(2 * Z), L.ptr(a16b(n - 1)), L.i32(1),
+                      L.i64(H), L.ptr(g["enc.mu.weight"]), L.i64(H), L.i32(2 * Z), L.i32(H), L.i32(B), L.i32(1), ss)
+            self._side_used = self._side_used or (side is not main)
+        else:
+            _call("ark_zproj_bwd", L.ptr(w["dH0"]), L.ptr(h0rm), L.ptr(w["z"]), L.ptr(p["dec.z_proj.weight"]),
+                  L.ptr(w["dz"]), L.ptr(g["dec.z_proj.weight"]), L.ptr(g["dec.z_proj.bias"]), L.i32(B), L.i32(Z), L.i32(D), L.i32(1), st)
+            _call("ark_latent_bwd", L.ptr(w["dz"]), L.ptr(w["head"]), L.ptr(self._eps), L.ptr(self.hyper), L.ptr(w["dhead"]),
+                  L.i32(B), L.i32(Z), st)
+            if ext_dhead is not None:
+                w["dhead"].add_(ext_dhead)
+            self._colsum(w["dhead"], 2 * Z, g["enc.mu.bias"], B, 2 * Z)
         if w["v2"]:
             pb = self.prec_bwd
             a16b = lambda i: (w["act16b"][i] if w["act16b"][i] is not None else w["act16a"][i])
             g16b = w["g16b"] if w["g16b"] is not None else w["g16a"]
-            _call("ark_gemm_wgrad", L.i32(pb), L.ptr(w["dhead"]), L.i32(0), L.i64(2 * Z), L.ptr(a16b(n - 1)), L.i32(1), L.i64(H),
-                  L.ptr(g["enc.mu.weight"]), L.i64(H), L.i32(2 * Z), L.i32(H), L.i32(B), L.i32(1), st)
-            # K = 2Z is not a multiple of 64 -> register-staged engine for this one product, then a 16-bit copy
-            self._gemm(KM, MM, L.EPI_MUL_DGELU, w["dhead"], 2 * Z, p["enc.mu.weight"], H, w["dA"], H, B, H, 2 * Z,
-                       aux=w["pre"][n - 1])
-            _call("ark_cast16", L.i32(pb), L.ptr(w["dA"]), L.ptr(w["dpre16"][n - 1]), L.i64(B * H), st)
+            if not fused:
+                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(w["dhead"]), L.i32(0), L.i64(2 * Z), L.ptr(a16b(n - 1)), L.i32(1), L.i64(H),
+                      L.ptr(g["enc.mu.weight"]), L.i64(H), L.i32(2 * Z), L.i32(H), L.i32(B), L.i32(1), st)
+                # K = 2Z is not a multiple of 64 -> register-staged engine for this one product, then a 16-bit copy
+                self._gemm(KM, MM, L.EPI_MUL_DGELU, w["dhead"], 2 * Z, p["enc.mu.weight"], H, w["dA"], H, B, H, 2 * Z,
+                           aux=w["pre"][n - 1])
+                _call("ark_cast16", L.i32(pb), L.ptr(w["dA"]), L.ptr(w["dpre16"][n - 1]), L.i64(B * H), st)
             dpre, other = w["dA"], w["dB"]
             group = []
             for i in range(n - 1, -1, -1):

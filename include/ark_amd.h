@@ -231,6 +231,16 @@ int ark_zproj_fwd(const float* z, const float* w_z, const float* b_z, float* h0,
                   int B, int Z, int D, void* stream);
 int ark_zproj_bwd(float* dh0, const float* h0, const float* z, const float* w_z, float* dz, float* d_w_z,
                   float* d_b_z, int B, int Z, int D, int accumulate, void* stream);
+/* the batch reductions of ark_zproj_bwd alone (dzp = dh0 * (1 - h0^2) already formed) */
+int ark_zproj_bwd_dw(const float* dzp, const float* z, float* d_w_z, float* d_b_z, int B, int Z, int D, int accumulate,
+                     void* stream);
+/* Per-row latent backward in one launch (Z <= 64): dh0 -> dzp (in place) -> dz -> dhead[B,2Z] (KL + reparameterisation
+ * backward of models.py:61-63,199-200, plus optional external [dmu | dlogv]) -> dA[B,H] = (dhead W_head) * gelu'(pre)
+ * and its 16-bit copy.  The reductions over the batch (ark_zproj_bwd_dw, db_head, dW_head) are separate. */
+int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_z, const float* head, const float* eps,
+                         const float* hyper, const float* ext_dhead /* nullable */, const float* w_head /* [2Z,H] */,
+                         const float* pre /* [B,H] */, float* dhead, float* dA, void* dA16, int prec16, int B, int Z, int D,
+                         int H, void* stream);
 int ark_count_targets(const int64_t* seq, int64_t ld_seq, int B, int L, float* hyper, void* stream);
 /* rows are time-major (t,b); target of row (t,b) is seq[b, t+1]; dlogits may alias logits or be NULL */
 /* dlogits16 (nullable): additional [B*L, ld16] copy of dlogits in 16 bits (prec16), zero beyond V */
