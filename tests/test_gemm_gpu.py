@@ -107,3 +107,71 @@ def test_wgrad16_tr_read_kernel(prec, tile, nbuf, shape):
     ref = C0.double() + A.double().t() @ B.double()
     err = (C.cpu().double() - ref).abs().max().item()
     assert err <= 3e-5 * (K ** 0.5) + 1e-4, err
+
+
+@pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_F16])
+@pytest.mark.parametrize("B,Lq,V", [(16, 3, 55), (48, 10, 130)])
+def test_onehot16(prec, B, Lq, V):
+    """one-hot rows of the decoder input tokens, time-major, padded to a multiple of 64 columns"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    seq = torch.randint(0, V, (B, Lq + 1), generator=g)
+    Vp = (V + 63) // 64 * 64
+    out = torch.full((B * Lq, Vp), 7, dtype=torch.int16, device=dev)
+    seq_d = seq.to(dev)
+    L.check(L.lib().ark_onehot16(L.i32(prec), L.ptr(seq_d), L.i64(Lq + 1), L.ptr(out), L.i32(B), L.i32(Lq), L.i32(Vp),
+                                 L.cur_stream()), "ark_onehot16")
+    torch.cuda.synchronize()
+    got = out.view(torch.bfloat16 if prec == L.PREC_BF16 else torch.float16).float().cpu()
+    want = torch.zeros(B * Lq, Vp)
+    for t in range(Lq):
+        want[t * B + torch.arange(B), seq[:, t]] = 1.0
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("B,Z,D,H,with_ext", [(8, 10, 64, 192, False), (37, 10, 512, 1536, True), (64, 32, 128, 384, False)])
+def test_latent_chain_bwd_matches_autograd(B, Z, D, H, with_ext):
+    """ark_latent_chain_bwd (dh0 -> dz -> dhead -> dA in one launch) and ark_zproj_bwd_dw against torch autograd of
+    h0 = tanh(z Wz^T + bz), z = mu + eps*exp(0.5*clamp(logv)), loss = <dh0, h0> + beta*kl_norm-scaled KL (+ <ext, head>)"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    head = (rn(B, 2 * Z) * 2).double()
+    head[0, Z] = 11.0   # outside the clamp: no gradient through logv there
+    head[1, Z + 1] = -12.0
+    eps, Wz, bz = rn(B, Z).double(), (rn(D, Z) * 0.3).double(), rn(D).double()
+    Whead, pre, act_in = (rn(2 * Z, H) * 0.1).double(), rn(B, H).double(), rn(B, H).double()
+    dh0_up, ext = rn(B, D).double(), rn(B, 2 * Z).double()
+    beta, kl_norm = 0.3, 1.0 / (B * Z)
+    # torch reference: act_in -> gelu(pre stand-in) is not needed; dA is the gradient wrt `pre` of head = gelu(pre) Whead^T
+    pre_t = pre.clone().requires_grad_(True)
+    Wz_t, bz_t, Wh_t = Wz.clone().requires_grad_(True), bz.clone().requires_grad_(True), Whead.clone().requires_grad_(True)
+    a = torch.nn.functional.gelu(pre_t)
+    head_t = a @ Wh_t.t() + (head - (torch.nn.functional.gelu(pre) @ Whead.t())).detach()   # value == head, gradient flows
+    mu, lv = head_t[:, :Z], head_t[:, Z:].clamp(-10, 10)
+    z = mu + eps * torch.exp(0.5 * lv)
+    h0 = torch.tanh(z @ Wz_t.t() + bz_t)
+    kl = -0.5 * (1 + lv - mu * mu - lv.exp()).sum() * kl_norm
+    loss = (dh0_up * h0).sum() + beta * kl + ((ext * head_t).sum() if with_ext else 0.0)
+    loss.backward()
+    f = lambda t: t.float().to(dev).contiguous()
+    hyper = torch.zeros(16, device=dev)
+    hyper[1], hyper[2] = beta, kl_norm    # ARK_HP_BETA, ARK_HP_KL_NORM
+    dh0_d, h0_d, z_d = f(dh0_up), f(h0.detach()), f(z.detach())
+    bufs = dict(Wz=f(Wz), head=f(head), eps=f(eps), ext=f(ext), Wh=f(Whead), pre=f(pre))
+    dhead, dA = torch.zeros(B, 2 * Z, device=dev), torch.zeros(B, H, device=dev)
+    dA16 = torch.zeros(B, H, dtype=torch.int16, device=dev)
+    L.check(L.lib().ark_latent_chain_bwd(L.ptr(dh0_d), L.ptr(h0_d), L.ptr(bufs["Wz"]), L.ptr(bufs["head"]), L.ptr(bufs["eps"]),
+                                         L.ptr(hyper), L.ptr(bufs["ext"] if with_ext else None), L.ptr(bufs["Wh"]),
+                                         L.ptr(bufs["pre"]), L.ptr(dhead), L.ptr(dA), L.ptr(dA16), L.i32(L.PREC_BF16), L.i32(B),
+                                         L.i32(Z), L.i32(D), L.i32(H), L.cur_stream()), "ark_latent_chain_bwd")
+    dWz, dbz = torch.zeros(D, Z, device=dev), torch.zeros(D, device=dev)
+    L.check(L.lib().ark_zproj_bwd_dw(L.ptr(dh0_d), L.ptr(z_d), L.ptr(dWz), L.ptr(dbz), L.i32(B), L.i32(Z), L.i32(D), L.i32(0),
+                                     L.cur_stream()), "ark_zproj_bwd_dw")
+    torch.cuda.synchronize()
+    close = lambda got, want, tol: (got.double().cpu() - want).abs().max().item() <= tol * (want.abs().max().item() + 1e-12)
+    assert close(dA, pre_t.grad, 2e-5)
+    assert close(dA16.view(torch.bfloat16).float(), pre_t.grad, 1e-2)
+    assert close(dWz, Wz_t.grad, 2e-5) and close(dbz, bz_t.grad, 2e-5)
+    # dhead^T gelu(pre) is the head weight gradient: checks dhead itself
+    assert close(dhead.double().cpu().t() @ torch.nn.functional.gelu(pre), Wh_t.grad, 2e-5)
