@@ -162,6 +162,7 @@ class Engine:
         self._shadow_ok = False
         self._side = None
         self._side_used = False
+        self._defer_wgrads = False
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
         self._layer_streams = []
         self.diag_cells = bool(cfg.get("ark_diag_cells", True))
@@ -624,7 +625,7 @@ class Engine:
 
     def backward_encoder(self, ext_dhead=None):
         """latent + encoder half of the backward pass (SAIL): fills flat-buffer gradients [0, dec_grad_offset)
-        plus dec.z_proj."""
+        (which includes dec.z_proj)."""
         self.prec = self.prec_bwd
         w, B, T, Lq = self.ws, self._B, self._T, self._Lrun
         D, n, V, Z = self.D, self.n, self.V, self.Z
@@ -910,45 +911,10 @@ class Engine:
                 r.drop_p = self.p_drop if drop else 0.0
                 k += 1
             _call("ark_gru_diag_bwd", L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
-        items = []
-        for l in range(n):
-            if l == 0:
-                xin = w["X0b"] if w["X0b"] is not None else w["X0a"]
-            elif use_drop:
-                xin = w["Yd16b"][l - 1] if w["Yd16b"][l - 1] is not None else w["Yd16a"][l - 1]
-            else:
-                xin = yb(l - 1)[B:]
-            items += [(w["dGH16"][l], 3 * D, yb(l), D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R),
-                      (w["dGI16"][l], 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)]
-        side.wait_stream(main)   # gate-gradient panels complete
-        with torch.cuda.stream(side):
-            ss = L.cur_stream()
-            if R % 64 == 0:
-                for i0 in range(0, len(items), 8):
-                    self._wgrad_group(items[i0:i0 + 8])
-            else:
-                for (a, lda, x, ldx, out, ldo, M, N, K) in items:
-                    _call("ark_gemm_wgrad", L.i32(pb), L.ptr(a), L.i32(1), L.i64(lda), L.ptr(x), L.i32(1), L.i64(ldx), L.ptr(out),
-                          L.i64(ldo), L.i32(M), L.i32(N), L.i32(K), L.i32(1), ss)
-            if w["emb_gemm"]:
-                # dW_tok += onehot^T dX0 = (onehot^T dgi_0) W_ih_0: a [Vp,3D] reduction over the tokens on the
-                # matrix cores, then one small exact-fp32 product -- no [R,D] input gradient, no scatter
-                w["S_tok"].zero_()
-                _call("ark_onehot16", L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(w["onehot16"]), L.i32(B), L.i32(Lq),
-                      L.i32(self.Vp), ss)
-                _call("ark_wgrad16", L.i32(pb), L.ptr(w["onehot16"]), L.i64(self.Vp), L.ptr(w["dGI16"][0]), L.i64(3 * D),
-                      L.ptr(w["S_tok"]), L.i64(3 * D), L.i32(self.Vp), L.i32(3 * D), L.i32(R), ss)
-                _call("ark_gemm", L.i32(L.PREC_F32), L.i32(KM), L.i32(MM), L.i32(L.EPI_NONE), L.ptr(w["S_tok"]), L.i64(3 * D),
-                      L.ptr(p["dec.gru.weight_ih_l0"]), L.i64(D), L.ptr(g["dec.tok_emb.weight"]), L.i64(D), L.ptr(None),
-                      L.ptr(None), L.ptr(None), L.i32(V), L.i32(D), L.i32(3 * D), L.i32(1), ss)
-            else:
-                _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dGI16"][0]), L.i64(3 * D), L.ptr(self.wihT16[0]),
-                      L.i64(3 * D), L.ptr(w["dX0"]), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(3 * D),
-                      L.i32(0), ss)
-                _call("ark_tok_scatter", L.ptr(seq), L.i64(ld_seq), L.ptr(w["dX0"]), L.ptr(g["dec.tok_emb.weight"]), L.i32(B),
-                      L.i32(Lq), L.i32(D), L.i32(V), ss)
-                if self.mt == "ARK":
-                    self._colsum(w["dX0"], D, g["dec.pos_emb.weight"], B, D, n_batch=Lq, bs_in=B * D, bs_out=D)
+        if not self._defer_wgrads:   # (data parallel schedules them itself, bucket by bucket)
+            side.wait_stream(main)   # gate-gradient panels complete
+            with torch.cuda.stream(side):
+                self._gru_wgrads(w, B, Lq, seq, use_drop, range(n), emb=True)
         self._side_used = side is not main
         if self.mt == "SAIL":   # continues on the main stream into the encoder half
             # dH0 = sum over layers of (carry + dgh_0 W_hh): all layers as roles of ONE more launch
@@ -958,6 +924,56 @@ class Engine:
                 r.dgh_next16, r.w_hhT16 = L.dptr(w["dGH16"][l]), L.dptr(self.whhT16[l])
                 r.carry_t, r.dh0 = L.dptr(w["carry_l"][l]), L.dptr(w["dH0"])
             _call("ark_gru_diag_bwd", L.i32(pb), L.i32(n), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
+
+    def _gru_wgrads(self, w, B, Lq, seq, use_drop, layers, emb):
+        """weight gradients of the given GRU layers as ONE grouped launch on the current stream, plus
+        (emb=True) the input-embedding gradient, which needs layer 0's gate-gradient panel"""
+        D, n, V = self.D, self.n, self.V
+        R = Lq * B
+        p, g = self.p, self.g
+        pb = self.prec_bwd
+        KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
+        ld_seq = seq.shape[1]
+        ss = L.cur_stream()
+        yb = lambda l: (w["Y16b"][l] if w["Y16b"][l] is not None else w["Y16a"][l])
+        items = []
+        for l in layers:
+            if l == 0:
+                xin = w["X0b"] if w["X0b"] is not None else w["X0a"]
+            elif use_drop:
+                xin = w["Yd16b"][l - 1] if w["Yd16b"][l - 1] is not None else w["Yd16a"][l - 1]
+            else:
+                xin = yb(l - 1)[B:]
+            items += [(w["dGH16"][l], 3 * D, yb(l), D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R),
+                      (w["dGI16"][l], 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)]
+        if R % 64 == 0:
+            for i0 in range(0, len(items), 8):
+                self._wgrad_group(items[i0:i0 + 8])
+        else:
+            for (a, lda, x, ldx, out, ldo, M, N, K) in items:
+                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(a), L.i32(1), L.i64(lda), L.ptr(x), L.i32(1), L.i64(ldx), L.ptr(out),
+                      L.i64(ldo), L.i32(M), L.i32(N), L.i32(K), L.i32(1), ss)
+        if not emb:
+            return
+        if w["emb_gemm"]:
+            # dW_tok += onehot^T dX0 = (onehot^T dgi_0) W_ih_0: a [Vp,3D] reduction over the tokens on the
+            # matrix cores, then one small exact-fp32 product -- no [R,D] input gradient, no scatter
+            w["S_tok"].zero_()
+            _call("ark_onehot16", L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(w["onehot16"]), L.i32(B), L.i32(Lq),
+                  L.i32(self.Vp), ss)
+            _call("ark_wgrad16", L.i32(pb), L.ptr(w["onehot16"]), L.i64(self.Vp), L.ptr(w["dGI16"][0]), L.i64(3 * D),
+                  L.ptr(w["S_tok"]), L.i64(3 * D), L.i32(self.Vp), L.i32(3 * D), L.i32(R), ss)
+            _call("ark_gemm", L.i32(L.PREC_F32), L.i32(KM), L.i32(MM), L.i32(L.EPI_NONE), L.ptr(w["S_tok"]), L.i64(3 * D),
+                  L.ptr(p["dec.gru.weight_ih_l0"]), L.i64(D), L.ptr(g["dec.tok_emb.weight"]), L.i64(D), L.ptr(None),
+                  L.ptr(None), L.ptr(None), L.i32(V), L.i32(D), L.i32(3 * D), L.i32(1), ss)
+        else:
+            _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dGI16"][0]), L.i64(3 * D), L.ptr(self.wihT16[0]),
+                  L.i64(3 * D), L.ptr(w["dX0"]), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(3 * D),
+                  L.i32(0), ss)
+            _call("ark_tok_scatter", L.ptr(seq), L.i64(ld_seq), L.ptr(w["dX0"]), L.ptr(g["dec.tok_emb.weight"]), L.i32(B),
+                  L.i32(Lq), L.i32(D), L.i32(V), ss)
+            if self.mt == "ARK":
+                self._colsum(w["dX0"], D, g["dec.pos_emb.weight"], B, D, n_batch=Lq, bs_in=B * D, bs_out=D)
 
     def _layer_stream(self, l):
         while len(self._layer_streams) <= l:
@@ -992,39 +1008,63 @@ class Engine:
         if self.mt == "SAIL":
             self.set_hyper(kl_norm=1.0 / (B * self.world_size * self.Z))
 
-    def _dp_sync(self, stage, handle=None):
-        """bucketed gradient all-reduce (sum) over torch.distributed (RCCL): stage 0 launches the
-        decoder bucket asynchronously, stage 1 reduces the encoder bucket and waits for both."""
-        import torch.distributed as dist
-        off = self.layout.dec_grad_offset
-        if stage == 0:
-            return dist.all_reduce(self.G[off:], op=dist.ReduceOp.SUM, async_op=True)
-        if off > 0:
-            dist.all_reduce(self.G[:off], op=dist.ReduceOp.SUM)
-        handle.wait()
-        return None
+    def _dp_steps(self, triples, seq, eps, ce_count):
+        """Data-parallel schedule of one step as a generator: every next() launches the work that COMPLETES one
+        contiguous bucket [lo, hi) of the flat gradient buffer and yields it, so the caller can start that
+        bucket's all-reduce while the next bucket is still being computed.  The buckets tile [0, total).
+
+        SAIL on the diagonal path: the dependent chain goes first -- forward, decoder chain (biases, tied
+        projection, dh0), latent and encoder backward -> bucket [0, dec_grad_offset) -- and the GRU weight
+        gradients (one grouped launch that depends on no collective) + the token-embedding gradient last
+        -> bucket [dec_grad_offset, total): the larger (encoder) reduction rides underneath them and the
+        exposed one is the smaller.  Measured alternative, not kept: one bucket per MLP / GRU layer -- a
+        weight-gradient launch takes ~190 us whether it carries 2 or 6 products (every workgroup walks the
+        whole K = B*L alone), so per-layer launches cost more than the finer overlap returns
+        (1-rank step 1.76 ms vs 1.5 ms).  Other configurations: decoder bucket, then encoder bucket."""
+        tot, off = self.layout.total, self.layout.dec_grad_offset
+        self.forward(triples, seq, eps, ce_count=ce_count)
+        w = self.ws
+        if not (self.mt == "SAIL" and w["v2"] and w.get("diag") and self.diag_bwd):
+            more = self.backward_decoder()
+            self._join_side()
+            yield (off, tot)
+            if more:
+                self.backward_encoder()
+                yield (0, off)
+            return
+        self._defer_wgrads = True
+        try:
+            self.backward_decoder()
+        finally:
+            self._defer_wgrads = False
+        self.backward_encoder()   # (joins the side queue)
+        yield (0, off)
+        self._gru_wgrads(w, self._B, self._Lrun, self._seq, self.training and self.p_drop > 0, range(self.n), emb=True)
+        yield (off, tot)
 
     def train_step(self, triples, seq, eps=None, grad_sync=None, ce_count=None, dp=False):
         """forward + ELBO + backward (+ gradient all-reduce) + Adam.  Returns the device tensor
-        out4 = [loss, ce, kl, token-loss sum] (no host sync).  `dp=True`: bucketed all-reduce over the
-        default process group, overlapped with the encoder half of the backward pass; `grad_sync`: a
-        caller-supplied callable(flat_grad) run between backward and Adam."""
+        out4 = [loss, ce, kl, token-loss sum] (no host sync).  `dp=True`: bucketed all-reduce (sum) over
+        the default process group (RCCL), every bucket launched as soon as its gradients are complete
+        (`_dp_steps`); `grad_sync`: a caller-supplied callable(flat_grad) run between backward and Adam."""
         self._default_norms(seq.shape[0])
         if ce_count is not None:
             self.set_hyper(ce_count=ce_count)
-        w = self.forward(triples, seq, eps, ce_count=ce_count)
-        more = self.backward_decoder()
         if dp:
-            self._join_side()
-            h = self._dp_sync(0)
-        if more:
-            self.backward_encoder()
-        if dp:
-            self._dp_sync(1, h)
+            import torch.distributed as dist
+            handles = [dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+                       for lo, hi in self._dp_steps(triples, seq, eps, ce_count)]
+            self._dp_nseg = len(handles)
+            for h in handles:
+                h.wait()
+        else:
+            self.forward(triples, seq, eps, ce_count=ce_count)
+            if self.backward_decoder():
+                self.backward_encoder()
         if grad_sync is not None:
             grad_sync(self.G)
         self.adam()
-        return w["out4"]
+        return self.ws["out4"]
 
     def eval_loss(self, triples, seq, eps=None):
         self._default_norms(seq.shape[0])
@@ -1040,10 +1080,11 @@ class Engine:
     def capture_train_step(self, triples, seq, eps=None, ce_count=None, grad_sync=None, dp=False):
         """Capture the train step for fixed-address inputs into hipGraphs; returns replay().
 
-        Single process: ONE graph (fwd + bwd + Adam).  Data parallel (`dp=True`): three graphs --
-        [fwd + decoder bwd] | async all-reduce of the decoder-gradient bucket | [encoder bwd] |
-        all-reduce of the encoder bucket | [Adam] -- so the first collective rides underneath the
-        encoder backward.  `grad_sync` (callable) is the unbucketed alternative: [fwd+bwd] | call | [Adam].
+        Single process: ONE graph (fwd + bwd + Adam).  Data parallel (`dp=True`): one graph per gradient
+        bucket of `_dp_steps` with that bucket's asynchronous all-reduce launched right after its replay,
+        then [Adam] once all reductions have landed -- every collective except the last (smallest) bucket's
+        rides underneath the segments that follow it.  `grad_sync` (callable) is the unbucketed
+        alternative: [fwd+bwd] | call | [Adam].
         The caller refreshes the CONTENTS of `triples`, `seq`, `eps` in place between replays; step
         scalars live in the device `hyper` array."""
         self._default_norms(seq.shape[0])
@@ -1066,14 +1107,18 @@ class Engine:
 
         steps0 = self.adam_steps
         if dp:
-            more = [True]
-
-            def a():
-                self.forward(triples, seq, eps, ce_count=ce_count)
-                more[0] = self.backward_decoder()
-                self._join_side()
-            ga = cap(a)
-            gb = cap(self.backward_encoder) if more[0] else None
+            # one graph per bucket of the data-parallel schedule; the collectives run between the replays
+            segs = []
+            gen = self._dp_steps(triples, seq, eps, ce_count)
+            for _ in range(self._dp_nseg):   # (counted by the eager warm-up step above)
+                box = []
+                gseg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gseg):
+                    box.append(next(gen))
+                graphs.append(gseg)
+                segs.append((gseg, box[0]))
+            assert next(gen, None) is None, "data-parallel schedule changed between warm-up and capture"
+            ga, gb = None, None
             gc = cap(self.adam)
         elif grad_sync is not None:
             def a():
@@ -1101,14 +1146,18 @@ class Engine:
             if use is not cur:
                 use.wait_stream(cur)
             with torch.cuda.stream(use):
-                ga.replay()
                 if dp:
-                    h = self._dp_sync(0)
-                    if gb is not None:
-                        gb.replay()
-                    self._dp_sync(1, h)
-                elif grad_sync is not None:
-                    grad_sync(self.G)
+                    import torch.distributed as dist
+                    handles = []
+                    for gseg, (lo, hi) in segs:
+                        gseg.replay()
+                        handles.append(dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                    for h in handles:
+                        h.wait()
+                else:
+                    ga.replay()
+                    if grad_sync is not None:
+                        grad_sync(self.G)
                 if gc is not None:
                     gc.replay()
             if use is not cur:

@@ -161,6 +161,59 @@ def test_shard_gradients_sum_to_full_batch():
     assert (acc - full).abs().max() <= 2e-4 * scale, ((acc - full).abs().max(), scale)
 
 
+@pytest.mark.parametrize("dropout", [0.0])
+def test_dp_schedule_two_virtual_ranks(dropout):
+    """Engine._dp_steps (the bucket-by-bucket data-parallel schedule) on two virtual ranks in one process: the
+    ranks walk the schedule in lockstep, every yielded bucket is summed across them (what the all-reduce does),
+    then both run Adam.  The buckets must tile the gradient buffer, the ranks must stay identical, and the
+    result must equal the single-process step on the full batch."""
+    from oracle import sail_oracle as O
+    from ark_amd.engine import Engine
+    cfg = dict(_big_cfg(), dec_dropout=dropout, learning_rate=1e-3)
+    P = O.init_params(cfg, 0)
+    B = 256
+    triples, seq = synth_batch(cfg, B, seed=4)
+    torch.manual_seed(9)
+    eps = torch.randn(B, cfg["d_latent"])
+    count = int((seq[:, 1:] != 0).sum())
+    full = make_engine(cfg, P, "mixed", lr=1e-3)
+    dev = full.device
+    tri_d, seq_d, eps_d = triples.to(dev), seq.to(dev), eps.to(dev)
+    full.train_step(tri_d, seq_d, eps_d, ce_count=count)
+    ranks = []
+    for k in range(2):
+        e = Engine(dict(cfg), dev, precision="mixed", world_size=2)
+        e.load_params(P)
+        e.set_hyper(lr=1e-3)
+        ranks.append(e)
+    sl = [slice(0, B // 2), slice(B // 2, B)]
+    gens = []
+    for e, s_ in zip(ranks, sl):
+        e._default_norms(B // 2)
+        e.set_hyper(ce_count=count)
+        gens.append(e._dp_steps(tri_d[s_].contiguous(), seq_d[s_].contiguous(), eps_d[s_].contiguous(), count))
+    covered = []
+    for spans in zip(*gens):
+        assert spans[0] == spans[1]
+        lo, hi = spans[0]
+        torch.cuda.synchronize()
+        tot = ranks[0].G[lo:hi] + ranks[1].G[lo:hi]
+        ranks[0].G[lo:hi] = tot
+        ranks[1].G[lo:hi] = tot
+        covered.append((lo, hi))
+    covered.sort()
+    assert covered[0][0] == 0 and covered[-1][1] == full.layout.total
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), covered
+    assert len(covered) == 2
+    gd = (ranks[0].G - full.G).abs().max().item()
+    assert gd <= 3e-3 * full.G.abs().max().item(), gd
+    for e in ranks:
+        e.adam()
+    torch.cuda.synchronize()
+    assert torch.equal(ranks[0].P, ranks[1].P)
+    assert (ranks[0].P - full.P).abs().max().item() <= 2.5e-3   # Adam's first step moves every weight by ~lr
+
+
 def test_graph_replay_matches_eager():
     from oracle import sail_oracle as O
     cfg = _big_cfg()
