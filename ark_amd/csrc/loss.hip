@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void zproj_bwd_dz_kernel(float* __restrict__ d
 //   dhead = d(beta*kl)/d(mu,logv) + dz through the reparameterisation (+ external dmu/dlogv)
 //   dA  = (dhead W_head) * gelu'(pre)   (heads models.py:43-44, last MLP activation models.py:32-41)
 // The reductions over the batch (dWz, dbz, db_head, dW_head) only need dzp / dhead and run elsewhere.
-template <int ZT>
+template <int ZT, int RW>   // RW rows per workgroup (waves RW..3 only help with the dA columns)
 __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict__ dh0, const float* __restrict__ h0,
                                                                const float* __restrict__ Wz, const float* __restrict__ head,
                                                                const float* __restrict__ eps, const float* __restrict__ hyper,
@@ -123,14 +123,15 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
                                                                const float* __restrict__ Whead, const float* __restrict__ pre,
                                                                float* __restrict__ dhead, float* __restrict__ dA, void* dA16,
                                                                int prec16, int B, int Z, int D, int H) {
-  __shared__ float sh[4][2 * ZT];
+  __shared__ float sh[RW][2 * ZT];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + wave;
-  const bool valid = b < B;
+  const int b = blockIdx.x * RW + wave;
+  const bool valid = wave < RW && b < B;
   const int bb = valid ? b : B - 1;
   float acc[ZT];
 #pragma unroll
   for (int j = 0; j < ZT; ++j) acc[j] = 0.f;
+  if (wave < RW)
   for (int d = lane; d < D; d += 64) {
     const long i = (long)bb * D + d;
     const float h = h0[i];
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
       const float a = wave_sum(acc[j]);
       if (lane == j) mydz = a;
     }
-  if (lane < Z) {
+  if (wave < RW && lane < Z) {
     const float ks = hyper[ARK_HP_BETA] * hyper[ARK_HP_KL_NORM];  // beta / (B_global * Z)
     const float m = head[(long)bb * 2 * Z + lane];
     const float raw = head[(long)bb * 2 * Z + Z + lane];
@@ -168,24 +169,43 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
     }
   }
   __syncthreads();
-  // dA for the workgroup's 4 rows: thread -> column (every W_head element is loaded once per workgroup
-  // and used for all 4 rows; dhead rows are LDS broadcasts)
-  const int row0 = blockIdx.x * 4;
-  for (int c = threadIdx.x; c < H; c += 256) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int j = 0; j < 2 * Z; ++j) {
-      const float wv = Whead[(long)j * H + c];
-      s0 += sh[0][j] * wv; s1 += sh[1][j] * wv; s2 += sh[2][j] * wv; s3 += sh[3][j] * wv;
-    }
-    const float sv[4] = {s0, s1, s2, s3};
+  // dA for the workgroup's 4 rows: thread -> KC columns at a time (every W_head element is loaded once per
+  // workgroup and used for all 4 rows; each dhead value is one LDS broadcast per KC columns)
+  const int row0 = blockIdx.x * RW;
+  constexpr int KC = 6;
+  for (int cb = 0; cb < H; cb += 256 * KC) {
+    float acc4[KC][RW];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (row0 + r >= B) break;
-      const long o = (long)(row0 + r) * H + c;
-      const float v = sv[r] * dgelu_erf(pre[o]);
-      dA[o] = v;
-      if (prec16 == 2) reinterpret_cast<_Float16*>(dA16)[o] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-      else reinterpret_cast<__bf16*>(dA16)[o] = (__bf16)v;
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+      for (int r = 0; r < RW; ++r) acc4[k][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2 * ZT; ++j)
+      if (j < 2 * Z) {
+        float dj[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) dj[r] = sh[r][j];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+          const int c = cb + 256 * k + threadIdx.x;
+          const float wv = (c < H) ? Whead[(long)j * H + c] : 0.f;
+#pragma unroll
+          for (int r = 0; r < RW; ++r) acc4[k][r] += dj[r] * wv;
+        }
+      }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int c = cb + 256 * k + threadIdx.x;
+      if (c >= H) continue;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        if (row0 + r >= B) break;
+        const long o = (long)(row0 + r) * H + c;
+        const float v = acc4[k][r] * dgelu_erf(pre[o]);
+        dA[o] = v;
+        if (prec16 == 2) reinterpret_cast<_Float16*>(dA16)[o] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+        else reinterpret_cast<__bf16*>(dA16)[o] = (__bf16)v;
+      }
     }
   }
 }
@@ -423,7 +443,7 @@ extern "C" int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_
   if (Z > 64) return ARK_ERR_SHAPE;
   if (prec16 != 1 && prec16 != 2) return ARK_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-#define ARK_LC(ZT) hipLaunchKernelGGL(latent_chain_bwd_kernel<ZT>, dim3((B + 3) / 4), dim3(256), 0, st, dh0, h0, w_z, head, eps, hyper, ext_dhead, w_head, pre, dhead, dA, dA16, prec16, B, Z, D, H)
+#define ARK_LC(ZT) hipLaunchKernelGGL((latent_chain_bwd_kernel<ZT, 2>), dim3((B + 1) / 2), dim3(256), 0, st, dh0, h0, w_z, head, eps, hyper, ext_dhead, w_head, pre, dhead, dA, dA16, prec16, B, Z, D, H)
   if (Z <= 16) ARK_LC(16);
   else if (Z <= 32) ARK_LC(32);
   else ARK_LC(64);
