@@ -159,9 +159,13 @@ class Engine:
                 self.wmT16 = [i16(H, H) for _ in range(self.n)]     # their transposes, backward type
                 self.wh16 = i16(2 * self.Z, H)                      # [mu; logv] head, forward type
             self._shadow_jobs = self._build_shadow_jobs()
+            self._shadow_jobs_part = {"dec": self._build_shadow_jobs("dec"), "enc": self._build_shadow_jobs("enc")}
         self._shadow_ok = False
         self._side = None
         self._side_used = False
+        self._dp_pending = None      # data parallel: the decoder bucket's reduction + Adam still owed (see dp_flush)
+        self._dp_flush_graph = None
+        self.dp_pipeline = bool(cfg.get("ark_dp_pipeline", True))
         self._defer_wgrads = False
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
         self._layer_streams = []
@@ -172,6 +176,7 @@ class Engine:
 
     # ------------------------------------------------------------------ parameters
     def load_params(self, named):
+        self.dp_flush()
         with torch.no_grad():
             for k, v in named.items():
                 if k == "dec.out.weight" and self.layout.tied:
@@ -181,16 +186,20 @@ class Engine:
 
     def mark_params_dirty(self):
         """call after anything other than Engine.adam() changed the parameters"""
+        self.dp_flush()
         self._shadow_ok = False
 
-    def _build_shadow_jobs(self):
+    def _build_shadow_jobs(self, which="all"):
+        """16-bit shadow refresh jobs: `dec` = GRU + tied vocabulary weights (gradient bucket
+        [dec_grad_offset, total)), `enc` = encoder MLP + heads, `all` = both."""
         import ctypes
         jobs = []
-        for l in range(self.n):
-            jobs.append((self.p[f"dec.gru.weight_ih_l{l}"], self.wih16[l], self.wihT16[l], 3 * self.D, self.D))
-            jobs.append((self.p[f"dec.gru.weight_hh_l{l}"], self.whh16[l], self.whhT16[l], 3 * self.D, self.D))
-        jobs.append((self.p["dec.out.weight"], self.wtok16, self.wtokT16, self.V, self.D, self.Vp))
-        if self.mt == "SAIL":
+        if which in ("all", "dec"):
+            for l in range(self.n):
+                jobs.append((self.p[f"dec.gru.weight_ih_l{l}"], self.wih16[l], self.wihT16[l], 3 * self.D, self.D))
+                jobs.append((self.p[f"dec.gru.weight_hh_l{l}"], self.whh16[l], self.whhT16[l], 3 * self.D, self.D))
+            jobs.append((self.p["dec.out.weight"], self.wtok16, self.wtokT16, self.V, self.D, self.Vp))
+        if self.mt == "SAIL" and which in ("all", "enc"):
             H = 3 * self.D
             for i in range(self.n):
                 jobs.append((self.p[f"enc.mlp.{2 * i}.weight"], self.wm16[i], self.wmT16[i], H, H))
@@ -210,11 +219,13 @@ class Engine:
             chunks.append((n, src, dst, dstT, R, C, pf, pb, ldT))
         return chunks
 
-    def refresh_shadows(self):
+    def refresh_shadows(self, which="all"):
         if self.use_dma:
-            for (n, src, dst, dstT, R, C, pf, pb, ldT) in self._shadow_jobs:
+            jobs = self._shadow_jobs if which == "all" else self._shadow_jobs_part[which]
+            for (n, src, dst, dstT, R, C, pf, pb, ldT) in jobs:
                 _call("ark_weight_shadows", L.i32(n), src, dst, dstT, R, C, pf, pb, ldT, L.cur_stream())
-        self._shadow_ok = True
+        if which == "all":
+            self._shadow_ok = True
 
     def set_hyper(self, lr=None, beta=None, kl_norm=None, ce_count=None, grad_scale=None):
         """update device-resident step scalars (tiny async fills, only when a value changes)"""
@@ -335,6 +346,15 @@ class Engine:
     def forward(self, triples, seq, eps=None, with_loss=True, with_dlogits=True, L_run=None, ce_count=None):
         """Launch the forward pass.  triples [B,T,3] int64 (SAIL), seq [B,seq_len] int64 (device).
         Results stay on the device in the workspace (out4 = loss, ce, kl, token-loss sum)."""
+        for _ in self._forward_steps(triples, seq, eps, with_loss, with_dlogits, L_run, ce_count):
+            self.dp_flush()   # a decoder-bucket update still owed by a data-parallel step lands before the decoder runs
+        return self.ws
+
+    def _forward_steps(self, triples, seq, eps=None, with_loss=True, with_dlogits=True, L_run=None, ce_count=None):
+        """forward() as a generator with ONE seam: it yields after the encoder half (encoder MLP, heads, latent,
+        z-projection: parameters of the gradient bucket [0, dec_grad_offset)) and before the decoder half (GRU,
+        vocabulary projection: the other bucket).  The pipelined data-parallel step finishes the previous
+        step's decoder-bucket all-reduce + Adam in that seam."""
         self.prec = self.prec_fwd
         self._dlog16_valid = False
         if not self._shadow_ok:
@@ -396,6 +416,8 @@ class Engine:
                     w["Y16a"][l][:B].zero_()
                     if w["Y16b"][l] is not None:
                         w["Y16b"][l][:B].zero_()
+        yield
+        st = L.cur_stream()
         self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop)
         if with_loss:
             if ce_count is None:
@@ -408,7 +430,6 @@ class Engine:
             self._dlog16_valid = d16 is not None
             _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R), L.ptr(w["kl"] if self.mt == "SAIL" else None),
                   L.ptr(self.hyper), L.ptr(w["out4"]), st)
-        return w
 
     def _decode_h0(self, w, z, B):
         p = self.p
@@ -996,12 +1017,43 @@ class Engine:
 
     # ------------------------------------------------------------------ optimiser
     def adam(self):
+        self.dp_flush()
         st = L.cur_stream()
         _call("ark_adam_tick", L.ptr(self.hyper), st)
         _call("ark_adam_step", L.ptr(self.P), L.ptr(self.G), L.ptr(self.M), L.ptr(self.Vv), L.i64(self.layout.total),
               L.ptr(self.hyper), st)
         self.adam_steps += 1
         self.refresh_shadows()
+
+    def _adam_part(self, which):
+        """Adam + shadow refresh of ONE gradient bucket (pipelined data parallel): `enc` = [0, dec_grad_offset)
+        comes first and ticks the step counter, `dec` = [dec_grad_offset, total) follows with the same
+        step scalars -- together exactly adam()."""
+        st = L.cur_stream()
+        off, tot = self.layout.dec_grad_offset, self.layout.total
+        if which == "enc":
+            _call("ark_adam_tick", L.ptr(self.hyper), st)
+            lo, hi = 0, off
+            self.adam_steps += 1
+        else:
+            lo, hi = off, tot
+        _call("ark_adam_step", L.ptr(self.P[lo:]), L.ptr(self.G[lo:]), L.ptr(self.M[lo:]), L.ptr(self.Vv[lo:]), L.i64(hi - lo),
+              L.ptr(self.hyper), st)
+        self.refresh_shadows(which)
+
+    def dp_flush(self):
+        """Finish a pipelined data-parallel step: wait for the decoder bucket's all-reduce and apply its Adam
+        update.  Called automatically before anything reads the decoder parameters (the seam of the next
+        forward, adam(), load_params, mark_params_dirty); call it yourself before reading parameters
+        from outside the engine (checkpoints, state_dict)."""
+        if self._dp_pending is None:
+            return
+        h, self._dp_pending = self._dp_pending, None
+        h.wait()
+        if self._dp_flush_graph is not None:
+            self._dp_flush_graph.replay()
+        else:
+            self._adam_part("dec")
 
     # ------------------------------------------------------------------ whole step
     def _default_norms(self, B):
@@ -1022,7 +1074,11 @@ class Engine:
         whole K = B*L alone), so per-layer launches cost more than the finer overlap returns
         (1-rank step 1.76 ms vs 1.5 ms).  Other configurations: decoder bucket, then encoder bucket."""
         tot, off = self.layout.total, self.layout.dec_grad_offset
-        self.forward(triples, seq, eps, ce_count=ce_count)
+        fwd = self._forward_steps(triples, seq, eps, ce_count=ce_count)
+        next(fwd)
+        yield "seam"   # (encoder half done; the caller finishes the previous step's decoder bucket here)
+        for _ in fwd:
+            pass
         w = self.ws
         if not (self.mt == "SAIL" and w["v2"] and w.get("diag") and self.diag_bwd):
             more = self.backward_decoder()
@@ -1052,10 +1108,24 @@ class Engine:
             self.set_hyper(ce_count=ce_count)
         if dp:
             import torch.distributed as dist
-            handles = [dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
-                       for lo, hi in self._dp_steps(triples, seq, eps, ce_count)]
-            self._dp_nseg = len(handles)
-            for h in handles:
+            handles = {}
+            nseg = 0
+            for item in self._dp_steps(triples, seq, eps, ce_count):
+                nseg += 1
+                if item == "seam":
+                    self.dp_flush()
+                    continue
+                handles[item] = dist.all_reduce(self.G[item[0]:item[1]], op=dist.ReduceOp.SUM, async_op=True)
+            self._dp_nseg = nseg
+            off, tot = self.layout.dec_grad_offset, self.layout.total
+            if self.dp_pipeline and grad_sync is None and set(handles) == {(0, off), (off, tot)}:
+                # Adam of the encoder bucket now; the decoder bucket's reduction keeps flying underneath it and
+                # the next step's encoder forward, and is finished in that forward's seam (dp_flush)
+                handles[(0, off)].wait()
+                self._adam_part("enc")
+                self._dp_pending = handles[(off, tot)]
+                return self.ws["out4"]
+            for h in handles.values():
                 h.wait()
         else:
             self.forward(triples, seq, eps, ce_count=ce_count)
@@ -1083,8 +1153,9 @@ class Engine:
         Single process: ONE graph (fwd + bwd + Adam).  Data parallel (`dp=True`): one graph per gradient
         bucket of `_dp_steps` with that bucket's asynchronous all-reduce launched right after its replay,
         then [Adam] once all reductions have landed -- every collective except the last (smallest) bucket's
-        rides underneath the segments that follow it.  `grad_sync` (callable) is the unbucketed
-        alternative: [fwd+bwd] | call | [Adam].
+        rides underneath the segments that follow it.  With `ark_dp_pipeline` (default) the decoder bucket's
+        reduction and Adam are finished in the NEXT step's forward seam (see dp_flush; call Engine.dp_flush()
+        after the last step).  `grad_sync` (callable) is the unbucketed alternative: [fwd+bwd] | call | [Adam].
         The caller refreshes the CONTENTS of `triples`, `seq`, `eps` in place between replays; step
         scalars live in the device `hyper` array."""
         self._default_norms(seq.shape[0])
@@ -1094,6 +1165,7 @@ class Engine:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up outside capture (allocates the workspace)
             self.train_step(triples, seq, eps, ce_count=ce_count, grad_sync=grad_sync, dp=dp)
+            self.dp_flush()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graphs = []
@@ -1118,8 +1190,14 @@ class Engine:
                 graphs.append(gseg)
                 segs.append((gseg, box[0]))
             assert next(gen, None) is None, "data-parallel schedule changed between warm-up and capture"
+            off, tot = self.layout.dec_grad_offset, self.layout.total
+            pipelined = self.dp_pipeline and {it for _, it in segs if it != "seam"} == {(0, off), (off, tot)}
             ga, gb = None, None
-            gc = cap(self.adam)
+            if pipelined:
+                gc = cap(lambda: self._adam_part("enc"))
+                self._dp_flush_graph = cap(lambda: self._adam_part("dec"))
+            else:
+                gc = cap(self.adam)
         elif grad_sync is not None:
             def a():
                 self.forward(triples, seq, eps, ce_count=ce_count)
@@ -1148,18 +1226,27 @@ class Engine:
             with torch.cuda.stream(use):
                 if dp:
                     import torch.distributed as dist
-                    handles = []
-                    for gseg, (lo, hi) in segs:
+                    handles = {}
+                    for gseg, item in segs:
                         gseg.replay()
-                        handles.append(dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
-                    for h in handles:
-                        h.wait()
+                        if item == "seam":
+                            self.dp_flush()   # previous step's decoder bucket: wait for its reduction, replay its Adam
+                        else:
+                            handles[item] = dist.all_reduce(self.G[item[0]:item[1]], op=dist.ReduceOp.SUM, async_op=True)
+                    if pipelined:
+                        handles[(0, off)].wait()
+                        gc.replay()
+                        self._dp_pending = handles[(off, tot)]
+                    else:
+                        for h in handles.values():
+                            h.wait()
+                        gc.replay()
                 else:
                     ga.replay()
                     if grad_sync is not None:
                         grad_sync(self.G)
-                if gc is not None:
-                    gc.replay()
+                    if gc is not None:
+                        gc.replay()
             if use is not cur:
                 cur.wait_stream(use)
             self.adam_steps += 1

@@ -254,6 +254,7 @@ def main():
         for i in range(args.steps):
             feed(args.warmup + i)
             out4 = step()
+        eng.dp_flush()   # pipelined data parallel: the last step's decoder-bucket update is part of the K steps
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

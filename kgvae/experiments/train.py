@@ -133,6 +133,7 @@ def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), ma
         nb += 1
         if max_steps and nb >= max_steps:
             break
+    model.engine().dp_flush()    # pipelined data parallel: land the last step's decoder-bucket update
     if nranks > 1:
         import torch.distributed as dist
         dist.all_reduce(sums)    # token-loss sums add up; ce/loss are re-derived below
