@@ -131,6 +131,47 @@ def test_elbo_parity_b1024(precision, tol):
     assert rel_err(float(out4[0]), float(loss)) < tol, (out4, float(loss), float(ce), float(kl))
 
 
+@pytest.mark.parametrize("precision,rel,cos", [("mixed", 1.5e-2, 0.9998), ("f32", 3e-4, 0.999999)])
+def test_gradients_match_oracle_fast_path(precision, rel, cos):
+    """every parameter's gradient of the shipped fast path (layer-diagonal kernels, 16-bit operands, token
+    reduction on MFMA, fused latent backward, two queues) against the CPU oracle's autograd on the same
+    weights / batch / eps at the syn-paths model size: norm-relative error and cosine per tensor.  The
+    tolerance of the mixed mode is the bf16 operand rounding of the backward products (2^-9 per operand)."""
+    from oracle import sail_oracle as O
+    cfg = dict(_big_cfg(), dec_dropout=0.0)
+    P = O.init_params(cfg, 0)
+    B = 128
+    triples, seq = synth_batch(cfg, B, seed=6)
+    torch.manual_seed(12)
+    eps = torch.randn(B, cfg["d_latent"])
+    eng = make_engine(cfg, P, precision)
+    dev = eng.device
+    eng.set_hyper(beta=0.5)
+    eng._default_norms(B)
+    eng.forward(triples.to(dev), seq.to(dev), eps.to(dev))
+    eng.backward()
+    torch.cuda.synchronize()
+    got = {k: v.detach().double().cpu().clone() for k, v in eng.g.items()}
+    Pc = O._detach_tied(P, True)
+    leaves = O.leaf_params(Pc)
+    for _, t in leaves:
+        t.requires_grad_(True)
+    loss, *_ = O.sail_elbo(Pc, triples, seq, eps, 0.5, cfg)
+    loss.backward()
+    checked = 0
+    for k, t in leaves:
+        want = t.grad.double()
+        g = got[k]
+        nw = want.norm().item()
+        if nw < 1e-12:
+            assert g.norm().item() < 1e-9, k
+            continue
+        assert (g - want).norm().item() <= rel * nw, (k, (g - want).norm().item() / nw)
+        assert torch.dot(g.flatten(), want.flatten()).item() / (g.norm().item() * nw) >= cos, k
+        checked += 1
+    assert checked >= 20
+
+
 def test_shard_gradients_sum_to_full_batch():
     """size-independent DP property at B=1024: gradients of 4 shards (global CE count and global
     KL normaliser) sum to the full-batch gradient."""
