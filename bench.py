@@ -331,6 +331,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(dict(cfg, dec_dropout=0.0), B, steps=args.cpu_steps)
         print(json.dumps(res))
     if dist is not None:
+        dist.barrier()   # leave together: rank 0 is still timing its dominant kernel while the others are done
         dist.destroy_process_group()
 
 
