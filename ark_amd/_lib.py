@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libark_amd.so")
+# ARK_AMD_LIB: explicit path of an alternative build of the SAME library (timing ablations, tools/ablate_diag.sh)
+LIB_PATH = os.environ.get("ARK_AMD_LIB") or os.path.join(_HERE, "lib", "libark_amd.so")
 
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 LAY_KMAJ, LAY_MMAJ = 0, 1

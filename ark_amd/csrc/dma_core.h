@@ -130,17 +130,33 @@ struct DmaTile {
       for (int s2 = 0; s2 < 2 * KI; ++s2) {
         typename PT::h8 a[TM], b[TN];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm) {
+#if defined(ARK_ABL) && (ARK_ABL & 1)
+          a[tm] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f});
+#else
           a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + (s2 >> 1) * A_IMG +
                                                             lds_off(wm * WTM + tm * 16 + lr, 4 * (s2 & 1) + lq));
+#endif
+        }
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+        for (int tn = 0; tn < TN; ++tn) {
+#if defined(ARK_ABL) && (ARK_ABL & 2)
+          b[tn] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f + tn});
+#else
           b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + (s2 >> 1) * B_IMG +
                                                             lds_off(wn * WTN + tn * 16 + lr, 4 * (s2 & 1) + lq));
+#endif
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = PT::mfma(a[tm], b[tn], acc[tm][tn]);
+          for (int tn = 0; tn < TN; ++tn) {
+#if defined(ARK_ABL) && (ARK_ABL & 4)
+            acc[tm][tn][0] += (float)a[tm][0] * (float)b[tn][0];
+#else
+            acc[tm][tn] = PT::mfma(a[tm], b[tn], acc[tm][tn]);
+#endif
+          }
       }
       if (s + NBUF < NS) {
         // every wave has consumed ring slot s%NBUF (its fragment reads are complete) -> refill it
@@ -179,6 +195,9 @@ struct DmaTile {
     }
     const int NS1 = K1 / KS, NS = NS1 + K2 / KS;   // host guarantees K1 % KS == 0 && K2 % KS == 0
     auto issue = [&](int s) {
+#if defined(ARK_ABL) && (ARK_ABL & 8)
+      return;
+#endif
       char* base = lds + (s % NBUF) * STAGE_BYTES;
       const bool first = s < NS1;
       const h_t* A = first ? A1 : A2;
@@ -207,17 +226,33 @@ struct DmaTile {
       for (int s2 = 0; s2 < 2 * KI; ++s2) {
         typename PT::h8 a[TM], b[TN];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm) {
+#if defined(ARK_ABL) && (ARK_ABL & 1)
+          a[tm] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f});
+#else
           a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + (s2 >> 1) * A_IMG +
                                                             lds_off(wm * WTM + tm * 16 + lr, 4 * (s2 & 1) + lq));
+#endif
+        }
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+        for (int tn = 0; tn < TN; ++tn) {
+#if defined(ARK_ABL) && (ARK_ABL & 2)
+          b[tn] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f + tn});
+#else
           b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + (s2 >> 1) * B_IMG +
                                                             lds_off(wn * WTN + tn * 16 + lr, 4 * (s2 & 1) + lq));
+#endif
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = PT::mfma(a[tm], b[tn], acc[tm][tn]);
+          for (int tn = 0; tn < TN; ++tn) {
+#if defined(ARK_ABL) && (ARK_ABL & 4)
+            acc[tm][tn][0] += (float)a[tm][0] * (float)b[tn][0];
+#else
+            acc[tm][tn] = PT::mfma(a[tm], b[tn], acc[tm][tn]);
+#endif
+          }
       }
     };
     for (int s = 0; s < NS; ++s) {
@@ -263,6 +298,9 @@ struct DmaTile {
     }
     const int NS1 = K1 / KS, NS = NS1 + K2 / KS;   // host guarantees K1 % KS == 0 && K2 % KS == 0
     auto issue = [&](int s) {
+#if defined(ARK_ABL) && (ARK_ABL & 8)
+      return;
+#endif
       char* base = lds + (s % NBUF) * STAGE_BYTES;
       const bool first = s < NS1;
       const h_t* A = first ? A1 : A2;
@@ -281,6 +319,9 @@ struct DmaTile {
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int tn = 0; tn <= TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if defined(ARK_ABL) && (ARK_ABL & 64)
+    return;
+#endif
     if (NS <= 0) return;
     const int pre = NS < NBUF ? NS : NBUF;
     for (int s = 0; s < pre; ++s) issue(s);
@@ -291,20 +332,34 @@ struct DmaTile {
       for (int s2 = 0; s2 < 2 * KI; ++s2) {
         typename PT::h8 a[TM], b[TN];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm) {
+#if defined(ARK_ABL) && (ARK_ABL & 1)
+          a[tm] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f});
+#else
           a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + (s2 >> 1) * A_IMG +
                                                             lds_off(wm * WTM + tm * 16 + lr, 4 * (s2 & 1) + lq));
+#endif
+        }
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+        for (int tn = 0; tn < TN; ++tn) {
+#if defined(ARK_ABL) && (ARK_ABL & 2)
+          b[tn] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f + tn});
+#else
           b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + (s2 >> 1) * B_IMG +
                                                             lds_off(wn * WTN + tn * 16 + lr, 4 * (s2 & 1) + lq));
+#endif
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn) {
             constexpr int LC = decltype(last_col)::value;
             const int c = (tn == TN - 1) ? LC : tn;
+#if defined(ARK_ABL) && (ARK_ABL & 4)
+            acc[tm][c][0] += (float)a[tm][0] * (float)b[tn][0];
+#else
             acc[tm][c] = PT::mfma(a[tm], b[tn], acc[tm][c]);
+#endif
           }
       }
     };

@@ -9,6 +9,11 @@
 // is the forward cell of gru_dma.hip.  Reference op replaced: torch.nn.GRU (kgvae/model/models.py:121-127).
 #include "dma_core.h"
 #include "../../include/ark_amd.h"
+#ifdef ARK_ABL
+#define ARK_ABL_V ARK_ABL
+#else
+#define ARK_ABL_V 0
+#endif
 
 namespace ark {
 
@@ -31,6 +36,7 @@ __global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagAr
   using h_t = typename G::h_t;
   using hb_t = typename PrecTraits<PRECB>::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (ARK_ABL_V & 32) return;
   const int B = p.B, D = p.D;
   const int UT = D / BU, MT = (B + BM - 1) / BM;
   int role, mt, ut;
@@ -96,6 +102,7 @@ __global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagAr
                  [=](int r) -> long { return (long)min(m0 + r, B - 1); },
                  [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); }, smem);
 
+  if (ARK_ABL_V & 128) return;
   __syncthreads();   // ring is free: reuse it to assemble row-major 16-bit rows [BM][32+pad]
   constexpr int TS = BU + 8;   // row stride in elements: 16-B aligned rows, spreads banks
   constexpr int ARR = BM * TS * 2;
@@ -122,8 +129,10 @@ __global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagAr
       n[i] = tanhf(acc[tm][2][i] + bin + r[i] * hn[i]);
       h[i] = (1.0f - z[i]) * n[i] + z[i] * hpv[i];
     }
+#if !(defined(ARK_ABL) && (ARK_ABL & 16))
     *reinterpret_cast<f32x4*>(R.y_out_t + o[tm]) = h;
-    if (sr) {
+#endif
+    if (sr && !(ARK_ABL_V & 16)) {
       *reinterpret_cast<dhalf4_t*>(sr + o[tm]) = dhalf4_t{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
       *reinterpret_cast<dhalf4_t*>(sz + o[tm]) = dhalf4_t{(_Float16)z[0], (_Float16)z[1], (_Float16)z[2], (_Float16)z[3]};
       *reinterpret_cast<dhalf4_t*>(sn + o[tm]) = dhalf4_t{(_Float16)n[0], (_Float16)n[1], (_Float16)n[2], (_Float16)n[3]};
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagAr
   for (int r0 = 0; r0 < BM; r0 += RPP) {
     const int rr = r0 + t / CPR, ch = t % CPR;
     const int row = m0 + rr;
-    if (rr < BM && row < B) {
+    if (rr < BM && row < B && !(ARK_ABL_V & 16)) {
       const long go = (long)row * D + u0 + ch * 8;
       *reinterpret_cast<uint4*>(reinterpret_cast<h_t*>(R.y16a) + go) = *reinterpret_cast<const uint4*>(ta + rr * TS + ch * 8);
       if (R.y16b) *reinterpret_cast<uint4*>(reinterpret_cast<hb_t*>(R.y16b) + go) = *reinterpret_cast<const uint4*>(tb + rr * TS + ch * 8);
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagAr
 }
 
 // measured on MI355X (syn-paths, B=1024): see DESIGN.md section 6
-static int g_diag_rows = 64, g_diag_ki = 2, g_diag_nbuf = 2, g_diag_xcd = 1, g_diag_units = 32;
+static int g_diag_rows = 64, g_diag_ki = 1, g_diag_nbuf = 2, g_diag_xcd = 1, g_diag_units = 32;
 
 template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU>
 static void launch_diag(const GruDiagArgs& p, hipStream_t st) {

@@ -326,7 +326,7 @@ def test_in_kernel_dropout_is_consistent_forward_and_backward():
         assert torch.allclose(dropped, plain * ref, rtol=1e-6, atol=1e-7)
 
 
-DIAG_DEFAULT = (64, 2, 2, 1, 32)   # library defaults (rows, ki, nbuf, xcd_map, units) of the forward diagonal kernel
+DIAG_DEFAULT = (64, 1, 2, 1, 32)   # library defaults (rows, ki, nbuf, xcd_map, units) of the forward diagonal kernel
 
 
 @pytest.mark.parametrize("rows,ki,nbuf,xcd,units", [(32, 2, 2, 0, 32), (64, 1, 2, 0, 32), (64, 2, 2, 1, 32), (32, 1, 4, 1, 32),
