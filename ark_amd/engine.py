@@ -167,6 +167,8 @@ class Engine:
         self._dp_flush_graph = None
         self.dp_pipeline = bool(cfg.get("ark_dp_pipeline", True))
         self._defer_wgrads = False
+        self._fork_pending = None
+        self.fork_after = int(cfg.get("ark_fork_after", 1))   # measured: 0 -> 1.281, 1 -> 1.266, 2 -> 1.296 ms/step
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
         self._layer_streams = []
         self.diag_cells = bool(cfg.get("ark_diag_cells", True))
@@ -668,6 +670,8 @@ class Engine:
                   L.ptr(self._eps), L.ptr(self.hyper), L.ptr(ext), L.ptr(p["enc.mu.weight"]), L.ptr(w["pre"][n - 1]),
                   L.ptr(w["dhead"]), L.ptr(w["dA"]), L.ptr(w["dpre16"][n - 1]), L.i32(pb), L.i32(B), L.i32(Z), L.i32(D),
                   L.i32(H), st)
+            if self._fork_pending is not None:
+                self._fork_pending()
             main = torch.cuda.current_stream()
             side = self._side_stream() if self.overlap_wgrad else main
             side.wait_stream(main)
@@ -680,6 +684,8 @@ class Engine:
                       L.i64(H), L.ptr(g["enc.mu.weight"]), L.i64(H), L.i32(2 * Z), L.i32(H), L.i32(B), L.i32(1), ss)
             self._side_used = self._side_used or (side is not main)
         else:
+            if self._fork_pending is not None:
+                self._fork_pending()
             _call("ark_zproj_bwd", L.ptr(w["dH0"]), L.ptr(h0rm), L.ptr(w["z"]), L.ptr(p["dec.z_proj.weight"]),
                   L.ptr(w["dz"]), L.ptr(g["dec.z_proj.weight"]), L.ptr(g["dec.z_proj.bias"]), L.i32(B), L.i32(Z), L.i32(D), L.i32(1), st)
             _call("ark_latent_bwd", L.ptr(w["dz"]), L.ptr(w["head"]), L.ptr(self._eps), L.ptr(self.hyper), L.ptr(w["dhead"]),
@@ -932,11 +938,23 @@ class Engine:
                 r.drop_p = self.p_drop if drop else 0.0
                 k += 1
             _call("ark_gru_diag_bwd", L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
-        if not self._defer_wgrads:   # (data parallel schedules them itself, bucket by bucket)
-            side.wait_stream(main)   # gate-gradient panels complete
+        def fork_wgrads():
+            # the big weight-gradient launch starves small dependent kernels that run beside it (the 13-us dh0
+            # launch took 83 us: its 48 KB of LDS do not fit next to two 64-KB weight-gradient workgroups), so it
+            # is forked off the main queue only after that launch (fork_after: 0 right after the diagonals,
+            # 1 after the dh0 roles, 2 after the latent kernel as well)
+            side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self._gru_wgrads(w, B, Lq, seq, use_drop, range(n), emb=True)
+            self._side_used = side is not main
+            self._fork_pending = None
         self._side_used = side is not main
+        self._fork_pending = None
+        if not self._defer_wgrads:   # (data parallel schedules them itself, bucket by bucket)
+            if self.mt == "SAIL" and self.fork_after > 0 and side is not main:
+                self._fork_pending = fork_wgrads
+            else:
+                fork_wgrads()
         if self.mt == "SAIL":   # continues on the main stream into the encoder half
             # dH0 = sum over layers of (carry + dgh_0 W_hh): all layers as roles of ONE more launch
             roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
@@ -945,6 +963,8 @@ class Engine:
                 r.dgh_next16, r.w_hhT16 = L.dptr(w["dGH16"][l]), L.dptr(self.whhT16[l])
                 r.carry_t, r.dh0 = L.dptr(w["carry_l"][l]), L.dptr(w["dH0"])
             _call("ark_gru_diag_bwd", L.i32(pb), L.i32(n), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
+            if self._fork_pending is not None and self.fork_after == 1:
+                self._fork_pending()
 
     def _gru_wgrads(self, w, B, Lq, seq, use_drop, layers, emb):
         """weight gradients of the given GRU layers as ONE grouped launch on the current stream, plus
