@@ -168,6 +168,8 @@ class Engine:
         self.dp_pipeline = bool(cfg.get("ark_dp_pipeline", True))
         self._defer_wgrads = False
         self._fork_pending = None
+        self._finalize = None
+        self._defer_finalize = False   # set by train_step / _dp_steps around forward(): backward follows at once
         self.fork_after = int(cfg.get("ark_fork_after", 1))   # measured: 0 -> 1.281, 1 -> 1.266, 2 -> 1.296 ms/step
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
         self._layer_streams = []
@@ -430,8 +432,14 @@ class Engine:
                   L.i32(self.prec_bwd if d16 is not None else 0), L.i64(self.Vp if d16 is not None else 0), L.i32(B), L.i32(Lq),
                   L.i32(V), st)
             self._dlog16_valid = d16 is not None
-            _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R), L.ptr(w["kl"] if self.mt == "SAIL" else None),
-                  L.ptr(self.hyper), L.ptr(w["out4"]), st)
+            self._finalize = lambda: _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R),
+                                           L.ptr(w["kl"] if self.mt == "SAIL" else None), L.ptr(self.hyper), L.ptr(w["out4"]),
+                                           L.cur_stream())
+            if not (self._defer_finalize and with_dlogits and w["v2"] and w.get("diag") and self.diag_bwd):
+                self._finalize()
+                self._finalize = None
+            # (else: the two-queue backward launches it on its side queue -- the loss scalars are not on the
+            #  dependent chain)
 
     def _decode_h0(self, w, z, B):
         p = self.p
@@ -632,6 +640,9 @@ class Engine:
                 self._join_side()
                 return False
             return True
+        if self._finalize is not None:   # (deferred by forward for the two-queue backward only)
+            self._finalize()
+            self._finalize = None
         self.G.zero_()
         if w["v2"]:
             dX0 = self._backward_decoder_v2(w, B, Lq, seq, use_drop)
@@ -892,6 +903,9 @@ class Engine:
         side.wait_stream(main)
         filled = torch.cuda.Event()
         with torch.cuda.stream(side):
+            if self._finalize is not None:   # loss scalars of this step (deferred by forward)
+                self._finalize()
+                self._finalize = None
             self.G.zero_()   # ONE fill; every reduction of the step accumulates into it
             if self.mt == "SAIL":
                 w["dH0"].zero_()   # the initial-state roles add into it
@@ -1148,7 +1162,11 @@ class Engine:
             for h in handles.values():
                 h.wait()
         else:
-            self.forward(triples, seq, eps, ce_count=ce_count)
+            self._defer_finalize = True
+            try:
+                self.forward(triples, seq, eps, ce_count=ce_count)
+            finally:
+                self._defer_finalize = False
             if self.backward_decoder():
                 self.backward_encoder()
         if grad_sync is not None:
@@ -1227,7 +1245,11 @@ class Engine:
             gc = cap(self.adam)
         else:
             def a():
-                self.forward(triples, seq, eps, ce_count=ce_count)
+                self._defer_finalize = True
+                try:
+                    self.forward(triples, seq, eps, ce_count=ce_count)
+                finally:
+                    self._defer_finalize = False
                 self.backward()
                 self.adam()
             ga, gb, gc = cap(a), None, None

@@ -208,8 +208,19 @@ def main():
     eng.set_hyper(lr=cfg["learning_rate"], beta=cfg["beta"])
     Lq = cfg["seq_len"] - 1
 
-    # synthetic data ring, resident in HBM before the timed region
+    # synthetic data ring, resident in HBM before the timed region.  Each batch is ONE packed byte buffer
+    # [triples int64 | seq int64 | eps f32] and the step's fixed-address inputs are views of one such buffer,
+    # so refreshing the inputs of a captured step is a single device-to-device copy.
     NB = 8
+    T = cfg["max_triples"]
+    n_tri, n_seq, n_eps = B * T * 3 * 8, B * cfg["seq_len"] * 8, B * cfg["d_latent"] * 4
+
+    def views(buf):
+        tri = buf[:n_tri].view(torch.int64).view(B, T, 3)
+        sq = buf[n_tri:n_tri + n_seq].view(torch.int64).view(B, cfg["seq_len"])
+        ep = buf[n_tri + n_seq:n_tri + n_seq + n_eps].view(torch.float32).view(B, cfg["d_latent"])
+        return tri, sq, ep
+
     ring = []
     ce_counts = []
     for i in range(NB):
@@ -217,19 +228,20 @@ def main():
         torch.manual_seed(1000 + i)
         eps = torch.randn(Bg, cfg["d_latent"])
         sl = slice(rank * B, (rank + 1) * B)
-        ring.append((tr[sl].contiguous().to(dev), sq[sl].contiguous().to(dev), eps[sl].contiguous().to(dev)))
+        buf = torch.empty(n_tri + n_seq + n_eps, dtype=torch.uint8, device=dev)
+        a_, b_, c_ = views(buf)
+        a_.copy_(tr[sl]); b_.copy_(sq[sl]); c_.copy_(eps[sl])
+        ring.append(buf)
         ce_counts.append(float((sq[:, 1:] != 0).sum()))   # non-PAD targets of the GLOBAL batch
     ce_count = ce_counts[0]
-    tri_in, seq_in, eps_in = (x.clone() for x in ring[0])
+    stage = ring[0].clone()
+    tri_in, seq_in, eps_in = views(stage)
 
     use_dp = world > 1 or args.force_dist
 
     def feed(i):
-        a, b, c = ring[i % NB]
         eng.set_hyper(ce_count=ce_counts[i % NB])   # device-side scalar; a no-op while the count is unchanged
-        tri_in.copy_(a, non_blocking=True)
-        seq_in.copy_(b, non_blocking=True)
-        eps_in.copy_(c, non_blocking=True)
+        stage.copy_(ring[i % NB], non_blocking=True)
 
     # everything (input refresh copies, graph replays, collectives) runs on ONE explicit stream:
     # ordering between plain copies on the legacy null stream and hipGraphLaunch is not relied on
