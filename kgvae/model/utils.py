@@ -75,6 +75,80 @@ def triples_to_seq(triples, special_tokens, ENT_BASE, REL_BASE, seq_len):
     return torch.tensor(toks, dtype=torch.long)
 
 
+def sample_perms(n, T):
+    """n successive `random.sample(range(T), T)` draws from Python's global generator, bit for bit -- same
+    permutations, same generator state afterwards -- computed in numpy instead of n interpreter-level calls
+    (the per-epoch permutation redraw of GraphSeqDataset was the slowest part of an epoch on the GPU path).
+
+    How CPython draws (Lib/random.py, Python 3.8-3.12): sample(pop, k=T) with T <= 21 + 4**ceil(log4(3T)) uses the
+    pool method -- for i in range(T): j = _randbelow(T - i); result[i] = pool[j]; pool[j] = pool[T - i - 1] --
+    and _randbelow(m) = getrandbits(m.bit_length()) until < m, getrandbits(k <= 32) = next 32-bit
+    Mersenne-Twister output >> (32 - k).  numpy's MT19937 bit generator is the same generator, so its raw
+    stream started from random.getstate() is the stream CPython would consume.  The only sequential part, "where
+    does graph g start in the stream", is a function iteration x -> F[x]; its orbit is built by doubling."""
+    if n == 0 or T <= 1:
+        return np.zeros((n, max(T, 0)), dtype=np.int64)
+    ver, internal, gauss = random.getstate()
+    if ver != 3:
+        return np.array([random.sample(range(T), T) for _ in range(n)], dtype=np.int64)
+    key, pos0 = np.array(internal[:-1], dtype=np.uint32), int(internal[-1])
+    needs = list(range(T, 0, -1))
+    exp_draws = sum((1 << m.bit_length()) / m for m in needs)      # expected raw outputs per graph
+    M = int(n * exp_draws * 1.10) + 4096
+    while True:
+        bg = np.random.MT19937()
+        bg.state = {"bit_generator": "MT19937", "state": {"key": key, "pos": pos0}}
+        raw = bg.random_raw(M).astype(np.uint32)
+        INF = M   # "no accepted draw left in this block"
+        nxt, val = {}, {}
+        for m in needs:
+            r = raw >> np.uint32(32 - m.bit_length())
+            ok = r < m
+            idx = np.where(ok, np.arange(M), INF)
+            nx = np.minimum.accumulate(idx[::-1])[::-1]             # first accepted position >= i
+            nxt[m] = np.append(nx, INF)                              # (index M maps to INF)
+            val[m] = r.astype(np.int64)
+        # F[i] = stream position after one whole sample() that starts at position i
+        F = np.arange(M + 1)
+        for m in needs:
+            a = nxt[m][np.minimum(F, M)]
+            F = np.minimum(a + 1, M)
+            F[a >= INF] = M
+        # start position of every graph: orbit of 0 under F, by doubling
+        starts = np.zeros(n, dtype=np.int64)
+        have, Fp = 1, F
+        while have < n:
+            take = min(have, n - have)
+            starts[have:have + take] = Fp[starts[:take]]
+            have += take
+            if have < n:
+                Fp = Fp[Fp]
+        end = F[starts[-1]]
+        if end < M:   # every draw of every graph was found inside the block
+            break
+        M *= 2
+    js = np.empty((n, T), dtype=np.int64)
+    cur = starts.copy()
+    for c, m in enumerate(needs):
+        a = nxt[m][cur]
+        js[:, c] = val[m][a]
+        cur = a + 1
+    pool = np.tile(np.arange(T, dtype=np.int64), (n, 1))
+    out = np.empty((n, T), dtype=np.int64)
+    rows = np.arange(n)
+    for i in range(T):
+        j = js[:, i]
+        out[:, i] = pool[rows, j]
+        pool[rows, j] = pool[:, T - i - 1]
+    # leave Python's generator exactly where n sample() calls would have left it
+    bg = np.random.MT19937()
+    bg.state = {"bit_generator": "MT19937", "state": {"key": key, "pos": pos0}}
+    bg.random_raw(int(end))
+    stt = bg.state["state"]
+    random.setstate((3, tuple(int(x) for x in stt["key"]) + (int(stt["pos"]),), gauss))
+    return out
+
+
 class GraphSeqDataset(Dataset):
     """items are (triples long[T,3], seq long[seq_len]); same constructor as the reference."""
 
@@ -143,8 +217,7 @@ class GraphSeqDataset(Dataset):
                 if self.fast_rng is not None:   # opt-in: numpy generator, one vectorised draw (not Python-RNG identical)
                     perm = self.fast_rng.permuted(np.tile(np.arange(T), (n, 1)), axis=1)
                 else:
-                    rng = range(T)
-                    perm = np.array([random.sample(rng, T) for _ in range(n)], dtype=np.int64)
+                    perm = sample_perms(n, T)   # == [random.sample(range(T), T) for _ in range(n)], vectorised
                 tri = np.take_along_axis(tri, perm[:, :, None], axis=1)
         T = tri.shape[1]
         seq = np.full((n, self.seq_len), st["PAD"], dtype=np.int64)

@@ -163,3 +163,24 @@ def test_epoch_batches_shards_and_counts():
             assert counts[i] == dp.count_targets(seq[i * B:(i + 1) * B], 0)
     t_n, s_n, c_n = epoch_batches(None, seq, B, True, 0)
     assert t_n is None and s_n.shape == full_s.shape and sum(c_n) <= int((seq[:, 1:] != 0).sum())
+
+
+def test_sample_perms_is_random_sample_bit_for_bit():
+    """kgvae.model.utils.sample_perms == n successive random.sample(range(T), T) calls on Python's global
+    generator: same permutations, same generator state afterwards (so everything drawn later matches too)"""
+    import random
+    import numpy as np
+    from kgvae.model.utils import sample_perms
+    for T in (2, 3, 4, 6, 23):
+        for seed in (0, 7):
+            random.seed(seed)
+            for _ in range(seed):
+                random.random()
+            st = random.getstate()
+            ref = np.array([random.sample(range(T), T) for _ in range(777)])
+            after = random.getstate()
+            random.setstate(st)
+            got = sample_perms(777, T)
+            assert (ref == got).all(), (T, seed)
+            assert random.getstate() == after, (T, seed)
+    assert sample_perms(0, 3).shape == (0, 3) and sample_perms(4, 1).tolist() == [[0]] * 4
