@@ -172,11 +172,9 @@ class Engine:
         self._defer_finalize = False   # set by train_step / _dp_steps around forward(): backward follows at once
         self.fork_after = int(cfg.get("ark_fork_after", 1))   # measured: 0 -> 1.281, 1 -> 1.266, 2 -> 1.296 ms/step
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
-        self._layer_streams = []
         self.diag_cells = bool(cfg.get("ark_diag_cells", True))
         self.diag_bwd = bool(cfg.get("ark_diag_bwd", True))
         self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))   # one launch per (layer, time) anti-diagonal
-        self.pipeline_layers = bool(cfg.get("ark_pipeline_layers", False))   # measured slower on MI355X
 
     # ------------------------------------------------------------------ parameters
     def load_params(self, named):
@@ -489,51 +487,13 @@ class Engine:
                   L.ptr(w["SN"][l][sl] if save else None), L.ptr(w["SHN"][l][sl] if save else None),
                   L.i32(B), L.i32(D), L.cur_stream())
 
-        def mask_gen(l):
-            pass   # nothing to materialise: cells and the input-gradient product hash the mask in-kernel
-
         if w["diag"]:
             self._diag_sweep(w, B, Lq, use_drop, save)
-        elif self.pipeline_layers and n > 1:
-            # Layer wavefront: layer l runs on its own stream, one step behind layer l-1.  cell(l,t) needs
-            # gi[l][t] (a [B,D]x[D,3D] product of the layer below's step-t output) and cell(l,t-1); cells of
-            # different layers overlap, so the dependent chain is L+n-1 steps long instead of n*L.
-            main = torch.cuda.current_stream()
-            streams = [main] + [self._layer_stream(l) for l in range(1, n)]
-            ev = [[None] * Lq for _ in range(n)]
-            in_gemm(0, w["X0a"], R, 0)
-            start = torch.cuda.Event()
-            start.record(main)
-            for l in range(1, n):
-                streams[l].wait_event(start)
-            # issue in diagonal order so every wait refers to an event already recorded
-            for d in range(Lq + n - 1):
-                for l in range(n):
-                    t = d - l
-                    if t < 0 or t >= Lq:
-                        continue
-                    drop = use_drop and l < n - 1
-                    with torch.cuda.stream(streams[l]):
-                        if t == 0 and drop:
-                            mask_gen(l)
-                        if l > 0:
-                            streams[l].wait_event(ev[l - 1][t])
-                            below_drop = use_drop
-                            src = w["Yd16a"][l - 1][t * B:] if below_drop else w["Y16a"][l - 1][(t + 1) * B:]
-                            in_gemm(l, src, B, t * B)
-                        cell(l, t, drop)
-                        if l < n - 1:
-                            ev[l][t] = torch.cuda.Event()
-                            ev[l][t].record(streams[l])
-            for l in range(1, n):
-                main.wait_stream(streams[l])
         else:
             xin = w["X0a"]
             for l in range(n):
                 in_gemm(l, xin, R, 0)
-                drop = use_drop and l < n - 1
-                if drop:
-                    mask_gen(l)
+                drop = use_drop and l < n - 1   # (the cells hash the mask in-kernel)
                 for t in range(Lq):
                     cell(l, t, drop)
                 xin = w["Yd16a"][l] if drop else w["Y16a"][l][B:]
@@ -1029,11 +989,6 @@ class Engine:
                   L.i32(Lq), L.i32(D), L.i32(V), ss)
             if self.mt == "ARK":
                 self._colsum(w["dX0"], D, g["dec.pos_emb.weight"], B, D, n_batch=Lq, bs_in=B * D, bs_out=D)
-
-    def _layer_stream(self, l):
-        while len(self._layer_streams) <= l:
-            self._layer_streams.append(torch.cuda.Stream(device=self.device))
-        return self._layer_streams[l]
 
     def _side_stream(self):
         if self._side is None:

@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--tuning", default="", help="speed-only kernel knobs, e.g. '1=32,2=1' (ark_set_tuning)")
     ap.add_argument("--no-splitk", action="store_true")
-    ap.add_argument("--cfg", default="", help="extra engine config ints, e.g. ark_pipeline_layers=0,ark_overlap_wgrad=0")
+    ap.add_argument("--cfg", default="", help="extra engine config ints, e.g. ark_diag_cells=0,ark_overlap_wgrad=0")
     ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path even with one rank")
     ap.add_argument("--knobs", default="", help="speed-only knobs: ring=F:B,g16=NBUF:FORCE64,wg128=0|1")
     args = ap.parse_args()
@@ -198,7 +198,7 @@ def main():
         L.check(fn(*vals), k)
 
     cfg = build_cfg(args.dropout, args.workload)
-    for kv in filter(None, args.cfg.split(",")):   # engine options, e.g. ark_pipeline_layers=0
+    for kv in filter(None, args.cfg.split(",")):   # engine options, e.g. ark_diag_bwd=0
         k, v = kv.split("=")
         cfg[k] = int(v)
     B = args.batch or cfg["batch"]
