@@ -29,6 +29,10 @@ def lib():
                 f"{LIB_PATH} not found: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()'). No CPU fallback exists."
             )
+        # torch ships its own copy of the HIP runtime; load it FIRST so that this library's libamdhip64
+        # dependency binds to the same runtime instance (loading the system copy first leaves two runtimes in
+        # the process and every launch from here fails with hipErrorNoDevice)
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
     return _lib
 
