@@ -1,14 +1,16 @@
 """Data-parallel helpers: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm)
 or gloo on CPU for tests.  The hot path shards naturally over graphs: rank k of N
-takes rows [k*B/N, (k+1)*B/N) of every global batch and of that step's eps; the only exchange is
-ONE all-reduce(sum) of the flat gradient buffer.  Exactness needs global normalisers:
+takes rows [k*B/N, (k+1)*B/N) of every global batch and of that step's eps; the only exchange is the
+all-reduce(sum) of the flat gradient buffer (two buckets, overlapped / pipelined by the engine:
+Engine._dp_steps, Engine.dp_flush; `make_grad_sync` below is the plain single-call alternative).
+Exactness needs global normalisers:
 
   * CE is a mean over the non-PAD targets of the GLOBAL batch -> every rank divides by the global
     count (computed on the host from the index tensor, no collective needed);
   * kl_mean is a mean over B_global * Z elements -> KL_NORM = 1 / (B_global * Z).
 
 With those, the summed shard gradients equal the single-process gradient (tests/test_dp_cpu.py,
-tests/test_engine_gpu.py::test_shard_gradients_sum_to_full_batch).
+tests/test_engine_gpu.py::test_shard_gradients_sum_to_full_batch, tests/test_dp_gpu.py).
 """
 import os
 
