@@ -90,18 +90,23 @@ static void launch16_cfg(Gemm16Args p, hipStream_t st) {
   hipLaunchKernelGGL((gemm16_kernel<PREC, BM, BN, NBUF>), dim3((unsigned)tiles), dim3(256), G::LDS_BYTES, st, p);
 }
 
-int g_g16_tile = 1;   // 0: heuristic below, 1: 64x64, 2: 128x64, 3: 128x128
+int g_g16_tile = 0;   // 0: heuristic below, 1: 64x64, 2: 128x64, 3: 128x128, 4: 32x64, 5: 64x32
 
 template <int PREC>
 static int launch16(Gemm16Args p, hipStream_t st) {
   int tile = g_g16_tile;
   if (tile == 0) {
-    // 128x64 tiles halve the per-CU L2->LDS traffic of the A panel (these products are bound by the
-    // ~75 GB/s per-CU LDS-DMA rate, not by MFMA issue) while still giving >= 4 workgroups per CU
-    const long t128x64 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
-    tile = (g_g16_force64 || t128x64 < 1024) ? 1 : 2;
+    // these products are latency-bound, not MFMA-bound: what counts is how many workgroups a CU can keep
+    // resident.  64x64 tiles unless that leaves fewer than two workgroups per CU (the [B,3D]x[3D,3D] encoder
+    // products at B = 1024: 384 tiles) -- then 32x64 tiles, 24 KB of LDS each (measured 1.221 -> 1.211 ms/step)
+    const long t64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    tile = (g_g16_force64 || t64 >= 512) ? 1 : 4;
   }
-  if (tile == 3) {
+  if (tile == 4) {   // small tiles: more workgroups resident per CU for the short-M encoder products
+    if (g_g16_nbuf == 4) launch16_cfg<PREC, 32, 64, 4>(p, st); else launch16_cfg<PREC, 32, 64, 2>(p, st);
+  } else if (tile == 5) {
+    if (g_g16_nbuf == 4) launch16_cfg<PREC, 64, 32, 4>(p, st); else launch16_cfg<PREC, 64, 32, 2>(p, st);
+  } else if (tile == 3) {
     if (g_g16_nbuf == 3) launch16_cfg<PREC, 128, 128, 3>(p, st); else launch16_cfg<PREC, 128, 128, 2>(p, st);
   } else if (tile == 2) {
     if (g_g16_nbuf == 4) launch16_cfg<PREC, 128, 64, 4>(p, st);
@@ -201,9 +206,9 @@ __global__ __launch_bounds__(256) void to_tiled_kernel(const float* __restrict__
 
 }  // namespace ark
 
-// speed-only knobs of the LDS-DMA GEMM: ring depth {2,3,4}; tile 0 auto | 1 64x64 | 2 128x64 | 3 128x128
+// speed-only knobs of the LDS-DMA GEMM: ring depth {2,3,4}; tile 0 auto | 1 64x64 | 2 128x64 | 3 128x128 | 4 32x64 | 5 64x32
 extern "C" int ark_set_gemm16_tuning(int nbuf, int tile) {
-  if (nbuf < 2 || nbuf > 4 || tile < 0 || tile > 3) return ARK_ERR_ARG;
+  if (nbuf < 2 || nbuf > 4 || tile < 0 || tile > 5) return ARK_ERR_ARG;
   ark::g_g16_nbuf = nbuf;
   ark::g_g16_tile = tile;
   return 0;
