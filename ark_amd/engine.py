@@ -168,6 +168,7 @@ class Engine:
         self.dp_pipeline = bool(cfg.get("ark_dp_pipeline", True))
         self._defer_wgrads = False
         self._fork_pending = None
+        self.h0_ride = bool(cfg.get("ark_h0_ride", True))
         self._finalize = None
         self._defer_finalize = False   # set by train_step / _dp_steps around forward(): backward follows at once
         self.fork_after = int(cfg.get("ark_fork_after", 1))   # measured: 0 -> 1.281, 1 -> 1.266, 2 -> 1.296 ms/step
@@ -883,6 +884,7 @@ class Engine:
             self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
             _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
         main.wait_event(filled)   # the cells accumulate bias gradients into the flat buffer
+        h0_done = set()
         for e in range(Lq + n - 1):
             roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
             k = 0
@@ -911,6 +913,14 @@ class Engine:
                 r.drop_base = t * B * D
                 r.drop_p = self.p_drop if drop else 0.0
                 k += 1
+            if self.mt == "SAIL" and self.h0_ride:
+                # a layer's initial-state role (dH0 += carry + dgh_0 W_hh) may ride any diagonal after the one
+                # that finished its step 0; layers >= 1 fit into the under-filled last diagonals
+                for l in range(n - 1, 0, -1):
+                    if e == (n - 1 - l) + Lq and k < L.DIAG_MAX_ROLES:
+                        self._h0_role(roles[k], w, l)
+                        h0_done.add(l)
+                        k += 1
             _call("ark_gru_diag_bwd", L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
         def fork_wgrads():
             # the big weight-gradient launch starves small dependent kernels that run beside it (the 13-us dh0
@@ -932,13 +942,16 @@ class Engine:
         if self.mt == "SAIL":   # continues on the main stream into the encoder half
             # dH0 = sum over layers of (carry + dgh_0 W_hh): all layers as roles of ONE more launch
             roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
-            for l in range(n):
-                r = roles[l]
-                r.dgh_next16, r.w_hhT16 = L.dptr(w["dGH16"][l]), L.dptr(self.whhT16[l])
-                r.carry_t, r.dh0 = L.dptr(w["carry_l"][l]), L.dptr(w["dH0"])
-            _call("ark_gru_diag_bwd", L.i32(pb), L.i32(n), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
+            rest = [l for l in range(n) if l not in h0_done]
+            for k, l in enumerate(rest):
+                self._h0_role(roles[k], w, l)
+            _call("ark_gru_diag_bwd", L.i32(pb), L.i32(len(rest)), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
             if self._fork_pending is not None and self.fork_after == 1:
                 self._fork_pending()
+
+    def _h0_role(self, r, w, l):
+        r.dgh_next16, r.w_hhT16 = L.dptr(w["dGH16"][l]), L.dptr(self.whhT16[l])
+        r.carry_t, r.dh0 = L.dptr(w["carry_l"][l]), L.dptr(w["dH0"])
 
     def _gru_wgrads(self, w, B, Lq, seq, use_drop, layers, emb):
         """weight gradients of the given GRU layers as ONE grouped launch on the current stream, plus
