@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--no-splitk", action="store_true")
     ap.add_argument("--cfg", default="", help="extra engine config ints, e.g. ark_diag_cells=0,ark_overlap_wgrad=0")
     ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path even with one rank")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL, one GPU per rank (the measured configuration); gloo = functional rehearsal, ranks may share a GPU")
     ap.add_argument("--knobs", default="", help="speed-only knobs: ring=F:B,g16=NBUF:FORCE64,wg128=0|1")
     args = ap.parse_args()
 
@@ -173,14 +175,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:   # rehearsal of the multi-rank script on fewer GPUs than ranks (collectives staged through the host)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from ark_amd.engine import Engine
     from ark_amd import initlib
