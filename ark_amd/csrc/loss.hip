@@ -274,14 +274,14 @@ __global__ __launch_bounds__(256) void ce_kernel(float* logits, long ld, const i
   const float lse = mx + logf(se);
   const bool live = (tgt != ARK_TOK_PAD);
   if (lane == 0) row_loss[row] = live ? (lse - x[tgt]) : 0.f;
-  if (dlogits) {
+  if (dlogits || d16bf || d16h) {
     const float s = live ? hyper[ARK_HP_CE_INV_COUNT] : 0.f;
-    float* d = dlogits + (long)row * ld;
-    const long nc = (d16bf || d16h) ? (ld16 > ld ? ld16 : ld) : ld;
+    float* d = dlogits ? dlogits + (long)row * ld : nullptr;   // (16-bit copy alone: the fp32 round trip is skipped)
+    const long nc = (d16bf || d16h) ? ((ld16 > ld || !d) ? ld16 : ld) : ld;
     for (int c = lane; c < nc; c += 64) {
       float g = 0.f;
       if (c < V) g = (expf(x[c] - lse) - ((long)c == tgt ? 1.0f : 0.f)) * s;
-      if (c < ld) d[c] = g;
+      if (d && c < ld) d[c] = g;
       // K-padded 16-bit copy (zeros beyond V) for the input-gradient product on the LDS-DMA engine
       if (c < ld16) {
         if (d16bf) d16bf[(long)row * ld16 + c] = (__bf16)g;
@@ -465,7 +465,7 @@ extern "C" int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int
                               void* stream) {
   using namespace ark;
   if (!logits || !seq || !hyper || !row_loss || B <= 0 || L <= 0 || V <= 0 || ld < V) return ARK_ERR_ARG;
-  if (dlogits16 && (!dlogits || ld16 < V || (prec16 != 1 && prec16 != 2))) return ARK_ERR_ARG;
+  if (dlogits16 && (ld16 < V || (prec16 != 1 && prec16 != 2))) return ARK_ERR_ARG;
   hipLaunchKernelGGL(ce_kernel, dim3((B * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, seq, (long)ld_seq,
                      hyper, row_loss, dlogits, prec16 == 1 ? (__bf16*)dlogits16 : nullptr,
                      prec16 == 2 ? (_Float16*)dlogits16 : nullptr, (long)ld16, B, L, V);

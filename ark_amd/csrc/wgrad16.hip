@@ -26,6 +26,7 @@ struct Wgrad16Args {
   const void* A; const void* B; float* C;
   long lda, ldb, ldc;
   int M, N, K, k_chunk, tiles_n, use_atomics;
+  int m_valid;   // rows of C that exist (<= M): A may be column-padded to a tile multiple, C is not
 };
 // several independent products in ONE launch (e.g. dW_ih / dW_hh of every GRU layer at the end of
 // the backward pass): enough workgroups to fill the chip without deep split-K and its atomics
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(Wgrad16Group grp) {
       for (int i = 0; i < 4; ++i) {
         const int row = m0 + wm * WTM + ta * 16 + 4 * (lane >> 4) + i;
         const int col = n0 + wn * WTN + tb * 16 + (lane & 15);
+        if (row >= p.m_valid) continue;
         float* c = p.C + (long)row * p.ldc + col;
         if (atomics) atomicAdd(c, acc[ta][tb][i]);
         else *c += acc[ta][tb][i];
@@ -268,7 +270,7 @@ extern "C" int ark_wgrad16(int prec, const void* A16, int64_t lda, const void* B
   if (rc) return rc;
   Wgrad16Group g{};
   g.n = 1;
-  g.p[0] = Wgrad16Args{A16, B16, C, (long)lda, (long)ldb, (long)ldc, M, N, K, K, 1, 0};
+  g.p[0] = Wgrad16Args{A16, B16, C, (long)lda, (long)ldb, (long)ldc, M, N, K, K, 1, 0, M};
   if (prec == PREC_F16) return launch_wg_prec<PREC_F16>(g, (hipStream_t)stream);
   if (prec == PREC_BF16) return launch_wg_prec<PREC_BF16>(g, (hipStream_t)stream);
   return ARK_ERR_ARG;
@@ -285,8 +287,24 @@ extern "C" int ark_wgrad16_group(int prec, int n, const void* const* A16, const 
   for (int i = 0; i < n; ++i) {
     int rc = check_one(A16[i], lda[i], B16[i], ldb[i], C[i], M[i], N[i], K[i]);
     if (rc) return rc;
-    g.p[i] = Wgrad16Args{A16[i], B16[i], C[i], (long)lda[i], (long)ldb[i], (long)ldc[i], M[i], N[i], K[i], K[i], 1, 0};
+    g.p[i] = Wgrad16Args{A16[i], B16[i], C[i], (long)lda[i], (long)ldb[i], (long)ldc[i], M[i], N[i], K[i], K[i], 1, 0, M[i]};
   }
+  if (prec == PREC_F16) return launch_wg_prec<PREC_F16>(g, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch_wg_prec<PREC_BF16>(g, (hipStream_t)stream);
+  return ARK_ERR_ARG;
+}
+
+// as ark_wgrad16, for an A operand whose M columns are padded to a tile multiple while C has only m_valid rows
+// (e.g. the K-padded 16-bit dlogits against the [V,D] vocabulary gradient): rows >= m_valid are not written
+extern "C" int ark_wgrad16_rows(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
+                                int M, int m_valid, int N, int K, void* stream) {
+  using namespace ark;
+  int rc = check_one(A16, lda, B16, ldb, C, M, N, K);
+  if (rc) return rc;
+  if (m_valid <= 0 || m_valid > M) return ARK_ERR_ARG;
+  Wgrad16Group g{};
+  g.n = 1;
+  g.p[0] = Wgrad16Args{A16, B16, C, (long)lda, (long)ldb, (long)ldc, M, N, K, K, 1, 0, m_valid};
   if (prec == PREC_F16) return launch_wg_prec<PREC_F16>(g, (hipStream_t)stream);
   if (prec == PREC_BF16) return launch_wg_prec<PREC_BF16>(g, (hipStream_t)stream);
   return ARK_ERR_ARG;

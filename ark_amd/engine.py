@@ -168,6 +168,8 @@ class Engine:
         self.dp_pipeline = bool(cfg.get("ark_dp_pipeline", True))
         self._defer_wgrads = False
         self._fork_pending = None
+        self._dlog16_only = False
+        self.dlog16_only = bool(cfg.get("ark_dlog16_only", True))
         self.h0_ride = bool(cfg.get("ark_h0_ride", True))
         self._finalize = None
         self._defer_finalize = False   # set by train_step / _dp_steps around forward(): backward follows at once
@@ -426,11 +428,15 @@ class Engine:
             if ce_count is None:
                 _call("ark_count_targets", L.ptr(seq), L.i64(ld_seq), L.i32(B), L.i32(Lq), L.ptr(self.hyper), st)
             d16 = w["dlog16"] if (with_dlogits and w["v2"]) else None
+            # the diagonal backward takes every consumer of dlogits (dY, dW_tok, db_out) from the 16-bit copy:
+            # the fp32 gradient is then never written
+            only16 = d16 is not None and w.get("diag") and self.diag_bwd and R % 64 == 0 and self.dlog16_only
             _call("ark_ce_fwd_bwd", L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper),
-                  L.ptr(w["row_loss"]), L.ptr(w["logits"] if with_dlogits else None), L.ptr(d16),
+                  L.ptr(w["row_loss"]), L.ptr(w["logits"] if (with_dlogits and not only16) else None), L.ptr(d16),
                   L.i32(self.prec_bwd if d16 is not None else 0), L.i64(self.Vp if d16 is not None else 0), L.i32(B), L.i32(Lq),
                   L.i32(V), st)
             self._dlog16_valid = d16 is not None
+            self._dlog16_only = bool(only16)
             self._finalize = lambda: _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R),
                                            L.ptr(w["kl"] if self.mt == "SAIL" else None), L.ptr(self.hyper), L.ptr(w["out4"]),
                                            L.cur_stream())
@@ -871,9 +877,15 @@ class Engine:
             if self.mt == "SAIL":
                 w["dH0"].zero_()   # the initial-state roles add into it
             filled.record(side)
-            self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
-            _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dlog), L.i32(0), L.i64(self.ldl), L.ptr(yb(n - 1)[B:]), L.i32(1), L.i64(D),
-                  L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(V), L.i32(D), L.i32(R), L.i32(1), L.cur_stream())
+            if getattr(self, "_dlog16_valid", False) and self._dlog16_only:
+                _call("ark_colsum16", L.i32(pb), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(g["dec.out.bias"]), L.i32(R), L.i32(V),
+                      L.i32(1), L.cur_stream())
+                _call("ark_wgrad16_rows", L.i32(pb), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(yb(n - 1)[B:]), L.i64(D),
+                      L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(self.Vp), L.i32(V), L.i32(D), L.i32(R), L.cur_stream())
+            else:
+                self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
+                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dlog), L.i32(0), L.i64(self.ldl), L.ptr(yb(n - 1)[B:]), L.i32(1), L.i64(D),
+                      L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(V), L.i32(D), L.i32(R), L.i32(1), L.cur_stream())
         self._side_used = side is not main
         st = L.cur_stream()
         if getattr(self, "_dlog16_valid", False):

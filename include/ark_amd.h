@@ -190,6 +190,9 @@ int ark_gemm_wgrad(int prec, const void* A, int a_is16, int64_t lda, const void*
  * needs M, N, K multiples of 64 and both operands 16-bit */
 int ark_wgrad16(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc, int M,
                 int N, int K, void* stream);
+/* ark_wgrad16 for an A operand column-padded to a tile multiple (M) while C has only m_valid rows */
+int ark_wgrad16_rows(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc, int M,
+                     int m_valid, int N, int K, void* stream);
 int ark_wgrad16_group(int prec, int n, const void* const* A16, const int64_t* lda, const void* const* B16,
                       const int64_t* ldb, float* const* C, const int64_t* ldc, const int* M, const int* N, const int* K,
                       void* stream);
@@ -243,7 +246,8 @@ int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_z, const fl
                          int H, void* stream);
 int ark_count_targets(const int64_t* seq, int64_t ld_seq, int B, int L, float* hyper, void* stream);
 /* rows are time-major (t,b); target of row (t,b) is seq[b, t+1]; dlogits may alias logits or be NULL */
-/* dlogits16 (nullable): additional [B*L, ld16] copy of dlogits in 16 bits (prec16), zero beyond V */
+/* dlogits16 (nullable): [B*L, ld16] copy of dlogits in 16 bits (prec16), zero beyond V; may be the ONLY gradient
+ * output (dlogits NULL): the fp32 [B*L,V] round trip is then skipped */
 int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int64_t ld_seq, const float* hyper,
                    float* row_loss, float* dlogits, void* dlogits16, int prec16, int64_t ld16, int B, int L, int V,
                    void* stream);
