@@ -296,6 +296,7 @@ static int g_ce_lds = 1;
 // Large-vocabulary edition: ONE workgroup per row, the row cached in LDS -- the [B*L,V] fp32 logits are read from
 // HBM exactly once (the wave-per-row kernel above streams every row three times: max, sum-exp, gradient; at
 // V = 24 101 that was 1.8 ms of a 5.2 ms step).  Used when the row fits LDS (V * 4 B <= 144 KB).
+template <int NR>   // NR 16-byte loads per thread cover a row: NR * 1024 * 4 >= ld
 __global__ __launch_bounds__(1024) void ce_row_lds_kernel(float* logits, long ld, const int64_t* __restrict__ seq, long ld_seq,
                                                           const float* __restrict__ hyper, float* __restrict__ row_loss,
                                                           float* dlogits, __bf16* d16bf, _Float16* d16h, long ld16, int B, int L,
@@ -303,52 +304,70 @@ __global__ __launch_bounds__(1024) void ce_row_lds_kernel(float* logits, long ld
   extern __shared__ __attribute__((aligned(16))) char smem_ce[];
   float* xs = reinterpret_cast<float*>(smem_ce);
   __shared__ float red_m[16], red_s[16];
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = row / B, b = row % B;
-  const long tgt = seq[(long)b * ld_seq + t + 1];
-  const float* x = logits + (long)row * ld;   // ld % 4 == 0 (host-checked): rows are 16-byte aligned
-  // one pass over HBM (16-byte loads): copy into LDS with an online (max, sum-exp) per thread
-  float m = -INFINITY, se = 0.f;
-  const int V4 = V >> 2;
-  for (int c4 = tid; c4 < V4; c4 += 1024) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * c4);
-    *reinterpret_cast<f32x4*>(xs + 4 * c4) = v;
-    const float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-    if (vm > m) { se *= expf(m - vm); m = vm; }
-    se += expf(v[0] - m) + expf(v[1] - m) + expf(v[2] - m) + expf(v[3] - m);
-  }
-  for (int c = 4 * V4 + tid; c < V; c += 1024) {   // (tail of a vocabulary that is not a multiple of 4)
-    const float v = x[c];
-    xs[c] = v;
-    if (v > m) { se = se * expf(m - v) + 1.0f; m = v; }
-    else se += expf(v - m);
-  }
-  const float wm = wave_max(m);
-  se = wave_sum(m == -INFINITY ? 0.f : se * expf(m - wm));
-  if (lane == 0) { red_m[wave] = wm; red_s[wave] = se; }
-  __syncthreads();
-  float M = red_m[0];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int R = B * L, LD4 = (int)(ld >> 2);   // ld % 4 == 0 (host-checked): rows are 16-byte aligned
+  // Persistent over rows; the NEXT row travels HBM -> registers while this row's gradient goes LDS -> HBM, so the
+  // read stream and the write stream overlap although only one workgroup fits a CU.
+  f32x4 nx[NR];
+  auto fetch = [&](int row) {
+    const float* x = logits + (long)row * ld;
 #pragma unroll
-  for (int i = 1; i < 16; ++i) M = fmaxf(M, red_m[i]);
-  float S = 0.f;
+    for (int i = 0; i < NR; ++i) {
+      const int c4 = tid + 1024 * i;
+      nx[i] = (c4 < LD4) ? *reinterpret_cast<const f32x4*>(x + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int row = blockIdx.x;
+  if (row < R) fetch(row);
+  for (; row < R; row += gridDim.x) {
+    const int t = row / B, b = row % B;
+    const long tgt = seq[(long)b * ld_seq + t + 1];
+    // registers -> LDS with an online (max, sum-exp) per thread; columns >= V (row padding) do not count
+    float m = -INFINITY, se = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) S += (red_m[i] == -INFINITY) ? 0.f : red_s[i] * expf(red_m[i] - M);
-  const float lse = M + logf(S);
-  const bool live = (tgt != ARK_TOK_PAD);
-  if (tid == 0) row_loss[row] = live ? (lse - xs[tgt]) : 0.f;
-  if (dlogits || d16bf || d16h) {
-    const float sc = live ? hyper[ARK_HP_CE_INV_COUNT] : 0.f;
-    float* d = dlogits ? dlogits + (long)row * ld : nullptr;
-    const long nc = (d16bf || d16h) ? ((ld16 > ld || !d) ? ld16 : ld) : ld;
-    for (int c = tid; c < nc; c += 1024) {
-      float g = 0.f;
-      if (c < V) g = (expf(xs[c] - lse) - ((long)c == tgt ? 1.0f : 0.f)) * sc;
-      if (d && c < ld) d[c] = g;
-      if (c < ld16) {
-        if (d16bf) d16bf[(long)row * ld16 + c] = (__bf16)g;
-        if (d16h) d16h[(long)row * ld16 + c] = (_Float16)fminf(fmaxf(g, -65504.f), 65504.f);
+    for (int i = 0; i < NR; ++i) {
+      const int c4 = tid + 1024 * i;
+      if (c4 < LD4) {
+        f32x4 v = nx[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * c4 + e >= V) v[e] = -INFINITY;
+        *reinterpret_cast<f32x4*>(xs + 4 * c4) = v;
+        const float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (vm > m) { se *= expf(m - vm); m = vm; }
+        if (m > -INFINITY) se += expf(v[0] - m) + expf(v[1] - m) + expf(v[2] - m) + expf(v[3] - m);
       }
     }
+    const float wm = wave_max(m);
+    se = wave_sum(m == -INFINITY ? 0.f : se * expf(m - wm));
+    if (lane == 0) { red_m[wave] = wm; red_s[wave] = se; }
+    __syncthreads();
+    const int nrow = row + gridDim.x;
+    if (nrow < R) fetch(nrow);   // in flight underneath the gradient phase below
+    float M = red_m[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) M = fmaxf(M, red_m[i]);
+    float S = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S += (red_m[i] == -INFINITY) ? 0.f : red_s[i] * expf(red_m[i] - M);
+    const float lse = M + logf(S);
+    const bool live = (tgt != ARK_TOK_PAD);
+    if (tid == 0) row_loss[row] = live ? (lse - xs[tgt]) : 0.f;
+    if (dlogits || d16bf || d16h) {
+      const float sc = live ? hyper[ARK_HP_CE_INV_COUNT] : 0.f;
+      float* d = dlogits ? dlogits + (long)row * ld : nullptr;
+      const long nc = (d16bf || d16h) ? ((ld16 > ld || !d) ? ld16 : ld) : ld;
+      for (int c = tid; c < nc; c += 1024) {
+        float g = 0.f;
+        if (c < V) g = (expf(xs[c] - lse) - ((long)c == tgt ? 1.0f : 0.f)) * sc;
+        if (d && c < ld) d[c] = g;
+        if (c < ld16) {
+          if (d16bf) d16bf[(long)row * ld16 + c] = (__bf16)g;
+          if (d16h) d16h[(long)row * ld16 + c] = (_Float16)fminf(fmaxf(g, -65504.f), 65504.f);
+        }
+      }
+    }
+    __syncthreads();   // the row in LDS is done before the next one overwrites it
   }
 }
 
@@ -529,13 +548,21 @@ extern "C" int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int
   if (dlogits16 && (ld16 < V || (prec16 != 1 && prec16 != 2))) return ARK_ERR_ARG;
   __bf16* dbf = prec16 == 1 ? (__bf16*)dlogits16 : nullptr;
   _Float16* dh = prec16 == 2 ? (_Float16*)dlogits16 : nullptr;
-  const size_t row_bytes = (size_t)V * sizeof(float);
-  if (V >= 4096 && row_bytes <= 144 * 1024 && ld % 4 == 0 && g_ce_lds) {   // large vocabulary: one workgroup per row, row cached in LDS
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(ce_row_lds_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024), true);
-    (void)once;
-    hipLaunchKernelGGL(ce_row_lds_kernel, dim3((unsigned)(B * L)), dim3(1024), row_bytes, (hipStream_t)stream, logits, (long)ld, seq,
-                       (long)ld_seq, hyper, row_loss, dlogits, dbf, dh, (long)ld16, B, L, V);
+  const size_t ld_bytes = (size_t)ld * sizeof(float);
+  if (V >= 4096 && ld_bytes <= 144 * 1024 && ld % 4 == 0 && g_ce_lds) {   // large vocabulary: row cached in LDS, read once
+    const int nr = (int)((ld / 4 + 1023) / 1024);   // 16-byte loads per thread per row (<= 9 at 144 KB)
+    int grid = 256 * 1;                              // one workgroup per CU (LDS), persistent over the rows
+    if (grid > B * L) grid = B * L;
+#define ARK_CE_LDS(NRV)                                                                                                   \
+    {                                                                                                                     \
+      static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(ce_row_lds_kernel<NRV>),               \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024), true);      \
+      (void)once;                                                                                                         \
+      hipLaunchKernelGGL(ce_row_lds_kernel<NRV>, dim3((unsigned)grid), dim3(1024), ld_bytes, (hipStream_t)stream, logits,  \
+                         (long)ld, seq, (long)ld_seq, hyper, row_loss, dlogits, dbf, dh, (long)ld16, B, L, V);            \
+    }
+    if (nr <= 2) ARK_CE_LDS(2) else if (nr <= 4) ARK_CE_LDS(4) else if (nr <= 6) ARK_CE_LDS(6) else ARK_CE_LDS(9)
+#undef ARK_CE_LDS
   } else {
     hipLaunchKernelGGL(ce_kernel, dim3((B * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, seq, (long)ld_seq,
                        hyper, row_loss, dlogits, dbf, dh, (long)ld16, B, L, V);
