@@ -175,3 +175,43 @@ def test_latent_chain_bwd_matches_autograd(B, Z, D, H, with_ext):
     assert close(dWz, Wz_t.grad, 2e-5) and close(dbz, bz_t.grad, 2e-5)
     # dhead^T gelu(pre) is the head weight gradient: checks dhead itself
     assert close(dhead.double().cpu().t() @ torch.nn.functional.gelu(pre), Wh_t.grad, 2e-5)
+
+
+@pytest.mark.parametrize("V", [55, 4099, 24101, 40000])
+@pytest.mark.parametrize("only16", [False, True])
+def test_cross_entropy_kernels_match_torch(V, only16):
+    """ark_ce_fwd_bwd against F.cross_entropy(ignore_index=PAD) and its autograd: the wave-per-row kernel (small and
+    very large V) and the LDS-cached persistent kernel (4096 <= V, row <= 144 KB), with the fp32 gradient or the
+    16-bit copy alone as the output"""
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(V)
+    B, Lq = 6, 5
+    R = B * Lq
+    ld = (V + 3) // 4 * 4
+    Vp = (V + 63) // 64 * 64
+    logits = torch.zeros(R, ld)
+    logits[:, :V] = torch.randn(R, V, generator=g) * 3
+    seq = torch.randint(0, V, (B, Lq + 1), generator=g)
+    seq[1, 3:] = 0                     # PAD targets are ignored
+    tgt = seq[:, 1:].t().reshape(-1)   # rows are time-major: row (t, b) -> seq[b, t+1]
+    x = logits[:, :V].double().clone().requires_grad_(True)
+    ref = F.cross_entropy(x, tgt, ignore_index=0, reduction="sum")
+    count = int((tgt != 0).sum())
+    (ref / count).backward()
+    hyper = torch.zeros(16, device=dev)
+    hyper[3], hyper[4] = 1.0 / count, count          # ARK_HP_CE_INV_COUNT, ARK_HP_CE_COUNT
+    lg, sq = logits.to(dev), seq.to(dev)
+    row_loss = torch.zeros(R, device=dev)
+    d16 = torch.full((R, Vp), 7, dtype=torch.int16, device=dev)
+    L.check(L.lib().ark_ce_fwd_bwd(L.ptr(lg), L.i64(ld), L.ptr(sq), L.i64(Lq + 1), L.ptr(hyper), L.ptr(row_loss),
+                                   L.ptr(None if only16 else lg), L.ptr(d16), L.i32(L.PREC_BF16), L.i64(Vp), L.i32(B), L.i32(Lq),
+                                   L.i32(V), L.cur_stream()), "ark_ce_fwd_bwd")
+    torch.cuda.synchronize()
+    assert abs(row_loss.double().sum().item() - ref.item()) <= 1e-5 * abs(ref.item())
+    want = x.grad
+    got16 = d16.view(torch.bfloat16).float().cpu().double()
+    assert (got16[:, V:] == 0).all()
+    assert (got16[:, :V] - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-12
+    if not only16:
+        assert (lg[:, :V].double().cpu() - want).abs().max().item() <= 1e-6 * want.abs().max().item() + 1e-12
