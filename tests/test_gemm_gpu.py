@@ -215,3 +215,22 @@ def test_cross_entropy_kernels_match_torch(V, only16):
     assert (got16[:, :V] - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-12
     if not only16:
         assert (lg[:, :V].double().cpu() - want).abs().max().item() <= 1e-6 * want.abs().max().item() + 1e-12
+
+
+def test_wgrad16_rows_guard():
+    """ark_wgrad16_rows: A is column-padded to a tile multiple, C has only m_valid rows -- rows beyond are not touched"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    K, M, mv, N = 1024, 128, 100, 128
+    A = torch.randn(K, M, generator=g)
+    A[:, mv:] = 0
+    X = torch.randn(K, N, generator=g)
+    Ad, Xd = A.to(dev).to(torch.bfloat16), X.to(dev).to(torch.bfloat16)
+    C = torch.full((M, N), 5.0, device=dev)          # rows >= mv are "somebody else's memory"
+    L.check(L.lib().ark_wgrad16_rows(L.i32(L.PREC_BF16), L.ptr(Ad), L.i64(M), L.ptr(Xd), L.i64(N), L.ptr(C), L.i64(N), L.i32(M),
+                                     L.i32(mv), L.i32(N), L.i32(K), L.cur_stream()), "ark_wgrad16_rows")
+    torch.cuda.synchronize()
+    ref = 5.0 + Ad.float().t().double().cpu() @ Xd.float().double().cpu()
+    got = C.double().cpu()
+    assert torch.equal(got[mv:], torch.full((M - mv, N), 5.0, dtype=torch.float64))
+    assert (got[:mv] - ref[:mv]).abs().max().item() <= 1e-4 * ref.abs().max().item()
