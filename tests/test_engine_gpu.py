@@ -414,3 +414,52 @@ def test_diagonal_cells_match_layer_order(rows, ki, nbuf, xcd, units, drop):
         L.check(L.lib().ark_set_diag_units(DIAG_DEFAULT[4]), "ark_set_diag_units")
         L.check(L.lib().ark_set_diag_tuning(*DIAG_DEFAULT[:4]), "ark_set_diag_tuning")
         L.check(L.lib().ark_set_diag_bwd_tuning(32, 2, 2), "ark_set_diag_bwd_tuning")
+
+
+@pytest.mark.parametrize("B,D,n_roles", [(64, 128, 1), (48, 256, 3)])
+def test_gru_diag_fwd_matches_torch_gru_cell(B, D, n_roles):
+    """ark_gru_diag_fwd through the C-ABI against torch.nn.functional GRU-cell math in fp32 on the same fp16-rounded
+    operands: every role of one launch, new state (tile-native fp32 + row-major 16-bit copies) and the gate saves"""
+    from ark_amd import _lib as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + D)
+    idx = _tile_native_index(B, D).reshape(-1)
+    roles = (L.GruDiagRole * L.DIAG_MAX_ROLES)()
+    keep, refs = [], []
+    for k in range(n_roles):
+        x = (torch.randn(B, D, generator=g) * 0.5).half()
+        h = torch.tanh(torch.randn(B, D, generator=g))
+        wih = (torch.randn(3 * D, D, generator=g) * 0.1).half()
+        whh = (torch.randn(3 * D, D, generator=g) * 0.1).half()
+        bih, bhh = torch.randn(3 * D, generator=g) * 0.1, torch.randn(3 * D, generator=g) * 0.1
+        h16 = h.half()
+        gi = x.float() @ wih.float().t() + bih
+        gh = h16.float() @ whh.float().t() + bhh
+        r = torch.sigmoid(gi[:, :D] + gh[:, :D])
+        z = torch.sigmoid(gi[:, D:2 * D] + gh[:, D:2 * D])
+        n = torch.tanh(gi[:, 2 * D:] + r * gh[:, 2 * D:])
+        hn = (1 - z) * n + z * h
+        refs.append((hn, r, z, n, gh[:, 2 * D:]))
+        y_prev_t = torch.zeros(B * D)
+        y_prev_t[idx] = h.reshape(-1)
+        bufs = dict(x=x.to(dev), h16=h16.to(dev), wih=wih.to(dev), whh=whh.to(dev), bih=bih.to(dev), bhh=bhh.to(dev),
+                    yp=y_prev_t.to(dev), yo=torch.zeros(B * D, device=dev), ya=torch.zeros(B, D, dtype=torch.float16, device=dev),
+                    yb=torch.zeros(B, D, dtype=torch.bfloat16, device=dev),
+                    sv=[torch.zeros(B * D, dtype=torch.float16, device=dev) for _ in range(4)])
+        keep.append(bufs)
+        ro = roles[k]
+        ro.x16, ro.h_prev16, ro.w_ih16, ro.w_hh16 = (L.dptr(bufs[n_]) for n_ in ("x", "h16", "wih", "whh"))
+        ro.b_ih, ro.b_hh, ro.y_prev_t, ro.y_out_t = (L.dptr(bufs[n_]) for n_ in ("bih", "bhh", "yp", "yo"))
+        ro.y16a, ro.y16b = L.dptr(bufs["ya"]), L.dptr(bufs["yb"])
+        ro.save_r, ro.save_z, ro.save_n, ro.save_hn = (L.dptr(t) for t in bufs["sv"])
+        ro.drop_p = 0.0
+    L.check(L.lib().ark_gru_diag_fwd(L.i32(L.PREC_F16), L.i32(L.PREC_BF16), L.i32(n_roles), roles, L.ptr(None), L.i32(B), L.i32(D),
+                                     L.cur_stream()), "ark_gru_diag_fwd")
+    torch.cuda.synchronize()
+    for bufs, (hn, r, z, n, ghn) in zip(keep, refs):
+        got = bufs["yo"].cpu()[idx].reshape(B, D)
+        assert (got - hn).abs().max().item() < 2e-5
+        assert (bufs["ya"].float().cpu() - hn).abs().max().item() < 1e-3       # fp16 copy
+        assert (bufs["yb"].float().cpu() - hn).abs().max().item() < 8e-3       # bf16 copy
+        for sv, want in zip(bufs["sv"], (r, z, n, ghn)):
+            assert (sv.float().cpu()[idx].reshape(B, D) - want).abs().max().item() < 2e-3
