@@ -463,3 +463,59 @@ def test_gru_diag_fwd_matches_torch_gru_cell(B, D, n_roles):
         assert (bufs["yb"].float().cpu() - hn).abs().max().item() < 8e-3       # bf16 copy
         for sv, want in zip(bufs["sv"], (r, z, n, ghn)):
             assert (sv.float().cpu()[idx].reshape(B, D) - want).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("top", [False, True])
+def test_gru_diag_bwd_matches_autograd(top):
+    """ark_gru_diag_bwd through the C-ABI against torch autograd of one GRU cell: dh = carry + dgh_next W_hh + dy with
+    dy given (top layer) or formed in the kernel as dgi_above W_ih_above; outputs dgi / dgh panels, carry, bias sums"""
+    from ark_amd import _lib as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5 + top)
+    B, D = 64, 128
+    idx = _tile_native_index(B, D).reshape(-1)
+    bf = lambda t: t.to(torch.bfloat16)
+    tn = lambda t, dt=torch.float32: (lambda o: (o.__setitem__(idx, t.reshape(-1).to(dt)), o)[1])(torch.zeros(B * D, dtype=dt))
+    gi = torch.randn(B, 3 * D, generator=g).double().requires_grad_(True)
+    gh = torch.randn(B, 3 * D, generator=g).double().requires_grad_(True)
+    h_prev = torch.tanh(torch.randn(B, D, generator=g)).double()
+    r = torch.sigmoid(gi[:, :D] + gh[:, :D])
+    z = torch.sigmoid(gi[:, D:2 * D] + gh[:, D:2 * D])
+    n = torch.tanh(gi[:, 2 * D:] + r * gh[:, 2 * D:])
+    h = (1 - z) * n + z * h_prev
+    # saves exactly as the forward pass stores them (fp16): the reference differentiates at those values
+    carry = torch.randn(B, D, generator=g) * 0.1
+    dgh_next = bf(torch.randn(B, 3 * D, generator=g) * 0.1)
+    whh = bf(torch.randn(3 * D, D, generator=g) * 0.1)           # W_hh [3D, D]
+    dgi_up = bf(torch.randn(B, 3 * D, generator=g) * 0.1)
+    wih_up = bf(torch.randn(3 * D, D, generator=g) * 0.1)        # W_ih of the layer above [3D, D]
+    dy_top = torch.randn(B, D, generator=g) * 0.1
+    dy = dy_top if top else dgi_up.float() @ wih_up.float()
+    dh = (carry + dgh_next.float() @ whh.float() + dy).double()
+    (dh * h).sum().backward()
+    roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
+    ro = roles[0]
+    bufs = dict(dgn=dgh_next.to(dev), whhT=whh.t().contiguous().to(dev), carry=tn(carry).to(dev),
+                sr=tn(r.detach(), torch.float16).to(dev), sz=tn(z.detach(), torch.float16).to(dev),
+                sn=tn(n.detach(), torch.float16).to(dev), shn=tn(gh[:, 2 * D:].detach(), torch.float16).to(dev),
+                yp=tn(h_prev).to(dev), dgi=torch.zeros(B, 3 * D, dtype=torch.bfloat16, device=dev),
+                dgh=torch.zeros(B, 3 * D, dtype=torch.bfloat16, device=dev), dbi=torch.zeros(3 * D, device=dev),
+                dbh=torch.zeros(3 * D, device=dev), dy=tn(dy_top).to(dev), up=dgi_up.to(dev),
+                wupT=wih_up.t().contiguous().to(dev))
+    if top:
+        ro.dy_t = L.dptr(bufs["dy"])
+    else:
+        ro.dgi_up16, ro.w_ihT_up16 = L.dptr(bufs["up"]), L.dptr(bufs["wupT"])
+    ro.dgh_next16, ro.w_hhT16, ro.carry_t = L.dptr(bufs["dgn"]), L.dptr(bufs["whhT"]), L.dptr(bufs["carry"])
+    ro.save_r, ro.save_z, ro.save_n, ro.save_hn = (L.dptr(bufs[k]) for k in ("sr", "sz", "sn", "shn"))
+    ro.y_prev_t, ro.dgi16, ro.dgh16 = L.dptr(bufs["yp"]), L.dptr(bufs["dgi"]), L.dptr(bufs["dgh"])
+    ro.db_ih, ro.db_hh = L.dptr(bufs["dbi"]), L.dptr(bufs["dbh"])
+    ro.first, ro.drop_p = 0, 0.0
+    L.check(L.lib().ark_gru_diag_bwd(L.i32(L.PREC_BF16), L.i32(1), roles, L.ptr(None), L.i32(B), L.i32(D), L.cur_stream()),
+            "ark_gru_diag_bwd")
+    torch.cuda.synchronize()
+    close = lambda got, want, tol: (got.double().cpu() - want).abs().max().item() <= tol * want.abs().max().item()
+    assert close(bufs["dgi"].float(), gi.grad, 1.5e-2)      # bf16 outputs, fp16 saves
+    assert close(bufs["dgh"].float(), gh.grad, 1.5e-2)
+    assert close(bufs["carry"].cpu()[idx].reshape(B, D), (dh * z).detach(), 2e-3)
+    assert close(bufs["dbi"], gi.grad.sum(0), 1.5e-2) and close(bufs["dbh"], gh.grad.sum(0), 1.5e-2)
