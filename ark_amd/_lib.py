@@ -72,6 +72,8 @@ def u64(x):
 
 
 DIAG_MAX_ROLES = 4
+WGRAD_MAX_GROUP = 12
+ADAM_MAX_JOBS = 48
 
 
 class GruDiagRole(ctypes.Structure):
@@ -90,6 +92,23 @@ def dptr(t):
 class GruDiagBwdRole(ctypes.Structure):
     """ArkGruDiagBwdRole of include/ark_amd.h"""
     _fields_ = [(k, ctypes.c_void_p) for k in (
-        "dgi_up16", "w_ihT_up16", "dgh_next16", "w_hhT16", "dy_t", "carry_t", "save_r", "save_z", "save_n", "save_hn",
-        "y_prev_t", "dgi16", "dgh16", "db_ih", "db_hh", "dh0")] + [
+        "dgi_up16", "w_ihT_up16", "dg_next16", "w_hhT16", "dy_t", "carry_t", "save_r", "save_z", "save_n", "save_hn",
+        "y_prev_t", "dg16", "db_ih", "db_hh", "dh0")] + [
         ("drop_seed", ctypes.c_uint64), ("drop_base", ctypes.c_int64), ("drop_p", ctypes.c_float), ("first", ctypes.c_int)]
+
+
+class DiagTuning(ctypes.Structure):
+    """ArkDiagTuning of include/ark_amd.h (speed-only tile / ring choices, passed per call)"""
+    _fields_ = [(k, ctypes.c_int) for k in ("fwd_rows", "fwd_ki", "fwd_nbuf", "fwd_xcd", "fwd_units", "bwd_rows", "bwd_ki",
+                                            "bwd_nbuf", "bwd_xcd_rows")]
+
+
+def diag_tuning(**kw):
+    """the library's measured defaults with the given fields replaced"""
+    t = DiagTuning()
+    lib().ark_diag_tuning_default(ctypes.byref(t))
+    for k, v in kw.items():
+        if k not in dict(DiagTuning._fields_):
+            raise KeyError(k)
+        setattr(t, k, int(v))
+    return t

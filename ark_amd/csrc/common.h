@@ -39,19 +39,52 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   return cdf + x * pdf;
 }
 
-// counter-based dropout: keep-scale of element i of a layer's [B*L, D] output at optimiser step `step`.
-// One definition shared by the mask kernel (register-staged path) and the in-kernel use of the
-// LDS-DMA path (forward cell epilogue and the input-gradient product), so both directions agree.
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
+// hardware transcendentals for the 16-bit-operand (mixed precision) GRU epilogues: v_exp_f32 / v_rcp_f32 are ~1 ulp,
+// far inside the fp16 operand rounding of that path; 4-5 instructions instead of ~25 (expf + division) / ~40 (tanhf).
+// The exact-fp32 path (gru.hip) keeps expf / tanhf.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
-__device__ __forceinline__ float dropout_keep_scale(uint64_t seed, uint64_t step, uint64_t i, float p, float keep_scale) {
-  const uint64_t h = splitmix64(seed ^ splitmix64(step * 0x100000001B3ull + i));
-  const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
-  return (u >= p) ? keep_scale : 0.f;
+__device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2/(1 + e^{2x}); exp2 -> inf / 0 gives the +-1 limits
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+// counter-based dropout: keep-scale of element i of a layer's [B*L, D] output for dropout draw `step`
+// (hyper[ARK_HP_DROP_STEP], a uint32 the token gather bumps once per training forward).  One 64-bit hash
+// serves FOUR consecutive elements (a quad = one lane's 4 accumulator rows in the tile-native layout),
+// 16 bits each, so p is quantised to 1/65536.  One definition shared by the mask kernel, the forward cell
+// epilogue and the backward cell, so both directions agree.  (Round 1 hashed every element with two
+// splitmix64 rounds -- 64-bit multiplies -- ~80 VALU instructions per element.)
+constexpr int kHpDropStep = 12;   // == ARK_HP_DROP_STEP (include/ark_amd.h; static_assert in optim.hip)
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+struct DropCtx { uint32_t s0, s1, step, p16; float ks; };
+__device__ __forceinline__ DropCtx drop_ctx(uint64_t seed, const float* hyper, float p) {
+  DropCtx c;
+  c.s0 = (uint32_t)seed; c.s1 = (uint32_t)(seed >> 32);
+  c.step = reinterpret_cast<const uint32_t*>(hyper)[kHpDropStep];
+  c.p16 = (uint32_t)(p * 65536.0f + 0.5f);
+  c.ks = 1.0f / (1.0f - p);
+  return c;
+}
+__device__ __forceinline__ f32x4 dropout_quad(const DropCtx& c, uint64_t quad) {
+  const uint32_t q0 = (uint32_t)quad, q1 = (uint32_t)(quad >> 32);
+  uint32_t a = fmix32(q0 * 0x9E3779B1u + c.step * 0x85EBCA77u + c.s0);
+  a = fmix32(a ^ (q1 * 0xC2B2AE3Du + c.s1));
+  const uint32_t b = fmix32(a + 0x6C8E9CF5u);
+  f32x4 m;
+  m[0] = ((a & 0xFFFFu) >= c.p16) ? c.ks : 0.f;
+  m[1] = ((a >> 16) >= c.p16) ? c.ks : 0.f;
+  m[2] = ((b & 0xFFFFu) >= c.p16) ? c.ks : 0.f;
+  m[3] = ((b >> 16) >= c.p16) ? c.ks : 0.f;
+  return m;
+}
+__device__ __forceinline__ float dropout_one(const DropCtx& c, uint64_t i) {
+  const f32x4 m = dropout_quad(c, i >> 2);
+  const int e = (int)(i & 3);
+  return e == 0 ? m[0] : e == 1 ? m[1] : e == 2 ? m[2] : m[3];
 }
 
 // XCD-aware workgroup remap (MI355X: 8 XCDs, private 4 MB L2 each; workgroups are dealt round-robin

@@ -15,8 +15,16 @@
 // lane*16), so the swizzle is applied to the per-lane SOURCE address instead: lane i of the
 // wave-instruction that fills rows 8p..8p+7 of an image supplies row 8p + i/8, logical chunk
 // (i%8) ^ ((row>>1)&7).
+//
+// ONE runner, `run_segs`, serves every user: a product is a list of K-SEGMENTS (operand pair + length)
+// that stream through the same ring back to back without draining between them; the caller's functor
+// says which accumulators a segment's MFMAs go to.  Each segment gets its OWN consume loop: with a
+// single loop and a run-time "which accumulator" select, hipcc moved every accumulator between AGPRs
+// and VGPRs on every stage (rocprofv3 round 2: 2 700 VALU instructions per wave against 192 MFMAs in
+// the forward diagonal kernel; SQ_ACTIVE_INST + SQ_WAIT_INST = 71 % of the wave cycles).
 #pragma once
 #include <type_traits>
+#include <utility>
 #include "gemm_core.h"
 
 namespace ark {
@@ -30,6 +38,27 @@ __device__ __forceinline__ long tile_native_off(int row, int col, int ld) {
   return ((long)(row >> 4) * (ld >> 4) + (col >> 4)) * 256 + ((((row >> 2) & 3) << 4) + (col & 15)) * 4 + (row & 3);
 }
 
+// selects between wave-uniform values on the scalar unit (operands are forced into SGPRs)
+__device__ __forceinline__ uint64_t s_select64(int cond, uint64_t a, uint64_t b) {
+  uint64_t r;
+  asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b64 %0, %2, %3" : "=s"(r) : "s"(cond), "s"(a), "s"(b) : "scc");
+  return r;
+}
+__device__ __forceinline__ int s_select32(int cond, int a, int b) {
+  int r;
+  asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(r) : "s"(cond), "s"(a), "s"(b) : "scc");
+  return r;
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int PREC, int BM, int BN, int NBUF, int WGM, int WGN, int KI = 1>
 struct DmaTile {
   static_assert(PREC == PREC_F16 || PREC == PREC_BF16, "LDS-DMA engine takes 16-bit operands");
@@ -38,6 +67,7 @@ struct DmaTile {
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
+  using h8 = typename PT::h8;
   // one pipeline stage = KI 64-wide k-images of both operands; NBUF stages ride a ring in LDS
   static constexpr int KS = 64 * KI;
   static constexpr int A_IMG = BM * 128, B_IMG = BN * 128;
@@ -58,325 +88,134 @@ struct DmaTile {
   static __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
   }
-  // wait until all but the youngest `stages` stages of this wave's LDS-DMA have landed
-  static __device__ __forceinline__ void wait_stages(int stages) {
-    switch (stages) {
-      case 0: wait_vmcnt<0>(); break;
-      case 1: wait_vmcnt<LPS>(); break;
-      case 2: wait_vmcnt<(NBUF > 2 ? 2 : 0) * LPS>(); break;
-      case 3: wait_vmcnt<(NBUF > 3 ? 3 : 0) * LPS>(); break;
-      case 4: wait_vmcnt<(NBUF > 4 ? 4 : 0) * LPS>(); break;
-      case 5: wait_vmcnt<(NBUF > 5 ? 5 : 0) * LPS>(); break;
-      case 6: wait_vmcnt<(NBUF > 6 ? 6 : 0) * LPS>(); break;
-      default: wait_vmcnt<(NBUF > 7 ? 7 : 0) * LPS>(); break;
-    }
-  }
 
-  // rma / rmb: tile row -> memory row (must be a valid row; clamp out-of-range rows on the caller side)
-  template <class RMA, class RMB>
-  static __device__ __forceinline__ void run(f32x4 (&acc)[TM][TN], const h_t* A, long lda, RMA rma, const h_t* B,
-                                             long ldb, RMB rmb, int K, char* lds) {
+  // K-segments of one product: acc(seg) += A[seg] x B[seg]^T over K[seg] (K % KS == 0, 0 allowed);
+  // all segments share the leading dimensions and the tile -> memory row maps.
+  template <int NSEG>
+  struct Segs {
+    const h_t* A[NSEG];
+    const h_t* B[NSEG];
+    int K[NSEG];
+  };
+
+  // rma / rmb: tile row -> memory row (must be a valid row; clamp out-of-range rows on the caller side).
+  // mm(std::integral_constant<int, seg>, a[TM], b[TN]): the segment's MFMAs for one 32-wide k-step.
+  template <int NSEG, class RMA, class RMB, class MM>
+  static __device__ __forceinline__ void run_segs(const Segs<NSEG>& sg, long lda, long ldb, RMA rma, RMB rmb, char* lds,
+                                                  MM&& mm) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int lr = lane & 15, lq = lane >> 4;
-
-    // piece q of an operand's stage: image j = q / (R/8), rows 8p..8p+7 with p = q % (R/8)
-    const h_t* ap[NPA];
-    const h_t* bp[NPB];
+    // piece q of an operand's stage: image j = q / (R/8), rows 8p..8p+7 with p = q % (R/8); these are this
+    // lane's element offsets inside the operand (the same for every segment)
+    long ao[NPA], bo[NPB];
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       const int q = wave + NW * i, j = q / (BM / 8), pr = q % (BM / 8);
       const int row = 8 * pr + (lane >> 3);
-      ap[i] = A + rma(row) * lda + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+      ao[i] = rma(row) * lda + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
       const int q = wave + NW * i, j = q / (BN / 8), pr = q % (BN / 8);
       const int row = 8 * pr + (lane >> 3);
-      bp[i] = B + rmb(row) * ldb + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+      bo[i] = rmb(row) * ldb + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
     }
-    auto issue = [&](int s) {
-      char* base = lds + (s % NBUF) * STAGE_BYTES;
-      const int k0 = s * KS;
+    // stages per segment, cumulative: segment i owns global stages [cum[i-1], cum[i])
+    int cum[NSEG];
+    {
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < NSEG; ++i) { c += sg.K[i] / KS; cum[i] = c; }
+    }
+    int left = cum[NSEG - 1];             // stages not issued yet
+    if (left <= 0) return;
+    int remaining = left;                 // stages not consumed yet
+    int gi = 0, islot = 0;                // issue cursor: global stage, ring slot (wave-uniform)
+    auto issue_next = [&]() {
+      // operand bases of the segment that owns stage gi, selected on the SCALAR unit (hipcc if-converted the
+      // plain C++ selects into v_cndmask chains on VGPR copies of these wave-uniform pointers)
+      uint64_t A = reinterpret_cast<uint64_t>(sg.A[0]), B = reinterpret_cast<uint64_t>(sg.B[0]);
+      int start = 0;
+#pragma unroll
+      for (int i = 1; i < NSEG; ++i) {
+        const int in_i = __builtin_amdgcn_readfirstlane(gi >= cum[i - 1] ? 1 : 0);
+        A = s_select64(in_i, reinterpret_cast<uint64_t>(sg.A[i]), A);
+        B = s_select64(in_i, reinterpret_cast<uint64_t>(sg.B[i]), B);
+        start = s_select32(in_i, cum[i - 1], start);
+      }
+      const int ik = (gi - start) * KS;
+      const h_t* Ap = reinterpret_cast<const h_t*>(A) + ik;
+      const h_t* Bp = reinterpret_cast<const h_t*>(B) + ik;
+      char* base = lds + islot * STAGE_BYTES;
 #pragma unroll
       for (int i = 0; i < NPA; ++i)   // piece q lands at byte q*1024 of the operand's stage (images are contiguous)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap[i] + k0),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ap + ao[i]),
                                          (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
 #pragma unroll
       for (int i = 0; i < NPB; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp[i] + k0),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bp + bo[i]),
                                          (__attribute__((address_space(3))) void*)(base + A_STAGE + (wave + NW * i) * 1024), 16, 0, 0);
+      ++gi;
+      islot = (islot + 1 == NBUF) ? 0 : islot + 1;
+      --left;
     };
+    {
+      const int pre = left < NBUF ? left : NBUF;
+      for (int s = 0; s < pre; ++s) issue_next();
+    }
+    int cslot = 0;
+    static_for<NSEG>([&](auto segc) {
+      const int ns = sg.K[decltype(segc)::value] / KS;
+      for (int s = 0; s < ns; ++s) {
+        // min(NBUF, remaining) stages are in flight; the oldest must have landed.  (Ring tails deeper than two
+        // slots drain completely: exact counting there bought nothing measurable.)
+        if (remaining >= NBUF) wait_vmcnt<(NBUF - 1) * LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* bufA = lds + cslot * STAGE_BYTES;
+        const char* bufB = bufA + A_STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2 * KI; ++s2) {
+          h8 a[TM], b[TN];
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+            a[tm] = *reinterpret_cast<const h8*>(bufA + (s2 >> 1) * A_IMG + lds_off(wm * WTM + tm * 16 + lr, 4 * (s2 & 1) + lq));
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            b[tn] = *reinterpret_cast<const h8*>(bufB + (s2 >> 1) * B_IMG + lds_off(wn * WTN + tn * 16 + lr, 4 * (s2 & 1) + lq));
+          mm(segc, a, b);
+        }
+        --remaining;
+        cslot = (cslot + 1 == NBUF) ? 0 : cslot + 1;
+        if (left > 0) {
+          // every wave has consumed the ring slot (its fragment reads are complete) -> refill it
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          issue_next();
+        }
+      }
+    });
+  }
 
+  // plain product: acc = A x B^T over K
+  template <class RMA, class RMB>
+  static __device__ __forceinline__ void run(f32x4 (&acc)[TM][TN], const h_t* A, long lda, RMA rma, const h_t* B,
+                                             long ldb, RMB rmb, int K, char* lds) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int NS = K / KS;  // host guarantees K % KS == 0
-    if (NS <= 0) return;
-    const int pre = NS < NBUF ? NS : NBUF;
-    for (int s = 0; s < pre; ++s) issue(s);
-    for (int s = 0; s < NS; ++s) {
-      // stages s+1 .. min(NS, s+NBUF)-1 may stay in flight while stage s is consumed
-      const int ahead = (NS - 1 - s) < (NBUF - 1) ? (NS - 1 - s) : (NBUF - 1);
-      wait_stages(ahead);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      const char* bufA = lds + (s % NBUF) * STAGE_BYTES;
-      const char* bufB = bufA + A_STAGE;
+    Segs<1> sg{{A}, {B}, {K}};
+    run_segs<1>(sg, lda, ldb, rma, rmb, lds, [&](auto, const h8 (&a)[TM], const h8 (&b)[TN]) {
 #pragma unroll
-      for (int s2 = 0; s2 < 2 * KI; ++s2) {
-        typename PT::h8 a[TM], b[TN];
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#if defined(ARK_ABL) && (ARK_ABL & 1)
-          a[tm] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f});
-#else
-          a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + (s2 >> 1) * A_IMG +
-                                                            lds_off(wm * WTM + tm * 16 + lr, 4 * (s2 & 1) + lq));
-#endif
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-#if defined(ARK_ABL) && (ARK_ABL & 2)
-          b[tn] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f + tn});
-#else
-          b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + (s2 >> 1) * B_IMG +
-                                                            lds_off(wn * WTN + tn * 16 + lr, 4 * (s2 & 1) + lq));
-#endif
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-#if defined(ARK_ABL) && (ARK_ABL & 4)
-            acc[tm][tn][0] += (float)a[tm][0] * (float)b[tn][0];
-#else
-            acc[tm][tn] = PT::mfma(a[tm], b[tn], acc[tm][tn]);
-#endif
-          }
-      }
-      if (s + NBUF < NS) {
-        // every wave has consumed ring slot s%NBUF (its fragment reads are complete) -> refill it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        issue(s + NBUF);
-      }
-    }
-  }
-
-  // Two K-segments through ONE ring: acc1 += A1 x B1^T over K1, then acc2 += A2 x B2^T over K2, with the
-  // stages of segment 2 already in flight while segment 1 is still being consumed (no drain between
-  // them).  Both segments share the tile -> memory row maps.  Used by the layer-diagonal GRU cell
-  // (x W_ih^T and h W_hh^T must stay separate for the candidate gate).
-  template <class RMA, class RMB>
-  static __device__ __forceinline__ void run2(f32x4 (&acc1)[TM][TN], f32x4 (&acc2)[TM][TN], const h_t* A1, const h_t* B1,
-                                              int K1, const h_t* A2, const h_t* B2, int K2, long lda, long ldb, RMA rma,
-                                              RMB rmb, char* lds) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int lr = lane & 15, lq = lane >> 4;
-    long ao[NPA], bo[NPB];   // element offsets of this lane's piece rows (same in both segments)
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-      const int q = wave + NW * i, j = q / (BM / 8), pr = q % (BM / 8);
-      const int row = 8 * pr + (lane >> 3);
-      ao[i] = rma(row) * lda + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
-    }
-#pragma unroll
-    for (int i = 0; i < NPB; ++i) {
-      const int q = wave + NW * i, j = q / (BN / 8), pr = q % (BN / 8);
-      const int row = 8 * pr + (lane >> 3);
-      bo[i] = rmb(row) * ldb + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
-    }
-    const int NS1 = K1 / KS, NS = NS1 + K2 / KS;   // host guarantees K1 % KS == 0 && K2 % KS == 0
-    auto issue = [&](int s) {
-#if defined(ARK_ABL) && (ARK_ABL & 8)
-      return;
-#endif
-      char* base = lds + (s % NBUF) * STAGE_BYTES;
-      const bool first = s < NS1;
-      const h_t* A = first ? A1 : A2;
-      const h_t* B = first ? B1 : B2;
-      const int k0 = (first ? s : s - NS1) * KS;
-#pragma unroll
-      for (int i = 0; i < NPA; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + ao[i] + k0),
-                                         (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NPB; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + bo[i] + k0),
-                                         (__attribute__((address_space(3))) void*)(base + A_STAGE + (wave + NW * i) * 1024), 16, 0, 0);
-    };
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc1[tm][tn] = acc2[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (NS <= 0) return;
-    const int pre = NS < NBUF ? NS : NBUF;
-    for (int s = 0; s < pre; ++s) issue(s);
-    auto consume = [&](f32x4 (&acc)[TM][TN], int s) {
-      const char* bufA = lds + (s % NBUF) * STAGE_BYTES;
-      const char* bufB = bufA + A_STAGE;
-#pragma unroll
-      for (int s2 = 0; s2 < 2 * KI; ++s2) {
-        typename PT::h8 a[TM], b[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#if defined(ARK_ABL) && (ARK_ABL & 1)
-          a[tm] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f});
-#else
-          a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + (s2 >> 1) * A_IMG +
-                                                            lds_off(wm * WTM + tm * 16 + lr, 4 * (s2 & 1) + lq));
-#endif
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-#if defined(ARK_ABL) && (ARK_ABL & 2)
-          b[tn] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f + tn});
-#else
-          b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + (s2 >> 1) * B_IMG +
-                                                            lds_off(wn * WTN + tn * 16 + lr, 4 * (s2 & 1) + lq));
-#endif
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-#if defined(ARK_ABL) && (ARK_ABL & 4)
-            acc[tm][tn][0] += (float)a[tm][0] * (float)b[tn][0];
-#else
-            acc[tm][tn] = PT::mfma(a[tm], b[tn], acc[tm][tn]);
-#endif
-          }
-      }
-    };
-    for (int s = 0; s < NS; ++s) {
-      const int ahead = (NS - 1 - s) < (NBUF - 1) ? (NS - 1 - s) : (NBUF - 1);
-      wait_stages(ahead);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (s < NS1) consume(acc1, s);
-      else consume(acc2, s);
-      if (s + NBUF < NS) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        issue(s + NBUF);
-      }
-    }
-  }
-
-  // run2 with SHARED accumulators for all but the last 16-column block of the wave tile: segment 1 adds
-  // into acc[.][0..TN-1], segment 2 into acc[.][0..TN-2] and acc[.][TN].  The GRU forward cell needs
-  // x W_ih^T and h W_hh^T apart for the candidate gate only (last block of the r|z|n wave tile), so
-  // it carries 4 instead of 6 accumulator tiles per 16 rows.
-  template <class RMA, class RMB>
-  static __device__ __forceinline__ void run2_shared(f32x4 (&acc)[TM][TN + 1], const h_t* A1, const h_t* B1,
-                                              int K1, const h_t* A2, const h_t* B2, int K2, long lda, long ldb, RMA rma,
-                                              RMB rmb, char* lds) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int lr = lane & 15, lq = lane >> 4;
-    long ao[NPA], bo[NPB];   // element offsets of this lane's piece rows (same in both segments)
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-      const int q = wave + NW * i, j = q / (BM / 8), pr = q % (BM / 8);
-      const int row = 8 * pr + (lane >> 3);
-      ao[i] = rma(row) * lda + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
-    }
-#pragma unroll
-    for (int i = 0; i < NPB; ++i) {
-      const int q = wave + NW * i, j = q / (BN / 8), pr = q % (BN / 8);
-      const int row = 8 * pr + (lane >> 3);
-      bo[i] = rmb(row) * ldb + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
-    }
-    const int NS1 = K1 / KS, NS = NS1 + K2 / KS;   // host guarantees K1 % KS == 0 && K2 % KS == 0
-    auto issue = [&](int s) {
-#if defined(ARK_ABL) && (ARK_ABL & 8)
-      return;
-#endif
-      char* base = lds + (s % NBUF) * STAGE_BYTES;
-      const bool first = s < NS1;
-      const h_t* A = first ? A1 : A2;
-      const h_t* B = first ? B1 : B2;
-      const int k0 = (first ? s : s - NS1) * KS;
-#pragma unroll
-      for (int i = 0; i < NPA; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + ao[i] + k0),
-                                         (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NPB; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + bo[i] + k0),
-                                         (__attribute__((address_space(3))) void*)(base + A_STAGE + (wave + NW * i) * 1024), 16, 0, 0);
-    };
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn <= TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if defined(ARK_ABL) && (ARK_ABL & 64)
-    return;
-#endif
-    if (NS <= 0) return;
-    const int pre = NS < NBUF ? NS : NBUF;
-    for (int s = 0; s < pre; ++s) issue(s);
-    auto consume = [&](auto last_col, int s) {   // last_col: accumulator column of the wave tile's last block
-      const char* bufA = lds + (s % NBUF) * STAGE_BYTES;
-      const char* bufB = bufA + A_STAGE;
-#pragma unroll
-      for (int s2 = 0; s2 < 2 * KI; ++s2) {
-        typename PT::h8 a[TM], b[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#if defined(ARK_ABL) && (ARK_ABL & 1)
-          a[tm] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f});
-#else
-          a[tm] = *reinterpret_cast<const typename PT::h8*>(bufA + (s2 >> 1) * A_IMG +
-                                                            lds_off(wm * WTM + tm * 16 + lr, 4 * (s2 & 1) + lq));
-#endif
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-#if defined(ARK_ABL) && (ARK_ABL & 2)
-          b[tn] = __builtin_bit_cast(typename PT::h8, f32x4{1.f + lr, 2.f, 3.f + lq, 4.f + tn});
-#else
-          b[tn] = *reinterpret_cast<const typename PT::h8*>(bufB + (s2 >> 1) * B_IMG +
-                                                            lds_off(wn * WTN + tn * 16 + lr, 4 * (s2 & 1) + lq));
-#endif
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            constexpr int LC = decltype(last_col)::value;
-            const int c = (tn == TN - 1) ? LC : tn;
-#if defined(ARK_ABL) && (ARK_ABL & 4)
-            acc[tm][c][0] += (float)a[tm][0] * (float)b[tn][0];
-#else
-            acc[tm][c] = PT::mfma(a[tm], b[tn], acc[tm][c]);
-#endif
-          }
-      }
-    };
-    for (int s = 0; s < NS; ++s) {
-      const int ahead = (NS - 1 - s) < (NBUF - 1) ? (NS - 1 - s) : (NBUF - 1);
-      wait_stages(ahead);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (s < NS1) consume(std::integral_constant<int, TN - 1>{}, s);
-      else consume(std::integral_constant<int, TN>{}, s);
-      if (s + NBUF < NS) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        issue(s + NBUF);
-      }
-    }
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = PT::mfma(a[tm], b[tn], acc[tm][tn]);
+    });
   }
 };
 

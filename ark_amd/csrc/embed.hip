@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void enc_pool_fwd_kernel(const int64_t* __rest
 // ---- decoder input: x[(t,b), :] = W_tok[seq[b, t]] (+ W_pos[t])   (time-major rows) -----------
 __global__ __launch_bounds__(256) void tok_gather_kernel(const int64_t* __restrict__ seq, long ld_seq,
                                                          const float* __restrict__ Wt, const float* __restrict__ Wp,
-                                                         float* __restrict__ x, int B, int L, int D) {
+                                                         float* __restrict__ x, int B, int L, int D, float* hyper_tick) {
+  // training forward: bump the dropout draw counter (see common.h; the GRU cells run after this kernel)
+  if (hyper_tick && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<uint32_t*>(hyper_tick)[kHpDropStep] += 1u;
   const int D4 = D >> 2;
   const long total = (long)B * L * D4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -285,14 +287,14 @@ extern "C" int ark_enc_pool_bwd(const int64_t* triples, const float* dg, const f
 }
 
 extern "C" int ark_tok_gather(const int64_t* seq, int64_t ld_seq, const float* w_tok, const float* w_pos, float* x,
-                              int B, int L, int D, void* stream) {
+                              int B, int L, int D, float* hyper_tick, void* stream) {
   using namespace ark;
   if (!seq || !w_tok || !x || B <= 0 || L <= 0 || D <= 0) return ARK_ERR_ARG;
   if (D % 4 != 0) return ARK_ERR_SHAPE;
   long total = (long)B * L * (D / 4);
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(tok_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, seq, (long)ld_seq, w_tok, w_pos,
-                     x, B, L, D);
+                     x, B, L, D, hyper_tick);
   ARK_LAUNCH_CHECK();
   return 0;
 }

@@ -15,7 +15,6 @@ struct Gemm16Args {
   long lda, ldb, ldc;
   int M, N, K, epi, c_tiled, tiles_n;
   void* c16a; void* c16b; int prec_a, prec_b;   // optional row-major 16-bit copies of the result (ld = ldc)
-  float drop_p; uint64_t drop_seed; const float* hyper;   // ARK_EPI_DROPOUT (tile-native C only)
 };
 
 template <int PREC, int BM, int BN, int NBUF>
@@ -44,12 +43,6 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
       if (p.c_tiled) {  // M % 16 == 0 and ldc % 16 == 0 (checked on the host): the quad is whole
         const long o = tile_native_off(row0, col, (int)p.ldc);
         if (p.epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
-        if (p.epi == ARK_EPI_DROPOUT) {   // the mask the forward cell applied to this element (same hash, same index)
-          const uint64_t step = (uint64_t)p.hyper[ARK_HP_ADAM_STEP];
-          const float ks = 1.0f / (1.0f - p.drop_p);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] *= dropout_keep_scale(p.drop_seed, step, (uint64_t)(o + i), p.drop_p, ks);
-        }
         *reinterpret_cast<f32x4*>(p.C + o) = v;
       } else {
 #pragma unroll
@@ -123,8 +116,11 @@ static int launch16(Gemm16Args p, hipStream_t st) {
 template <int PA, int PB2>
 __global__ __launch_bounds__(256) void tok_gather16_kernel(const int64_t* __restrict__ seq, long ld_seq,
                                                            const float* __restrict__ Wt, const float* __restrict__ Wp,
-                                                           void* xa_, void* xb_, int B, int L, int D) {
+                                                           void* xa_, void* xb_, int B, int L, int D, float* hyper_tick) {
   using HA = typename PrecTraits<PA>::h_t;
+  // a training forward draws fresh dropout masks: bump the draw counter the GRU cells hash (they run after this
+  // kernel in stream order; the previous step's backward ran before it)
+  if (hyper_tick && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<uint32_t*>(hyper_tick)[kHpDropStep] += 1u;
   using HB = typename PrecTraits<PB2>::h_t;
   typedef HA ha4 __attribute__((ext_vector_type(4)));
   typedef HB hb4 __attribute__((ext_vector_type(4)));
@@ -214,35 +210,23 @@ extern "C" int ark_set_gemm16_tuning(int nbuf, int tile) {
   return 0;
 }
 
-struct Gemm16Dropout { float p; uint64_t seed; const float* hyper; };
-
 static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
                        int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* c16a,
-                       void* c16b, int prec_b, void* stream, Gemm16Dropout drop = Gemm16Dropout{0.f, 0, nullptr}) {
+                       void* c16b, int prec_b, void* stream) {
   using namespace ark;
   if (!A16 || !B16 || !C || M <= 0 || N <= 0 || K <= 0) return ARK_ERR_ARG;
   if (K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0) return ARK_ERR_SHAPE;
   if (((uintptr_t)A16 | (uintptr_t)B16) & 15) return ARK_ERR_ALIGN;
-  if (epi < ARK_EPI_NONE || epi > ARK_EPI_DROPOUT) return ARK_ERR_ARG;
-  if (epi == ARK_EPI_DROPOUT && (!c_tiled || !drop.hyper || drop.p <= 0.f || drop.p >= 1.f)) return ARK_ERR_ARG;
+  if (epi < ARK_EPI_NONE || epi > ARK_EPI_MUL_AUX) return ARK_ERR_ARG;
   if ((epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU) && !bias) return ARK_ERR_ARG;
   if ((epi == ARK_EPI_MUL_AUX || epi == ARK_EPI_MUL_DGELU) && !aux) return ARK_ERR_ARG;
   if (c_tiled && (M % 16 != 0 || ldc % 16 != 0 || N > ldc)) return ARK_ERR_SHAPE;
   if (c_tiled && (epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_MUL_DGELU || c16a || c16b)) return ARK_ERR_ARG;
   if (c16b && prec_b != PREC_F16 && prec_b != PREC_BF16) return ARK_ERR_ARG;
-  Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0, c16a, c16b, prec, prec_b,
-               drop.p, drop.seed, drop.hyper};
+  Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0, c16a, c16b, prec, prec_b};
   if (prec == PREC_F16) return launch16<PREC_F16>(p, (hipStream_t)stream);
   if (prec == PREC_BF16) return launch16<PREC_BF16>(p, (hipStream_t)stream);
   return ARK_ERR_ARG;
-}
-
-// C (tile-native) = (A16 B16^T) * dropout_keep_scale(seed, step, element index): the input gradient of a
-// dropped layer output, with the mask regenerated from the same counter-based hash the forward cell used
-extern "C" int ark_gemm16_dropout(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
-                                  int M, int N, int K, float drop_p, uint64_t drop_seed, const float* hyper, void* stream) {
-  return gemm16_impl(prec, ARK_EPI_DROPOUT, A16, lda, B16, ldb, C, ldc, nullptr, nullptr, M, N, K, 1, nullptr, nullptr, 0,
-                     stream, Gemm16Dropout{drop_p, drop_seed, hyper});
 }
 
 extern "C" int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
@@ -261,14 +245,14 @@ extern "C" int ark_gemm16_ex(int prec, int epi, const void* A16, int64_t lda, co
 }
 
 extern "C" int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,
-                                const float* w_pos, void* x16a, void* x16b, int B, int L, int D, void* stream) {
+                                const float* w_pos, void* x16a, void* x16b, int B, int L, int D, float* hyper_tick, void* stream) {
   using namespace ark;
   if (!seq || !w_tok || !x16a || B <= 0 || L <= 0 || D <= 0) return ARK_ERR_ARG;
   if (D % 4 != 0) return ARK_ERR_SHAPE;
   long total = (long)B * L * (D / 4);
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
   hipStream_t st = (hipStream_t)stream;
-#define ARK_TG(PA, PB2) hipLaunchKernelGGL((tok_gather16_kernel<PA, PB2>), dim3(grid), dim3(256), 0, st, seq, (long)ld_seq, w_tok, w_pos, x16a, x16b, B, L, D)
+#define ARK_TG(PA, PB2) hipLaunchKernelGGL((tok_gather16_kernel<PA, PB2>), dim3(grid), dim3(256), 0, st, seq, (long)ld_seq, w_tok, w_pos, x16a, x16b, B, L, D, hyper_tick)
   if (prec_a == PREC_F16 && prec_b == PREC_BF16) ARK_TG(PREC_F16, PREC_BF16);
   else if (prec_a == PREC_F16 && prec_b == PREC_F16) ARK_TG(PREC_F16, PREC_F16);
   else if (prec_a == PREC_BF16 && prec_b == PREC_BF16) ARK_TG(PREC_BF16, PREC_BF16);

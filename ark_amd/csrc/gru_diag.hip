@@ -1,19 +1,21 @@
-// Layer-diagonal GRU forward (engine: dma_core.h, DmaTile::run2).
+// Layer-diagonal GRU forward and BPTT (engine: dma_core.h, DmaTile::run_segs).
 //
 // In a stacked GRU cell (l, t) depends on (l, t-1) and (l-1, t) only, so the cells of one
 // anti-diagonal d = l + t are independent.  One launch runs them all: workgroup -> (role = layer,
 // row tile, unit tile).  Each role forms BOTH products itself -- x_t W_ih^T and h_{t-1} W_hh^T stream
-// through one LDS-DMA ring back to back -- so the per-layer input GEMM, its [B*L,3D] fp32 `gi`
-// round trip and 2 of every 3 dependent launches disappear.  Everything else (tile-native fp32
-// state, fp16 gate saves, row-major 16-bit copies assembled in LDS, in-kernel counter-hash dropout)
-// is the forward cell of gru_dma.hip.  Reference op replaced: torch.nn.GRU (kgvae/model/models.py:121-127).
+// through one LDS-DMA ring back to back as two K-segments -- so the per-layer input GEMM, its
+// [B*L,3D] fp32 `gi` round trip and 2 of every 3 dependent launches disappear.  State is tile-native
+// fp32, gate saves are tile-native fp16, the row-major 16-bit copies later products read are
+// assembled in LDS, dropout masks come from a counter hash (common.h) in both directions.
+// Reference op replaced: torch.nn.GRU (kgvae/model/models.py:121-127) and its autograd backward.
+//
+// Round-2 rebuild (rocprofv3 SQ counters, profiles/r02_diag_sq_counters.json): the kernels were
+// instruction-issue bound, not memory bound -- 2 700 / 1 870 VALU instructions per wave against
+// 192 / 160 MFMAs.  Fixed here: one consume loop per K-segment (no accumulator shuffling), hardware
+// exp / rcp gate math, one 64-bit hash per 4 mask elements, and the backward cell writes ONE
+// [B,4D] panel [dr | dz | dn | dn*r] instead of two [B,3D] panels that shared two thirds.
 #include "dma_core.h"
 #include "../../include/ark_amd.h"
-#ifdef ARK_ABL
-#define ARK_ABL_V ARK_ABL
-#else
-#define ARK_ABL_V 0
-#endif
 
 namespace ark {
 
@@ -26,17 +28,16 @@ struct GruDiagArgs {
 };
 
 // BM rows x BU hidden units (x 3 gates) per workgroup, 2 x (BU/16) waves; wave tile (BM/2) x 48 = 16 units x 3 gates.
-// The per-CU LDS-DMA rate (~72 GB/s) bounds a launch, so what counts is the operand rows a CU streams:
-// 768 tiles of 64 x 32u are 3 x (64+96) rows per CU, 192 tiles of 128 x 64u are 128+192 on 3/4 of the CUs.
 template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU>
 __global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagArgs p) {
   constexpr int BN = 3 * BU, WGN = BU / 16, NTHR = 128 * WGN;
   using G = DmaTile<PREC, BM, BN, NBUF, 2, WGN, KI>;
-  constexpr int TM = G::TM;
+  constexpr int TM = G::TM, TN = G::TN;
+  static_assert(TN == 3, "wave tile = 16 units x (r, z, n)");
   using h_t = typename G::h_t;
+  using h8 = typename G::h8;
   using hb_t = typename PrecTraits<PRECB>::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (ARK_ABL_V & 32) return;
   const int B = p.B, D = p.D;
   const int UT = D / BU, MT = (B + BM - 1) / BM;
   int role, mt, ut;
@@ -67,43 +68,43 @@ __global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagAr
   constexpr bool PRE = TM <= 2;
   int rl[TM];
   long o[TM];
-  f32x4 hp[PRE ? TM : 1], mk[PRE ? TM : 1];
+  f32x4 hp[PRE ? TM : 1];
   const bool drop = R.drop_p > 0.f;
-  uint64_t step = 0;
-  float ks = 1.f;
-  if (drop) {
-    step = (uint64_t)p.hyper[ARK_HP_ADAM_STEP];
-    ks = 1.0f / (1.0f - R.drop_p);
-  }
-  auto mask_of = [&](long off) -> f32x4 {
-    f32x4 m = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (drop) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) m[i] = dropout_keep_scale(R.drop_seed, step, (uint64_t)(R.drop_base + off + i), R.drop_p, ks);
-    }
-    return m;
-  };
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(R.drop_seed, p.hyper, R.drop_p);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     rl[tm] = wm * G::WTM + tm * 16 + 4 * (lane >> 4);
     const int rowc = min(m0 + rl[tm], B - 4);   // B % 16 == 0: clamped quads stay in bounds
     o[tm] = tile_native_off(rowc, u, D);
-    if constexpr (PRE) {
-      hp[tm] = *reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]);
-      mk[tm] = mask_of(o[tm]);
-    }
+    if constexpr (PRE) hp[tm] = *reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]);
   }
   const float br = R.b_ih[u] + R.b_hh[u], bz = R.b_ih[D + u] + R.b_hh[D + u];
   const float bin = R.b_ih[2 * D + u], bhn = R.b_hh[2 * D + u];
 
-  f32x4 acc[TM][G::TN + 1];   // r, z (input + recurrent parts summed), W_in x, W_hn h
-  G::run2_shared(acc, reinterpret_cast<const h_t*>(R.x16), reinterpret_cast<const h_t*>(R.w_ih16), D,
-                 reinterpret_cast<const h_t*>(R.h_prev16), reinterpret_cast<const h_t*>(R.w_hh16), D, (long)D, (long)D,
-                 [=](int r) -> long { return (long)min(m0 + r, B - 1); },
-                 [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); }, smem);
+  // r, z: input + recurrent parts summed; the candidate gate needs W_in x and W_hn h apart
+  f32x4 acc[TM][TN + 1];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn <= TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typename G::template Segs<2> sg{{reinterpret_cast<const h_t*>(R.x16), reinterpret_cast<const h_t*>(R.h_prev16)},
+                                  {reinterpret_cast<const h_t*>(R.w_ih16), reinterpret_cast<const h_t*>(R.w_hh16)},
+                                  {D, D}};
+  G::template run_segs<2>(
+      sg, (long)D, (long)D, [=](int r) -> long { return (long)min(m0 + r, B - 1); },
+      [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); }, smem,
+      [&](auto seg, const h8 (&a)[TM], const h8 (&b)[TN]) {
+        constexpr int NCOL = decltype(seg)::value == 0 ? TN - 1 : TN;   // accumulator of the candidate-gate block
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          acc[tm][0] = G::PT::mfma(a[tm], b[0], acc[tm][0]);
+          acc[tm][1] = G::PT::mfma(a[tm], b[1], acc[tm][1]);
+          acc[tm][NCOL] = G::PT::mfma(a[tm], b[2], acc[tm][NCOL]);
+        }
+      });
 
-  if (ARK_ABL_V & 128) return;
-  __syncthreads();   // ring is free: reuse it to assemble row-major 16-bit rows [BM][32+pad]
+  __syncthreads();   // ring is free: reuse it to assemble row-major 16-bit rows [BM][BU+pad]
   constexpr int TS = BU + 8;   // row stride in elements: 16-B aligned rows, spreads banks
   constexpr int ARR = BM * TS * 2;
   h_t* ta = reinterpret_cast<h_t*>(smem);
@@ -117,33 +118,34 @@ __global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagAr
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     if (m0 + rl[tm] >= B) continue;
-    f32x4 hpv, mkv;
-    if constexpr (PRE) { hpv = hp[tm]; mkv = mk[tm]; }
-    else { hpv = *reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]); mkv = mask_of(o[tm]); }
+    f32x4 hpv;
+    if constexpr (PRE) hpv = hp[tm];
+    else hpv = *reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]);
     f32x4 r, z, n, hn, h;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      r[i] = sigmoidf_(acc[tm][0][i] + br);
-      z[i] = sigmoidf_(acc[tm][1][i] + bz);
+      r[i] = fast_sigmoid(acc[tm][0][i] + br);
+      z[i] = fast_sigmoid(acc[tm][1][i] + bz);
       hn[i] = acc[tm][3][i] + bhn;
-      n[i] = tanhf(acc[tm][2][i] + bin + r[i] * hn[i]);
-      h[i] = (1.0f - z[i]) * n[i] + z[i] * hpv[i];
+      n[i] = fast_tanh(acc[tm][2][i] + bin + r[i] * hn[i]);
+      h[i] = n[i] + z[i] * (hpv[i] - n[i]);   // (1-z) n + z h_prev
     }
-#if !(defined(ARK_ABL) && (ARK_ABL & 16))
     *reinterpret_cast<f32x4*>(R.y_out_t + o[tm]) = h;
-#endif
-    if (sr && !(ARK_ABL_V & 16)) {
+    if (sr) {
       *reinterpret_cast<dhalf4_t*>(sr + o[tm]) = dhalf4_t{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
       *reinterpret_cast<dhalf4_t*>(sz + o[tm]) = dhalf4_t{(_Float16)z[0], (_Float16)z[1], (_Float16)z[2], (_Float16)z[3]};
       *reinterpret_cast<dhalf4_t*>(sn + o[tm]) = dhalf4_t{(_Float16)n[0], (_Float16)n[1], (_Float16)n[2], (_Float16)n[3]};
       *reinterpret_cast<dhalf4_t*>(shn + o[tm]) = dhalf4_t{(_Float16)hn[0], (_Float16)hn[1], (_Float16)hn[2], (_Float16)hn[3]};
     }
-    const f32x4 hd = h * mkv;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ta[(rl[tm] + i) * TS + ul] = G::PT::cvt(h[i]);
       if (R.y16b) tb[(rl[tm] + i) * TS + ul] = PrecTraits<PRECB>::cvt(h[i]);
-      if (drop) {
+    }
+    if (drop) {
+      const f32x4 hd = h * dropout_quad(dc, (uint64_t)(R.drop_base + o[tm]) >> 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
         tda[(rl[tm] + i) * TS + ul] = G::PT::cvt(hd[i]);
         tdb[(rl[tm] + i) * TS + ul] = PrecTraits<PRECB>::cvt(hd[i]);
       }
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagAr
   for (int r0 = 0; r0 < BM; r0 += RPP) {
     const int rr = r0 + t / CPR, ch = t % CPR;
     const int row = m0 + rr;
-    if (rr < BM && row < B && !(ARK_ABL_V & 16)) {
+    if (rr < BM && row < B) {
       const long go = (long)row * D + u0 + ch * 8;
       *reinterpret_cast<uint4*>(reinterpret_cast<h_t*>(R.y16a) + go) = *reinterpret_cast<const uint4*>(ta + rr * TS + ch * 8);
       if (R.y16b) *reinterpret_cast<uint4*>(reinterpret_cast<hb_t*>(R.y16b) + go) = *reinterpret_cast<const uint4*>(tb + rr * TS + ch * 8);
@@ -168,9 +170,6 @@ __global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagAr
     }
   }
 }
-
-// measured on MI355X (syn-paths, B=1024): see DESIGN.md section 6
-static int g_diag_rows = 64, g_diag_ki = 1, g_diag_nbuf = 2, g_diag_xcd = 1, g_diag_units = 32;
 
 template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU>
 static void launch_diag(const GruDiagArgs& p, hipStream_t st) {
@@ -186,69 +185,68 @@ static void launch_diag(const GruDiagArgs& p, hipStream_t st) {
 }
 
 template <int PREC, int PRECB>
-static int launch_diag_cfg(GruDiagArgs& p, hipStream_t st) {
-  bool ki2 = g_diag_ki == 2 && p.D % 128 == 0;
-  int rows = g_diag_rows;
-  const int units = (g_diag_units == 64 && p.D % 64 == 0) ? 64 : 32;
+static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t st) {
+  bool ki2 = tn.fwd_ki == 2 && p.D % 128 == 0;
+  int rows = tn.fwd_rows;
+  const int units = (tn.fwd_units == 64 && p.D % 64 == 0) ? 64 : 32;
   if (rows == 64 && units == 32 && (long)p.n_roles * ((p.B + 63) / 64) * (p.D / 32) < 256) {
     // small batch x width (e.g. B = 256, D = 128): 64-row tiles leave most CUs empty -> 32-row tiles, two k-images per
     // stage (measured on the wd-movies shape: 4.33 -> 4.12 ms/step)
     rows = 32;
     ki2 = p.D % 128 == 0;
   }
+  if (rows == 128 && units != 64) rows = 64;   // 128-row tiles exist for 64-unit tiles only
   const int MT = (p.B + rows - 1) / rows, UT = p.D / units;
-  p.xcd_map = (g_diag_xcd && UT % 4 == 0 && MT % 2 == 0) ? 1 : 0;
+  p.xcd_map = (tn.fwd_xcd && UT % 4 == 0 && MT % 2 == 0) ? 1 : 0;
   if (units == 64) {   // 8 waves
-    if (rows == 128) {
-      if (g_diag_nbuf >= 4) launch_diag<PREC, PRECB, 3, 1, 128, 64>(p, st);   // 3 x 40 KB
-      else launch_diag<PREC, PRECB, 2, 1, 128, 64>(p, st);
-    } else {
-      if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 64>(p, st);
-      else launch_diag<PREC, PRECB, 2, 1, 64, 64>(p, st);
-    }
+    if (rows == 128) launch_diag<PREC, PRECB, 2, 1, 128, 64>(p, st);
+    else if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 64>(p, st);
+    else launch_diag<PREC, PRECB, 2, 1, 64, 64>(p, st);
   } else if (rows == 64) {
     if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 32>(p, st);
-    else if (g_diag_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 64, 32>(p, st);
+    else if (tn.fwd_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 64, 32>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 64, 32>(p, st);
   } else {
     if (ki2) launch_diag<PREC, PRECB, 2, 2, 32, 32>(p, st);
-    else if (g_diag_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 32, 32>(p, st);
+    else if (tn.fwd_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 32, 32>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 32, 32>(p, st);
   }
   ARK_LAUNCH_CHECK();
   return 0;
 }
 
-}  // namespace ark
-
-extern "C" int ark_set_diag_tuning(int rows, int ki, int nbuf, int xcd_map) {
-  if ((rows != 32 && rows != 64 && rows != 128) || (ki != 1 && ki != 2) || (nbuf != 2 && nbuf != 4)) return ARK_ERR_ARG;
-  if (rows == 128 && ark::g_diag_units != 64) return ARK_ERR_ARG;   // 128-row tiles exist for 64-unit tiles only
-  ark::g_diag_rows = rows;
-  ark::g_diag_ki = ki;
-  ark::g_diag_nbuf = nbuf;
-  ark::g_diag_xcd = xcd_map ? 1 : 0;
-  return 0;
+static bool diag_tuning_ok(const ArkDiagTuning& t) {
+  return (t.fwd_rows == 32 || t.fwd_rows == 64 || t.fwd_rows == 128) && (t.fwd_ki == 1 || t.fwd_ki == 2) &&
+         (t.fwd_nbuf == 2 || t.fwd_nbuf == 4) && (t.fwd_units == 32 || t.fwd_units == 64) &&
+         (t.bwd_rows == 32 || t.bwd_rows == 64) && (t.bwd_ki == 1 || t.bwd_ki == 2) && (t.bwd_nbuf == 2 || t.bwd_nbuf == 4) &&
+         (t.bwd_xcd_rows == 1 || t.bwd_xcd_rows == 2 || t.bwd_xcd_rows == 4 || t.bwd_xcd_rows == 8);
 }
 
-extern "C" int ark_set_diag_units(int units) {
-  if (units != 32 && units != 64) return ARK_ERR_ARG;
-  ark::g_diag_units = units;
-  if (units == 32 && ark::g_diag_rows == 128) ark::g_diag_rows = 64;
-  return 0;
+}  // namespace ark
+
+// measured on MI355X (syn-paths, B=1024): see DESIGN.md section 6
+extern "C" void ark_diag_tuning_default(ArkDiagTuning* t) {
+  if (!t) return;
+  t->fwd_rows = 64; t->fwd_ki = 1; t->fwd_nbuf = 2; t->fwd_xcd = 1; t->fwd_units = 32;
+  t->bwd_rows = 32; t->bwd_ki = 2; t->bwd_nbuf = 2; t->bwd_xcd_rows = 4;
 }
 
 extern "C" int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruDiagRole* roles, const float* hyper, int B, int D,
-                                void* stream) {
+                                const ArkDiagTuning* tuning, void* stream) {
   using namespace ark;
   if (!roles || n_roles <= 0 || n_roles > ARK_DIAG_MAX_ROLES || B <= 0 || D <= 0) return ARK_ERR_ARG;
   if (D % 64 != 0 || B % 16 != 0) return ARK_ERR_SHAPE;
+  ArkDiagTuning tn;
+  ark_diag_tuning_default(&tn);
+  if (tuning) tn = *tuning;
+  if (!diag_tuning_ok(tn)) return ARK_ERR_ARG;
   GruDiagArgs p;
   for (int i = 0; i < n_roles; ++i) {
     const ArkGruDiagRole& r = roles[i];
     if (!r.x16 || !r.h_prev16 || !r.w_ih16 || !r.w_hh16 || !r.b_ih || !r.b_hh || !r.y_prev_t || !r.y_out_t || !r.y16a)
       return ARK_ERR_ARG;
     if (r.drop_p < 0.f || r.drop_p >= 1.f || (r.drop_p > 0.f && (!r.yd16a || !hyper))) return ARK_ERR_ARG;
+    if ((r.drop_base & 3) != 0) return ARK_ERR_ALIGN;   // one hash serves a quad of elements
     if (r.save_r && (!r.save_z || !r.save_n || !r.save_hn)) return ARK_ERR_ARG;
     p.role[i] = r;
   }
@@ -259,18 +257,20 @@ extern "C" int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruD
   p.D = D;
   p.xcd_map = 0;
   hipStream_t st = (hipStream_t)stream;
-  if (prec == PREC_F16 && prec_b == PREC_BF16) return launch_diag_cfg<PREC_F16, PREC_BF16>(p, st);
-  if (prec == PREC_F16 && prec_b == PREC_F16) return launch_diag_cfg<PREC_F16, PREC_F16>(p, st);
-  if (prec == PREC_BF16 && prec_b == PREC_BF16) return launch_diag_cfg<PREC_BF16, PREC_BF16>(p, st);
+  if (prec == PREC_F16 && prec_b == PREC_BF16) return launch_diag_cfg<PREC_F16, PREC_BF16>(p, tn, st);
+  if (prec == PREC_F16 && prec_b == PREC_F16) return launch_diag_cfg<PREC_F16, PREC_F16>(p, tn, st);
+  if (prec == PREC_BF16 && prec_b == PREC_BF16) return launch_diag_cfg<PREC_BF16, PREC_BF16>(p, tn, st);
   return ARK_ERR_ARG;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Layer-diagonal BPTT.  Cell (l, t) needs (l, t+1) [dgh, carry] and (l+1, t) [dgi]; the cells of one
-// backward anti-diagonal are independent.  A role streams [dgi_up | dgh_next] against
-// [W_ih(l+1)^T | W_hh(l)^T] through one ring (two accumulators: the part arriving from the layer above
-// passes through this layer's output-dropout mask), then runs the gate-derivative epilogue of
-// gru_dma.hip: row-major 16-bit dgi / dgh panels assembled in LDS, bias gradients as column sums.
+// Layer-diagonal BPTT.  Cell (l, t) needs (l, t+1) [its gate-gradient panel, carry] and (l+1, t) [dgi]; the
+// cells of one backward anti-diagonal are independent.  A role streams three K-segments through one ring:
+//   dgi(l+1,t)   [B,3D]  x  W_ih(l+1)^T            -> ax  (passes through this layer's output-dropout mask)
+//   [dr|dz](l,t+1) [B,2D] x  W_hh(l)^T[:, 0:2D]    -> ah
+//   dn*r (l,t+1)  [B,D]   x  W_hh(l)^T[:, 2D:3D]   -> ah
+// then runs the gate-derivative epilogue: the row-major 16-bit panel [dr | dz | dn | dn*r] is assembled in
+// LDS, bias gradients are column sums of the tile.
 namespace ark {
 
 struct GruDiagBwdArgs {
@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
   using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;   // wave tile (BM/2) x 32
   constexpr int TM = G::TM, TN = G::TN, WN = BN / 2;
   using h_t = typename G::h_t;
+  using h8 = typename G::h8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int B = p.B, D = p.D;
   const int NT = D / BN, MT = (B + BM - 1) / BM;
@@ -320,14 +321,10 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
   const _Float16* shn = reinterpret_cast<const _Float16*>(R.save_hn);
   // epilogue operands first (older than the LDS-DMA ops -> they land underneath the products)
   int rl[TM];
-  f32x4 pc[TM][TN], pdy[TM][TN], phy[TM][TN], mk[TM][TN];
+  f32x4 pc[TM][TN], pdy[TM][TN], phy[TM][TN];
   dhalf4_t psr[TM][TN], psz[TM][TN], psn[TM][TN], phn[TM][TN];
-  uint64_t step = 0;
-  float ks = 1.f;
-  if (drop) {
-    step = (uint64_t)p.hyper[ARK_HP_ADAM_STEP];
-    ks = 1.0f / (1.0f - R.drop_p);
-  }
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(R.drop_seed, p.hyper, R.drop_p);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     rl[tm] = wm * G::WTM + tm * 16 + 4 * (lane >> 4);
@@ -337,26 +334,38 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
       const long o = tile_native_off(rowc, n0 + wn * WN + tn * 16 + (lane & 15), D);
       pc[tm][tn] = R.first ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(R.carry_t + o);
       pdy[tm][tn] = R.dy_t ? *reinterpret_cast<const f32x4*>(R.dy_t + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-      mk[tm][tn] = f32x4{1.f, 1.f, 1.f, 1.f};
       if (fin) continue;
       phy[tm][tn] = *reinterpret_cast<const f32x4*>(R.y_prev_t + o);
       psr[tm][tn] = *reinterpret_cast<const dhalf4_t*>(sr + o);
       psz[tm][tn] = *reinterpret_cast<const dhalf4_t*>(sz + o);
       psn[tm][tn] = *reinterpret_cast<const dhalf4_t*>(sn + o);
       phn[tm][tn] = *reinterpret_cast<const dhalf4_t*>(shn + o);
-      if (drop) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          mk[tm][tn][i] = dropout_keep_scale(R.drop_seed, step, (uint64_t)(R.drop_base + o + i), R.drop_p, ks);
-      }
     }
   }
 
   f32x4 ax[TM][TN], ah[TM][TN];
-  G::run2(ax, ah, reinterpret_cast<const h_t*>(R.dgi_up16), reinterpret_cast<const h_t*>(R.w_ihT_up16), top ? 0 : 3 * D,
-          reinterpret_cast<const h_t*>(R.dgh_next16), reinterpret_cast<const h_t*>(R.w_hhT16), R.first ? 0 : 3 * D,
-          3L * D, 3L * D, [=](int r) -> long { return (long)min(m0 + r, B - 1); },
-          [=](int r) -> long { return (long)(n0 + r); }, smem);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) ax[tm][tn] = ah[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const h_t* gup = reinterpret_cast<const h_t*>(R.dgi_up16);
+  const h_t* gnx = reinterpret_cast<const h_t*>(R.dg_next16);
+  const h_t* whT = reinterpret_cast<const h_t*>(R.w_hhT16);
+  const bool rec = !R.first;   // a successor step exists (always true for the initial-state role)
+  typename G::template Segs<3> sg{{gup, gnx, gnx + 3 * D},
+                                  {reinterpret_cast<const h_t*>(R.w_ihT_up16), whT, whT + 2 * D},
+                                  {top ? 0 : 3 * D, rec ? 2 * D : 0, rec ? D : 0}};
+  G::template run_segs<3>(
+      sg, 4L * D, 3L * D, [=](int r) -> long { return (long)min(m0 + r, B - 1); }, [=](int r) -> long { return (long)(n0 + r); },
+      smem, [&](auto seg, const h8 (&a)[TM], const h8 (&b)[TN]) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            if constexpr (decltype(seg)::value == 0) ax[tm][tn] = G::PT::mfma(a[tm], b[tn], ax[tm][tn]);
+            else ah[tm][tn] = G::PT::mfma(a[tm], b[tn], ah[tm][tn]);
+          }
+      });
 
   if (fin) {
 #pragma unroll
@@ -374,10 +383,9 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
     return;   // block-uniform: every wave of this workgroup serves the same role
   }
   __syncthreads();
-  // LDS assembly of the six row-major 16-bit output panels: [gate 0..2][BM rows][BN+8] for dgi and dgh
+  // LDS assembly of the row-major 16-bit output panel: [part 0..3 = dr, dz, dn, dn*r][BM rows][BN+8]
   constexpr int TS = BN + 8;
-  h_t* tgi = reinterpret_cast<h_t*>(smem);
-  h_t* tgh = tgi + 3 * BM * TS;
+  h_t* tg = reinterpret_cast<h_t*>(smem);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int row0 = m0 + rl[tm];
@@ -386,7 +394,9 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
     for (int tn = 0; tn < TN; ++tn) {
       const int ul = wn * WN + tn * 16 + (lane & 15);
       const long o = tile_native_off(row0, n0 + ul, D);
-      const f32x4 dh = ah[tm][tn] + pc[tm][tn] + pdy[tm][tn] + ax[tm][tn] * mk[tm][tn];
+      f32x4 dh = ah[tm][tn] + pc[tm][tn] + pdy[tm][tn];
+      if (drop) dh += ax[tm][tn] * dropout_quad(dc, (uint64_t)(R.drop_base + o) >> 2);
+      else dh += ax[tm][tn];
       const f32x4 hp = phy[tm][tn];
       f32x4 cz;
 #pragma unroll
@@ -397,51 +407,48 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
         const float dr_pre = dn_pre * hn * r * (1.0f - r);
         cz[i] = dh[i] * z;
         const int ro = (rl[tm] + i) * TS + ul;
-        tgi[ro] = G::PT::cvt(dr_pre); tgi[BM * TS + ro] = G::PT::cvt(dz_pre); tgi[2 * BM * TS + ro] = G::PT::cvt(dn_pre);
-        tgh[ro] = G::PT::cvt(dr_pre); tgh[BM * TS + ro] = G::PT::cvt(dz_pre); tgh[2 * BM * TS + ro] = G::PT::cvt(dn_pre * r);
+        tg[ro] = G::PT::cvt(dr_pre);
+        tg[BM * TS + ro] = G::PT::cvt(dz_pre);
+        tg[2 * BM * TS + ro] = G::PT::cvt(dn_pre);
+        tg[3 * BM * TS + ro] = G::PT::cvt(dn_pre * r);
       }
       *reinterpret_cast<f32x4*>(R.carry_t + o) = cz;
     }
   }
   __syncthreads();
-  // 3 gates x BM rows x 128 B per array: thread t -> (row, 16-byte chunk) for each gate, 32 rows per pass
+  // 4 parts x BM rows x 128 B: thread t -> (row, 16-byte chunk) for each part, 32 rows per pass
   const int t = threadIdx.x;
   constexpr int CPR = BN / 8;   // 8 chunks per row -> 32 rows per 256 threads
-  h_t* gi16 = reinterpret_cast<h_t*>(R.dgi16);
-  h_t* gh16 = reinterpret_cast<h_t*>(R.dgh16);
+  h_t* g16 = reinterpret_cast<h_t*>(R.dg16);
 #pragma unroll
   for (int r0 = 0; r0 < BM; r0 += 32) {
     const int rr = r0 + t / CPR, ch = t % CPR;
     const int row = m0 + rr;
     if (row < B) {
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        const long go = (long)row * 3 * D + (long)g * D + n0 + ch * 8;
-        *reinterpret_cast<uint4*>(gi16 + go) = *reinterpret_cast<const uint4*>(tgi + g * BM * TS + rr * TS + ch * 8);
-        *reinterpret_cast<uint4*>(gh16 + go) = *reinterpret_cast<const uint4*>(tgh + g * BM * TS + rr * TS + ch * 8);
+      for (int g = 0; g < 4; ++g) {
+        const long go = (long)row * 4 * D + (long)g * D + n0 + ch * 8;
+        *reinterpret_cast<uint4*>(g16 + go) = *reinterpret_cast<const uint4*>(tg + g * BM * TS + rr * TS + ch * 8);
       }
     }
   }
-  // bias gradients: column sums of this tile's panels straight from LDS, one atomic per (gate, unit)
-  if (R.db_ih && t < 3 * BN) {
-    const int g = t / BN, ul = t % BN;
+  // bias gradients: column sums of this tile straight from LDS, one atomic per (gate, unit):
+  // db_ih = colsum [dr | dz | dn], db_hh = colsum [dr | dz | dn*r]
+  if (R.db_ih) {
+    const int g = t / BN, ul = t % BN;   // 256 threads = 4 parts x 64 units
     const int nrows = min(BM, B - m0);
-    float si = 0.f, sh = 0.f;
-    for (int r2 = 0; r2 < nrows; ++r2) {
-      si += (float)tgi[g * BM * TS + r2 * TS + ul];
-      sh += (float)tgh[g * BM * TS + r2 * TS + ul];
-    }
-    atomicAdd(&R.db_ih[(long)g * D + n0 + ul], si);
-    atomicAdd(&R.db_hh[(long)g * D + n0 + ul], sh);
+    float s = 0.f;
+    for (int r2 = 0; r2 < nrows; ++r2) s += (float)tg[g * BM * TS + r2 * TS + ul];
+    if (g < 3) atomicAdd(&R.db_ih[(long)g * D + n0 + ul], s);
+    if (g < 2) atomicAdd(&R.db_hh[(long)g * D + n0 + ul], s);
+    if (g == 3) atomicAdd(&R.db_hh[2L * D + n0 + ul], s);
   }
 }
-
-static int g_dbwd_rows = 32, g_dbwd_ki = 2, g_dbwd_nbuf = 2, g_dbwd_xcd_m = 4;
 
 template <int PREC, int NBUF, int KI, int BM>
 static void launch_diag_bwd(const GruDiagBwdArgs& p, hipStream_t st) {
   using G = DmaTile<PREC, BM, 64, NBUF, 2, 2, KI>;
-  constexpr int MINL = 2 * 3 * BM * (64 + 8) * 2;
+  constexpr int MINL = 4 * BM * (64 + 8) * 2;
   constexpr int LDS = G::LDS_BYTES > MINL ? G::LDS_BYTES : MINL;
   auto kern = gru_diag_bwd_kernel<PREC, NBUF, KI, BM>;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
@@ -451,20 +458,20 @@ static void launch_diag_bwd(const GruDiagBwdArgs& p, hipStream_t st) {
 }
 
 template <int PREC>
-static int launch_diag_bwd_cfg(GruDiagBwdArgs& p, hipStream_t st) {
-  const bool ki2 = g_dbwd_ki == 2 && (3 * p.D) % 128 == 0;
+static int launch_diag_bwd_cfg(GruDiagBwdArgs& p, const ArkDiagTuning& tn, hipStream_t st) {
+  const bool ki2 = tn.bwd_ki == 2 && p.D % 128 == 0;   // every K-segment (3D, 2D, D) must be a whole number of stages
   {
-    const int MT = (p.B + g_dbwd_rows - 1) / g_dbwd_rows, NT = p.D / 64;
-    const int xm = g_dbwd_xcd_m;
+    const int MT = (p.B + tn.bwd_rows - 1) / tn.bwd_rows, NT = p.D / 64;
+    const int xm = tn.bwd_xcd_rows;
     p.xcd_m = (xm > 1 && MT % xm == 0 && NT % (8 / xm) == 0) ? xm : 1;
   }
-  if (g_dbwd_rows == 64) {
+  if (tn.bwd_rows == 64) {
     if (ki2) launch_diag_bwd<PREC, 2, 2, 64>(p, st);
-    else if (g_dbwd_nbuf >= 4) launch_diag_bwd<PREC, 4, 1, 64>(p, st);
+    else if (tn.bwd_nbuf >= 4) launch_diag_bwd<PREC, 4, 1, 64>(p, st);
     else launch_diag_bwd<PREC, 2, 1, 64>(p, st);
   } else {
     if (ki2) launch_diag_bwd<PREC, 2, 2, 32>(p, st);
-    else if (g_dbwd_nbuf >= 4) launch_diag_bwd<PREC, 4, 1, 32>(p, st);
+    else if (tn.bwd_nbuf >= 4) launch_diag_bwd<PREC, 4, 1, 32>(p, st);
     else launch_diag_bwd<PREC, 2, 1, 32>(p, st);
   }
   ARK_LAUNCH_CHECK();
@@ -473,40 +480,31 @@ static int launch_diag_bwd_cfg(GruDiagBwdArgs& p, hipStream_t st) {
 
 }  // namespace ark
 
-extern "C" int ark_set_diag_bwd_xcd(int row_classes) {
-  if (row_classes != 1 && row_classes != 2 && row_classes != 4 && row_classes != 8) return ARK_ERR_ARG;
-  ark::g_dbwd_xcd_m = row_classes;
-  return 0;
-}
-
-extern "C" int ark_set_diag_bwd_tuning(int rows, int ki, int nbuf) {
-  if ((rows != 32 && rows != 64) || (ki != 1 && ki != 2) || (nbuf != 2 && nbuf != 4)) return ARK_ERR_ARG;
-  ark::g_dbwd_rows = rows;
-  ark::g_dbwd_ki = ki;
-  ark::g_dbwd_nbuf = nbuf;
-  return 0;
-}
-
 extern "C" int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* roles, const float* hyper, int B, int D,
-                                void* stream) {
+                                const ArkDiagTuning* tuning, void* stream) {
   using namespace ark;
   if (!roles || n_roles <= 0 || n_roles > ARK_DIAG_MAX_ROLES || B <= 0 || D <= 0) return ARK_ERR_ARG;
   if (D % 64 != 0 || B % 16 != 0) return ARK_ERR_SHAPE;
+  ArkDiagTuning tn;
+  ark_diag_tuning_default(&tn);
+  if (tuning) tn = *tuning;
+  if (!diag_tuning_ok(tn)) return ARK_ERR_ARG;
   GruDiagBwdArgs p;
   for (int i = 0; i < n_roles; ++i) {
     const ArkGruDiagBwdRole& r = roles[i];
     if (!r.w_hhT16 || !r.carry_t) return ARK_ERR_ARG;
     if (r.dh0) {   // initial-state role
-      if (!r.dgh_next16 || r.first || r.dgi_up16 || r.w_ihT_up16 || r.dy_t) return ARK_ERR_ARG;
+      if (!r.dg_next16 || r.first || r.dgi_up16 || r.w_ihT_up16 || r.dy_t) return ARK_ERR_ARG;
       p.role[i] = r;
       continue;
     }
-    if (!r.save_r || !r.save_z || !r.save_n || !r.save_hn || !r.y_prev_t || !r.dgi16 || !r.dgh16) return ARK_ERR_ARG;
-    if (!r.first && !r.dgh_next16) return ARK_ERR_ARG;
+    if (!r.save_r || !r.save_z || !r.save_n || !r.save_hn || !r.y_prev_t || !r.dg16) return ARK_ERR_ARG;
+    if (!r.first && !r.dg_next16) return ARK_ERR_ARG;
     if ((r.dgi_up16 == nullptr) != (r.w_ihT_up16 == nullptr)) return ARK_ERR_ARG;
     if ((r.dgi_up16 == nullptr) == (r.dy_t == nullptr)) return ARK_ERR_ARG;   // exactly one source of dy
     if ((r.db_ih == nullptr) != (r.db_hh == nullptr)) return ARK_ERR_ARG;
     if (r.drop_p < 0.f || r.drop_p >= 1.f || (r.drop_p > 0.f && !hyper)) return ARK_ERR_ARG;
+    if ((r.drop_base & 3) != 0) return ARK_ERR_ALIGN;
     p.role[i] = r;
   }
   for (int i = n_roles; i < ARK_DIAG_MAX_ROLES; ++i) p.role[i] = roles[0];
@@ -515,7 +513,7 @@ extern "C" int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* 
   p.B = B;
   p.D = D;
   p.xcd_m = 1;
-  if (prec == PREC_F16) return launch_diag_bwd_cfg<PREC_F16>(p, (hipStream_t)stream);
-  if (prec == PREC_BF16) return launch_diag_bwd_cfg<PREC_BF16>(p, (hipStream_t)stream);
+  if (prec == PREC_F16) return launch_diag_bwd_cfg<PREC_F16>(p, tn, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch_diag_bwd_cfg<PREC_BF16>(p, tn, (hipStream_t)stream);
   return ARK_ERR_ARG;
 }

@@ -109,13 +109,19 @@ __global__ __launch_bounds__(256) void zproj_bwd_dz_kernel(float* __restrict__ d
 }
 
 // The whole per-row part of the latent backward in ONE launch (it sits on the dependent chain between
-// the GRU's initial-state gradient and the encoder MLP backward), one wave per batch row:
+// the GRU's initial-state gradient and the encoder MLP backward):
 //   dzp = dh0 * (1 - h0^2)              (in place, for the batch reductions that follow off-chain)
 //   dz  = dzp Wz                        (z-projection, models.py:139)
 //   dhead = d(beta*kl)/d(mu,logv) + dz through the reparameterisation (+ external dmu/dlogv)
 //   dA  = (dhead W_head) * gelu'(pre)   (heads models.py:43-44, last MLP activation models.py:32-41)
 // The reductions over the batch (dWz, dbz, db_head, dW_head) only need dzp / dhead and run elsewhere.
-template <int ZT, int RW>   // RW rows per workgroup (waves RW..3 only help with the dA columns)
+//
+// RW = 4 rows per 256-thread workgroup, one wave per row for the [D] -> [Z] reduction (Wz^T staged once per
+// workgroup in LDS, row stride D+1: conflict-free fill and reads), then all 256 threads form the [RW, H] block
+// of dA with every W_head element loaded once per workgroup.  Round 1 used 2 rows per workgroup with half of
+// the waves idle in the first phase and scalar, strided Wz reads: 39 us alone (104 us beside the weight
+// gradients) for 31 MFLOP; this one is bound by its ~15 MB of HBM traffic.
+template <int ZT, int RW>
 __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict__ dh0, const float* __restrict__ h0,
                                                                const float* __restrict__ Wz, const float* __restrict__ head,
                                                                const float* __restrict__ eps, const float* __restrict__ hyper,
@@ -123,24 +129,28 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
                                                                const float* __restrict__ Whead, const float* __restrict__ pre,
                                                                float* __restrict__ dhead, float* __restrict__ dA, void* dA16,
                                                                int prec16, int B, int Z, int D, int H) {
+  static_assert(RW == 4, "one wave per row");
+  extern __shared__ __attribute__((aligned(16))) char smem_lc[];
+  float* zs = reinterpret_cast<float*>(smem_lc);   // Wz^T: [Z][D + 1]
   __shared__ float sh[RW][2 * ZT];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int DS = D + 1;
+  for (int i = threadIdx.x; i < D * Z; i += 256) zs[(i % Z) * DS + i / Z] = Wz[i];   // coalesced read, stride-(D+1) write
   const int b = blockIdx.x * RW + wave;
-  const bool valid = wave < RW && b < B;
+  const bool valid = b < B;
   const int bb = valid ? b : B - 1;
+  __syncthreads();
   float acc[ZT];
 #pragma unroll
   for (int j = 0; j < ZT; ++j) acc[j] = 0.f;
-  if (wave < RW)
   for (int d = lane; d < D; d += 64) {
     const long i = (long)bb * D + d;
     const float h = h0[i];
     const float g = dh0[i] * (1.0f - h * h);
     if (valid) dh0[i] = g;
-    const float* wr = Wz + (long)d * Z;
 #pragma unroll
     for (int j = 0; j < ZT; ++j)
-      if (j < Z) acc[j] += g * wr[j];
+      if (j < Z) acc[j] += g * zs[j * DS + d];
   }
   float mydz = 0.f;
 #pragma unroll
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
       const float a = wave_sum(acc[j]);
       if (lane == j) mydz = a;
     }
-  if (wave < RW && lane < Z) {
+  if (lane < Z) {
     const float ks = hyper[ARK_HP_BETA] * hyper[ARK_HP_KL_NORM];  // beta / (B_global * Z)
     const float m = head[(long)bb * 2 * Z + lane];
     const float raw = head[(long)bb * 2 * Z + Z + lane];
@@ -169,10 +179,10 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
     }
   }
   __syncthreads();
-  // dA for the workgroup's 4 rows: thread -> KC columns at a time (every W_head element is loaded once per
-  // workgroup and used for all 4 rows; each dhead value is one LDS broadcast per KC columns)
+  // dA for the workgroup's RW rows: thread -> KC columns at a time (every W_head element is loaded once per
+  // workgroup and used for all rows; each dhead value is one LDS broadcast per KC columns)
   const int row0 = blockIdx.x * RW;
-  constexpr int KC = 6;
+  constexpr int KC = 3;
   for (int cb = 0; cb < H; cb += 256 * KC) {
     float acc4[KC][RW];
 #pragma unroll
@@ -523,10 +533,19 @@ extern "C" int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_
   if (Z > 64) return ARK_ERR_SHAPE;
   if (prec16 != 1 && prec16 != 2) return ARK_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-#define ARK_LC(ZT) hipLaunchKernelGGL((latent_chain_bwd_kernel<ZT, 2>), dim3((B + 1) / 2), dim3(256), 0, st, dh0, h0, w_z, head, eps, hyper, ext_dhead, w_head, pre, dhead, dA, dA16, prec16, B, Z, D, H)
-  if (Z <= 16) ARK_LC(16);
-  else if (Z <= 32) ARK_LC(32);
-  else ARK_LC(64);
+  const size_t lds = (size_t)Z * (D + 1) * sizeof(float);   // Wz^T
+  if (lds > 150 * 1024) return ARK_ERR_SHAPE;
+#define ARK_LC(ZT)                                                                                                          \
+  {                                                                                                                         \
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_bwd_kernel<ZT, 4>),            \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), true);           \
+    (void)once;                                                                                                             \
+    hipLaunchKernelGGL((latent_chain_bwd_kernel<ZT, 4>), dim3((B + 3) / 4), dim3(256), lds, st, dh0, h0, w_z, head, eps,     \
+                       hyper, ext_dhead, w_head, pre, dhead, dA, dA16, prec16, B, Z, D, H);                                  \
+  }
+  if (Z <= 16) ARK_LC(16)
+  else if (Z <= 32) ARK_LC(32)
+  else ARK_LC(64)
 #undef ARK_LC
   ARK_LAUNCH_CHECK();
   return 0;

@@ -1,10 +1,12 @@
 // Fused Adam over the flat parameter buffer, bias-gradient column sums, dropout masks.
 // Replaces torch.optim.Adam.step (reference kgvae/experiments/ablation_study.py:571,76) and the
 // bias / broadcast reductions autograd performs for nn.Linear / nn.GRU biases.
-#include "common.h"
+#include "gemm_core.h"
 #include "../../include/ark_amd.h"
 
 namespace ark {
+
+static_assert(kHpDropStep == ARK_HP_DROP_STEP, "common.h and ark_amd.h disagree on the dropout-draw slot");
 
 // advance the optimiser step counter and refresh the bias corrections (1 thread; keeps the step
 // state on the device so a captured graph replays correctly)
@@ -72,17 +74,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   }
 }
 
-// counter-based dropout mask: mask[i] = keep ? 1/(1-p) : 0, keep ~ Bernoulli(1-p) from a
-// splitmix64 hash of (seed, offset + i).  Statistically equivalent to torch's inter-layer GRU
-// dropout, not bit-identical (the reference draws from the CPU/cuRAND generator).
+// counter-based dropout mask: mask[i] = keep ? 1/(1-p) : 0, keep ~ Bernoulli(1-p) from the counter hash of
+// common.h (seed, draw counter hyper[ARK_HP_DROP_STEP], element index).  Statistically equivalent to torch's
+// inter-layer GRU dropout, not bit-identical (the reference draws from the CPU/cuRAND generator).
+// n % 4 == 0: one hash serves a quad of consecutive elements.
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, long n, float p, uint64_t seed,
                                                            const float* __restrict__ hyper) {
-  // the optimiser step counter is folded into the stream so a replayed graph draws fresh masks
-  const uint64_t step = (uint64_t)hyper[ARK_HP_ADAM_STEP];
-  const float keep_scale = 1.0f / (1.0f - p);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    mask[i] = dropout_keep_scale(seed, step, (uint64_t)i, p, keep_scale);
-  }
+  const DropCtx dc = drop_ctx(seed, hyper, p);
+  const long n4 = n >> 2;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x)
+    reinterpret_cast<f32x4*>(mask)[q] = dropout_quad(dc, (uint64_t)q);
 }
 
 __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -90,9 +91,185 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, c
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
 }
 
+// ---- 16-bit shadows (plain and transposed) of a list of fp32 matrices, one launch ------------
+struct ShadowJob { const float* src; void* dst; void* dstT; int R, C, prec, precT, ldT; };   // dstT[c*ldT + r]
+struct ShadowJobs { ShadowJob j[12]; int n; };
+
+__global__ __launch_bounds__(256) void weight_shadow_kernel(ShadowJobs jobs) {
+  __shared__ float tile[32][33];
+  const ShadowJob jb = jobs.j[blockIdx.z];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  if (r0 >= jb.R || c0 >= jb.C) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < jb.R && c < jb.C) {
+      v = jb.src[(long)r * jb.C + c];
+      if (jb.dst) put16(jb.dst, (long)r * jb.C + c, v, jb.prec);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (jb.dstT)
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;
+      if (r < jb.R && c < jb.C) put16(jb.dstT, (long)c * jb.ldT + r, tile[tx][i], jb.precT);
+    }
+}
+
+// ---- Adam over the flat buffer WITH the 16-bit weight shadows written from the same registers ----------
+// A job is either a LINEAR range of the flat buffer (embeddings, biases: 1024 floats per workgroup) or a
+// MATRIX [R, C] whose plain / transposed 16-bit shadows the next forward / backward stream by LDS-DMA: a
+// workgroup updates one 32x32 tile (128-byte row segments of p, g, m, v), stores the plain 16-bit copy from
+// registers and the transposed one through LDS.  Round 1 ran a separate shadow launch that re-read every
+// parameter Adam had just written (114 MB, 24 us per step).
+struct AdamJob { long off; void* dst; void* dstT; int R, C, prec, precT, ldT, tile0; };   // R == 0: linear, C = length
+struct AdamJobs { AdamJob j[ARK_ADAM_MAX_JOBS]; int n; };
+
+struct AdamScalars { float b1, b2, eps, gs, step_size, inv_sqrt_bc2; };
+__device__ __forceinline__ AdamScalars adam_scalars(const float* hyper) {
+  AdamScalars a;
+  a.b1 = hyper[ARK_HP_ADAM_B1]; a.b2 = hyper[ARK_HP_ADAM_B2]; a.eps = hyper[ARK_HP_ADAM_EPS]; a.gs = hyper[ARK_HP_GRAD_SCALE];
+  a.step_size = hyper[ARK_HP_LR] / hyper[ARK_HP_ADAM_BC1];
+  a.inv_sqrt_bc2 = 1.0f / sqrtf(hyper[ARK_HP_ADAM_BC2]);
+  return a;
+}
+__device__ __forceinline__ f32x4 adam_quad(const AdamScalars& a, float* p, const float* g, float* m, float* v, long i) {
+  f32x4 pp = *reinterpret_cast<f32x4*>(p + i);
+  const f32x4 gg = *reinterpret_cast<const f32x4*>(g + i) * a.gs;
+  f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mm[e] = a.b1 * mm[e] + (1.0f - a.b1) * gg[e];
+    vv[e] = a.b2 * vv[e] + (1.0f - a.b2) * gg[e] * gg[e];
+    pp[e] -= a.step_size * (mm[e] / (sqrtf(vv[e]) * a.inv_sqrt_bc2 + a.eps));
+  }
+  *reinterpret_cast<f32x4*>(p + i) = pp;
+  *reinterpret_cast<f32x4*>(m + i) = mm;
+  *reinterpret_cast<f32x4*>(v + i) = vv;
+  return pp;
+}
+
+__global__ __launch_bounds__(256) void adam_shadow_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, AdamJobs jobs,
+                                                          const float* __restrict__ hyper) {
+  __shared__ float tile[32][33];
+  int ji = 0;
+  for (int k = 1; k < jobs.n; ++k)
+    if ((int)blockIdx.x >= jobs.j[k].tile0) ji = k;
+  const AdamJob jb = jobs.j[ji];
+  const int t = blockIdx.x - jb.tile0;
+  const AdamScalars a = adam_scalars(hyper);
+  if (jb.R == 0) {   // linear range, length jb.C (% 4 == 0)
+    const long i = (long)t * 1024 + 4 * threadIdx.x;
+    if (i < jb.C) adam_quad(a, p, g, m, v, jb.off + i);
+    return;
+  }
+  const int tiles_c = (jb.C + 31) / 32;
+  const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+  const int ty = threadIdx.x >> 3, tx4 = (threadIdx.x & 7) * 4;
+  const int r = r0 + ty, c = c0 + tx4;
+  f32x4 pp = {0.f, 0.f, 0.f, 0.f};
+  if (r < jb.R && c < jb.C) {   // C % 4 == 0 (host-checked): the quad is whole
+    const long e = (long)r * jb.C + c;
+    pp = adam_quad(a, p, g, m, v, jb.off + e);
+    if (jb.dst) {
+      if (jb.prec == PREC_F16) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        using PT = PrecTraits<PREC_F16>;
+        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(jb.dst) + e) = h4{PT::cvt(pp[0]), PT::cvt(pp[1]), PT::cvt(pp[2]), PT::cvt(pp[3])};
+      } else {
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(jb.dst) + e) = bf16x4{(__bf16)pp[0], (__bf16)pp[1], (__bf16)pp[2], (__bf16)pp[3]};
+      }
+    }
+  }
+  if (!jb.dstT) return;   // block-uniform
+#pragma unroll
+  for (int e = 0; e < 4; ++e) tile[ty][tx4 + e] = pp[e];
+  __syncthreads();
+  // transposed copy: thread -> column c0 + ty of the source tile, 4 consecutive source rows r0 + tx4 .. +3
+  const int cT = c0 + ty, rT = r0 + tx4;
+  if (cT < jb.C && rT < jb.R) {
+    const long eT = (long)cT * jb.ldT + rT;   // ldT % 4 == 0 (host-checked): 8-byte aligned
+    const float x0 = tile[tx4][ty], x1 = tile[tx4 + 1][ty], x2 = tile[tx4 + 2][ty], x3 = tile[tx4 + 3][ty];
+    if (rT + 3 < jb.R) {
+      if (jb.precT == PREC_F16) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        using PT = PrecTraits<PREC_F16>;
+        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(jb.dstT) + eT) = h4{PT::cvt(x0), PT::cvt(x1), PT::cvt(x2), PT::cvt(x3)};
+      } else {
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(jb.dstT) + eT) = bf16x4{(__bf16)x0, (__bf16)x1, (__bf16)x2, (__bf16)x3};
+      }
+    } else {   // last rows of a matrix whose row count is not a multiple of 4 (e.g. a 55-token vocabulary)
+      const float xs[4] = {x0, x1, x2, x3};
+      for (int e = 0; e < 4 && rT + e < jb.R; ++e) put16(jb.dstT, eT + e, xs[e], jb.precT);
+    }
+  }
+}
+
 }  // namespace ark
 
-extern "C" int ark_version(void) { return 100; }
+extern "C" int ark_version(void) { return 200; }
+
+// Adam (as ark_adam_step) over the jobs' ranges of the flat buffers, writing the 16-bit weight shadows of
+// every matrix job from the updated values.  Job i: R[i] == 0 -> linear range [off[i], off[i] + C[i]);
+// else matrix [R[i], C[i]] at off[i] with optional plain (dst, prec) / transposed (dstT, precT, ldT) shadows.
+extern "C" int ark_adam_step_shadows(float* p, const float* g, float* m, float* v, int n_jobs, const int64_t* off,
+                                     const int* R, const int* C, void* const* dst, void* const* dstT, const int* prec,
+                                     const int* precT, const int* ldT, const float* hyper, void* stream) {
+  using namespace ark;
+  if (!p || !g || !m || !v || !hyper || n_jobs <= 0 || n_jobs > ARK_ADAM_MAX_JOBS || !off || !R || !C) return ARK_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+       reinterpret_cast<uintptr_t>(v)) & 15) return ARK_ERR_ALIGN;
+  AdamJobs jobs;
+  jobs.n = n_jobs;
+  long tiles = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    if (off[i] < 0 || (off[i] & 3) || C[i] <= 0 || R[i] < 0 || (C[i] & 3)) return ARK_ERR_ALIGN;
+    void* d = dst ? dst[i] : nullptr;
+    void* dT = dstT ? dstT[i] : nullptr;
+    int ld = 0;
+    if (R[i] > 0) {
+      if ((d || dT) && (!prec || !precT)) return ARK_ERR_ARG;
+      if (d && prec[i] != PREC_F16 && prec[i] != PREC_BF16) return ARK_ERR_ARG;
+      if (dT) {
+        if (precT[i] != PREC_F16 && precT[i] != PREC_BF16) return ARK_ERR_ARG;
+        ld = (ldT && ldT[i] > 0) ? ldT[i] : R[i];
+        if (ld < R[i] || (ld & 3)) return ARK_ERR_ALIGN;
+      }
+    }
+    jobs.j[i] = AdamJob{(long)off[i], R[i] > 0 ? d : nullptr, R[i] > 0 ? dT : nullptr, R[i], C[i], prec ? prec[i] : 0,
+                        precT ? precT[i] : 0, ld, (int)tiles};
+    tiles += R[i] > 0 ? (long)((R[i] + 31) / 32) * ((C[i] + 31) / 32) : ((long)C[i] + 1023) / 1024;
+    if (tiles > 0x7fffffffL) return ARK_ERR_SHAPE;
+  }
+  hipLaunchKernelGGL(adam_shadow_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p, g, m, v, jobs, hyper);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// up to 12 jobs: dst = cast(src [R,C]) in `prec`, dstT = cast(src^T [C,R]) in `precT` (either may be NULL)
+extern "C" int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, void* const* dstT, const int* R,
+                                  const int* C, const int* prec, const int* precT, const int* ldT, void* stream) {
+  using namespace ark;
+  if (n_jobs <= 0 || n_jobs > 12 || !src || !dst || !dstT || !R || !C || !prec || !precT) return ARK_ERR_ARG;
+  ShadowJobs jobs;
+  jobs.n = n_jobs;
+  int maxR = 0, maxC = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    if (!src[i] || R[i] <= 0 || C[i] <= 0) return ARK_ERR_ARG;
+    const int ld = (ldT && ldT[i] > 0) ? ldT[i] : R[i];
+    if (ld < R[i]) return ARK_ERR_ARG;
+    jobs.j[i] = ShadowJob{src[i], dst[i], dstT[i], R[i], C[i], prec[i], precT[i], ld};
+    if (R[i] > maxR) maxR = R[i];
+    if (C[i] > maxC) maxC = C[i];
+  }
+  hipLaunchKernelGGL(weight_shadow_kernel, dim3((maxC + 31) / 32, (maxR + 31) / 32, n_jobs), dim3(256), 0,
+                     (hipStream_t)stream, jobs);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int ark_adam_tick(float* hyper, void* stream) {
   if (!hyper) return ARK_ERR_ARG;
@@ -139,6 +316,7 @@ extern "C" int ark_colsum(const float* x, int64_t ld, int64_t batch_stride_in, f
 
 extern "C" int ark_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, const float* hyper, void* stream) {
   if (!mask || !hyper || n <= 0 || p < 0.f || p >= 1.f) return ARK_ERR_ARG;
+  if (n & 3) return ARK_ERR_SHAPE;
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(ark::dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (long)n, p,

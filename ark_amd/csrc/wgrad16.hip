@@ -30,7 +30,7 @@ struct Wgrad16Args {
 };
 // several independent products in ONE launch (e.g. dW_ih / dW_hh of every GRU layer at the end of
 // the backward pass): enough workgroups to fill the chip without deep split-K and its atomics
-constexpr int kMaxGroup = 8;
+constexpr int kMaxGroup = ARK_WGRAD_MAX_GROUP;
 struct Wgrad16Group {
   Wgrad16Args p[kMaxGroup];
   int tile_start[kMaxGroup + 1];
@@ -276,7 +276,7 @@ extern "C" int ark_wgrad16(int prec, const void* A16, int64_t lda, const void* B
   return ARK_ERR_ARG;
 }
 
-// n (<= 8) independent products of the kind above in ONE launch
+// n (<= ARK_WGRAD_MAX_GROUP) independent products of the kind above in ONE launch
 extern "C" int ark_wgrad16_group(int prec, int n, const void* const* A16, const int64_t* lda, const void* const* B16,
                                  const int64_t* ldb, float* const* C, const int64_t* ldc, const int* M, const int* N,
                                  const int* K, void* stream) {

@@ -30,7 +30,8 @@ def init(backend=None):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # ARK_DP_BACKEND=gloo: functional rehearsal with several ranks on ONE GPU (tests); nccl = RCCL
+                backend = os.environ.get("ARK_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             kw = {}
             if backend == "nccl":
                 torch.cuda.set_device(local_rank)

@@ -25,7 +25,7 @@ import torch
 from . import _lib as L
 
 HP = dict(LR=0, BETA=1, KL_NORM=2, CE_INV_COUNT=3, CE_COUNT=4, ADAM_STEP=5, ADAM_BC1=6, ADAM_BC2=7, ADAM_B1=8,
-          ADAM_B2=9, ADAM_EPS=10, GRAD_SCALE=11, COUNT=16)
+          ADAM_B2=9, ADAM_EPS=10, GRAD_SCALE=11, DROP_STEP=12, COUNT=16)
 
 # precision policy -> (forward products, backward products)
 #   "mixed": fp16 operands forward (3 more mantissa bits than bf16 at the same MFMA rate keeps the
@@ -88,7 +88,7 @@ class ParamLayout:
 
 
 class Engine:
-    def __init__(self, cfg, device, precision="f32", world_size=1):
+    def __init__(self, cfg, device, precision="f32", world_size=1, rank=0):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -106,6 +106,7 @@ class Engine:
         self.pad_rid = cfg.get("pad_rid")
         self.p_drop = float(cfg.get("dec_dropout", 0.1)) if self.n > 1 else 0.0
         self.world_size = world_size
+        self.rank = rank     # data-parallel rank: mixed into the dropout seed so row b of every rank draws its own mask
         if self.D % 32 != 0:
             raise L.ArkError("d_model must be a multiple of 32 for the gfx950 GRU tiles")
         self.layout = ParamLayout(cfg)
@@ -138,11 +139,13 @@ class Engine:
         self._ws_cache = {}
         self._pinned_B = set()
         self._graph_steps = {}
-        # 16-bit-operand / LDS-DMA path ("v2"): 16-bit shadows of the decoder weights, refreshed after
-        # every optimiser step: W_ih, W_hh, W_tok in the forward type; W_ih^T, W_hh^T in the backward type
+        self.fwd_gen = 0   # forward-call generation (the autograd wrappers check that backward follows ITS forward)
+        # fast path ("v2"): 16-bit operands streamed by LDS-DMA, layer-diagonal GRU kernels; needs 16-bit shadows of
+        # the GEMM weights, refreshed with every optimiser step: W_ih, W_hh, W_tok, encoder MLP / heads in the forward
+        # type; W_ih^T, W_hh^T, W_tok^T, W_mlp^T in the backward type
         self.use_dma = (self.prec_fwd != L.PREC_F32 and self.prec_bwd != L.PREC_F32 and self.D % 64 == 0
                         and not cfg.get("ark_no_dma", False))
-        self._v2 = False
+        self.tune = L.diag_tuning(**dict(cfg.get("ark_diag_tuning") or {})) if self.use_dma else None
         if self.use_dma:
             D, V = self.D, self.V
             i16 = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.int16)
@@ -159,13 +162,16 @@ class Engine:
                 self.wmT16 = [i16(H, H) for _ in range(self.n)]     # their transposes, backward type
                 self.wh16 = i16(2 * self.Z, H)                      # [mu; logv] head, forward type
             self._shadow_jobs = self._build_shadow_jobs()
-            self._shadow_jobs_part = {"dec": self._build_shadow_jobs("dec"), "enc": self._build_shadow_jobs("enc")}
+            off, tot = self.layout.dec_grad_offset, self.layout.total
+            self._adam_jobs = {"all": self._build_adam_jobs(0, tot), "enc": self._build_adam_jobs(0, off),
+                               "dec": self._build_adam_jobs(off, tot)}
         self._shadow_ok = False
         self._side = None
         self._side_used = False
         self._dp_pending = None      # data parallel: the decoder bucket's reduction + Adam still owed (see dp_flush)
         self._dp_flush_graph = None
         self.dp_pipeline = bool(cfg.get("ark_dp_pipeline", True))
+        self.dp_bf16 = bool(cfg.get("ark_dp_bf16", False))   # all-reduce 16-bit copies of the gradient buckets
         self._defer_wgrads = False
         self._fork_pending = None
         self._dlog16_only = False
@@ -175,9 +181,11 @@ class Engine:
         self._defer_finalize = False   # set by train_step / _dp_steps around forward(): backward follows at once
         self.fork_after = int(cfg.get("ark_fork_after", 1))   # measured: 0 -> 1.281, 1 -> 1.266, 2 -> 1.296 ms/step
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
-        self.diag_cells = bool(cfg.get("ark_diag_cells", True))
-        self.diag_bwd = bool(cfg.get("ark_diag_bwd", True))
-        self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))   # one launch per (layer, time) anti-diagonal
+        self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))
+
+    def _layer_seed(self, l):
+        """dropout stream of layer l's output on this rank (hashed with the draw counter and the element index)"""
+        return (self.drop_seed + 7919 * l + 104729 * self.rank) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------ parameters
     def load_params(self, named):
@@ -194,17 +202,15 @@ class Engine:
         self.dp_flush()
         self._shadow_ok = False
 
-    def _build_shadow_jobs(self, which="all"):
-        """16-bit shadow refresh jobs: `dec` = GRU + tied vocabulary weights (gradient bucket
-        [dec_grad_offset, total)), `enc` = encoder MLP + heads, `all` = both."""
+    def _build_shadow_jobs(self):
+        """job table of ark_weight_shadows: every GEMM weight -> plain (forward type) / transposed (backward type) copy"""
         import ctypes
         jobs = []
-        if which in ("all", "dec"):
-            for l in range(self.n):
-                jobs.append((self.p[f"dec.gru.weight_ih_l{l}"], self.wih16[l], self.wihT16[l], 3 * self.D, self.D))
-                jobs.append((self.p[f"dec.gru.weight_hh_l{l}"], self.whh16[l], self.whhT16[l], 3 * self.D, self.D))
-            jobs.append((self.p["dec.out.weight"], self.wtok16, self.wtokT16, self.V, self.D, self.Vp))
-        if self.mt == "SAIL" and which in ("all", "enc"):
+        for l in range(self.n):
+            jobs.append((self.p[f"dec.gru.weight_ih_l{l}"], self.wih16[l], self.wihT16[l], 3 * self.D, self.D))
+            jobs.append((self.p[f"dec.gru.weight_hh_l{l}"], self.whh16[l], self.whhT16[l], 3 * self.D, self.D))
+        jobs.append((self.p["dec.out.weight"], self.wtok16, self.wtokT16, self.V, self.D, self.Vp))
+        if self.mt == "SAIL":
             H = 3 * self.D
             for i in range(self.n):
                 jobs.append((self.p[f"enc.mlp.{2 * i}.weight"], self.wm16[i], self.wmT16[i], H, H))
@@ -224,13 +230,70 @@ class Engine:
             chunks.append((n, src, dst, dstT, R, C, pf, pb, ldT))
         return chunks
 
-    def refresh_shadows(self, which="all"):
+    def refresh_shadows(self):
+        """16-bit shadows of every GEMM weight from the fp32 parameters (after load_params / an external optimiser;
+        Engine.adam() writes them itself, from the registers that hold the updated weights)"""
         if self.use_dma:
-            jobs = self._shadow_jobs if which == "all" else self._shadow_jobs_part[which]
-            for (n, src, dst, dstT, R, C, pf, pb, ldT) in jobs:
+            for (n, src, dst, dstT, R, C, pf, pb, ldT) in self._shadow_jobs:
                 _call("ark_weight_shadows", L.i32(n), src, dst, dstT, R, C, pf, pb, ldT, L.cur_stream())
-        if which == "all":
-            self._shadow_ok = True
+        self._shadow_ok = True
+
+    def _build_adam_jobs(self, lo, hi):
+        """job table of ark_adam_step_shadows for the flat range [lo, hi): one MATRIX job per shadowed weight (its
+        16-bit shadows are written from the updated values), LINEAR jobs for everything between them"""
+        import ctypes
+        shadows = {}   # parameter name -> (dst, dstT, ldT)
+        for l in range(self.n):
+            shadows[f"dec.gru.weight_ih_l{l}"] = (self.wih16[l], self.wihT16[l], 0)
+            shadows[f"dec.gru.weight_hh_l{l}"] = (self.whh16[l], self.whhT16[l], 0)
+        tokname = "dec.tok_emb.weight" if self.layout.tied else "dec.out.weight"
+        shadows[tokname] = (self.wtok16, self.wtokT16, self.Vp)
+        if self.mt == "SAIL":
+            for i in range(self.n):
+                shadows[f"enc.mlp.{2 * i}.weight"] = (self.wm16[i], self.wmT16[i], 0)
+        jobs, cur = [], lo
+        def linear(a, b):
+            if b > a:
+                jobs.append((a, 0, b - a, None, None, 0))
+        ents = list(self.layout.entries.items())
+        k = 0
+        while k < len(ents):
+            name, (off, shape, numel) = ents[k]
+            mat = None
+            if name in shadows and len(shape) == 2 and shape[1] % 4 == 0:
+                mat = (off, shape[0], shape[1]) + shadows[name]
+            elif name == "enc.mu.weight" and self.mt == "SAIL" and shape[1] % 4 == 0:
+                mat = (off, 2 * self.Z, shape[1], self.wh16, None, 0)   # [mu; logv] are adjacent: one [2Z, 3D] matrix
+                k += 1                                                    # (skips enc.logv.weight)
+            if mat is not None and lo <= mat[0] and mat[0] + mat[1] * mat[2] <= hi:
+                linear(cur, mat[0])
+                jobs.append(mat)
+                cur = mat[0] + mat[1] * mat[2]
+            k += 1
+        linear(cur, hi)
+        chunks = []
+        for c0 in range(0, len(jobs), L.ADAM_MAX_JOBS):
+            ch = jobs[c0:c0 + L.ADAM_MAX_JOBS]
+            n = len(ch)
+            chunks.append((n, (ctypes.c_int64 * n)(*[j[0] for j in ch]), (ctypes.c_int * n)(*[j[1] for j in ch]),
+                           (ctypes.c_int * n)(*[j[2] for j in ch]),
+                           (ctypes.c_void_p * n)(*[(j[3].data_ptr() if j[3] is not None else 0) for j in ch]),
+                           (ctypes.c_void_p * n)(*[(j[4].data_ptr() if j[4] is not None else 0) for j in ch]),
+                           (ctypes.c_int * n)(*[self.prec_fwd] * n), (ctypes.c_int * n)(*[self.prec_bwd] * n),
+                           (ctypes.c_int * n)(*[j[5] for j in ch])))
+        return chunks
+
+    def _adam_launch(self, which):
+        st = L.cur_stream()
+        if self.use_dma:
+            for (n, off, R, C, dst, dstT, pf, pb, ldT) in self._adam_jobs[which]:
+                _call("ark_adam_step_shadows", L.ptr(self.P), L.ptr(self.G), L.ptr(self.M), L.ptr(self.Vv), L.i32(n), off, R, C,
+                      dst, dstT, pf, pb, ldT, L.ptr(self.hyper), st)
+        else:
+            lo, hi = {"all": (0, self.layout.total), "enc": (0, self.layout.dec_grad_offset),
+                      "dec": (self.layout.dec_grad_offset, self.layout.total)}[which]
+            _call("ark_adam_step", L.ptr(self.P[lo:]), L.ptr(self.G[lo:]), L.ptr(self.M[lo:]), L.ptr(self.Vv[lo:]), L.i64(hi - lo),
+                  L.ptr(self.hyper), st)
 
     def set_hyper(self, lr=None, beta=None, kl_norm=None, ce_count=None, grad_scale=None):
         """update device-resident step scalars (tiny async fills, only when a value changes)"""
@@ -248,6 +311,19 @@ class Engine:
         self.Vv.zero_()
         self.adam_steps = 0
         self.hyper[HP["ADAM_STEP"]:HP["ADAM_BC2"] + 1].zero_()
+
+    def set_optimizer_step(self, t):
+        """resume: optimiser step count and its bias corrections (what ark_adam_tick leaves behind after t steps)"""
+        self.adam_steps = int(t)
+        self.hyper[HP["ADAM_STEP"]:HP["ADAM_BC2"] + 1].copy_(torch.tensor(
+            [float(t), 1.0 - 0.9 ** t, 1.0 - 0.999 ** t], dtype=torch.float32))
+
+    def dropout_draws(self):
+        """number of training forwards so far = the dropout draw counter (device uint32; synchronises)"""
+        return int(self.hyper.view(torch.int32)[HP["DROP_STEP"]].item()) & 0xFFFFFFFF
+
+    def set_dropout_draws(self, n):
+        self.hyper.view(torch.int32)[HP["DROP_STEP"]:HP["DROP_STEP"] + 1].fill_(int(n) - (1 << 32) if int(n) >= (1 << 31) else int(n))
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, B, T):
@@ -274,6 +350,8 @@ class Engine:
             w["dz"], w["dhead"] = f(B, Z), f(B, 2 * Z)
             w["dH0"] = f(B, D)
             w["dA"], w["dB"] = f(B, H), f(B, H)
+        # fast path: 16-bit operands + layer-diagonal GRU kernels.  (Batches that are not a multiple of 16 rows run
+        # the register-staged kernels: same results, several times slower -- pad the batch instead.)
         v2 = self.use_dma and B % 16 == 0
         w["v2"] = v2
         i16 = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.int16)
@@ -288,20 +366,16 @@ class Engine:
             # "16": row-major 16-bit copies (a: forward type, b: backward type); "_t": tile-native
             w["X0a"] = i16(R, D)
             w["X0b"] = i16(R, D) if two else None
-            w["diag"] = self.diag_cells and n <= L.DIAG_MAX_ROLES
-            if not w["diag"]:   # the diagonal cells project their inputs themselves: no gi buffers
-                w["GI"] = [f(R, 3 * D) for _ in range(n)]                   # tile-native fp32
             w["Y"] = [torch.zeros((Lq + 1) * B, D, device=dev) for _ in range(n)]   # tile-native fp32 state
             w["Y16a"] = [torch.zeros((Lq + 1) * B, D, device=dev, dtype=torch.int16) for _ in range(n)]
             w["Y16b"] = [torch.zeros((Lq + 1) * B, D, device=dev, dtype=torch.int16) if two else None for _ in range(n)]
             for nm in ("SR", "SZ", "SN", "SHN"):
                 w[nm] = [i16(R, D) for _ in range(n)]                        # tile-native fp16 saves
-            w["dGI16"] = [i16(R, 3 * D) for _ in range(n)]
-            w["dGH16"] = [i16(R, 3 * D) for _ in range(n)]
+            w["dG16"] = [i16(R, 4 * D) for _ in range(n)]                    # gate-gradient panels [dr | dz | dn | dn*r]
             w["dlog16"] = torch.zeros(R, self.Vp, device=dev, dtype=torch.int16)   # K-padded 16-bit dlogits
             # small vocabularies: the token-embedding gradient as (onehot^T x dgi_0) x W_ih_0 instead of
             # input-gradient GEMM + scatter (SAIL; ARK also needs dX0 for the position embedding)
-            w["emb_gemm"] = bool(w["diag"] and self.mt == "SAIL" and self.Vp <= 256 and R % 64 == 0 and self.emb_gemm)
+            w["emb_gemm"] = bool(self.mt == "SAIL" and self.Vp <= 256 and R % 64 == 0 and self.emb_gemm)
             if w["emb_gemm"]:
                 w["onehot16"] = i16(R, self.Vp)
                 w["S_tok"] = f(self.Vp, 3 * D)
@@ -310,6 +384,7 @@ class Engine:
             if self.p_drop > 0:   # the dropout mask itself is regenerated in-kernel from a counter hash
                 w["Yd16a"] = [i16(R, D) for _ in range(n - 1)]
                 w["Yd16b"] = [i16(R, D) if two else None for _ in range(n - 1)]
+            w["carry_l"] = [f(B, D) for _ in range(n)]   # the diagonal BPTT keeps one carry per layer
         else:
             w["X0"] = f(R, D)
             w["GI"] = [f(R, 3 * D) for _ in range(n)]       # gi forward, overwritten by dgi in backward
@@ -326,8 +401,6 @@ class Engine:
         w["out4"] = torch.zeros(4, device=dev)
         w["dYa"], w["dYb"] = f(R, D), f(R, D)
         w["carry"] = f(B, D)
-        if v2 and w.get("diag"):
-            w["carry_l"] = [f(B, D) for _ in range(n)]   # the diagonal BPTT keeps one carry per layer
         w["tok_next"] = torch.zeros(B, dtype=torch.int64, device=dev)
         if len(self._ws_cache) >= 6:   # bound the cache; batch sizes with captured graphs stay pinned
             for k in [k for k in self._ws_cache if k not in self._pinned_B][:1]:
@@ -362,6 +435,7 @@ class Engine:
         step's decoder-bucket all-reduce + Adam in that seam."""
         self.prec = self.prec_fwd
         self._dlog16_valid = False
+        self.fwd_gen += 1
         if not self._shadow_ok:
             self.refresh_shadows()
         B = seq.shape[0]
@@ -427,10 +501,11 @@ class Engine:
         if with_loss:
             if ce_count is None:
                 _call("ark_count_targets", L.ptr(seq), L.i64(ld_seq), L.i32(B), L.i32(Lq), L.ptr(self.hyper), st)
+                self._hp.pop("CE_COUNT", None)   # the device slot no longer holds what set_hyper last wrote
             d16 = w["dlog16"] if (with_dlogits and w["v2"]) else None
             # the diagonal backward takes every consumer of dlogits (dY, dW_tok, db_out) from the 16-bit copy:
             # the fp32 gradient is then never written
-            only16 = d16 is not None and w.get("diag") and self.diag_bwd and R % 64 == 0 and self.dlog16_only
+            only16 = d16 is not None and R % 64 == 0 and self.dlog16_only
             _call("ark_ce_fwd_bwd", L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper),
                   L.ptr(w["row_loss"]), L.ptr(w["logits"] if (with_dlogits and not only16) else None), L.ptr(d16),
                   L.i32(self.prec_bwd if d16 is not None else 0), L.i64(self.Vp if d16 is not None else 0), L.i32(B), L.i32(Lq),
@@ -440,7 +515,7 @@ class Engine:
             self._finalize = lambda: _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R),
                                            L.ptr(w["kl"] if self.mt == "SAIL" else None), L.ptr(self.hyper), L.ptr(w["out4"]),
                                            L.cur_stream())
-            if not (self._defer_finalize and with_dlogits and w["v2"] and w.get("diag") and self.diag_bwd):
+            if not (self._defer_finalize and with_dlogits and w["v2"]):
                 self._finalize()
                 self._finalize = None
             # (else: the two-queue backward launches it on its side queue -- the loss scalars are not on the
@@ -464,7 +539,7 @@ class Engine:
             _call("ark_zproj_fwd", *zp, L.ptr(w["Y"][l]), L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(self.D), st)
 
     def _decoder_forward_v2(self, w, seq, ld_seq, B, Lq, use_drop, save=True):
-        """16-bit-operand / LDS-DMA decoder forward (see include/ark_amd.h, LDS-DMA section)"""
+        """fast decoder forward: token gather -> layer-diagonal GRU sweep -> tied vocabulary projection"""
         D, n, V = self.D, self.n, self.V
         R = Lq * B
         st = L.cur_stream()
@@ -472,80 +547,50 @@ class Engine:
         pf, pb = self.prec_fwd, self.prec_bwd
         _call("ark_tok_gather16", L.i32(pf), L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(p["dec.tok_emb.weight"]),
               L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0a"]), L.ptr(w["X0b"]), L.i32(B),
-              L.i32(Lq), L.i32(D), st)
-        def in_gemm(l, xin, rows, row0):
-            # gi[l][row0 : row0+rows] = xin x W_ih^T + b_ih   (tile-native; B % 16 == 0 keeps slices tile-aligned)
-            _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(xin), L.i64(D), L.ptr(self.wih16[l]), L.i64(D),
-                  L.ptr(w["GI"][l][row0:]), L.i64(3 * D), L.ptr(p[f"dec.gru.bias_ih_l{l}"]), L.ptr(None), L.i32(rows),
-                  L.i32(3 * D), L.i32(D), L.i32(1), L.cur_stream())
-
-        def cell(l, t, drop):
-            Y, Ya, Yb = w["Y"][l], w["Y16a"][l], w["Y16b"][l]
-            sl = slice(t * B, (t + 1) * B)
-            nx = slice((t + 1) * B, (t + 2) * B)
-            _call("ark_gru_cell_fwd_dma", L.i32(pf), L.i32(pb), L.ptr(Ya[sl]), L.ptr(self.whh16[l]), L.ptr(Y[sl]),
-                  L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l][sl]), L.ptr(Y[nx]), L.ptr(Ya[nx]),
-                  L.ptr(Yb[nx] if Yb is not None else None),
-                  L.ptr(w["Yd16a"][l][sl] if drop else None),
-                  L.ptr(w["Yd16b"][l][sl] if (drop and w["Yd16b"][l] is not None) else None),
-                  L.f32(self.p_drop if drop else 0.0), L.u64(self.drop_seed + 7919 * l), L.i64(t * B * D),
-                  L.ptr(self.hyper),
-                  L.ptr(w["SR"][l][sl] if save else None), L.ptr(w["SZ"][l][sl] if save else None),
-                  L.ptr(w["SN"][l][sl] if save else None), L.ptr(w["SHN"][l][sl] if save else None),
-                  L.i32(B), L.i32(D), L.cur_stream())
-
-        if w["diag"]:
-            self._diag_sweep(w, B, Lq, use_drop, save)
-        else:
-            xin = w["X0a"]
-            for l in range(n):
-                in_gemm(l, xin, R, 0)
-                drop = use_drop and l < n - 1   # (the cells hash the mask in-kernel)
-                for t in range(Lq):
-                    cell(l, t, drop)
-                xin = w["Yd16a"][l] if drop else w["Y16a"][l][B:]
+              L.i32(Lq), L.i32(D), L.ptr(self.hyper if use_drop else None), st)
+        self._diag_sweep(w, B, Lq, use_drop, save)
         _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(w["Y16a"][n - 1][B:]), L.i64(D), L.ptr(self.wtok16), L.i64(D),
               L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(p["dec.out.bias"]), L.ptr(None), L.i32(R), L.i32(V), L.i32(D),
               L.i32(0), st)
 
     def _diag_sweep(self, w, B, Lq, use_drop, save=True):
         """Layer-diagonal forward recurrence: cells (l, d-l) of one anti-diagonal are independent -> ONE
-        launch per diagonal, each role doing its own input projection (no gi buffers, no per-layer
-        input GEMM): L+n-1 dependent launches instead of n*L + n."""
+        launch per diagonal (one per ARK_DIAG_MAX_ROLES cells for deeper stacks), each role doing its own input
+        projection (no gi buffers, no per-layer input GEMM): L+n-1 dependent launches instead of n*L + n."""
+        import ctypes
         D, n, p = self.D, self.n, self.p
         pf, pb = self.prec_fwd, self.prec_bwd
         for d in range(Lq + n - 1):
-            roles = (L.GruDiagRole * L.DIAG_MAX_ROLES)()
-            k = 0
-            for l in range(n):
-                t = d - l
-                if t < 0 or t >= Lq:
-                    continue
-                drop = use_drop and l < n - 1
-                Y, Ya, Yb = w["Y"][l], w["Y16a"][l], w["Y16b"][l]
-                sl = slice(t * B, (t + 1) * B)
-                nx = slice((t + 1) * B, (t + 2) * B)
-                if l == 0:
-                    x = w["X0a"][sl]
-                else:
-                    x = w["Yd16a"][l - 1][sl] if use_drop else w["Y16a"][l - 1][nx]
-                r = roles[k]
-                r.x16, r.h_prev16 = L.dptr(x), L.dptr(Ya[sl])
-                r.w_ih16, r.w_hh16 = L.dptr(self.wih16[l]), L.dptr(self.whh16[l])
-                r.b_ih, r.b_hh = L.dptr(p[f"dec.gru.bias_ih_l{l}"]), L.dptr(p[f"dec.gru.bias_hh_l{l}"])
-                r.y_prev_t, r.y_out_t = L.dptr(Y[sl]), L.dptr(Y[nx])
-                r.y16a, r.y16b = L.dptr(Ya[nx]), L.dptr(Yb[nx] if Yb is not None else None)
-                r.yd16a = L.dptr(w["Yd16a"][l][sl] if drop else None)
-                r.yd16b = L.dptr(w["Yd16b"][l][sl] if (drop and w["Yd16b"][l] is not None) else None)
-                if save:
-                    r.save_r, r.save_z = L.dptr(w["SR"][l][sl]), L.dptr(w["SZ"][l][sl])
-                    r.save_n, r.save_hn = L.dptr(w["SN"][l][sl]), L.dptr(w["SHN"][l][sl])
-                r.drop_seed = (self.drop_seed + 7919 * l) & 0xFFFFFFFFFFFFFFFF
-                r.drop_base = t * B * D
-                r.drop_p = self.p_drop if drop else 0.0
-                k += 1
-            _call("ark_gru_diag_fwd", L.i32(pf), L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(B), L.i32(D),
-                  L.cur_stream())
+            cells = [l for l in range(n) if 0 <= d - l < Lq]
+            for c0 in range(0, len(cells), L.DIAG_MAX_ROLES):
+                roles = (L.GruDiagRole * L.DIAG_MAX_ROLES)()
+                chunk = cells[c0:c0 + L.DIAG_MAX_ROLES]
+                for k, l in enumerate(chunk):
+                    t = d - l
+                    drop = use_drop and l < n - 1
+                    Y, Ya, Yb = w["Y"][l], w["Y16a"][l], w["Y16b"][l]
+                    sl = slice(t * B, (t + 1) * B)
+                    nx = slice((t + 1) * B, (t + 2) * B)
+                    if l == 0:
+                        x = w["X0a"][sl]
+                    else:
+                        x = w["Yd16a"][l - 1][sl] if use_drop else w["Y16a"][l - 1][nx]
+                    r = roles[k]
+                    r.x16, r.h_prev16 = L.dptr(x), L.dptr(Ya[sl])
+                    r.w_ih16, r.w_hh16 = L.dptr(self.wih16[l]), L.dptr(self.whh16[l])
+                    r.b_ih, r.b_hh = L.dptr(p[f"dec.gru.bias_ih_l{l}"]), L.dptr(p[f"dec.gru.bias_hh_l{l}"])
+                    r.y_prev_t, r.y_out_t = L.dptr(Y[sl]), L.dptr(Y[nx])
+                    r.y16a, r.y16b = L.dptr(Ya[nx]), L.dptr(Yb[nx] if Yb is not None else None)
+                    r.yd16a = L.dptr(w["Yd16a"][l][sl] if drop else None)
+                    r.yd16b = L.dptr(w["Yd16b"][l][sl] if (drop and w["Yd16b"][l] is not None) else None)
+                    if save:
+                        r.save_r, r.save_z = L.dptr(w["SR"][l][sl]), L.dptr(w["SZ"][l][sl])
+                        r.save_n, r.save_hn = L.dptr(w["SN"][l][sl]), L.dptr(w["SHN"][l][sl])
+                    r.drop_seed = self._layer_seed(l)
+                    r.drop_base = t * B * D
+                    r.drop_p = self.p_drop if drop else 0.0
+                _call("ark_gru_diag_fwd", L.i32(pf), L.i32(pb), L.i32(len(chunk)), roles, L.ptr(self.hyper), L.i32(B),
+                      L.i32(D), ctypes.byref(self.tune), L.cur_stream())
 
     def _decoder_forward(self, w, seq, ld_seq, B, Lq, use_drop, save=True):
         if w["v2"]:
@@ -556,7 +601,8 @@ class Engine:
         p = self.p
         KM = L.LAY_KMAJ
         _call("ark_tok_gather", L.ptr(seq), L.i64(ld_seq), L.ptr(p["dec.tok_emb.weight"]),
-              L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0"]), L.i32(B), L.i32(Lq), L.i32(D), st)
+              L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0"]), L.i32(B), L.i32(Lq), L.i32(D),
+              L.ptr(self.hyper if use_drop else None), st)
         xin = w["X0"]
         for l in range(n):
             self._gemm(KM, KM, L.EPI_BIAS, xin, D, p[f"dec.gru.weight_ih_l{l}"], D, w["GI"][l], 3 * D, R, 3 * D, D,
@@ -565,7 +611,7 @@ class Engine:
             drop = use_drop and l < n - 1
             if drop:
                 _call("ark_dropout_mask", L.ptr(w["mask"][l]), L.i64(R * D), L.f32(self.p_drop),
-                      L.u64(self.drop_seed + 7919 * l), L.ptr(self.hyper), st)
+                      L.u64(self._layer_seed(l)), L.ptr(self.hyper), st)
             for t in range(Lq):
                 sl = slice(t * B, (t + 1) * B)
                 common = (L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l][sl]), L.ptr(Y[(t + 1) * B:]))
@@ -601,7 +647,7 @@ class Engine:
         use_drop = self.training and self.p_drop > 0
         # ONE fill of the flat gradient buffer; every reduction below (split-K weight gradients, bias
         # column sums, embedding scatters) then accumulates into it without its own memset launch
-        if w["v2"] and w.get("diag") and self.diag_bwd:
+        if w["v2"]:
             self._backward_decoder_diag(w, B, Lq, seq, use_drop)   # fills, scatters and forks streams itself
             if self.mt == "ARK":
                 self._join_side()
@@ -611,10 +657,7 @@ class Engine:
             self._finalize()
             self._finalize = None
         self.G.zero_()
-        if w["v2"]:
-            dX0 = self._backward_decoder_v2(w, B, Lq, seq, use_drop)
-        else:
-            dX0 = self._backward_decoder_v1(w, B, Lq, seq, use_drop)
+        dX0 = self._backward_decoder_v1(w, B, Lq, seq, use_drop)
         _call("ark_tok_scatter", L.ptr(seq), L.i64(ld_seq), L.ptr(dX0), L.ptr(g["dec.tok_emb.weight"]), L.i32(B), L.i32(Lq),
               L.i32(D), L.i32(V), st)
         if self.mt == "ARK":
@@ -767,88 +810,6 @@ class Engine:
             dy, dy_other = dy_other, dy
         return dy
 
-    def _backward_decoder_v2(self, w, B, Lq, seq, use_drop):
-        """16-bit-operand / LDS-DMA decoder backward: BPTT cells on the DMA engine, weight gradients
-        from the 16-bit gate-gradient panels, input gradients against transposed weight shadows."""
-        D, n, V = self.D, self.n, self.V
-        R = Lq * B
-        st = L.cur_stream()
-        KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
-        p, g = self.p, self.g
-        pb = self.prec_bwd
-        dlog = w["logits"]
-        yb = lambda l: (w["Y16b"][l] if w["Y16b"][l] is not None else w["Y16a"][l])
-        self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
-        _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dlog), L.i32(0), L.i64(self.ldl), L.ptr(yb(n - 1)[B:]), L.i32(1), L.i64(D),
-              L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(V), L.i32(D), L.i32(R), L.i32(1), st)
-        if getattr(self, "_dlog16_valid", False):
-            # dY of the top layer on the LDS-DMA engine: K-padded 16-bit dlogits x K-padded W_tok^T shadow
-            _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(self.wtokT16),
-                  L.i64(self.Vp), L.ptr(w["dYa"]), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(self.Vp),
-                  L.i32(1), st)
-        else:
-            # external dlogits (autograd path): register-staged engine on the fp32 buffer, then re-tile
-            self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
-            _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
-        dy, dy_other = w["dYa"], w["dYb"]
-        group = []
-        for l in range(n - 1, -1, -1):
-            Y = w["Y"][l]
-            dGI, dGH = w["dGI16"][l], w["dGH16"][l]
-            for t in range(Lq - 1, -1, -1):
-                sl = slice(t * B, (t + 1) * B)
-                first = (t == Lq - 1)
-                _call("ark_gru_cell_bwd_dma", L.i32(pb), L.ptr(None if first else dGH[(t + 1) * B:]), L.ptr(self.whhT16[l]),
-                      L.ptr(dy[sl]), L.ptr(w["carry"]), L.ptr(w["SR"][l][sl]), L.ptr(w["SZ"][l][sl]), L.ptr(w["SN"][l][sl]),
-                      L.ptr(w["SHN"][l][sl]), L.ptr(Y[sl]), L.ptr(dGI[sl]), L.ptr(dGH[sl]),
-                      L.ptr(g[f"dec.gru.bias_ih_l{l}"]), L.ptr(g[f"dec.gru.bias_hh_l{l}"]), L.i32(B), L.i32(D),
-                      L.i32(1 if first else 0), st)
-            if self.mt == "SAIL":
-                _call("ark_gru_h0_bwd_dma", L.i32(pb), L.ptr(dGH), L.ptr(self.whhT16[l]), L.ptr(w["carry"]), L.ptr(w["dH0"]),
-                      L.i32(0 if l == n - 1 else 1), L.i32(B), L.i32(D), st)
-            drop_below = use_drop and l > 0
-            if l == 0:
-                xin = w["X0b"] if w["X0b"] is not None else w["X0a"]
-            elif drop_below:
-                xin = w["Yd16b"][l - 1] if w["Yd16b"][l - 1] is not None else w["Yd16a"][l - 1]
-            else:
-                xin = yb(l - 1)[B:]
-            if R % 64 == 0:
-                # weight gradients of this layer go to the side stream: they only need this layer's
-                # finished gate-gradient panels, so they run underneath the (latency-bound) cell chain
-                # of the layers below and the encoder backward
-                items = [(dGH, 3 * D, yb(l), D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R),
-                         (dGI, 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)]
-                if self.overlap_wgrad:
-                    side = self._side_stream()
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        self._wgrad_group(items)
-                    self._side_used = True
-                else:
-                    group += items
-            else:
-                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGH), L.i32(1), L.i64(3 * D), L.ptr(yb(l)), L.i32(1), L.i64(D),
-                      L.ptr(g[f"dec.gru.weight_hh_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), L.i32(1), st)
-                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dGI), L.i32(1), L.i64(3 * D), L.ptr(xin), L.i32(1), L.i64(D),
-                      L.ptr(g[f"dec.gru.weight_ih_l{l}"]), L.i64(D), L.i32(3 * D), L.i32(D), L.i32(R), L.i32(1), st)
-            # (bias gradients were accumulated by the cell epilogues)
-            # input gradient: dgi [R,3D] x W_ih^T-shadow [D,3D]; tile-native for the layer below,
-            # row-major for the embedding scatter
-            out = dy_other if l > 0 else w["dX0"]
-            if drop_below:
-                _call("ark_gemm16_dropout", L.i32(pb), L.ptr(dGI), L.i64(3 * D), L.ptr(self.wihT16[l]), L.i64(3 * D), L.ptr(out),
-                      L.i64(D), L.i32(R), L.i32(D), L.i32(3 * D), L.f32(self.p_drop), L.u64(self.drop_seed + 7919 * (l - 1)),
-                      L.ptr(self.hyper), st)
-            else:
-                _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(dGI), L.i64(3 * D), L.ptr(self.wihT16[l]), L.i64(3 * D),
-                      L.ptr(out), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(3 * D),
-                      L.i32(1 if l > 0 else 0), st)
-            dy, dy_other = dy_other, dy
-        for i0 in range(0, len(group), 8):
-            self._wgrad_group(group[i0:i0 + 8])
-        return w["dX0"]
-
     def _backward_decoder_diag(self, w, B, Lq, seq, use_drop):
         """Decoder backward in layer-diagonal order.  Main stream = the dependent chain only
         (dY of the top layer -> one launch per backward anti-diagonal -> h0 gradients); everything that
@@ -896,44 +857,7 @@ class Engine:
             self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
             _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
         main.wait_event(filled)   # the cells accumulate bias gradients into the flat buffer
-        h0_done = set()
-        for e in range(Lq + n - 1):
-            roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
-            k = 0
-            for l in range(n - 1, -1, -1):
-                t = Lq - 1 - (e - (n - 1 - l))
-                if t < 0 or t >= Lq:
-                    continue
-                sl = slice(t * B, (t + 1) * B)
-                r = roles[k]
-                top = l == n - 1
-                if top:
-                    r.dy_t = L.dptr(w["dYa"][sl])
-                else:
-                    r.dgi_up16, r.w_ihT_up16 = L.dptr(w["dGI16"][l + 1][sl]), L.dptr(self.wihT16[l + 1])
-                r.first = 1 if t == Lq - 1 else 0
-                r.dgh_next16 = 0 if r.first else L.dptr(w["dGH16"][l][(t + 1) * B:])
-                r.w_hhT16 = L.dptr(self.whhT16[l])
-                r.carry_t = L.dptr(w["carry_l"][l])
-                r.save_r, r.save_z = L.dptr(w["SR"][l][sl]), L.dptr(w["SZ"][l][sl])
-                r.save_n, r.save_hn = L.dptr(w["SN"][l][sl]), L.dptr(w["SHN"][l][sl])
-                r.y_prev_t = L.dptr(w["Y"][l][sl])
-                r.dgi16, r.dgh16 = L.dptr(w["dGI16"][l][sl]), L.dptr(w["dGH16"][l][sl])
-                r.db_ih, r.db_hh = L.dptr(g[f"dec.gru.bias_ih_l{l}"]), L.dptr(g[f"dec.gru.bias_hh_l{l}"])
-                drop = use_drop and not top
-                r.drop_seed = (self.drop_seed + 7919 * l) & 0xFFFFFFFFFFFFFFFF
-                r.drop_base = t * B * D
-                r.drop_p = self.p_drop if drop else 0.0
-                k += 1
-            if self.mt == "SAIL" and self.h0_ride:
-                # a layer's initial-state role (dH0 += carry + dgh_0 W_hh) may ride any diagonal after the one
-                # that finished its step 0; layers >= 1 fit into the under-filled last diagonals
-                for l in range(n - 1, 0, -1):
-                    if e == (n - 1 - l) + Lq and k < L.DIAG_MAX_ROLES:
-                        self._h0_role(roles[k], w, l)
-                        h0_done.add(l)
-                        k += 1
-            _call("ark_gru_diag_bwd", L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
+
         def fork_wgrads():
             # the big weight-gradient launch starves small dependent kernels that run beside it (the 13-us dh0
             # launch took 83 us: its 48 KB of LDS do not fit next to two 64-KB weight-gradient workgroups), so it
@@ -944,30 +868,91 @@ class Engine:
                 self._gru_wgrads(w, B, Lq, seq, use_drop, range(n), emb=True)
             self._side_used = side is not main
             self._fork_pending = None
-        self._side_used = side is not main
-        self._fork_pending = None
-        if not self._defer_wgrads:   # (data parallel schedules them itself, bucket by bucket)
-            if self.mt == "SAIL" and self.fork_after > 0 and side is not main:
-                self._fork_pending = fork_wgrads
-            else:
-                fork_wgrads()
+
+        def after_cells():
+            self._side_used = side is not main
+            self._fork_pending = None
+            if not self._defer_wgrads:   # (data parallel schedules them itself, bucket by bucket)
+                if self.mt == "SAIL" and self.fork_after > 0 and side is not main:
+                    self._fork_pending = fork_wgrads
+                else:
+                    fork_wgrads()
+
+        self._diag_bwd_sweep(w, B, Lq, use_drop, after_cells)
+        if self.mt == "SAIL" and self._fork_pending is not None and self.fork_after == 1:
+            self._fork_pending()
+
+    def _diag_bwd_sweep(self, w, B, Lq, use_drop, after_cells=None):
+        """the dependent chain of the decoder backward: one launch per backward anti-diagonal, then (SAIL) the
+        initial-state roles.  Needs dY of the top layer in w["dYa"] and a zeroed w["dH0"]."""
+        import ctypes
+        D, n, g = self.D, self.n, self.g
+        pb = self.prec_bwd
+        tune = ctypes.byref(self.tune)
+
+        def launch(roles, k):
+            _call("ark_gru_diag_bwd", L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), tune, L.cur_stream())
+
+        h0_done = set()
+        for e in range(Lq + n - 1):
+            cells = [l for l in range(n - 1, -1, -1) if 0 <= Lq - 1 - (e - (n - 1 - l)) < Lq]
+            for c0 in range(0, len(cells), L.DIAG_MAX_ROLES):
+                roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
+                chunk = cells[c0:c0 + L.DIAG_MAX_ROLES]
+                k = 0
+                for l in chunk:
+                    t = Lq - 1 - (e - (n - 1 - l))
+                    sl = slice(t * B, (t + 1) * B)
+                    r = roles[k]
+                    top = l == n - 1
+                    if top:
+                        r.dy_t = L.dptr(w["dYa"][sl])
+                    else:
+                        r.dgi_up16, r.w_ihT_up16 = L.dptr(w["dG16"][l + 1][sl]), L.dptr(self.wihT16[l + 1])
+                    r.first = 1 if t == Lq - 1 else 0
+                    r.dg_next16 = 0 if r.first else L.dptr(w["dG16"][l][(t + 1) * B:])
+                    r.w_hhT16 = L.dptr(self.whhT16[l])
+                    r.carry_t = L.dptr(w["carry_l"][l])
+                    r.save_r, r.save_z = L.dptr(w["SR"][l][sl]), L.dptr(w["SZ"][l][sl])
+                    r.save_n, r.save_hn = L.dptr(w["SN"][l][sl]), L.dptr(w["SHN"][l][sl])
+                    r.y_prev_t = L.dptr(w["Y"][l][sl])
+                    r.dg16 = L.dptr(w["dG16"][l][sl])
+                    r.db_ih, r.db_hh = L.dptr(g[f"dec.gru.bias_ih_l{l}"]), L.dptr(g[f"dec.gru.bias_hh_l{l}"])
+                    drop = use_drop and not top
+                    r.drop_seed = self._layer_seed(l)
+                    r.drop_base = t * B * D
+                    r.drop_p = self.p_drop if drop else 0.0
+                    k += 1
+                if self.mt == "SAIL" and self.h0_ride and c0 + L.DIAG_MAX_ROLES >= len(cells):
+                    # a layer's initial-state role (dH0 += carry + dgh_0 W_hh) may ride any diagonal after the one
+                    # that finished its step 0; layers >= 1 fit into the under-filled last diagonals
+                    for l in range(n - 1, 0, -1):
+                        if e == (n - 1 - l) + Lq and k < L.DIAG_MAX_ROLES:
+                            self._h0_role(roles[k], w, l)
+                            h0_done.add(l)
+                            k += 1
+                launch(roles, k)
+        if after_cells is not None:
+            after_cells()
         if self.mt == "SAIL":   # continues on the main stream into the encoder half
-            # dH0 = sum over layers of (carry + dgh_0 W_hh): all layers as roles of ONE more launch
-            roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
+            # dH0 = sum over layers of (carry + dgh_0 W_hh): all remaining layers as roles of one more launch
             rest = [l for l in range(n) if l not in h0_done]
-            for k, l in enumerate(rest):
-                self._h0_role(roles[k], w, l)
-            _call("ark_gru_diag_bwd", L.i32(pb), L.i32(len(rest)), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), st)
-            if self._fork_pending is not None and self.fork_after == 1:
-                self._fork_pending()
+            for c0 in range(0, len(rest), L.DIAG_MAX_ROLES):
+                roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
+                chunk = rest[c0:c0 + L.DIAG_MAX_ROLES]
+                for k, l in enumerate(chunk):
+                    self._h0_role(roles[k], w, l)
+                launch(roles, len(chunk))
 
     def _h0_role(self, r, w, l):
-        r.dgh_next16, r.w_hhT16 = L.dptr(w["dGH16"][l]), L.dptr(self.whhT16[l])
+        r.dg_next16, r.w_hhT16 = L.dptr(w["dG16"][l]), L.dptr(self.whhT16[l])
         r.carry_t, r.dh0 = L.dptr(w["carry_l"][l]), L.dptr(w["dH0"])
 
     def _gru_wgrads(self, w, B, Lq, seq, use_drop, layers, emb):
         """weight gradients of the given GRU layers as ONE grouped launch on the current stream, plus
-        (emb=True) the input-embedding gradient, which needs layer 0's gate-gradient panel"""
+        (emb=True) the input-embedding gradient, which needs layer 0's gate-gradient panel.
+        Panel columns (ld 4D): [dr | dz | dn | dn*r] -> dW_ih = panel[:, 0:3D]^T x, dW_hh[0:2D] = panel[:, 0:2D]^T h,
+        dW_hh[2D:3D] = panel[:, 3D:4D]^T h."""
         D, n, V = self.D, self.n, self.V
         R = Lq * B
         p, g = self.p, self.g
@@ -984,30 +969,34 @@ class Engine:
                 xin = w["Yd16b"][l - 1] if w["Yd16b"][l - 1] is not None else w["Yd16a"][l - 1]
             else:
                 xin = yb(l - 1)[B:]
-            items += [(w["dGH16"][l], 3 * D, yb(l), D, g[f"dec.gru.weight_hh_l{l}"], D, 3 * D, D, R),
-                      (w["dGI16"][l], 3 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)]
+            G16 = w["dG16"][l]
+            ghh = g[f"dec.gru.weight_hh_l{l}"]
+            items += [(G16, 4 * D, yb(l), D, ghh, D, 2 * D, D, R),
+                      (G16[:, 3 * D:], 4 * D, yb(l), D, ghh[2 * D:], D, D, D, R),
+                      (G16, 4 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)]
         if R % 64 == 0:
-            for i0 in range(0, len(items), 8):
-                self._wgrad_group(items[i0:i0 + 8])
+            for i0 in range(0, len(items), L.WGRAD_MAX_GROUP):
+                self._wgrad_group(items[i0:i0 + L.WGRAD_MAX_GROUP])
         else:
             for (a, lda, x, ldx, out, ldo, M, N, K) in items:
                 _call("ark_gemm_wgrad", L.i32(pb), L.ptr(a), L.i32(1), L.i64(lda), L.ptr(x), L.i32(1), L.i64(ldx), L.ptr(out),
                       L.i64(ldo), L.i32(M), L.i32(N), L.i32(K), L.i32(1), ss)
         if not emb:
             return
+        G0 = w["dG16"][0]
         if w["emb_gemm"]:
             # dW_tok += onehot^T dX0 = (onehot^T dgi_0) W_ih_0: a [Vp,3D] reduction over the tokens on the
             # matrix cores, then one small exact-fp32 product -- no [R,D] input gradient, no scatter
             w["S_tok"].zero_()
             _call("ark_onehot16", L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(w["onehot16"]), L.i32(B), L.i32(Lq),
                   L.i32(self.Vp), ss)
-            _call("ark_wgrad16", L.i32(pb), L.ptr(w["onehot16"]), L.i64(self.Vp), L.ptr(w["dGI16"][0]), L.i64(3 * D),
+            _call("ark_wgrad16", L.i32(pb), L.ptr(w["onehot16"]), L.i64(self.Vp), L.ptr(G0), L.i64(4 * D),
                   L.ptr(w["S_tok"]), L.i64(3 * D), L.i32(self.Vp), L.i32(3 * D), L.i32(R), ss)
             _call("ark_gemm", L.i32(L.PREC_F32), L.i32(KM), L.i32(MM), L.i32(L.EPI_NONE), L.ptr(w["S_tok"]), L.i64(3 * D),
                   L.ptr(p["dec.gru.weight_ih_l0"]), L.i64(D), L.ptr(g["dec.tok_emb.weight"]), L.i64(D), L.ptr(None),
                   L.ptr(None), L.ptr(None), L.i32(V), L.i32(D), L.i32(3 * D), L.i32(1), ss)
         else:
-            _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dGI16"][0]), L.i64(3 * D), L.ptr(self.wihT16[0]),
+            _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(G0), L.i64(4 * D), L.ptr(self.wihT16[0]),
                   L.i64(3 * D), L.ptr(w["dX0"]), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(3 * D),
                   L.i32(0), ss)
             _call("ark_tok_scatter", L.ptr(seq), L.i64(ld_seq), L.ptr(w["dX0"]), L.ptr(g["dec.tok_emb.weight"]), L.i32(B),
@@ -1031,29 +1020,21 @@ class Engine:
 
     # ------------------------------------------------------------------ optimiser
     def adam(self):
+        """fused Adam over the flat buffer; on the fast path the same launch writes the 16-bit weight shadows"""
         self.dp_flush()
-        st = L.cur_stream()
-        _call("ark_adam_tick", L.ptr(self.hyper), st)
-        _call("ark_adam_step", L.ptr(self.P), L.ptr(self.G), L.ptr(self.M), L.ptr(self.Vv), L.i64(self.layout.total),
-              L.ptr(self.hyper), st)
+        _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
+        self._adam_launch("all")
         self.adam_steps += 1
-        self.refresh_shadows()
+        self._shadow_ok = True
 
     def _adam_part(self, which):
-        """Adam + shadow refresh of ONE gradient bucket (pipelined data parallel): `enc` = [0, dec_grad_offset)
+        """Adam (+ shadows) of ONE gradient bucket (pipelined data parallel): `enc` = [0, dec_grad_offset)
         comes first and ticks the step counter, `dec` = [dec_grad_offset, total) follows with the same
         step scalars -- together exactly adam()."""
-        st = L.cur_stream()
-        off, tot = self.layout.dec_grad_offset, self.layout.total
         if which == "enc":
-            _call("ark_adam_tick", L.ptr(self.hyper), st)
-            lo, hi = 0, off
+            _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
             self.adam_steps += 1
-        else:
-            lo, hi = off, tot
-        _call("ark_adam_step", L.ptr(self.P[lo:]), L.ptr(self.G[lo:]), L.ptr(self.M[lo:]), L.ptr(self.Vv[lo:]), L.i64(hi - lo),
-              L.ptr(self.hyper), st)
-        self.refresh_shadows(which)
+        self._adam_launch(which)
 
     def dp_flush(self):
         """Finish a pipelined data-parallel step: wait for the decoder bucket's all-reduce and apply its Adam
@@ -1094,7 +1075,7 @@ class Engine:
         for _ in fwd:
             pass
         w = self.ws
-        if not (self.mt == "SAIL" and w["v2"] and w.get("diag") and self.diag_bwd):
+        if not (self.mt == "SAIL" and w["v2"]):
             more = self.backward_decoder()
             self._join_side()
             yield (off, tot)
@@ -1303,48 +1284,89 @@ class Engine:
             self.refresh_shadows()
         return replay()
 
-    # ------------------------------------------------------------------ greedy decode (next row of SURVEY 8f)
+    # ------------------------------------------------------------------ incremental decode
+    def _decode_ws(self, B):
+        """persistent buffers of the one-token-at-a-time decoder (per batch size): nothing is allocated per call"""
+        ws = self.__dict__.setdefault("_dec_cache", {})
+        d = ws.get(B)
+        if d is None:
+            dev, D, n = self.device, self.D, self.n
+            f = lambda *sh: torch.zeros(*sh, device=dev, dtype=torch.float32)
+            d = {"x0": f(B, D), "gi": f(B, 3 * D), "logits": f(B, _rup(self.V, 4)), "Y": [f(2 * B, D) for _ in range(n)],
+                 "nxt": torch.zeros(B, dtype=torch.int64, device=dev), "z": f(B, max(self.Z, 1)),
+                 "toks": torch.zeros(B, self.seq_len, dtype=torch.int64, device=dev)}
+            if len(ws) >= 4:
+                ws.pop(next(iter(ws)))
+            ws[B] = d
+        return d
+
+    @torch.no_grad()
+    def decode_begin(self, B, z=None):
+        """start an incremental decode of B sequences: h0 = tanh(z_proj(z)) for every layer (SAIL, reference
+        models.py:139-140) or zeros (ARK, models.py:340-345).  Exact-fp32 register-staged kernels."""
+        self.dp_flush()
+        d = self._decode_ws(B)
+        st = L.cur_stream()
+        if self.mt == "SAIL":
+            d["z"].copy_(z.to(self.device, dtype=torch.float32))
+            for l in range(self.n):
+                _call("ark_zproj_fwd", L.ptr(d["z"]), L.ptr(self.p["dec.z_proj.weight"]), L.ptr(self.p["dec.z_proj.bias"]),
+                      L.ptr(d["Y"][l]), L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(self.D), st)
+        else:
+            for l in range(self.n):
+                d["Y"][l][:B].zero_()
+        return d
+
+    @torch.no_grad()
+    def decode_step(self, d, cur, t):
+        """advance the causal GRU by ONE token: `cur` [B] int64 are the tokens at position t; returns the logits
+        [B, V] of position t + 1 (a view of the persistent buffer).  Replaces the reference's re-run of the whole
+        prefix per generated token (models.py:291, :427)."""
+        B, D, n, V = cur.shape[0], self.D, self.n, self.V
+        p = self.p
+        st = L.cur_stream()
+        KM = L.LAY_KMAJ
+        prec = L.PREC_F32
+        pos = p["dec.pos_emb.weight"][t:] if self.mt == "ARK" else None
+        _call("ark_tok_gather", L.ptr(cur), L.i64(1), L.ptr(p["dec.tok_emb.weight"]), L.ptr(pos), L.ptr(d["x0"]),
+              L.i32(B), L.i32(1), L.i32(D), L.ptr(None), st)
+        xin = d["x0"]
+        for l in range(n):
+            _call("ark_gemm", L.i32(prec), L.i32(KM), L.i32(KM), L.i32(L.EPI_BIAS), L.ptr(xin), L.i64(D),
+                  L.ptr(p[f"dec.gru.weight_ih_l{l}"]), L.i64(D), L.ptr(d["gi"]), L.i64(3 * D), L.ptr(None),
+                  L.ptr(p[f"dec.gru.bias_ih_l{l}"]), L.ptr(None), L.i32(B), L.i32(3 * D), L.i32(D), L.i32(0), st)
+            a, b = d["Y"][l][(t % 2) * B:], d["Y"][l][((t + 1) % 2) * B:]
+            _call("ark_gru_cell_fwd", L.i32(prec), L.ptr(a), L.ptr(p[f"dec.gru.weight_hh_l{l}"]),
+                  L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(d["gi"]), L.ptr(b), L.ptr(None),
+                  L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), L.i32(B), L.i32(D), st)
+            xin = b
+        ldl = d["logits"].shape[1]
+        _call("ark_gemm", L.i32(prec), L.i32(KM), L.i32(KM), L.i32(L.EPI_BIAS), L.ptr(xin), L.i64(D), L.ptr(p["dec.out.weight"]),
+              L.i64(D), L.ptr(d["logits"]), L.i64(ldl), L.ptr(None), L.ptr(p["dec.out.bias"]), L.ptr(None), L.i32(B), L.i32(V),
+              L.i32(D), L.i32(0), st)
+        return d["logits"][:, :V]
+
     @torch.no_grad()
     def greedy_decode(self, z, max_len=None):
-        """token sequences of SAIL.decode_latent(z, beam=1) (reference models.py:282-300): the decoder
-        is a causal GRU, so instead of re-running the whole prefix we advance one step per token.
-        Uses the register-staged kernels on private buffers (exact in f32 precision)."""
+        """token sequences of SAIL.decode_latent(z, beam=1) (reference models.py:282-300): the decoder is a causal
+        GRU, so instead of re-running the whole prefix we advance one step per token.  Exact-fp32 kernels on
+        persistent buffers; every step is queued without a host round trip and the reference's stopping rule
+        (first position at which EVERY row's token is EOS) is applied once at the end -- positions up to there do
+        not depend on later ones, so the result is the reference's, token for token."""
         assert self.mt == "SAIL"
-        self.prec = self.prec_fwd
         B = z.shape[0]
         Lmax = (self.seq_len - 1) if max_len is None else max_len
-        D, n, V, dev = self.D, self.n, self.V, self.device
-        st = L.cur_stream()
-        p = self.p
-        KM = L.LAY_KMAJ
-        f = lambda *sh: torch.zeros(*sh, device=dev, dtype=torch.float32)
-        ldl = _rup(V, 4)
-        x0, gi, logits = f(B, D), f(B, 3 * D), f(B, ldl)
-        Y = [f(2 * B, D) for _ in range(n)]
-        nxt = torch.zeros(B, dtype=torch.int64, device=dev)
-        z = z.to(dev, dtype=torch.float32).contiguous()
-        for l in range(n):
-            _call("ark_zproj_fwd", L.ptr(z), L.ptr(p["dec.z_proj.weight"]), L.ptr(p["dec.z_proj.bias"]), L.ptr(Y[l]),
-                  L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(D), st)
-        toks = torch.full((B, self.seq_len), 2, dtype=torch.int64, device=dev)
+        d = self.decode_begin(B, z)
+        toks = d["toks"]
+        toks.fill_(2)
         toks[:, 0] = 1
-        cur = torch.full((B, 1), 1, dtype=torch.int64, device=dev)
+        st = L.cur_stream()
+        ldl = d["logits"].shape[1]
         for t in range(Lmax):
-            _call("ark_tok_gather", L.ptr(cur), L.i64(1), L.ptr(p["dec.tok_emb.weight"]), L.ptr(None), L.ptr(x0),
-                  L.i32(B), L.i32(1), L.i32(D), st)
-            xin = x0
-            for l in range(n):
-                self._gemm(KM, KM, L.EPI_BIAS, xin, D, p[f"dec.gru.weight_ih_l{l}"], D, gi, 3 * D, B, 3 * D, D,
-                           bias=p[f"dec.gru.bias_ih_l{l}"])
-                a, b = Y[l][(t % 2) * B:], Y[l][((t + 1) % 2) * B:]
-                _call("ark_gru_cell_fwd", L.i32(self.prec), L.ptr(a), L.ptr(p[f"dec.gru.weight_hh_l{l}"]),
-                      L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(gi), L.ptr(b), L.ptr(None),
-                      L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), L.i32(B), L.i32(D), st)
-                xin = b
-            self._gemm(KM, KM, L.EPI_BIAS, xin, D, p["dec.out.weight"], D, logits, ldl, B, V, D, bias=p["dec.out.bias"])
-            _call("ark_argmax_rows", L.ptr(logits), L.i64(ldl), L.ptr(nxt), L.i32(B), L.i32(V), st)
-            toks[:, t + 1] = nxt
-            cur = nxt.clone().view(B, 1)
-            if bool((cur == 2).all()):
-                return toks[:, :t + 2]
-        return toks[:, :Lmax + 1]
+            self.decode_step(d, toks[:, t].contiguous() if t == 0 else d["nxt"], t)
+            _call("ark_argmax_rows", L.ptr(d["logits"]), L.i64(ldl), L.ptr(d["nxt"]), L.i32(B), L.i32(self.V), st)
+            toks[:, t + 1] = d["nxt"]
+        done = (toks[:, 1:Lmax + 1] == 2).all(dim=0)          # ONE synchronisation, after the last step
+        hit = torch.nonzero(done)
+        stop = int(hit[0]) + 1 if hit.numel() else Lmax
+        return toks[:, :stop + 1].clone()

@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Headline benchmark: SAIL (VAE) training graphs/sec on synthetic syn-paths-shaped batches.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over one minibatch: index tensors already resident in HBM ->
+One step = one pass of the hot path over one minibatch: index tensors (pinned host memory) -> H2D ->
 encoder -> reparameterise -> GRU decoder -> tied logits -> CE + beta*KL -> full backward ->
 (RCCL gradient all-reduce when N>1) -> fused Adam.  Weak scaling: 1024 graphs per GPU per step
 (BASELINE.json configs[1]: autoreg_syn-paths, model_type SAIL, batch 1024, D=512 Z=10 n=3).
@@ -14,6 +14,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,8 +23,6 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: require
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch
 
 # workload presets: the reference YAML of each dataset with model_type SAIL (BASELINE.json configs);
 # dataset shapes (entities, relations, edges) are the synthetic generator's parameters.
@@ -73,79 +73,107 @@ def flops_per_graph(cfg):
 
 def cpu_baseline(cfg, B, steps=6, warmup=2):
     """the CPU oracle (PyTorch-CPU restatement of the reference step, pinned to reference goldens)
-    timed on this box's host cores: fwd + loss + autograd bwd + Adam, fp32."""
+    timed on this box's host cores: fwd + loss + autograd bwd + Adam, fp32, with the same inter-layer GRU
+    dropout rate as the GPU leg (masks drawn inside the step, as nn.GRU(dropout=p) does)."""
+    import torch
     from oracle import sail_oracle as O
     torch.set_num_threads(host_threads())
     P = O.init_params(cfg, 0)
     state = O.adam_init(O.leaf_params(P))
     triples, seq = synth_global_batch(cfg, B, 1)
+    p = float(cfg.get("dec_dropout", 0.0))
+    n, Lq, D = cfg["n_layers"], cfg["seq_len"] - 1, cfg["d_model"]
     ts = []
     for s in range(warmup + steps):
         torch.manual_seed(1000 + s)
         eps = torch.randn(B, cfg["d_latent"])
         t0 = time.perf_counter()
-        O.train_step(P, state, (triples, seq), cfg, cfg["learning_rate"], beta=cfg["beta"], eps=eps)
+        masks = None
+        if p > 0:
+            masks = [torch.empty(B, Lq, D).bernoulli_(1 - p).div_(1 - p) for _ in range(n - 1)]
+        O.train_step(P, state, (triples, seq), cfg, cfg["learning_rate"], beta=cfg["beta"], eps=eps, drop_masks=masks)
         ts.append(time.perf_counter() - t0)
     dt = sum(ts[warmup:]) / steps
     return {"value": B / dt, "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} SAIL train steps of batch {B} (syn-paths, fp32, dec_dropout 0) after {warmup} warm-ups, "
+            "sample": f"{steps} SAIL train steps of batch {B} (syn-paths, fp32, dec_dropout {p}) after {warmup} warm-ups, "
                       f"{dt * 1e3:.1f} ms/step"}
 
 
-def time_dominant_kernel(eng, B, reps=8):
-    """average duration of the dominant kernel (the per-timestep forward GRU cell: recurrent MFMA
-    product + fused gate epilogue), measured live with HIP events on the launch stream.  The launches
-    replay the real forward's cell sequence (every layer and timestep, its own gi / state / save
-    buffers, so cache residency matches the train step) from one hipGraph, so the figure is GPU-bound."""
-    from ark_amd import _lib as L
+def time_diag_kernels(eng, B, reps=8):
+    """average launch duration of the two layer-diagonal GRU kernels (forward, BPTT), measured live with HIP
+    events on the launch stream.  Each sweep replays the real step's launch sequence (every anti-diagonal,
+    its own state / save / panel buffers, so cache residency matches the train step) from one hipGraph, so the
+    figures are GPU-bound and contain nothing but that kernel."""
+    import torch
     w = eng.ws
-    D, n, Lq = eng.D, eng.n, eng.L
-    p = eng.p
+    n, Lq = eng.n, eng.L
+    use_drop = eng.training and eng.p_drop > 0
     st = torch.cuda.Stream()
+    out = {}
 
-    def launch(l, t):
-        sl, nx = slice(t * B, (t + 1) * B), slice((t + 1) * B, (t + 2) * B)
-        if w["v2"]:
-            Yb = w["Y16b"][l]
-            L.check(L.lib().ark_gru_cell_fwd_dma(
-                L.i32(eng.prec_fwd), L.i32(eng.prec_bwd), L.ptr(w["Y16a"][l][sl]), L.ptr(eng.whh16[l]), L.ptr(w["Y"][l][sl]),
-                L.ptr(p[f"dec.gru.bias_hh_l{l}"]), L.ptr(w["GI"][l][sl]), L.ptr(w["Y"][l][nx]), L.ptr(w["Y16a"][l][nx]),
-                L.ptr(Yb[nx] if Yb is not None else None), L.ptr(None), L.ptr(None), L.f32(0.0), L.u64(0), L.i64(0), L.ptr(None),
-                L.ptr(w["SR"][l][sl]),
-                L.ptr(w["SZ"][l][sl]), L.ptr(w["SN"][l][sl]), L.ptr(w["SHN"][l][sl]), L.i32(B), L.i32(D), L.cur_stream()),
-                "ark_gru_cell_fwd_dma")
-        else:
-            L.check(L.lib().ark_gru_cell_fwd(
-                L.i32(eng.prec_fwd), L.ptr(w["Y"][l][sl]), L.ptr(p[f"dec.gru.weight_hh_l{l}"]), L.ptr(p[f"dec.gru.bias_hh_l{l}"]),
-                L.ptr(w["GI"][l][sl]), L.ptr(w["Y"][l][nx]), L.ptr(None), L.ptr(None), L.ptr(w["SR"][l][sl]), L.ptr(w["SZ"][l][sl]),
-                L.ptr(w["SN"][l][sl]), L.ptr(w["SHN"][l][sl]), L.i32(B), L.i32(D), L.cur_stream()), "ark_gru_cell_fwd")
+    def bwd_sweep():
+        # the dependent chain of the decoder backward only (bias gradients pile up in the gradient buffer: timing only)
+        eng._diag_bwd_sweep(w, B, Lq, use_drop)
 
-    diag = bool(w.get("diag"))
-    launches = (Lq + n - 1) if diag else n * Lq
-
-    def sweep():
-        if diag:   # the real forward recurrence: one launch per (layer, time) anti-diagonal
-            eng._diag_sweep(w, B, Lq, eng.training and eng.p_drop > 0, True)
-            return
-        for l in range(n):
-            for t in range(Lq):
-                launch(l, t)
-
+    sweeps = {"gru_diag_fwd_kernel": (lambda: eng._diag_sweep(w, B, Lq, use_drop, True), Lq + n - 1),
+              "gru_diag_bwd_kernel": (bwd_sweep, Lq + n - 1 + (1 if eng.mt == "SAIL" else 0))}
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
-        sweep()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            sweep()
-        g.replay()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+        for name, (fn, launches) in sweeps.items():
+            fn()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
             g.replay()
-        e1.record()
-        e1.synchronize()
-    return e0.elapsed_time(e1) / (reps * launches) * 1e-3, launches
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            e1.synchronize()
+            out[name] = (e0.elapsed_time(e1) / (reps * launches) * 1e-3, launches)
+    return out
+
+
+def diag_byte_models(eng, B):
+    """algorithmic bytes per launch of the two diagonal kernels, averaged over the launches of one step.
+    `min`: SURVEY 8d's per-cell minimum (x, h and the five saved D-vectors of a cell in 16 bits + the 16-bit
+    weights; backward: the saved vectors, the two incoming and the outgoing gate-gradient panels);
+    `impl`: what this implementation's layout moves (fp32 state, both 16-bit types, dropped copies)."""
+    D, n, Lq = eng.D, eng.n, eng.L
+    two = eng.prec_fwd != eng.prec_bwd
+    drop = eng.training and eng.p_drop > 0
+    cells = n * Lq
+    wbytes = 2 * 3 * D * D * 2            # W_ih + W_hh (or their transposes), 16-bit
+    f_min = cells * (B * D * 2 * 7 + wbytes)
+    f_impl = cells * (B * D * (2 + 2 + 4 + 4 + 2 + (2 if two else 0) + 8) + wbytes + 2 * 3 * D * 4)
+    if drop:
+        f_impl += (n - 1) * Lq * B * D * 2 * (2 if two else 1)
+    b_min = cells * (B * D * 2 * (5 + 3 + 3 + 4) + wbytes)
+    # per cell: panel of the layer above (3D, non-top) + own panel at t+1 (3D) + dy/carry/h_prev fp32 + 4 fp16 saves in;
+    # panel (4D) + carry out
+    b_impl = 0
+    for l in range(n):
+        up = 0 if l == n - 1 else 3 * D * 2
+        dy = 4 * D if l == n - 1 else 0
+        b_impl += Lq * (B * (up + 3 * D * 2 + dy + 4 * D + 4 * D + 8 * D + 4 * D * 2 + 4 * D) + wbytes)
+    fl = cells * 2.0 * B * D * 6 * D
+    return {"gru_diag_fwd_kernel": dict(min=f_min, impl=f_impl, flops=fl),
+            "gru_diag_bwd_kernel": dict(min=b_min, impl=b_impl, flops=fl)}
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) as children of this process --
+    which has not touched the GPU -- and relay their exit code; rank 0's JSON line goes to our stdout."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log("launching", " ".join(cmd))
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
 
 
 def main():
@@ -160,21 +188,25 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
-    ap.add_argument("--tuning", default="", help="speed-only kernel knobs, e.g. '1=32,2=1' (ark_set_tuning)")
+    ap.add_argument("--tuning", default="", help="speed-only kernel knobs of the exact-fp32 cells, e.g. '1=32,2=1' (ark_set_tuning)")
     ap.add_argument("--no-splitk", action="store_true")
-    ap.add_argument("--cfg", default="", help="extra engine config ints, e.g. ark_diag_cells=0,ark_overlap_wgrad=0")
+    ap.add_argument("--cfg", default="", help="extra engine config ints, e.g. ark_overlap_wgrad=0,ark_fork_after=0")
+    ap.add_argument("--diag", default="", help="diagonal-kernel tiles, e.g. fwd_rows=64,fwd_units=32,bwd_rows=32,bwd_ki=2")
     ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path even with one rank")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (the measured configuration); gloo = functional rehearsal, ranks may share a GPU")
-    ap.add_argument("--knobs", default="", help="speed-only knobs: ring=F:B,g16=NBUF:FORCE64,wg128=0|1")
+    ap.add_argument("--knobs", default="", help="speed-only knobs: g16=NBUF:TILE,wg128=0|1,wg16=TILE:NBUF:TARGET,sc=N,wgbal=0|1")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -197,26 +229,29 @@ def main():
         L.check(L.lib().ark_set_tuning(int(k), int(v)), "ark_set_tuning")
     if args.no_splitk:
         L.lib().ark_set_split_k(0)
-    for kv in filter(None, args.knobs.split(",")):   # e.g. ring=8:8,g16=2:0,wg128=1
+    for kv in filter(None, args.knobs.split(",")):   # e.g. g16=2:0,wg128=1
         k, v = kv.split("=")
         vals = [int(x) for x in v.split(":")]
-        fn = {"ring": L.lib().ark_set_dma_ring, "g16": L.lib().ark_set_gemm16_tuning, "wg128": L.lib().ark_set_wgrad_tile128, "wg16": L.lib().ark_set_wgrad16_tuning, "ki": L.lib().ark_set_dma_stage, "fbm": L.lib().ark_set_dma_fwd_rows, "sc": L.lib().ark_set_scatter_chunk, "bbn": L.lib().ark_set_dma_bwd_units, "diag": L.lib().ark_set_diag_tuning, "dbwd": L.lib().ark_set_diag_bwd_tuning, "wgbal": L.lib().ark_set_wgrad16_balance, "dbx": L.lib().ark_set_diag_bwd_xcd, "du": L.lib().ark_set_diag_units}[k]
+        fn = {"g16": L.lib().ark_set_gemm16_tuning, "wg128": L.lib().ark_set_wgrad_tile128, "wg16": L.lib().ark_set_wgrad16_tuning,
+              "sc": L.lib().ark_set_scatter_chunk, "wgbal": L.lib().ark_set_wgrad16_balance}[k]
         L.check(fn(*vals), k)
 
     cfg = build_cfg(args.dropout, args.workload)
-    for kv in filter(None, args.cfg.split(",")):   # engine options, e.g. ark_diag_bwd=0
+    for kv in filter(None, args.cfg.split(",")):   # engine options, e.g. ark_overlap_wgrad=0
         k, v = kv.split("=")
         cfg[k] = int(v)
+    if args.diag:
+        cfg["ark_diag_tuning"] = {k: int(v) for k, v in (kv.split("=") for kv in args.diag.split(","))}
     B = args.batch or cfg["batch"]
     Bg = B * world
-    eng = Engine(cfg, dev, precision=args.precision, world_size=world)
+    eng = Engine(cfg, dev, precision=args.precision, world_size=world, rank=rank)
     eng.load_params(initlib.init_state(cfg, seed=0))
     eng.set_hyper(lr=cfg["learning_rate"], beta=cfg["beta"])
     Lq = cfg["seq_len"] - 1
 
-    # synthetic data ring, resident in HBM before the timed region.  Each batch is ONE packed byte buffer
-    # [triples int64 | seq int64 | eps f32] and the step's fixed-address inputs are views of one such buffer,
-    # so refreshing the inputs of a captured step is a single device-to-device copy.
+    # synthetic data ring in PINNED HOST memory.  Each batch is ONE packed byte buffer [triples int64 | seq int64 |
+    # eps f32]; the step's fixed-address device inputs are views of one staging buffer, so the per-step host->device
+    # transfer (part of the metric) is a single asynchronous copy inside the timed region.
     NB = 8
     T = cfg["max_triples"]
     n_tri, n_seq, n_eps = B * T * 3 * 8, B * cfg["seq_len"] * 8, B * cfg["d_latent"] * 4
@@ -234,22 +269,23 @@ def main():
         torch.manual_seed(1000 + i)
         eps = torch.randn(Bg, cfg["d_latent"])
         sl = slice(rank * B, (rank + 1) * B)
-        buf = torch.empty(n_tri + n_seq + n_eps, dtype=torch.uint8, device=dev)
+        buf = torch.empty(n_tri + n_seq + n_eps, dtype=torch.uint8).pin_memory()
         a_, b_, c_ = views(buf)
         a_.copy_(tr[sl]); b_.copy_(sq[sl]); c_.copy_(eps[sl])
         ring.append(buf)
         ce_counts.append(float((sq[:, 1:] != 0).sum()))   # non-PAD targets of the GLOBAL batch
     ce_count = ce_counts[0]
-    stage = ring[0].clone()
+    stage = ring[0].to(dev)
     tri_in, seq_in, eps_in = views(stage)
+    h2d_bytes = n_tri + n_seq + n_eps
 
     use_dp = world > 1 or args.force_dist
 
     def feed(i):
         eng.set_hyper(ce_count=ce_counts[i % NB])   # device-side scalar; a no-op while the count is unchanged
-        stage.copy_(ring[i % NB], non_blocking=True)
+        stage.copy_(ring[i % NB], non_blocking=True)   # pinned host -> device, on the run stream
 
-    # everything (input refresh copies, graph replays, collectives) runs on ONE explicit stream:
+    # everything (input H2D copies, graph replays, collectives) runs on ONE explicit stream:
     # ordering between plain copies on the legacy null stream and hipGraphLaunch is not relied on
     run_stream = torch.cuda.Stream(device=dev)
     run_stream.wait_stream(torch.cuda.current_stream())
@@ -288,68 +324,63 @@ def main():
     if rank == 0:
         gps = Bg * args.steps / dt
         fl = flops_per_graph(cfg)
-        # dominant kernel: the per-timestep recurrent GRU cell (MFMA + fused gate epilogue)
-        kt, launches = time_dominant_kernel(eng, B)
-        log(f'kernel avg {kt*1e6:.2f} us; cpu baseline next')
-        D = cfg["d_model"]
-        n_l, Lq = eng.n, eng.L
         mfma_peak = 2500.0 if args.precision != "f32" else 157.3
-        kfl = 2.0 * B * D * 3 * D  # [B,D]x[D,3D] recurrent product per launch
+        roof = None
         if eng.ws["v2"]:
-            two = eng.prec_fwd != eng.prec_bwd
-            if eng.ws.get("diag"):
-                # one launch = the cells of one (layer, time) anti-diagonal.  Per cell and graph:
-                # read x and h (16-bit) + h (f32); write h (f32 + 16-bit fwd/bwd copies) + 4 fp16 gate saves
-                # (+ the two dropped 16-bit copies below the top layer); per cell: 16-bit W_ih, W_hh and both biases.
-                kname = "gru_diag_fwd_kernel"
-                cells = n_l * Lq
-                drop_cells = (n_l - 1) * Lq if (eng.training and eng.p_drop > 0) else 0
-                per_graph = 2 * D * 2 + D * 4 + D * 4 + D * 2 * (2 if two else 1) + 4 * D * 2
-                tot = cells * (B * per_graph + 2 * 3 * D * D * 2 + 2 * 3 * D * 4) + drop_cells * B * D * 2 * (2 if two else 1)
-                kbytes = tot / launches
-                kfl = cells * 2.0 * B * D * 6 * D / launches   # x W_ih^T and h W_hh^T per cell
-            else:
-                # per graph the forward cell reads gi (3D f32), h (D f32 + D 16-bit) and writes h (D f32 + 2 x D 16-bit)
-                # + 4 fp16 gate saves; per launch it also reads the 16-bit W_hh and b_hh.
-                kname = "gru_cell_fwd_dma_kernel"
-                per_graph = 3 * D * 4 + D * 4 + D * 2 + D * 4 + D * 2 * (2 if two else 1) + 4 * D * 2
-                kbytes = B * per_graph + 3 * D * D * 2 + 3 * D * 4
-            traffic = None
-            try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-                traffic = [v["hbm_bytes_corrected"] for k, v in pm.items() if kname in k][0]
+            times = time_diag_kernels(eng, B)
+            models = diag_byte_models(eng, B)
+            traffic = {}
+            try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE x2 + WRITE_SIZE)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+                for k, v in pm.items():
+                    for name in times:
+                        if name in k:
+                            traffic[name] = v["hbm_bytes_corrected"]
             except Exception:
                 pass
-            # both editions sit below the chip's ~310 FLOP/B balance point, so the HBM roofline bounds them
-            roof = {"bound": "hbm", "kernel": kname, "achieved": kbytes / kt / 1e9, "peak": 8000.0,
-                    "unit": "GB/s", "frac": kbytes / kt / 1e9 / 8000.0, "traffic": traffic, "kernel_avg_us": kt * 1e6,
-                    "launches_per_step": launches, "bytes_per_launch": kbytes, "flops_per_launch": kfl,
-                    "mfma": {"achieved": kfl / kt / 1e12, "peak": mfma_peak, "unit": "TFLOP/s", "frac": kfl / kt / 1e12 / mfma_peak}}
-        else:
-            roof = {"bound": "mfma", "kernel": "gru_cell_fwd_kernel", "achieved": kfl / kt / 1e12, "peak": mfma_peak,
-                    "unit": "TFLOP/s", "frac": kfl / kt / 1e12 / mfma_peak, "traffic": None, "kernel_avg_us": kt * 1e6,
-                    "flops_per_launch": kfl}
+            kern = {}
+            for name, (kt, launches) in times.items():
+                m = models[name]
+                kern[name] = {"kernel_avg_us": kt * 1e6, "launches_per_step": launches, "us_per_step": kt * 1e6 * launches,
+                              "bytes_per_launch": m["impl"] / launches, "bytes_per_launch_min_8d": m["min"] / launches,
+                              "achieved": m["impl"] / launches / kt / 1e9, "frac": m["impl"] / launches / kt / 1e9 / 8000.0,
+                              "frac_min_8d": m["min"] / launches / kt / 1e9 / 8000.0, "traffic": traffic.get(name),
+                              "flops_per_launch": m["flops"] / launches,
+                              "mfma_frac": m["flops"] / launches / kt / 1e12 / mfma_peak}
+                log(f'{name}: {kt * 1e6:.2f} us/launch x {launches}')
+            dom = max(kern, key=lambda k: kern[k]["us_per_step"])   # dominant = most time per step
+            d = kern[dom]
+            # both kernels sit below the chip's ~310 FLOP/B balance point, so the HBM roofline bounds them
+            roof = {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": d["frac"],
+                    "traffic": d["traffic"], "traffic_source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc passes of this command)",
+                    "kernel_avg_us": d["kernel_avg_us"], "launches_per_step": d["launches_per_step"],
+                    "bytes_per_launch": d["bytes_per_launch"], "bytes_per_launch_min_8d": d["bytes_per_launch_min_8d"],
+                    "frac_min_8d": d["frac_min_8d"],
+                    "mfma": {"achieved": d["flops_per_launch"] / (d["kernel_avg_us"] * 1e-6) / 1e12, "peak": mfma_peak,
+                             "unit": "TFLOP/s", "frac": d["mfma_frac"]},
+                    "kernels": kern}
         res = {
             "metric": "training graphs/sec", "value": gps, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"mixed": "f16 fwd / bf16 bwd MFMA, f32 accumulate+state", "bf16": "bf16", "f16": "f16",
-                      "f32": "f32"}[args.precision],
+            "dtype": {"mixed": "f16 fwd / bf16 bwd MFMA operands (BASELINE configs[1] says bf16: bf16 forward operands miss the 1e-4 "
+                               "ELBO bar, fp16 has the same width and MFMA rate), f32 accumulate+state",
+                      "bf16": "bf16", "f16": "f16", "f32": "f32"}[args.precision],
             "data": f"synthetic (IntelliGraphs {args.workload}-shaped, uniform ids; random-init weights)",
-            "config": {"workload": f"autoreg_{args.workload} SAIL train step (fwd+ELBO+bwd+Adam)", "batch_per_gpu": B,
+            "config": {"workload": f"autoreg_{args.workload} SAIL train step (H2D+fwd+ELBO+bwd+Adam)", "batch_per_gpu": B,
                        "global_batch": Bg, "d_model": cfg["d_model"], "d_latent": cfg["d_latent"], "n_layers": 3, "seq_len": cfg["seq_len"],
                        "vocab": cfg["vocab_size"], "dec_dropout": args.dropout, "hipgraph": not args.no_graph,
-                       "parallelism": f"dp{world}"},
+                       "h2d_bytes_per_step": h2d_bytes, "parallelism": f"dp{world}"},
             "final_loss": loss[0],
             "model_tflops": gps * fl / 1e12,
             "model_mfma_frac": gps * fl / 1e12 / mfma_peak,
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(dict(cfg, dec_dropout=0.0), B, steps=args.cpu_steps)
-        print(json.dumps(res))
+            res["cpu_baseline"] = cpu_baseline(cfg, B, steps=args.cpu_steps)
+        print(json.dumps(res), flush=True)
     if dist is not None:
-        dist.barrier()   # leave together: rank 0 is still timing its dominant kernel while the others are done
+        dist.barrier()   # leave together: rank 0 is still timing its kernels while the others are done
         dist.destroy_process_group()
 
 

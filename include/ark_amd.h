@@ -30,7 +30,6 @@ extern "C" {
 #define ARK_EPI_BIAS_GELU 2 /* C = acc + bias (pre-act), C2 = gelu_erf(C) */
 #define ARK_EPI_MUL_DGELU 3 /* C = acc * gelu_erf'(aux[row,col])         */
 #define ARK_EPI_MUL_AUX 4   /* C = acc * aux[row,col]                    */
-#define ARK_EPI_DROPOUT 5   /* C = acc * counter-hash dropout scale (ark_gemm16_dropout only) */
 
 int ark_version(void);
 
@@ -61,6 +60,10 @@ int ark_set_tuning(int key, int value);
 #define ARK_HP_ADAM_B2 9
 #define ARK_HP_ADAM_EPS 10
 #define ARK_HP_GRAD_SCALE 11   /* multiplies every gradient inside Adam (1 for summed DP gradients)    */
+#define ARK_HP_DROP_STEP 12    /* uint32 (bit pattern in the float slot): dropout draw counter, bumped by
+                                  ark_tok_gather / ark_tok_gather16 once per TRAINING forward; the GRU cells hash
+                                  (seed, this counter, element index) -> forward and backward of one step agree,
+                                  consecutive forwards differ (reference: nn.GRU(dropout=p), models.py:121-127)  */
 #define ARK_HP_COUNT 16
 
 #define ARK_TOK_PAD 0 /* special_tokens["PAD"], the ignore_index of the reference's cross-entropy */
@@ -86,22 +89,11 @@ int ark_gru_h0_bwd(int prec, const float* dgh0, const float* w_hh, const float* 
  * Layout contract: "16" buffers are row-major 16-bit copies in the named precision's type;
  * "_t" buffers are fp32 (saves: fp16) in the 16x16 MFMA-tile-native order
  *   off(row,col,ld) = ((row>>4)*(ld>>4) + (col>>4))*256 + (((row>>2)&3)*16 + (col&15))*4 + (row&3). */
-int ark_gru_cell_fwd_dma(int prec, int prec_b, const void* h_prev16, const void* w_hh16, const float* y_prev_t,
-                         const float* b_hh, const float* gi_t, float* y_out_t, void* y16a, void* y16b, void* yd16a,
-                         void* yd16b, float drop_p /* 0: none */, uint64_t drop_seed, int64_t drop_base /* element index of
-                         this timestep in the layer's [B*L, D] space */, const float* hyper, void* save_r, void* save_z,
-                         void* save_n, void* save_hn, int B, int D, void* stream);
-int ark_gru_cell_bwd_dma(int prec, const void* dgh_next16, const void* w_hhT16, const float* dy_t, float* carry_t,
-                         const void* save_r, const void* save_z, const void* save_n, const void* save_hn,
-                         const float* y_prev_t, void* dgi16, void* dgh16, float* db_ih /* += colsum(dgi), nullable */,
-                         float* db_hh /* += colsum(dgh) */, int B, int D, int first, void* stream);
-int ark_gru_h0_bwd_dma(int prec, const void* dgh0_16, const void* w_hhT16, const float* carry_t, float* dh0,
-                       int accumulate, int B, int D, void* stream);
 /* Layer-diagonal forward step: up to ARK_DIAG_MAX_ROLES independent GRU cells -- cell (layer l, step
  * d-l) for every layer of one anti-diagonal d of the (layer, time) grid -- in ONE launch.  Each role
  * computes its input projection itself (x W_ih^T + b_ih; no gi buffer, no per-layer input GEMM), so
  * a stacked GRU of n layers over L steps is L+n-1 dependent launches instead of n*L + n.
- * Same math and outputs as ark_gru_cell_fwd_dma (reference: nn.GRU, kgvae/model/models.py:121-127). */
+ * Same math as ark_gru_cell_fwd on 16-bit operands (reference: nn.GRU, kgvae/model/models.py:121-127). */
 #define ARK_DIAG_MAX_ROLES 4
 typedef struct {
   const void* x16;       /* [B,D] row-major, forward type: this step's layer input                   */
@@ -125,17 +117,35 @@ typedef struct {
   float drop_p;
   int pad_;
 } ArkGruDiagRole;
+/* speed-only tile / ring choices of the two diagonal kernels; passed per call (NULL = the measured defaults of
+ * ark_diag_tuning_default), so the library keeps no mutable state */
+typedef struct {
+  int fwd_rows;      /* 32 | 64 | 128 (128: 64-unit tiles only)                                 */
+  int fwd_ki;        /* 64-wide k-images per ring stage: 1 | 2                                  */
+  int fwd_nbuf;      /* ring slots: 2 | 4                                                       */
+  int fwd_xcd;       /* XCD-aware tile order: 0 | 1                                             */
+  int fwd_units;     /* hidden units per forward workgroup: 32 (4 waves) | 64 (8 waves)         */
+  int bwd_rows;      /* 32 | 64                                                                 */
+  int bwd_ki;        /* 1 | 2                                                                   */
+  int bwd_nbuf;      /* 2 | 4                                                                   */
+  int bwd_xcd_rows;  /* row-tile classes per XCD octet: 1 (plain order) | 2 | 4 | 8             */
+} ArkDiagTuning;
+void ark_diag_tuning_default(ArkDiagTuning* t);
 int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruDiagRole* roles, const float* hyper, int B, int D,
-                     void* stream);
+                     const ArkDiagTuning* tuning, void* stream);
 /* Layer-diagonal BPTT step: cells (layer l, step t) of one anti-diagonal of the backward order in ONE
  * launch.  A role forms dh_t = carry + dgh_{t+1} W_hh (its own layer) + dy_t, where dy_t is given
  * (top layer: gradient of the vocabulary projection) or computed in place as
  * dropout_mask(l,t) * (dgi_t of the layer above) W_ih(above) -- so the per-layer input-gradient GEMM
- * disappears.  Outputs as ark_gru_cell_bwd_dma; `carry_t` is per layer here. */
+ * disappears.  Gate gradients go out as ONE row-major 16-bit panel per (layer, step):
+ *   dg16[b, 0:4D] = [ dr | dz | dn | dn*r ]    (ld = 4D)
+ * dgi = columns [0,3D) (weight gradient of W_ih, input gradient of the layer below), dgh = columns
+ * [0,2D) + [3D,4D) (weight gradient of W_hh, recurrence): the two [B,3D] panels of round 1 shared two thirds.
+ * `carry_t` is per layer.  Reference: autograd of nn.GRU, kgvae/model/models.py:121-127. */
 typedef struct {
-  const void* dgi_up16;    /* [B,3D] backward type: gate-input gradients of layer l+1 at step t (NULL: top layer) */
+  const void* dgi_up16;    /* [B, ld 4D] backward type: gate-gradient panel of layer l+1 at step t (NULL: top layer) */
   const void* w_ihT_up16;  /* [D,3D] W_ih^T shadow of layer l+1 (NULL: top layer)                             */
-  const void* dgh_next16;  /* [B,3D] this layer's dgh at step t+1 (ignored when first != 0)                   */
+  const void* dg_next16;   /* [B, ld 4D] this layer's panel at step t+1 (ignored when first != 0)             */
   const void* w_hhT16;     /* [D,3D] W_hh^T shadow                                                            */
   const float* dy_t;       /* tile-native fp32 [B,D], top layer only (NULL otherwise)                         */
   float* carry_t;          /* tile-native fp32 [B,D], this layer's dh_t * z_t carry (in/out)                  */
@@ -144,28 +154,19 @@ typedef struct {
   const void* save_n;
   const void* save_hn;
   const float* y_prev_t;   /* tile-native fp32 h_{t-1}                                                        */
-  void* dgi16;             /* row-major [B,3D] outputs, backward type                                         */
-  void* dgh16;
-  float* db_ih;            /* [3D] += column sums (nullable together)                                         */
-  float* db_hh;
+  void* dg16;              /* row-major [B, ld 4D] output panel, backward type                                */
+  float* db_ih;            /* [3D] += column sums of [dr|dz|dn] (nullable together)                           */
+  float* db_hh;            /* [3D] += column sums of [dr|dz|dn*r]                                             */
   float* dh0;              /* non-NULL: "initial state" role -- only dh0[B,D] (row-major, pre-zeroed) +=      */
-                           /* carry + dgh_next W_hh (dgh_next = the layer's step-0 panel); saves etc. unused  */
+                           /* carry + dgh_next W_hh (dg_next16 = the layer's step-0 panel); saves etc. unused */
   uint64_t drop_seed;      /* dropout of THIS layer's output (applied to the gradient arriving from above)    */
-  int64_t drop_base;
+  int64_t drop_base;       /* element index of this timestep in the layer's [B*L, D] space (% 4 == 0)         */
   float drop_p;
   int first;               /* last timestep: no successor                                                     */
 } ArkGruDiagBwdRole;
-int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* roles, const float* hyper, int B, int D, void* stream);
-int ark_set_diag_bwd_tuning(int rows /* 32 | 64 */, int ki /* 1 | 2 */, int nbuf /* 2 | 4 */);
-int ark_set_diag_bwd_xcd(int row_classes /* 1 (plain order) | 2 | 4 | 8: row-tile classes per XCD octet */);
-int ark_set_diag_tuning(int rows /* 32 | 64 | 128 (64-unit tiles only) */, int ki /* 1 | 2 */, int nbuf /* 2 | 4 */, int xcd_map /* 0 | 1 */);
-int ark_set_diag_units(int units /* hidden units per forward workgroup: 32 (4 waves) | 64 (8 waves) */);
-int ark_set_dma_ring(int fwd_nbuf, int bwd_nbuf);
-int ark_set_dma_stage(int fwd_ki, int bwd_ki);
-int ark_set_dma_fwd_rows(int bm);
-int ark_set_dma_bwd_units(int bn);
+int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* roles, const float* hyper, int B, int D,
+                     const ArkDiagTuning* tuning, void* stream);
 int ark_set_scatter_chunk(int items_per_workgroup);
-int ark_set_dma_debug(int mask); /* timing ablations only: results are invalid while mask != 0 */
 int ark_set_gemm16_tuning(int nbuf, int tile);
 int ark_set_wgrad_tile128(int enabled);
 /* up to 12 jobs in one launch: dst[i] = cast(src[i] [R,C]) in prec[i]; dstT[i] = cast(src[i]^T) in precT[i],
@@ -175,9 +176,6 @@ int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, vo
 /* C[M,N] = A16[M,K] B16[N,K]^T (+bias | *aux), C row-major or tile-native (c_tiled) */
 int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* stream);
-/* tile-native C = (A16 B16^T) * dropout scale regenerated from (seed, optimiser step, element index) */
-int ark_gemm16_dropout(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc, int M,
-                       int N, int K, float drop_p, uint64_t drop_seed, const float* hyper, void* stream);
 /* ark_gemm16 with row-major 16-bit copies of the result (c16a in `prec`, c16b nullable in `prec_b`);
  * BIAS_GELU: C = pre-activation, copies = gelu(C); MUL_DGELU: C = acc * gelu'(aux), copies = C */
 int ark_gemm16_ex(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
@@ -193,13 +191,15 @@ int ark_wgrad16(int prec, const void* A16, int64_t lda, const void* B16, int64_t
 /* ark_wgrad16 for an A operand column-padded to a tile multiple (M) while C has only m_valid rows */
 int ark_wgrad16_rows(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc, int M,
                      int m_valid, int N, int K, void* stream);
+#define ARK_WGRAD_MAX_GROUP 12
 int ark_wgrad16_group(int prec, int n, const void* const* A16, const int64_t* lda, const void* const* B16,
                       const int64_t* ldb, float* const* C, const int64_t* ldc, const int* M, const int* N, const int* K,
                       void* stream);
 int ark_set_wgrad16_tuning(int tile, int nbuf, int target_wgs);
 int ark_set_wgrad16_balance(int enabled);   /* whole tiles on every CU + k-slices of the remainder (default on) */
+/* hyper_tick (nullable): training forward -> ++hyper[ARK_HP_DROP_STEP] (fresh dropout masks for this step) */
 int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,
-                     const float* w_pos, void* x16a, void* x16b, int B, int L, int D, void* stream);
+                     const float* w_pos, void* x16a, void* x16b, int B, int L, int D, float* hyper_tick, void* stream);
 /* h0 = tanh(z_proj(z)) for all layers in every layout of the LDS-DMA path, one launch */
 int ark_zproj_fwd_v2(int prec_a, int prec_b, const float* z, const float* w_z, const float* b_z, float* h0, int n_layers,
                      float* const* y_t, void* const* y16a, void* const* y16b, int B, int Z, int D, void* stream);
@@ -221,7 +221,7 @@ int ark_enc_pool_fwd16(const int64_t* triples, const float* E, const float* R, f
 int ark_enc_pool_bwd(const int64_t* triples, const float* dg, const float* inv_cnt, float* dE, float* dR, int B,
                      int T, int D, int n_ent, int n_rel, int64_t pad_eid, int64_t pad_rid, void* stream);
 int ark_tok_gather(const int64_t* seq, int64_t ld_seq, const float* w_tok, const float* w_pos /* nullable */,
-                   float* x, int B, int L, int D, void* stream);
+                   float* x, int B, int L, int D, float* hyper_tick /* nullable, as ark_tok_gather16 */, void* stream);
 int ark_tok_scatter(const int64_t* seq, int64_t ld_seq, const float* dx, float* d_w_tok, int B, int L, int D,
                     int vocab, void* stream);
 
@@ -259,9 +259,17 @@ int ark_argmax_rows(const float* x, int64_t ld, int64_t* out, int rows, int V, v
 /* ---- optimiser and reductions (reference: optim.Adam, ablation_study.py:571,76) ---------------- */
 int ark_adam_tick(float* hyper, void* stream);
 int ark_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, void* stream);
+/* ark_adam_step over a job list, with the 16-bit weight shadows (ark_weight_shadows) of every matrix job written
+ * from the updated values in the same pass: job i is a linear range [off, off + C) of the flat buffers (R == 0)
+ * or a matrix [R, C] at `off` with optional plain (dst, prec) / transposed (dstT [C, ldT], precT) shadows. */
+#define ARK_ADAM_MAX_JOBS 48
+int ark_adam_step_shadows(float* p, const float* g, float* m, float* v, int n_jobs, const int64_t* off, const int* R,
+                          const int* C, void* const* dst, void* const* dstT, const int* prec, const int* precT,
+                          const int* ldT, const float* hyper, void* stream);
 /* accumulate != 0: add into `out` (caller zeroed it, e.g. the whole gradient buffer at once) */
 int ark_colsum(const float* x, int64_t ld, int64_t batch_stride_in, float* out, int64_t batch_stride_out, int M,
                int N, int n_batch, int accumulate, void* stream);
+/* mask[i] = keep-scale of element i for the current dropout draw (hyper[ARK_HP_DROP_STEP]); n % 4 == 0 */
 int ark_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, const float* hyper, void* stream);
 int ark_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
 

@@ -11,13 +11,17 @@ Differences that are deliberate:
     data falls back to synthetic IntelliGraphs-shaped graphs, semantic verification is skipped;
   * whole splits are tokenised once per epoch (GraphSeqDataset.tensorize) instead of per item;
   * launched under torchrun it trains data-parallel (one process per GPU, RCCL all-reduce);
+  * `resume_from_checkpoint: true` + `checkpoint_path` (keys the reference's YAMLs carry but never read,
+    configs/autoreg_syn-paths.yaml:35-36) continue a run from a checkpoint this module wrote;
   * extra optional keys: precision (mixed|bf16|f16|f32), synthetic_sizes, max_steps_per_epoch,
-    permute_rng (python|numpy), seed.
+    permute_rng (python|numpy), seed (data-parallel runs are always seeded: every rank must build the same model
+    and draw the same epoch order).
 """
 import argparse
 import json
 import math
 import os
+import random
 import time
 import uuid
 import warnings
@@ -87,7 +91,7 @@ def iterate_batches(tri, seq, batch_size, shuffle, drop_last, generator=None):
         yield (tri[idx] if tri is not None else None), seq[idx]
 
 
-def epoch_batches(tri, seq, batch_size, shuffle, pad, rank=0, nranks=1):
+def epoch_batches(tri, seq, batch_size, shuffle, pad, rank=0, nranks=1, generator=None):
     """Host side of one epoch: (optionally shuffled) full batches only (drop_last), stacked as
     [n_batches, B_local, ...] with this rank's contiguous row shard of every global batch, plus the
     GLOBAL target-token count of every batch (CE is a mean over the global batch's non-PAD targets;
@@ -95,7 +99,7 @@ def epoch_batches(tri, seq, batch_size, shuffle, pad, rank=0, nranks=1):
     B = batch_size
     nb = seq.shape[0] // B
     if shuffle:
-        order = torch.randperm(seq.shape[0])
+        order = torch.randperm(seq.shape[0], generator=generator)   # data parallel: the SAME generator state on every rank
         seq = seq[order]
         tri = tri[order] if tri is not None else None
     seq = seq[:nb * B].view(nb, B, -1)
@@ -109,7 +113,7 @@ def epoch_batches(tri, seq, batch_size, shuffle, pad, rank=0, nranks=1):
     return tri, seq, counts
 
 
-def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), max_steps=None):
+def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), max_steps=None, epoch_seed=None):
     """one pass over the training split; returns epoch means of (loss, recon, kl, 0) over batches,
     as the reference's train_epoch does (ablation_study.py:31-88).
 
@@ -117,9 +121,17 @@ def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), ma
     (`use_hip_graph: false` in the config falls back to eager launches), so the host only slices."""
     model.train()
     rank, nranks = world
+    gen = None
+    if epoch_seed is not None:
+        # every rank draws the same per-graph permutations and the same epoch order, then takes its row shard
+        random.seed(epoch_seed)
+        gen = torch.Generator().manual_seed(epoch_seed)
+        if getattr(dataset, "fast_rng", None) is not None:
+            import numpy as np
+            dataset.fast_rng = np.random.default_rng(epoch_seed)
     tri, seq = dataset.tensorize()   # redraws the per-graph permutations, like a fresh DataLoader pass
     tri, seq, counts = epoch_batches(tri, seq, config["batch_size"], config["shuffle_train"],
-                                     config["special_tokens"]["PAD"], rank, nranks)
+                                     config["special_tokens"]["PAD"], rank, nranks, generator=gen)
     nb_all = seq.shape[0]
     seq = seq.contiguous().to(device, non_blocking=True)
     tri = tri.contiguous().to(device, non_blocking=True) if tri is not None else None
@@ -149,39 +161,103 @@ def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), ma
 
 
 @torch.no_grad()
-def validate(model, dataset, config, device, compute_compression=False, b=1.0, special_tokens=None):
+def validate(model, dataset, config, device, compute_compression=False, b=1.0, special_tokens=None, world=(0, 1)):
     """mean loss / recon / kl over validation batches (+ compression bits when asked),
-    reference train.py:74-129 / ablation_study.py:92-187"""
+    reference train.py:74-129 / ablation_study.py:92-187.  Data parallel: rank k evaluates batches k, k+N, ...
+    and the sums are all-reduced, so every rank sees the same numbers and nobody idles; the compression bits
+    (a `sample_frac` pass) stay on rank 0."""
     model.eval()
+    rank, nranks = world
     tri, seq = dataset.tensorize()
-    tot = torch.zeros(4, device=device)
-    nb = 0
-    for tb, sb in iterate_batches(tri, seq, config["batch_size"], False, False):
-        tot += model.eval_loss(tb.to(device), sb.to(device), beta=b)
-        nb += 1
-    t = (tot / max(nb, 1)).tolist()
+    tot = torch.zeros(5, device=device)
+    for i, (tb, sb) in enumerate(iterate_batches(tri, seq, config["batch_size"], False, False)):
+        if i % nranks != rank:
+            continue
+        tot[:4] += model.eval_loss(tb.to(device), sb.to(device), beta=b)
+        tot[4] += 1
+    if nranks > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tot)
+    t = (tot[:4] / tot[4].clamp(min=1)).tolist()
     res = [t[0], t[1], t[2], 0.0]
-    if compute_compression:
+    if compute_compression and rank == 0:
         bits = model.posterior_bits(dataset, device, pad_id=config["special_tokens"]["PAD"],
                                     sample_frac=config.get("sample_frac", 0.1))
         res += [bits["avg_total_bits"], bits["avg_kl_bits"], bits["avg_ar_bits"], 0.0]
     return tuple(res)
 
 
-def save_checkpoint(path, epoch, model, config, val_loss, vocabs, dataset_meta, lr):
-    """same dict layout and legacy serialisation as the reference (train.py:566-591)"""
+def scheduler_state(base_lr, t_max, eta_min, last_epoch):
+    """state_dict() of the reference's CosineAnnealingLR(T_max=num_epochs, eta_min) after `last_epoch` epoch-end steps
+    (reference train.py:452-457, 561-563)"""
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=base_lr)
+    sd = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=t_max, eta_min=eta_min).state_dict()
+    sd.update(last_epoch=last_epoch, _step_count=last_epoch + 1, _last_lr=[cosine_lr(base_lr, last_epoch, t_max, eta_min)])
+    return sd
+
+
+def optimizer_state(model, lr, initial_lr=None):
+    """torch.optim.Adam(model.parameters(), lr).state_dict() with the engine's moments (loadable by load_state_dict)"""
+    eng = model.engine()
+    eng.dp_flush()
+    names = [k for k, _ in model.named_parameters()]
+    group = dict(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=lr).state_dict()["param_groups"][0])
+    group.update(lr=lr, params=list(range(len(names))))
+    if initial_lr is not None:
+        group["initial_lr"] = initial_lr   # the key CosineAnnealingLR adds to the groups of its optimizer
+    state = {}
+    if eng.adam_steps > 0:
+        for i, k in enumerate(names):
+            o, sh, n = eng.layout.entries[k]
+            state[i] = {"step": torch.tensor(float(eng.adam_steps)), "exp_avg": eng.M[o:o + n].view(sh).detach().cpu().clone(),
+                        "exp_avg_sq": eng.Vv[o:o + n].view(sh).detach().cpu().clone()}
+    return {"state": state, "param_groups": [group]}
+
+
+def save_checkpoint(path, epoch, model, config, val_loss, vocabs, dataset_meta, base_lr, use_sched, best_val_loss=None):
+    """Same dict layout and legacy serialisation as the reference (train.py:566-618), written at the same point of the
+    epoch: AFTER scheduler.step(), so `epoch` = finished epochs, the scheduler's last_epoch = epoch and the optimizer's
+    lr is the NEXT epoch's.  `ark_amd` is an extra key (resume state the reference has no place for)."""
+    eng = model.engine()
+    t_max, eta_min = config["num_epochs"], config.get("eta_min", 1e-6)
+    lr_next = cosine_lr(base_lr, epoch, t_max, eta_min) if use_sched else base_lr
+    ckpt = {"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+            "optimizer_state_dict": optimizer_state(model, lr_next, base_lr if use_sched else None),
+            "scheduler_state_dict": scheduler_state(base_lr, t_max, eta_min, epoch) if use_sched else None,
+            "val_loss": val_loss, "config": {k: v for k, v in config.items()}, "vocabs": vocabs, "dataset_meta": dataset_meta,
+            "ark_amd": {"adam_steps": eng.adam_steps, "dropout_draws": eng.dropout_draws(), "best_val_loss": best_val_loss,
+                        "cuda_rng_state": torch.cuda.get_rng_state(eng.device), "cpu_rng_state": torch.get_rng_state(),
+                        "python_rng_state": random.getstate()}}
+    torch.save(ckpt, path, _use_new_zipfile_serialization=False)
+
+
+def load_checkpoint(path, model, device):
+    """resume_from_checkpoint: weights, Adam moments and step, dropout draw counter, RNG streams.  Returns
+    (finished epochs, best validation loss so far).  The file is one this module wrote; it is read with the
+    restricted unpickler (tensors and plain containers only)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    model.load_state_dict(ckpt["model_state_dict"])
     eng = model.engine()
     names = [k for k, _ in model.named_parameters()]
-    opt_state = {"state": {i: {"step": torch.tensor(float(eng.adam_steps)),
-                               "exp_avg": eng.M[o:o + n].view(sh).clone(),
-                               "exp_avg_sq": eng.Vv[o:o + n].view(sh).clone()}
-                           for i, (o, sh, n) in enumerate(eng.layout.entries[k] for k in names)},
-                 "param_groups": [{"lr": lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
-                                   "params": list(range(len(names)))}]}
-    ckpt = {"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-            "optimizer_state_dict": opt_state, "scheduler_state_dict": {"last_epoch": epoch, "_last_lr": [lr]},
-            "val_loss": val_loss, "config": {k: v for k, v in config.items()}, "vocabs": vocabs, "dataset_meta": dataset_meta}
-    torch.save(ckpt, path, _use_new_zipfile_serialization=False)
+    st = ckpt["optimizer_state_dict"]["state"]
+    eng.reset_optimizer()
+    step = 0
+    for i, k in enumerate(names):
+        if i in st:
+            o, sh, n = eng.layout.entries[k]
+            eng.M[o:o + n].copy_(st[i]["exp_avg"].reshape(-1))
+            eng.Vv[o:o + n].copy_(st[i]["exp_avg_sq"].reshape(-1))
+            step = int(st[i]["step"])
+    extra = ckpt.get("ark_amd") or {}
+    eng.set_optimizer_step(int(extra.get("adam_steps", step)))
+    eng.set_dropout_draws(int(extra.get("dropout_draws", 0)))
+    if extra.get("cuda_rng_state") is not None:
+        torch.cuda.set_rng_state(extra["cuda_rng_state"], device)
+        torch.set_rng_state(extra["cpu_rng_state"])
+        ps = extra["python_rng_state"]
+        random.setstate((ps[0], tuple(ps[1]), ps[2]))
+    best = extra.get("best_val_loss")
+    return int(ckpt["epoch"]), (float("inf") if best is None else float(best))
 
 
 def main(argv=None):
@@ -197,6 +273,12 @@ def main(argv=None):
     rank, local_rank, nranks = dp.init()
     main_rank = rank == 0
     model_type = config.get("model_type", "ARK")
+    seeded = nranks > 1 or "seed" in config
+    seed = int(config.get("seed", 0))
+    if seeded:   # data parallel: identical initial weights and data order on every rank
+        random.seed(seed)
+        # (`seed_per_rank`: test switch -- ranks build DIFFERENT models, which the broadcast below must repair)
+        torch.manual_seed(seed + (rank if config.get("seed_per_rank", False) else 0))
 
     tracker = _Tracker(args.wandb_project, args.wandb_entity or os.getenv("WANDB_ENTITY"), config,
                        config.get("experiment_name", "ARK_experiment"), args.checkpoint_dir, enabled=main_rank)
@@ -267,7 +349,12 @@ def main(argv=None):
     if main_rank:
         print(f"Using model: {model_type}")
     eng = model.engine()
-    eng.world_size = nranks
+    eng.world_size, eng.rank = nranks, rank
+    if nranks > 1:
+        # the replicas must START equal (as DistributedDataParallel does): rank 0's weights win
+        import torch.distributed as dist
+        dist.broadcast(eng.P, src=0)
+        eng.mark_params_dirty()
 
     base_lr = config["learning_rate"]
     use_sched = bool(config.get("lr_scheduler", False))
@@ -276,8 +363,13 @@ def main(argv=None):
     vocabs = {"e2i": e2i, "i2e": i2e, "r2i": r2i, "i2r": i2r}
     dataset_meta = {"dataset": dataset_name, "n_entities": len(i2e), "n_relations": len(i2r)}
     best_val_loss = float("inf")
+    start_epoch = 0
+    if config.get("resume_from_checkpoint", False):
+        start_epoch, best_val_loss = load_checkpoint(config["checkpoint_path"], model, device)
+        if main_rank:
+            print(f"Resumed from {config['checkpoint_path']} at epoch {start_epoch}")
 
-    for epoch in range(num_epochs):
+    for epoch in range(start_epoch, num_epochs):
         if main_rank:
             print(f"\nEpoch {epoch + 1}/{num_epochs}")
         b = 1
@@ -286,12 +378,14 @@ def main(argv=None):
         lr = cosine_lr(base_lr, epoch, num_epochs, eta_min) if use_sched else base_lr
         t0 = time.time()
         train_loss, train_recon, train_kl, _ = train_epoch(model, train_ds, config, device, b, lr, (rank, nranks),
-                                                           config.get("max_steps_per_epoch"))
+                                                           config.get("max_steps_per_epoch"),
+                                                           epoch_seed=(seed * 1000003 + epoch) if nranks > 1 else None)
         dt = time.time() - t0
         do_comp = ((epoch + 1) % int(config.get("compression_log_every", 5)) == 0)
+        val = validate(model, val_ds, config, device, compute_compression=do_comp, b=b, special_tokens=special_tokens,
+                       world=(rank, nranks))
         if not main_rank:
             continue
-        val = validate(model, val_ds, config, device, compute_compression=do_comp, b=b, special_tokens=special_tokens)
         val_loss, val_recon, val_kl = val[:3]
         if do_comp and len(val) == 8:
             tracker.log({"val/compression_bits": val[4], "val/compression_kl_bits": val[5],
@@ -331,11 +425,11 @@ def main(argv=None):
         if val_loss < best_val_loss:
             best_val_loss = val_loss
             save_checkpoint(os.path.join(run_dir, f"{dataset_name}_{model_type}_best_model.pt"), epoch + 1, model, config,
-                            val_loss, vocabs, dataset_meta, lr)
+                            val_loss, vocabs, dataset_meta, base_lr, use_sched, best_val_loss)
             print(f"Saved best model with validation loss: {val_loss:.4f}")
         if (epoch + 1) % config.get("save_every", 10) == 0:
             save_checkpoint(os.path.join(run_dir, f"{dataset_name}_{model_type}_checkpoint_epoch_{epoch + 1}.pt"), epoch + 1,
-                            model, config, val_loss, vocabs, dataset_meta, lr)
+                            model, config, val_loss, vocabs, dataset_meta, base_lr, use_sched, best_val_loss)
 
     if main_rank:
         final = {}
@@ -346,6 +440,9 @@ def main(argv=None):
         tracker.log(final)
         tracker.finish()
         print("\nTraining and evaluation completed!")
+    if config.get("dump_final_params"):   # test hook: every rank's flat parameter buffer
+        eng.dp_flush()
+        torch.save(eng.P.detach().cpu(), f"{config['dump_final_params']}.rank{rank}.pt")
     if nranks > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -51,7 +51,10 @@ class _EngineModel(nn.Module):
             self.enc = _Holder(enc)
         self.dec = _Holder(dec)
         self._eng = None
+        self._versions = None
         self.precision = config.get("precision", "mixed")
+        # load_state_dict copies IN PLACE into the aliased flat buffer: the engine's 16-bit weight shadows are stale
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._params_written())
 
     # -- engine binding ---------------------------------------------------------------------
     def engine(self):
@@ -63,15 +66,28 @@ class _EngineModel(nn.Module):
         named = dict(self.named_parameters())
         if self._eng is None or self._eng.device != dev:
             from ark_amd.engine import Engine
-            self._eng = Engine(self.config, dev, precision=self.precision)
+            import torch.distributed as dist
+            live = dist.is_available() and dist.is_initialized()
+            self._eng = Engine(self.config, dev, precision=self.precision, world_size=dist.get_world_size() if live else 1,
+                               rank=dist.get_rank() if live else 0)
             self._adopt(named)
         else:
-            for k, prm in named.items():  # .to()/load_state_dict may have re-allocated storage
+            for k, prm in named.items():  # .to() re-allocates storage
                 if prm.data_ptr() != self._eng.p[k].data_ptr():
                     self._adopt(named)
                     break
+            else:
+                # in-place writers (torch.optim, load_state_dict, p.copy_) keep the storage and bump the version
+                ver = tuple(prm._version for prm in named.values())
+                if ver != self._versions:
+                    self._versions = ver
+                    self._eng.mark_params_dirty()
         self._eng.training = self.training
         return self._eng
+
+    def _params_written(self):
+        if self._eng is not None:
+            self._eng.mark_params_dirty()
 
     def _adopt(self, named):
         eng = self._eng
@@ -80,6 +96,7 @@ class _EngineModel(nn.Module):
                 eng.p[k].copy_(prm.data)
                 prm.data = eng.p[k]      # parameters now alias the engine's flat buffer
         eng.mark_params_dirty()
+        self._versions = tuple(prm._version for prm in named.values())
 
     def _params_in_order(self):
         return list(self.named_parameters())
@@ -105,22 +122,30 @@ class _EngineModel(nn.Module):
         return triples
 
 
+def _check_generation(eng, ctx):
+    """the engine keeps ONE set of saved activations: backward must belong to its most recent forward"""
+    if eng.fwd_gen != ctx.gen:
+        raise ArkError("backward() of an earlier forward: the engine has run another forward (training, evaluation or "
+                       "generation) since, and its saved activations are gone -- call loss.backward() before the next "
+                       "forward, as the reference's train_epoch does (kgvae/experiments/ablation_study.py:63-76)")
+
+
 class _SailFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, triples, seq_in, eps, *params):
-        eng = model.engine()
-        eng.mark_params_dirty()  # an external optimiser may have stepped the aliased parameters
+        eng = model.engine()   # (notices in-place writes of an external optimiser through the parameter versions)
         B, Lq = seq_in.shape
         w = eng.forward(triples, seq_in, eps, with_loss=False, L_run=Lq)
         V = eng.V
         logits = w["logits"][:Lq * B, :V].reshape(Lq, B, V).permute(1, 0, 2).contiguous()
-        ctx.model, ctx.shape = model, (B, Lq, V)
+        ctx.model, ctx.shape, ctx.gen = model, (B, Lq, V), eng.fwd_gen
         return logits, w["mu"].clone(), w["logv"].clone()
 
     @staticmethod
     def backward(ctx, dlogits, dmu, dlogv):
         model = ctx.model
         eng = model._eng
+        _check_generation(eng, ctx)
         B, Lq, V = ctx.shape
         w = eng.ws
         buf = w["logits"]
@@ -144,17 +169,17 @@ class _ArkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, seq_in, *params):
         eng = model.engine()
-        eng.mark_params_dirty()
         B, Lq = seq_in.shape
         w = eng.forward(None, seq_in, None, with_loss=False, L_run=Lq)
         V = eng.V
-        ctx.model, ctx.shape = model, (B, Lq, V)
+        ctx.model, ctx.shape, ctx.gen = model, (B, Lq, V), eng.fwd_gen
         return w["logits"][:Lq * B, :V].reshape(Lq, B, V).permute(1, 0, 2).contiguous()
 
     @staticmethod
     def backward(ctx, dlogits):
         model = ctx.model
         eng = model._eng
+        _check_generation(eng, ctx)
         B, Lq, V = ctx.shape
         buf = eng.ws["logits"]
         buf.zero_()
@@ -274,10 +299,11 @@ class SAIL(_EngineModel):
 
     # -- compression bits (reference models.py:202-260), one teacher-forced pass per batch -----
     @torch.no_grad()
-    def posterior_bits(self, dataset, device, pad_id=0, sample_frac=0.1, desc="posterior bits", batch_size=256):
+    def posterior_bits(self, dataset, device, pad_id=0, sample_frac=0.1, desc="posterior bits", batch_size=256, eps=None):
         """Same statistics as the reference (AR bits of the sequence given z ~ q(z|x), KL bits summed
-        over the latent dimension), computed with ONE decoder pass per batch: for a causal GRU the
-        reference's prefix-by-prefix loop re-computes exactly these per-token log-probabilities."""
+        over the latent dimension; models.py:202-260), computed with ONE decoder pass per batch: for a causal GRU
+        the reference's prefix-by-prefix loop re-computes exactly these per-token log-probabilities.
+        `eps` ([n, Z], optional): the reparameterisation noise per item instead of fresh N(0,1) draws."""
         eng = self.engine()
         n = max(1, int(sample_frac * len(dataset)))
         ln2 = math.log(2)
@@ -294,8 +320,8 @@ class SAIL(_EngineModel):
                     tri, seq = torch.stack([a for a, _ in items]), torch.stack([b for _, b in items])
                 tri, seq = tri.to(device), seq.to(device)
                 B = seq.shape[0]
-                eps = torch.randn(B, eng.Z, device=device)
-                w = eng.forward(tri, seq, eps, with_dlogits=False)
+                e = torch.randn(B, eng.Z, device=device) if eps is None else eps[i0:i0 + B].to(device, dtype=torch.float32).contiguous()
+                w = eng.forward(tri, seq, e, with_dlogits=False)
                 ar = (w["row_loss"][:eng.L * B].reshape(eng.L, B).sum(0) / ln2).cpu().numpy()
                 mu, logv = w["mu"], w["logv"]
                 kl = (-0.5 * torch.sum(1 + logv - mu.pow(2) - logv.exp(), dim=1) / ln2).cpu().numpy()
@@ -327,45 +353,48 @@ class ARK(_EngineModel):
         prm = [p for _, p in self._params_in_order()]
         return _ArkFn.apply(self, seq.contiguous(), *prm)
 
+    @staticmethod
+    def filtered_probs(logits, temperature=1.0, top_p=0.0, top_k=0):
+        """the distribution the reference samples the next token from (models.py:431-456), as dense probabilities
+        over the vocabulary: softmax(logits / temperature) -> keep the top_k -> keep the nucleus (the sorted prefix
+        up to AND including the token that crosses top_p) -> renormalise after each cut."""
+        if temperature and temperature != 1.0:
+            logits = logits / float(temperature)
+        probs = torch.softmax(logits, dim=-1)
+        if top_k and top_k > 0:
+            _, keep = probs.topk(top_k, dim=-1)
+            probs = probs * torch.zeros_like(probs).scatter_(-1, keep, 1.0)
+            probs = probs / probs.sum(dim=-1, keepdim=True).clamp_min(1e-12)
+        if top_p and 0.0 < top_p < 1.0:
+            sp, si = probs.sort(dim=-1, descending=True)
+            cut = sp.cumsum(dim=-1) > top_p
+            cut[..., 1:] = cut[..., :-1].clone()   # always keep the token that crosses top_p
+            cut[..., 0] = False
+            sp = sp.masked_fill(cut, 0.0)
+            sp = sp / sp.sum(dim=-1, keepdim=True).clamp_min(1e-12)
+            probs = torch.zeros_like(probs).scatter_(-1, si, sp)
+        return probs
+
     @torch.no_grad()
     def generate(self, seq_len, special_tokens, device=None, batch_size=1, beam=1, sample=False, temperature=1.0,
                  top_p=0.0, top_k=0):
-        """autoregressive generation with the reference's sampling rules (models.py:407-471): greedy,
-        or temperature / top-k / nucleus sampling drawn with torch.multinomial."""
+        """autoregressive generation with the reference's sampling rules (models.py:407-471): greedy, or
+        temperature / top-k / nucleus sampling drawn with torch.multinomial.  The causal GRU advances ONE token per
+        step on the engine (Engine.decode_step) instead of re-running the whole prefix."""
         device = device or next(self.parameters()).device
         B = batch_size
+        eng = self.engine()
+        d = eng.decode_begin(B)
         seq = torch.full((B, 1), special_tokens["BOS"], dtype=torch.long, device=device)
-        was = self.training
-        self.eval()
-        try:
-            for _ in range(seq_len - 1):
-                logits = self.forward(seq)[:, -1]
-                if not sample:
-                    nxt = logits.argmax(dim=-1, keepdim=True)
-                else:
-                    if temperature and temperature != 1.0:
-                        logits = logits / float(temperature)
-                    probs = torch.softmax(logits, dim=-1)
-                    if top_k and top_k > 0:
-                        _, keep = probs.topk(top_k, dim=-1)
-                        probs = probs * torch.zeros_like(probs).scatter_(-1, keep, 1.0)
-                        probs = probs / probs.sum(dim=-1, keepdim=True).clamp_min(1e-12)
-                    if top_p and 0.0 < top_p < 1.0:
-                        sp, si = probs.sort(dim=-1, descending=True)
-                        cut = sp.cumsum(dim=-1) > top_p
-                        cut[..., 1:] = cut[..., :-1].clone()   # always keep the token that crosses top_p
-                        cut[..., 0] = False
-                        sp = sp.masked_fill(cut, 0.0)
-                        sp = sp / sp.sum(dim=-1, keepdim=True).clamp_min(1e-12)
-                        pick = torch.multinomial(sp, 1)
-                        nxt = si.gather(-1, pick)
-                    else:
-                        nxt = torch.multinomial(probs, 1)
-                seq = torch.cat([seq, nxt], dim=1)
-                if bool((seq[:, -1] == special_tokens["EOS"]).all()):
-                    break
-        finally:
-            self.train(was)
+        for t in range(seq_len - 1):
+            logits = eng.decode_step(d, seq[:, -1].contiguous(), t)
+            if not sample:
+                nxt = logits.argmax(dim=-1, keepdim=True)
+            else:
+                nxt = torch.multinomial(self.filtered_probs(logits, temperature, top_p, top_k), 1)
+            seq = torch.cat([seq, nxt], dim=1)
+            if bool((seq[:, -1] == special_tokens["EOS"]).all()):
+                break
         if seq.size(1) < seq_len:
             fill = torch.full((B, seq_len - seq.size(1)), special_tokens["EOS"], dtype=torch.long, device=device)
             seq = torch.cat([seq, fill], dim=1)

@@ -20,6 +20,10 @@ Reference call sites restated (paths relative to the reference repo):
   ELBO assembly (ce + b*kl) ................ kgvae/experiments/ablation_study.py:59-73
   Adam step ................................ kgvae/experiments/ablation_study.py:571,76
   greedy decode (beam=1) ................... kgvae/model/models.py:262-266, 282-300
+  compression bits (AR + KL) ............... kgvae/model/models.py:202-260 (SAIL), 473-520 (ARK)
+  next-token sampling distribution ......... kgvae/model/models.py:431-456 (inline in ARK.generate: not
+                                             callable on its own, so this one restatement is pinned by its
+                                             own properties only -- see tests/test_oracle_golden.py)
   sequence codec ........................... kgvae/model/utils.py:70-78, 102-108
 """
 import math
@@ -275,6 +279,60 @@ def greedy_decode(P, z, cfg):
         if bool((s[:, -1] == EOS).all()):
             break
     return s
+
+
+@torch.no_grad()
+def posterior_bits(P, triples, seq, eps, cfg):
+    """per-graph (ar_bits, kl_bits) as SAIL.posterior_bits / bits_per_sequence compute them (models.py:202-260):
+    z ~ q(z|x) with the given eps; AR bits = sum over target positions t >= 1, up to the first PAD target, of
+    -log2 softmax(dec(z, seq[:t])[-1])[seq[t]], one decoder run per prefix exactly as the reference does;
+    KL bits = KL summed over the latent dimension / ln 2."""
+    ln2 = math.log(2)
+    ar, kl = [], []
+    for b in range(seq.shape[0]):
+        z, mu, logv = encoder_forward(P, triples[b:b + 1], eps[b:b + 1], cfg)
+        total = 0.0
+        for t in range(1, seq.shape[1]):
+            tgt = int(seq[b, t])
+            if tgt == PAD:
+                break
+            logits = decoder_forward(P, z, seq[b:b + 1, :t], cfg)[:, -1]
+            total += -float(F.log_softmax(logits, dim=-1)[0, tgt]) / ln2
+        ar.append(total)
+        kl.append(float(-0.5 * torch.sum(1 + logv - mu.pow(2) - logv.exp(), dim=1)) / ln2)
+    return ar, kl
+
+
+@torch.no_grad()
+def sampling_distribution(logits, temperature=1.0, top_p=0.0, top_k=0):
+    """dense next-token probabilities of ARK.generate(sample=True) (models.py:431-456), row by row with explicit
+    loops: temperature, softmax, top-k mask + renormalise, nucleus over the descending sort (the token that crosses
+    top_p stays in) + renormalise."""
+    if temperature and temperature != 1.0:
+        logits = logits / float(temperature)
+    probs = F.softmax(logits, dim=-1)
+    out = torch.zeros_like(probs)
+    for b in range(probs.shape[0]):
+        p = probs[b].clone()
+        if top_k and top_k > 0:
+            keep = sorted(range(p.numel()), key=lambda i: (-float(p[i]), i))[:top_k]
+            m = torch.zeros_like(p)
+            m[keep] = 1.0
+            p = p * m
+            p = p / p.sum().clamp_min(1e-12)
+        if top_p and 0.0 < top_p < 1.0:
+            order = sorted(range(p.numel()), key=lambda i: (-float(p[i]), i))
+            acc, kept = 0.0, []
+            for i in order:
+                kept.append(i)          # the token that takes the cumulative mass past top_p is still kept ...
+                acc += float(p[i])
+                if acc > top_p:
+                    break               # ... everything after it is cut
+            q = torch.zeros_like(p)
+            q[kept] = p[kept]
+            p = q / q.sum().clamp_min(1e-12)
+        out[b] = p
+    return out
 
 
 def triples_to_seq(triples, ent_base, rel_base, seq_len):

@@ -25,7 +25,7 @@ def main(rank, world, port, out_path, graph, steps):
     cfg = dict(cfg, dec_dropout=0.0, learning_rate=1e-3)
     P = O.init_params(cfg, 0)
     B = 128
-    eng = Engine(cfg, dev, precision="mixed", world_size=world)
+    eng = Engine(cfg, dev, precision="mixed", world_size=world, rank=rank)
     eng.load_params(P)
     eng.set_hyper(lr=1e-3, beta=0.5)
     Bl = B // world

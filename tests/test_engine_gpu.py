@@ -175,7 +175,7 @@ def test_gradients_match_oracle_fast_path(precision, rel, cos):
 def test_loss_trajectory_matches_oracle_fast_path():
     """12 consecutive optimiser steps of the shipped fast path (captured hipGraph, mixed precision, diagonal
     kernels, 16-bit shadows refreshed after every Adam) against the fp32 CPU oracle on the same batches and
-    eps: the ELBO of every step stays within 1e-3 relative (first step 1e-4; measured <= 1.2e-4 throughout), i.e. gradients, Adam state and the
+    eps: the ELBO of every step stays within 2e-4 relative (first step 1e-4; measured <= 1.2e-4 throughout), i.e. gradients, Adam state and the
     shadow refresh carry over correctly from step to step."""
     from oracle import sail_oracle as O
     cfg = dict(_big_cfg(), dec_dropout=0.0, learning_rate=2e-4)
@@ -207,7 +207,7 @@ def test_loss_trajectory_matches_oracle_fast_path():
         want.append(loss)
     assert want[-1] < want[0] - 0.05         # it trains
     for i, (g_, w_) in enumerate(zip(got, want)):
-        assert rel_err(float(g_[0]), w_) < (1e-4 if i == 0 else 1e-3), (i, float(g_[0]), w_)
+        assert rel_err(float(g_[0]), w_) < (1e-4 if i == 0 else 2e-4), (i, float(g_[0]), w_)
 
 
 def test_shard_gradients_sum_to_full_batch():
@@ -326,10 +326,26 @@ def _tile_native_index(rows, D):
     return ((r >> 4) * (D >> 4) + (c >> 4)) * 256 + ((((r >> 2) & 3) << 4) + (c & 15)) * 4 + (r & 3)
 
 
-def test_in_kernel_dropout_is_consistent_forward_and_backward():
-    """LDS-DMA path: the forward cell and the input-gradient product regenerate the SAME mask from the
-    counter hash that ark_dropout_mask materialises (seed, optimiser step, element index)."""
+def _row_major_masks(eng, B, Lq):
+    """the dropout masks of the current draw, as the oracle wants them: [B, L, D] per inter-layer gap, scaled by
+    1/(1-p).  ark_dropout_mask materialises the counter hash in the engine's element order (time-major rows, MFMA
+    tile-native inside a timestep block)."""
     from ark_amd import _lib as L
+    dev, D = eng.device, eng.D
+    idx = _tile_native_index(B, D).to(dev)
+    out = []
+    for l in range(eng.n - 1):
+        m = torch.empty(Lq * B * D, device=dev)
+        L.check(L.lib().ark_dropout_mask(L.ptr(m), L.i64(Lq * B * D), L.f32(eng.p_drop), L.u64(eng._layer_seed(l)),
+                                         L.ptr(eng.hyper), L.cur_stream()), "mask")
+        m = m.view(Lq, B * D)[:, idx.reshape(-1)].view(Lq, B, D)      # (t, b, d), row-major inside the block
+        out.append(m.permute(1, 0, 2).contiguous().cpu())
+    return out
+
+
+def test_in_kernel_dropout_matches_the_materialised_mask():
+    """fast path: the forward cells drop exactly the elements ark_dropout_mask marks for the same draw
+    (seed, draw counter, element index), and every training forward draws a NEW mask"""
     from oracle import sail_oracle as O
     cfg = dict(_big_cfg(), dec_dropout=0.5)
     P = O.init_params(cfg, 0)
@@ -339,42 +355,80 @@ def test_in_kernel_dropout_is_consistent_forward_and_backward():
     dev = eng.device
     eng.training = True
     eng._default_norms(B)
-    w = eng.forward(triples.to(dev), seq.to(dev), torch.randn(B, cfg["d_latent"]).to(dev))
-    assert w["v2"]
-    D, R = eng.D, eng.L * B
-    idx = _tile_native_index(R, D).to(dev)
+    args = (triples.to(dev), seq.to(dev), torch.randn(B, cfg["d_latent"]).to(dev))
+    w = eng.forward(*args)
+    assert w["v2"] and eng.dropout_draws() == 1
+    masks = _row_major_masks(eng, B, eng.L)
+    kept = []
     for l in range(eng.n - 1):
-        y = w["Y16a"][l][B:].view(torch.float16).float()
-        yd = w["Yd16a"][l].view(torch.float16).float()
-        ref = torch.empty(R * D, device=dev)
-        L.check(L.lib().ark_dropout_mask(L.ptr(ref), L.i64(R * D), L.f32(0.5), L.u64(eng.drop_seed + 7919 * l), L.ptr(eng.hyper),
-                                         L.cur_stream()), "mask")
-        m = ref[idx]                                   # row-major view of the tile-native mask
+        y = w["Y16a"][l][B:].view(torch.float16).float().view(eng.L, B, eng.D).permute(1, 0, 2).cpu()
+        yd = w["Yd16a"][l].view(torch.float16).float().view(eng.L, B, eng.D).permute(1, 0, 2).cpu()
+        m = masks[l]
         assert set(m.unique().tolist()) == {0.0, 2.0} and 0.45 < (m == 0).float().mean().item() < 0.55
         assert torch.allclose(yd, y * m, rtol=2e-3, atol=1e-4)
-        # backward: dropout-scaled input gradient == plain product * the same mask (buffer order)
-        A = (torch.randn(R, 3 * D, device=dev) * 0.1).to(torch.bfloat16)
-        plain, dropped = torch.empty(R * D, device=dev), torch.empty(R * D, device=dev)
-        L.check(L.lib().ark_gemm16(L.i32(L.PREC_BF16), L.i32(L.EPI_NONE), L.ptr(A), L.i64(3 * D), L.ptr(eng.wihT16[l + 1]),
-                                   L.i64(3 * D), L.ptr(plain), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D),
-                                   L.i32(3 * D), L.i32(1), L.cur_stream()), "gemm16")
-        L.check(L.lib().ark_gemm16_dropout(L.i32(L.PREC_BF16), L.ptr(A), L.i64(3 * D), L.ptr(eng.wihT16[l + 1]), L.i64(3 * D),
-                                           L.ptr(dropped), L.i64(D), L.i32(R), L.i32(D), L.i32(3 * D), L.f32(0.5),
-                                           L.u64(eng.drop_seed + 7919 * l), L.ptr(eng.hyper), L.cur_stream()), "gemm16_dropout")
-        assert torch.allclose(dropped, plain * ref, rtol=1e-6, atol=1e-7)
+        kept.append(m != 0)
+    eng.forward(*args)            # the next training forward must not reuse the mask
+    assert eng.dropout_draws() == 2
+    for l, m in enumerate(_row_major_masks(eng, B, eng.L)):
+        assert ((m != 0) != kept[l]).float().mean().item() > 0.3
+    eng.training = False
+    eng.forward(*args)            # evaluation draws nothing
+    assert eng.dropout_draws() == 2
 
 
-DIAG_DEFAULT = (64, 1, 2, 1, 32)   # library defaults (rows, ki, nbuf, xcd_map, units) of the forward diagonal kernel
+@pytest.mark.parametrize("B", [128, 1024])
+def test_dropout_on_fast_path_matches_oracle_with_the_same_masks(B):
+    """THE benchmarked configuration (syn-paths, mixed precision, dec_dropout 0.1, in-kernel counter-hash masks):
+    ELBO and every parameter's gradient against the CPU oracle fed the SAME masks (reference semantics:
+    nn.GRU(dropout=p), kgvae/model/models.py:121-127,184; loss kgvae/experiments/ablation_study.py:59-73)."""
+    from oracle import sail_oracle as O
+    cfg = dict(_big_cfg(), dec_dropout=0.1)
+    P = O.init_params(cfg, 0)
+    triples, seq = synth_batch(cfg, B, seed=11)
+    torch.manual_seed(13)
+    eps = torch.randn(B, cfg["d_latent"])
+    eng = make_engine(cfg, P, "mixed")
+    dev = eng.device
+    eng.training = True
+    eng.set_hyper(beta=0.1)
+    eng._default_norms(B)
+    eng.forward(triples.to(dev), seq.to(dev), eps.to(dev))
+    eng.backward()
+    torch.cuda.synchronize()
+    out4 = eng.ws["out4"].cpu().numpy()
+    got = {k: v.detach().double().cpu().clone() for k, v in eng.g.items()}
+    masks = _row_major_masks(eng, B, eng.L)
+    Pc = O._detach_tied(P, True)
+    leaves = O.leaf_params(Pc)
+    for _, t in leaves:
+        t.requires_grad_(True)
+    loss, ce, kl, *_ = O.sail_elbo(Pc, triples, seq, eps, 0.1, cfg, drop_masks=masks)
+    with torch.no_grad():
+        plain, *_ = O.sail_elbo(Pc, triples, seq, eps, 0.1, cfg)
+    assert abs(float(plain) - float(loss)) > 1e-3 * float(loss)          # the masks matter
+    assert rel_err(float(out4[0]), float(loss)) < 1e-4, (out4, float(loss), float(ce), float(kl))   # north_star's bar
+    loss.backward()
+    checked = 0
+    for k, t in leaves:
+        want = t.grad.double()
+        g = got[k]
+        nw = want.norm().item()
+        if nw < 1e-12:
+            assert g.norm().item() < 1e-9, k
+            continue
+        assert (g - want).norm().item() <= 1.5e-2 * nw, (k, (g - want).norm().item() / nw)
+        assert torch.dot(g.flatten(), want.flatten()).item() / (g.norm().item() * nw) >= 0.9998, k
+        checked += 1
+    assert checked >= 20
 
 
 @pytest.mark.parametrize("rows,ki,nbuf,xcd,units", [(32, 2, 2, 0, 32), (64, 1, 2, 0, 32), (64, 2, 2, 1, 32), (32, 1, 4, 1, 32),
-                                                   (128, 1, 2, 1, 64), (128, 1, 4, 0, 64), (64, 2, 2, 1, 64)])
+                                                   (128, 1, 2, 1, 64), (64, 1, 2, 0, 64), (64, 2, 2, 1, 64)])
 @pytest.mark.parametrize("drop", [0.0, 0.1])
-def test_diagonal_cells_match_layer_order(rows, ki, nbuf, xcd, units, drop):
-    """the layer-diagonal forward (one launch per anti-diagonal, in-cell input projection) computes the
-    same states, saves, losses and gradients as the layer-by-layer LDS-DMA path, and the same ELBO as
-    the CPU oracle within north_star's tolerance"""
-    from ark_amd import _lib as L
+def test_diagonal_tilings_agree(rows, ki, nbuf, xcd, units, drop):
+    """every tile / ring configuration of the two diagonal kernels (ArkDiagTuning, passed per call) computes the
+    same states, losses and gradients as the default one, and the same ELBO as the CPU oracle within north_star's
+    tolerance"""
     from oracle import sail_oracle as O
     cfg = dict(_big_cfg(), dec_dropout=drop)
     P = O.init_params(cfg, 0)
@@ -382,38 +436,32 @@ def test_diagonal_cells_match_layer_order(rows, ki, nbuf, xcd, units, drop):
     triples, seq = synth_batch(cfg, B, seed=3)
     torch.manual_seed(5)
     eps = torch.randn(B, cfg["d_latent"])
-    a = make_engine(dict(cfg, ark_diag_cells=False), P, "mixed")
-    b = make_engine(dict(cfg, ark_diag_cells=True, ark_diag_bwd=True), P, "mixed")
-    L.check(L.lib().ark_set_diag_units(units), "ark_set_diag_units")
-    L.check(L.lib().ark_set_diag_tuning(rows, ki, nbuf, xcd), "ark_set_diag_tuning")
-    L.check(L.lib().ark_set_diag_bwd_tuning(min(rows, 64), ki, nbuf), "ark_set_diag_bwd_tuning")
-    try:
-        dev = a.device
-        args = (triples.to(dev), seq.to(dev), eps.to(dev))
-        for eng in (a, b):
-            eng.set_hyper(beta=0.1)
-        a.drop_seed = b.drop_seed = 1234
-        if drop == 0.0:   # before any optimiser step: the oracle sees the same weights
-            with torch.no_grad():
-                loss, *_ = O.sail_elbo(P, triples, seq, eps, 0.1, cfg)
-            out = b.eval_loss(*args).cpu().numpy()
-            assert rel_err(float(out[0]), float(loss)) < 1e-4, (out, float(loss))
-        oa = a.train_step(*args).cpu().numpy()
-        ob = b.train_step(*args).cpu().numpy()
-        torch.cuda.synchronize()
-        assert rel_err(float(ob[0]), float(oa[0])) < 2e-5, (oa, ob)
-        n = cfg["n_layers"]
-        for l in range(n):
-            ya, yb = a.ws["Y"][l], b.ws["Y"][l]
-            assert (ya - yb).abs().max().item() < 2e-3, l
-            assert torch.equal(a.ws["Y16a"][l][:B], b.ws["Y16a"][l][:B])
-        for k in a.g:   # every parameter's gradient, relative to its own norm
-            da, db = a.g[k].float(), b.g[k].float()
-            assert (da - db).norm().item() <= 3e-3 * da.norm().item() + 1e-9, k
-    finally:
-        L.check(L.lib().ark_set_diag_units(DIAG_DEFAULT[4]), "ark_set_diag_units")
-        L.check(L.lib().ark_set_diag_tuning(*DIAG_DEFAULT[:4]), "ark_set_diag_tuning")
-        L.check(L.lib().ark_set_diag_bwd_tuning(32, 2, 2), "ark_set_diag_bwd_tuning")
+    tun = dict(fwd_rows=rows, fwd_ki=ki, fwd_nbuf=nbuf, fwd_xcd=xcd, fwd_units=units, bwd_rows=min(rows, 64), bwd_ki=ki,
+               bwd_nbuf=nbuf, bwd_xcd_rows=4 if xcd else 1)
+    a = make_engine(cfg, P, "mixed")
+    b = make_engine(dict(cfg, ark_diag_tuning=tun), P, "mixed")
+    dev = a.device
+    args = (triples.to(dev), seq.to(dev), eps.to(dev))
+    for eng in (a, b):
+        eng.set_hyper(beta=0.1)
+    a.drop_seed = b.drop_seed = 1234
+    if drop == 0.0:   # before any optimiser step: the oracle sees the same weights
+        with torch.no_grad():
+            loss, *_ = O.sail_elbo(P, triples, seq, eps, 0.1, cfg)
+        out = b.eval_loss(*args).cpu().numpy()
+        assert rel_err(float(out[0]), float(loss)) < 1e-4, (out, float(loss))
+    oa = a.train_step(*args).cpu().numpy()
+    ob = b.train_step(*args).cpu().numpy()
+    torch.cuda.synchronize()
+    assert rel_err(float(ob[0]), float(oa[0])) < 2e-5, (oa, ob)
+    n = cfg["n_layers"]
+    for l in range(n):
+        ya, yb = a.ws["Y"][l], b.ws["Y"][l]
+        assert (ya - yb).abs().max().item() < 2e-3, l
+        assert torch.equal(a.ws["Y16a"][l][:B], b.ws["Y16a"][l][:B])
+    for k in a.g:   # every parameter's gradient, relative to its own norm
+        da, db = a.g[k].float(), b.g[k].float()
+        assert (da - db).norm().item() <= 3e-3 * da.norm().item() + 1e-9, k
 
 
 @pytest.mark.parametrize("B,D,n_roles", [(64, 128, 1), (48, 256, 3)])
@@ -454,7 +502,7 @@ def test_gru_diag_fwd_matches_torch_gru_cell(B, D, n_roles):
         ro.save_r, ro.save_z, ro.save_n, ro.save_hn = (L.dptr(t) for t in bufs["sv"])
         ro.drop_p = 0.0
     L.check(L.lib().ark_gru_diag_fwd(L.i32(L.PREC_F16), L.i32(L.PREC_BF16), L.i32(n_roles), roles, L.ptr(None), L.i32(B), L.i32(D),
-                                     L.cur_stream()), "ark_gru_diag_fwd")
+                                     L.ptr(None), L.cur_stream()), "ark_gru_diag_fwd")
     torch.cuda.synchronize()
     for bufs, (hn, r, z, n, ghn) in zip(keep, refs):
         got = bufs["yo"].cpu()[idx].reshape(B, D)
@@ -468,7 +516,7 @@ def test_gru_diag_fwd_matches_torch_gru_cell(B, D, n_roles):
 @pytest.mark.parametrize("top", [False, True])
 def test_gru_diag_bwd_matches_autograd(top):
     """ark_gru_diag_bwd through the C-ABI against torch autograd of one GRU cell: dh = carry + dgh_next W_hh + dy with
-    dy given (top layer) or formed in the kernel as dgi_above W_ih_above; outputs dgi / dgh panels, carry, bias sums"""
+    dy given (top layer) or formed in the kernel as dgi_above W_ih_above; outputs the [dr|dz|dn|dn*r] panel, carry, bias sums"""
     from ark_amd import _lib as L
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(5 + top)
@@ -495,27 +543,30 @@ def test_gru_diag_bwd_matches_autograd(top):
     (dh * h).sum().backward()
     roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
     ro = roles[0]
-    bufs = dict(dgn=dgh_next.to(dev), whhT=whh.t().contiguous().to(dev), carry=tn(carry).to(dev),
+    junk = bf(torch.randn(B, D, generator=g))   # the dn column block of a panel is not part of dgh: must be ignored
+    panel_next = torch.cat([dgh_next[:, :2 * D], junk, dgh_next[:, 2 * D:]], dim=1).contiguous()
+    panel_up = torch.cat([dgi_up, junk], dim=1).contiguous()
+    bufs = dict(dgn=panel_next.to(dev), whhT=whh.t().contiguous().to(dev), carry=tn(carry).to(dev),
                 sr=tn(r.detach(), torch.float16).to(dev), sz=tn(z.detach(), torch.float16).to(dev),
                 sn=tn(n.detach(), torch.float16).to(dev), shn=tn(gh[:, 2 * D:].detach(), torch.float16).to(dev),
-                yp=tn(h_prev).to(dev), dgi=torch.zeros(B, 3 * D, dtype=torch.bfloat16, device=dev),
-                dgh=torch.zeros(B, 3 * D, dtype=torch.bfloat16, device=dev), dbi=torch.zeros(3 * D, device=dev),
-                dbh=torch.zeros(3 * D, device=dev), dy=tn(dy_top).to(dev), up=dgi_up.to(dev),
+                yp=tn(h_prev).to(dev), dg=torch.zeros(B, 4 * D, dtype=torch.bfloat16, device=dev), dbi=torch.zeros(3 * D, device=dev),
+                dbh=torch.zeros(3 * D, device=dev), dy=tn(dy_top).to(dev), up=panel_up.to(dev),
                 wupT=wih_up.t().contiguous().to(dev))
     if top:
         ro.dy_t = L.dptr(bufs["dy"])
     else:
         ro.dgi_up16, ro.w_ihT_up16 = L.dptr(bufs["up"]), L.dptr(bufs["wupT"])
-    ro.dgh_next16, ro.w_hhT16, ro.carry_t = L.dptr(bufs["dgn"]), L.dptr(bufs["whhT"]), L.dptr(bufs["carry"])
+    ro.dg_next16, ro.w_hhT16, ro.carry_t = L.dptr(bufs["dgn"]), L.dptr(bufs["whhT"]), L.dptr(bufs["carry"])
     ro.save_r, ro.save_z, ro.save_n, ro.save_hn = (L.dptr(bufs[k]) for k in ("sr", "sz", "sn", "shn"))
-    ro.y_prev_t, ro.dgi16, ro.dgh16 = L.dptr(bufs["yp"]), L.dptr(bufs["dgi"]), L.dptr(bufs["dgh"])
+    ro.y_prev_t, ro.dg16 = L.dptr(bufs["yp"]), L.dptr(bufs["dg"])
     ro.db_ih, ro.db_hh = L.dptr(bufs["dbi"]), L.dptr(bufs["dbh"])
     ro.first, ro.drop_p = 0, 0.0
-    L.check(L.lib().ark_gru_diag_bwd(L.i32(L.PREC_BF16), L.i32(1), roles, L.ptr(None), L.i32(B), L.i32(D), L.cur_stream()),
-            "ark_gru_diag_bwd")
+    L.check(L.lib().ark_gru_diag_bwd(L.i32(L.PREC_BF16), L.i32(1), roles, L.ptr(None), L.i32(B), L.i32(D), L.ptr(None),
+                                     L.cur_stream()), "ark_gru_diag_bwd")
     torch.cuda.synchronize()
     close = lambda got, want, tol: (got.double().cpu() - want).abs().max().item() <= tol * want.abs().max().item()
-    assert close(bufs["dgi"].float(), gi.grad, 1.5e-2)      # bf16 outputs, fp16 saves
-    assert close(bufs["dgh"].float(), gh.grad, 1.5e-2)
+    out = bufs["dg"].float()
+    assert close(out[:, :3 * D], gi.grad, 1.5e-2)      # bf16 outputs, fp16 saves
+    assert close(torch.cat([out[:, :2 * D], out[:, 3 * D:]], dim=1), gh.grad, 1.5e-2)
     assert close(bufs["carry"].cpu()[idx].reshape(B, D), (dh * z).detach(), 2e-3)
     assert close(bufs["dbi"], gi.grad.sum(0), 1.5e-2) and close(bufs["dbh"], gh.grad.sum(0), 1.5e-2)

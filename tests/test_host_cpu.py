@@ -22,7 +22,7 @@ def _golden(name):
 def test_library_loads_and_exports_every_declared_symbol():
     """every function declared in include/ark_amd.h is exported by the built library"""
     hdr = open(os.path.join(ROOT, "include", "ark_amd.h")).read()
-    names = sorted(set(re.findall(r"^int\s+(ark_\w+)\s*\(", hdr, flags=re.M)))
+    names = sorted(set(re.findall(r"^(?:int|void)\s+(ark_\w+)\s*\(", hdr, flags=re.M)))
     assert len(names) >= 30
     lib = ctypes.CDLL(os.path.join(ROOT, "ark_amd", "lib", "libark_amd.so"))
     missing = [n for n in names if not hasattr(lib, n)]
@@ -33,7 +33,9 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_argument_errors_are_negative_codes_without_touching_the_gpu():
     lib = ctypes.CDLL(os.path.join(ROOT, "ark_amd", "lib", "libark_amd.so"))
     assert lib.ark_set_tuning(99, 0) < 0
-    assert lib.ark_set_dma_ring(3, 3) < 0
+    bad = (ctypes.c_int * 9)(48, 1, 2, 1, 32, 32, 2, 2, 4)   # ArkDiagTuning with a forward row count that does not exist
+    role = (ctypes.c_char * 256)()
+    assert lib.ark_gru_diag_fwd(2, 1, 1, role, ctypes.c_void_p(0), 64, 128, bad, ctypes.c_void_p(0)) < 0
     null = ctypes.c_void_p(0)
     assert lib.ark_adam_step(null, null, null, null, ctypes.c_int64(0), null, null) < 0
 

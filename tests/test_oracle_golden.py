@@ -150,3 +150,48 @@ def OrderedDictFrom(z, prefix):
     if "dec.out.weight" in P and np.array_equal(P["dec.out.weight"].numpy(), P["dec.tok_emb.weight"].numpy()):
         P["dec.out.weight"] = P["dec.tok_emb.weight"]
     return P
+
+
+def test_posterior_bits_restatement_equals_teacher_forced_nll():
+    """the oracle's prefix-by-prefix restatement of bits_per_sequence (reference models.py:202-213) against ONE
+    teacher-forced decoder pass on the reference-generated golden batch: a causal GRU makes them the same numbers"""
+    import math
+    import torch.nn.functional as F
+    z, cfg = load("sail_tiny_pad")
+    P = O.init_params(cfg, int(z["seed"]))
+    tri, seq, eps = torch.from_numpy(z["triples"]), torch.from_numpy(z["seq"]), torch.from_numpy(z["eps0"])
+    ar, kl = O.posterior_bits(P, tri, seq, eps, cfg)
+    with torch.no_grad():
+        zz, mu, logv = O.encoder_forward(P, tri, eps, cfg)
+        logits = O.decoder_forward(P, zz, seq[:, :-1], cfg)
+        nll = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), seq[:, 1:].reshape(-1), ignore_index=0,
+                              reduction="none").reshape(seq.shape[0], -1).sum(1) / math.log(2)
+    np.testing.assert_allclose(ar, nll.numpy(), rtol=1e-5)
+    assert all(k >= 0 for k in kl)
+    # the golden fixture pins mu / logv, hence the KL bits
+    want_kl = (-0.5 * (1 + z["logv0"] - z["mu0"] ** 2 - np.exp(z["logv0"])).sum(1)) / math.log(2)
+    np.testing.assert_allclose(kl, want_kl, rtol=1e-4, atol=1e-7)
+
+
+def test_sampling_distribution_properties():
+    """ARK.generate's sampling rules (reference models.py:431-456) are inline code, not callable: the restatement is
+    pinned by the properties the reference's code implies"""
+    torch.manual_seed(0)
+    logits = torch.randn(5, 23) * 2
+    base = torch.softmax(logits, -1)
+    p = O.sampling_distribution(logits)
+    assert torch.allclose(p, base, atol=1e-7)
+    pk = O.sampling_distribution(logits, top_k=4)
+    assert ((pk > 0).sum(-1) == 4).all() and torch.allclose(pk.sum(-1), torch.ones(5), atol=1e-6)
+    for b in range(5):   # the survivors are the 4 most probable tokens, in their original proportions
+        top = base[b].topk(4).indices
+        assert set(top.tolist()) == set(torch.nonzero(pk[b]).flatten().tolist())
+        assert torch.allclose(pk[b, top] / pk[b, top].sum(), base[b, top] / base[b, top].sum(), atol=1e-6)
+    pp = O.sampling_distribution(logits, top_p=0.6)
+    for b in range(5):   # smallest descending-probability prefix whose mass EXCEEDS top_p
+        sp, si = base[b].sort(descending=True)
+        n = int((sp.cumsum(0) > 0.6).nonzero()[0]) + 1
+        assert set(si[:n].tolist()) == set(torch.nonzero(pp[b]).flatten().tolist())
+        assert float(sp[:n - 1].sum()) <= 0.6 < float(sp[:n].sum())
+    pt = O.sampling_distribution(logits, temperature=0.5)
+    assert torch.allclose(pt, torch.softmax(logits / 0.5, -1), atol=1e-7)
