@@ -1,0 +1,427 @@
+// Tied vocabulary projection fused with the token cross-entropy for LARGE vocabularies: the [B*L, V]
+// logits (1.7 GB fp32 per step at wd-movies B=256, 2.5 GB at wd-articles B=16) and their gradient
+// never exist in memory.  Replaces, for V in the tens of thousands, the sequence
+//   logits = y W_tok^T + b_out        (kgvae/model/models.py:128-134,142)
+//   F.cross_entropy(ignore_index=PAD) (kgvae/experiments/ablation_study.py:65-69)
+//   dY = dlogits W_tok, dW_tok += dlogits^T y, db_out = colsum(dlogits)   (autograd of the above)
+// with two launches, both of the flash-attention kind (softmax over the vocabulary axis):
+//
+//   ark_vocab_ce_fwd  one workgroup per 64 rows; W_tok streams through an LDS-DMA ring in tiles of 64 tokens.
+//                     S^T = W_tile y^T on the matrix cores (TRANSPOSED on purpose: the accumulator then has the
+//                     row index on the lane and the tokens in its registers, so the online max / sum-exp are
+//                     per-lane scalars and exp(S^T - m) IS the B fragment of the second product -- no LDS
+//                     round trip), U^T += W_tile^T P^T with the W fragments re-read transposed from the same
+//                     LDS image (ds_read_b64_tr_b16).  One sweep gives lse, the row loss AND
+//                     dY = (U / l - W_tok[target]) / count.
+//   ark_vocab_ce_dw   one workgroup per 64 tokens; the rows stream through the ring; S = y W_tile^T is
+//                     recomputed (W fragments in registers), G = exp(S + b - lse) - onehot becomes the B
+//                     fragment of dW^T += y^T G (y fragments transposed from the ring image), db_out = colsum(G).
+//
+// 16x16x32 MFMA throughout; the k index of the second product of each kernel is PERMUTED (slot (q, j) of a
+// lane's 8-element fragment = accumulator register j of token/row tile j>>2), which is legal because both
+// operands use the same permutation.  Both products use the forward operand type (fp16 in mixed precision):
+// probabilities are O(1), and the 1/count factor is applied in fp32 at the end.
+// 4 GEMM-equivalents instead of 3, ~6.8 GB (wd-movies) / ~10 GB (wd-articles) of HBM traffic less per step.
+#include "dma_core.h"
+#include "../../include/ark_amd.h"
+
+namespace ark {
+
+typedef short vs16x4 __attribute__((ext_vector_type(4)));
+typedef short vs16x8 __attribute__((ext_vector_type(8)));
+
+struct VocabCeArgs {
+  const void* Y16;        // [R, D] row-major, forward type: top GRU layer outputs, time-major rows (t, b)
+  const void* W16;        // [V, D] row-major, forward type: tied vocabulary weight shadow
+  const float* bias;      // [V]
+  const int64_t* seq;     // [B, ld_seq]: target of row (t, b) is seq[b, t + 1]
+  const float* hyper;
+  float* row_loss;        // [R]
+  float* lse;             // [R] natural-log sum-exp of the logits (input of the dW kernel)
+  float* dY_t;            // [R, D] tile-native fp32 (fwd kernel output, nullable)
+  float* dW;              // [V, D] += (dw kernel)
+  float* db;              // [V] +=
+  long ld_seq;
+  int R, B, V;
+};
+
+constexpr int kVcImg = 64 * 128;   // one k-image: 64 rows x 128 B (64 16-bit elements of the reduction index)
+constexpr int kVcAux = 256;        // per-wave side data of a stage: 64 dwords
+
+// issue one ring stage: DCH k-images of 64 rows; row -> memory row by `rowmap`; pieces dealt over the 8 waves
+template <int DCH, class T, class RM>
+__device__ __forceinline__ void vc_issue_stage(const T* src, int D, RM rowmap, char* slot, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < DCH; ++i) {
+    const int piece = wave + 8 * i, j = piece >> 3, pr = piece & 7;
+    const int row = 8 * pr + (lane >> 3);
+    const T* g = src + (long)rowmap(row) * D + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+  }
+}
+
+// transposed fragment for the second product: element j of lane (i16 = lane&15, q = lane>>4) = image[row(q, j)][16*dt + i16]
+// with row(q, j) = rbase + 16*(j>>2) + 4q + (j&3)
+template <class H8>
+__device__ __forceinline__ H8 vc_tr_frag(const char* img0, int rbase, int dt, int lane) {
+  const int i16 = lane & 15, q = lane >> 4;
+  const int row = rbase + 4 * q + (i16 >> 2);
+  const int chunk = 2 * (dt & 3) + ((i16 & 3) >> 1), within = (i16 & 1) * 8;
+  const char* b = img0 + (dt >> 2) * kVcImg;
+  const vs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) vs16x4*)(b + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + within));
+  const int row2 = row + 16;
+  const vs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) vs16x4*)(b + row2 * 128 + ((chunk ^ ((row2 >> 1) & 7)) << 4) + within));
+  const vs16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(H8, v);
+}
+
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+// ---------------------------------------------------------------------------------------------------------
+template <int PREC, int DCH, bool WITH_DY>
+__global__ __launch_bounds__(512) void vocab_ce_fwd_kernel(VocabCeArgs p) {
+  using PT = PrecTraits<PREC>;
+  using h_t = typename PT::h_t;
+  using h8 = typename PT::h8;
+  constexpr int D = 64 * DCH, KSTEPS = D / 32, DT = D / 16;
+  constexpr int STAGE = DCH * kVcImg, SLOT = STAGE + 8 * kVcAux, LPS = DCH + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave & 3, vh = wave >> 2;
+  const int c = lane & 15, q = lane >> 4;
+  const int R = p.R, V = p.V;
+  const int r = blockIdx.x * 64 + rg * 16 + c;
+  const int rc = min(r, R - 1);
+  const h_t* Y = reinterpret_cast<const h_t*>(p.Y16);
+  const h_t* W = reinterpret_cast<const h_t*>(p.W16);
+  // this lane's row as the B operand of S^T = W y^T: y[r][32s + 8q .. +7]
+  h8 yf[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) yf[s] = *reinterpret_cast<const h8*>(Y + (long)rc * D + 32 * s + 8 * q);
+  const int t = rc / p.B, b = rc % p.B;
+  const long tgt = p.seq[(long)b * p.ld_seq + t + 1];
+  const bool live = r < R && tgt != ARK_TOK_PAD;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on only LDS-DMA is outstanding (counted waits)
+
+  const int nsteps = (V + 63) / 64;
+  auto issue = [&](int s) {
+    char* slot = smem + (s & 1) * SLOT;
+    const int v0 = s * 64;
+    vc_issue_stage<DCH>(W, D, [=](int row) { return min(v0 + row, V - 1); }, slot, wave, lane);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + min(v0 + lane, V - 1)),
+                                     (__attribute__((address_space(3))) void*)(slot + STAGE + wave * kVcAux), 4, 0, 0);
+  };
+  issue(0);
+  if (nsteps > 1) issue(1);
+
+  float m2 = -INFINITY, lsum = 0.f, picked = 0.f;   // running max (log2 domain), this LANE's partial sum, target logit
+  f32x4 U[WITH_DY ? DT : 1];
+  if constexpr (WITH_DY) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) U[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const char* base = smem + (s & 1) * SLOT;
+    f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+      for (int vt = 0; vt < 2; ++vt) {
+        const h8 a = *reinterpret_cast<const h8*>(base + (ks >> 1) * kVcImg + lds_off(vh * 32 + 16 * vt + c, 4 * (ks & 1) + q));
+        S[vt] = PT::mfma(a, yf[ks], S[vt]);
+      }
+    }
+    const float* bw = reinterpret_cast<const float*>(base + STAGE + wave * kVcAux);
+    float sv[8];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int vloc = vh * 32 + 16 * (j >> 2) + 4 * q + (j & 3);
+      const int v = s * 64 + vloc;
+      float x = S[j >> 2][j & 3] + bw[vloc];
+      if ((long)v == tgt) picked = x;
+      x = (v < V) ? x * kLog2e : -INFINITY;
+      sv[j] = x;
+      mt = fmaxf(mt, x);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m2, mt);
+    const float ref = (mn == -INFINITY) ? 0.f : mn;     // (a half-tile beyond V has nothing to add)
+    const float scale = __builtin_amdgcn_exp2f(m2 - ref);   // m2 = -inf -> 0
+    float pj[8], ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { pj[j] = __builtin_amdgcn_exp2f(sv[j] - ref); ps += pj[j]; }
+    lsum = lsum * scale + ps;
+    if constexpr (WITH_DY) {
+      if (__any(scale != 1.0f)) {   // wave-uniform: after the first tiles the running max rarely moves
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) U[dt] *= scale;
+      }
+      h8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = PT::cvt(pj[j]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) U[dt] = PT::mfma(vc_tr_frag<h8>(base, vh * 32, dt, lane), pf, U[dt]);
+    }
+    m2 = mn;
+    if (s + 2 < nsteps) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      issue(s + 2);
+    }
+  }
+  // this lane's row sum over the 4 token quarters held by the lanes c, c+16, c+32, c+48
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  picked += __shfl_xor(picked, 16, 64);   // exactly one lane of one wave saw the target (others hold 0)
+  picked += __shfl_xor(picked, 32, 64);
+  // combine the two token halves (waves w and w+4 share their rows) through the ring space
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  float* xs = reinterpret_cast<float*>(smem);                  // [4 row groups][DT][64 lanes] f32x4 + stats
+  constexpr int UW = (WITH_DY ? DT : 0) * 64 * 4;              // floats per row group
+  float* st = xs + 4 * UW;                                     // [4][3][64]
+  if (vh == 1) {
+    if constexpr (WITH_DY) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(xs + rg * UW + (dt * 64 + lane) * 4) = U[dt];
+    }
+    st[(rg * 3 + 0) * 64 + lane] = m2;
+    st[(rg * 3 + 1) * 64 + lane] = lsum;
+    st[(rg * 3 + 2) * 64 + lane] = picked;
+  }
+  __syncthreads();
+  if (vh == 1) return;
+  const float mb = st[(rg * 3 + 0) * 64 + lane], lb = st[(rg * 3 + 1) * 64 + lane], pb = st[(rg * 3 + 2) * 64 + lane];
+  const float mm = fmaxf(m2, mb);
+  const float fa = __builtin_amdgcn_exp2f(m2 - mm), fb = (mb == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mb - mm);
+  const float l = lsum * fa + lb * fb;
+  const float lse = (mm + __builtin_amdgcn_logf(l)) * kLn2;   // v_log_f32 is log2
+  const float tl = picked + pb;
+  if (q == 0 && r < R) {
+    p.row_loss[r] = live ? (lse - tl) : 0.f;
+    p.lse[r] = lse;
+  }
+  if constexpr (WITH_DY) {
+    if (r >= R) return;
+    const float sc = live ? p.hyper[ARK_HP_CE_INV_COUNT] : 0.f;
+    const float il = 1.0f / l;
+    const h_t* wt = W + (live ? tgt : 0) * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const f32x4 ub = *reinterpret_cast<const f32x4*>(xs + rg * UW + (dt * 64 + lane) * 4);
+      typedef h_t h4 __attribute__((ext_vector_type(4)));
+      const h4 w4 = *reinterpret_cast<const h4*>(wt + 16 * dt + 4 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float g = sc * ((U[dt][i] * fa + ub[i] * fb) * il - (float)w4[i]);
+        p.dY_t[tile_native_off(r, 16 * dt + 4 * q + i, D)] = g;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int PREC, int DCH>
+__global__ __launch_bounds__(512) void vocab_ce_dw_kernel(VocabCeArgs p) {
+  using PT = PrecTraits<PREC>;
+  using h_t = typename PT::h_t;
+  using h8 = typename PT::h8;
+  constexpr int D = 64 * DCH, KSTEPS = D / 32, DT = D / 16;
+  constexpr int STAGE = DCH * kVcImg, SLOT = STAGE + 8 * 2 * kVcAux, LPS = DCH + 2;   // per wave: lse[64] + target[64]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int vg = wave & 3, rh = wave >> 2;
+  const int c = lane & 15, q = lane >> 4;
+  const int R = p.R, V = p.V, B = p.B;
+  const int v = blockIdx.x * 64 + vg * 16 + c;
+  const int vc = min(v, V - 1);
+  const h_t* Y = reinterpret_cast<const h_t*>(p.Y16);
+  const h_t* W = reinterpret_cast<const h_t*>(p.W16);
+  // this lane's token as the B operand of S = y W^T: W[v][32s + 8q .. +7]
+  h8 wf[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) wf[s] = *reinterpret_cast<const h8*>(W + (long)vc * D + 32 * s + 8 * q);
+  const float bv = p.bias[vc] * kLog2e;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const int nsteps = (R + 63) / 64;
+  auto issue = [&](int s) {
+    char* slot = smem + (s & 1) * SLOT;
+    const int r0 = s * 64;
+    vc_issue_stage<DCH>(Y, D, [=](int row) { return min(r0 + row, R - 1); }, slot, wave, lane);
+    // per-wave side data of the stage's 64 rows: lse and the target token (low dword of the int64)
+    const int rr = min(r0 + lane, R - 1);
+    const int t = rr / B, b = rr % B;
+    char* aux = slot + STAGE + wave * 2 * kVcAux;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lse + rr),
+                                     (__attribute__((address_space(3))) void*)aux, 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.seq + (long)b * p.ld_seq + t + 1),
+                                     (__attribute__((address_space(3))) void*)(aux + kVcAux), 4, 0, 0);
+  };
+  issue(0);
+  if (nsteps > 1) issue(1);
+
+  f32x4 dWt[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) dWt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbv = 0.f;
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const char* base = smem + (s & 1) * SLOT;
+    f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const h8 a = *reinterpret_cast<const h8*>(base + (ks >> 1) * kVcImg + lds_off(rh * 32 + 16 * rt + c, 4 * (ks & 1) + q));
+        S[rt] = PT::mfma(a, wf[ks], S[rt]);
+      }
+    }
+    const float* lw = reinterpret_cast<const float*>(base + STAGE + wave * 2 * kVcAux);
+    const int* tw = reinterpret_cast<const int*>(base + STAGE + wave * 2 * kVcAux + kVcAux);
+    h8 gf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int rloc = rh * 32 + 16 * (j >> 2) + 4 * q + (j & 3);
+      const int rr = s * 64 + rloc;
+      const int tg = tw[rloc];
+      float g = __builtin_amdgcn_exp2f(S[j >> 2][j & 3] * kLog2e + bv - lw[rloc] * kLog2e) - (tg == v ? 1.0f : 0.f);
+      if (rr >= R || tg == ARK_TOK_PAD || v >= V) g = 0.f;
+      dbv += g;
+      gf[j] = PT::cvt(g);
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dWt[dt] = PT::mfma(vc_tr_frag<h8>(base, rh * 32, dt, lane), gf, dWt[dt]);
+    if (s + 2 < nsteps) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      issue(s + 2);
+    }
+  }
+  dbv += __shfl_xor(dbv, 16, 64);
+  dbv += __shfl_xor(dbv, 32, 64);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  float* xs = reinterpret_cast<float*>(smem);   // [4 token groups][DT][64 lanes] f32x4, then [4][64] bias partials
+  constexpr int UW = DT * 64 * 4;
+  float* st = xs + 4 * UW;
+  if (rh == 1) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(xs + vg * UW + (dt * 64 + lane) * 4) = dWt[dt];
+    st[vg * 64 + lane] = dbv;
+  }
+  __syncthreads();
+  if (rh == 1 || v >= V) return;
+  const float sc = p.hyper[ARK_HP_CE_INV_COUNT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    const f32x4 ub = *reinterpret_cast<const f32x4*>(xs + vg * UW + (dt * 64 + lane) * 4);
+    f32x4* o = reinterpret_cast<f32x4*>(p.dW + (long)v * D + 16 * dt + 4 * q);
+    *o = *o + (dWt[dt] + ub) * sc;   // (v, d) is owned by exactly one workgroup: a plain read-modify-write
+  }
+  if (q == 0) p.db[v] += (dbv + st[vg * 64 + lane]) * sc;
+}
+
+template <class K>
+static void vc_allow_lds(K kernel, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int DCH>
+constexpr int vc_lds_bytes(int aux_per_wave) {
+  const int ring = 2 * (DCH * kVcImg + 8 * aux_per_wave);
+  const int comb = 4 * (64 * DCH / 16) * 64 * 16 + 4 * 3 * 64 * 4;
+  return ring > comb ? ring : comb;
+}
+
+template <int PREC, int DCH>
+static int vc_launch_fwd(const VocabCeArgs& p, bool with_dy, hipStream_t st) {
+  constexpr int LDS = vc_lds_bytes<DCH>(kVcAux);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  const unsigned grid = (unsigned)((p.R + 63) / 64);
+  if (with_dy) {
+    static bool once = (vc_allow_lds(vocab_ce_fwd_kernel<PREC, DCH, true>, LDS), true); (void)once;
+    hipLaunchKernelGGL((vocab_ce_fwd_kernel<PREC, DCH, true>), dim3(grid), dim3(512), LDS, st, p);
+  } else {
+    static bool once = (vc_allow_lds(vocab_ce_fwd_kernel<PREC, DCH, false>, LDS), true); (void)once;
+    hipLaunchKernelGGL((vocab_ce_fwd_kernel<PREC, DCH, false>), dim3(grid), dim3(512), LDS, st, p);
+  }
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int PREC, int DCH>
+static int vc_launch_dw(const VocabCeArgs& p, hipStream_t st) {
+  constexpr int LDS = vc_lds_bytes<DCH>(2 * kVcAux);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool once = (vc_allow_lds(vocab_ce_dw_kernel<PREC, DCH>, LDS), true); (void)once;
+  hipLaunchKernelGGL((vocab_ce_dw_kernel<PREC, DCH>), dim3((unsigned)((p.V + 63) / 64)), dim3(512), LDS, st, p);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+static int vc_check(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, const float* hyper, int B,
+                    int L, int V, int D) {
+  if (!Y16 || !W16 || !bias || !seq || !hyper || B <= 0 || L <= 0 || V <= 0) return ARK_ERR_ARG;
+  if (prec != PREC_F16 && prec != PREC_BF16) return ARK_ERR_ARG;
+  if (D != 64 && D != 128 && D != 256 && D != 512) return ARK_ERR_SHAPE;
+  if (((uintptr_t)Y16 | (uintptr_t)W16) & 15) return ARK_ERR_ALIGN;
+  return 0;
+}
+
+}  // namespace ark
+
+#define ARK_VC_DISPATCH(FN, ...)                                             \
+  do {                                                                       \
+    if (prec == PREC_F16) {                                                  \
+      if (D == 64) return FN<PREC_F16, 1>(__VA_ARGS__);                      \
+      if (D == 128) return FN<PREC_F16, 2>(__VA_ARGS__);                     \
+      if (D == 256) return FN<PREC_F16, 4>(__VA_ARGS__);                     \
+      return FN<PREC_F16, 8>(__VA_ARGS__);                                   \
+    }                                                                        \
+    if (D == 64) return FN<PREC_BF16, 1>(__VA_ARGS__);                       \
+    if (D == 128) return FN<PREC_BF16, 2>(__VA_ARGS__);                      \
+    if (D == 256) return FN<PREC_BF16, 4>(__VA_ARGS__);                      \
+    return FN<PREC_BF16, 8>(__VA_ARGS__);                                    \
+  } while (0)
+
+extern "C" int ark_vocab_ce_fwd(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq,
+                                int64_t ld_seq, const float* hyper, float* row_loss, float* lse, float* dY_t, int B, int L,
+                                int V, int D, void* stream) {
+  using namespace ark;
+  int rc = vc_check(prec, Y16, W16, bias, seq, hyper, B, L, V, D);
+  if (rc) return rc;
+  if (!row_loss || !lse) return ARK_ERR_ARG;
+  if (dY_t && (B * L) % 16 != 0) return ARK_ERR_SHAPE;   // tile-native dY
+  VocabCeArgs p{Y16, W16, bias, seq, hyper, row_loss, lse, dY_t, nullptr, nullptr, (long)ld_seq, B * L, B, V};
+  const bool with_dy = dY_t != nullptr;
+  ARK_VC_DISPATCH(vc_launch_fwd, p, with_dy, (hipStream_t)stream);
+}
+
+extern "C" int ark_vocab_ce_dw(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
+                               const float* hyper, const float* lse, float* dW, float* db, int B, int L, int V, int D,
+                               void* stream) {
+  using namespace ark;
+  int rc = vc_check(prec, Y16, W16, bias, seq, hyper, B, L, V, D);
+  if (rc) return rc;
+  if (!lse || !dW || !db) return ARK_ERR_ARG;
+  if ((uintptr_t)dW & 15) return ARK_ERR_ALIGN;
+  VocabCeArgs p{Y16, W16, bias, seq, hyper, nullptr, const_cast<float*>(lse), nullptr, dW, db, (long)ld_seq, B * L, B, V};
+  ARK_VC_DISPATCH(vc_launch_dw, p, (hipStream_t)stream);
+}

@@ -182,6 +182,10 @@ class Engine:
         self.fork_after = int(cfg.get("ark_fork_after", 1))   # measured: 0 -> 1.281, 1 -> 1.266, 2 -> 1.296 ms/step
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
         self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))
+        # large vocabularies: tied projection fused with the cross-entropy -- [B*L, V] logits / dlogits never exist
+        # (csrc/vocab_ce.hip); small ones keep the three short launches (W_tok is a few KB there)
+        self.fused_ce = bool(cfg.get("ark_fused_ce", self.use_dma and self.V >= 2048 and self.D in (64, 128, 256, 512)))
+        self._fused_ce_step = False
 
     def _layer_seed(self, l):
         """dropout stream of layer l's output on this rank (hashed with the draw counter and the element index)"""
@@ -372,7 +376,10 @@ class Engine:
             for nm in ("SR", "SZ", "SN", "SHN"):
                 w[nm] = [i16(R, D) for _ in range(n)]                        # tile-native fp16 saves
             w["dG16"] = [i16(R, 4 * D) for _ in range(n)]                    # gate-gradient panels [dr | dz | dn | dn*r]
-            w["dlog16"] = torch.zeros(R, self.Vp, device=dev, dtype=torch.int16)   # K-padded 16-bit dlogits
+            if self.fused_ce:
+                w["lse"] = f(R)
+            else:
+                w["dlog16"] = torch.zeros(R, self.Vp, device=dev, dtype=torch.int16)   # K-padded 16-bit dlogits
             # small vocabularies: the token-embedding gradient as (onehot^T x dgi_0) x W_ih_0 instead of
             # input-gradient GEMM + scatter (SAIL; ARK also needs dX0 for the position embedding)
             w["emb_gemm"] = bool(self.mt == "SAIL" and self.Vp <= 256 and R % 64 == 0 and self.emb_gemm)
@@ -396,7 +403,9 @@ class Engine:
                 w["mask"] = [f(R, D) for _ in range(n - 1)]
                 w["Ydrop"] = [f(R, D) for _ in range(n - 1)]
         self.ldl = _rup(V, 4)
-        w["logits"] = torch.zeros(R, self.ldl, device=dev)
+        if not (v2 and self.fused_ce):   # (the fused path allocates them on first use: reference-style loop, beam search)
+            w["logits"] = torch.zeros(R, self.ldl, device=dev)
+        w["_R"] = R
         w["row_loss"] = f(R)
         w["out4"] = torch.zeros(4, device=dev)
         w["dYa"], w["dYb"] = f(R, D), f(R, D)
@@ -408,6 +417,14 @@ class Engine:
         self._ws_cache[key] = w
         self.ws, self.ws_key = w, key
         return w
+
+    def _logits(self, w):
+        """the materialised [B*L, V] logits buffer (and its 16-bit gradient copy on the fast path), created on demand"""
+        if "logits" not in w:
+            w["logits"] = torch.zeros(w["_R"], self.ldl, device=self.device)
+        if w["v2"] and "dlog16" not in w:
+            w["dlog16"] = torch.zeros(w["_R"], self.Vp, device=self.device, dtype=torch.int16)
+        return w["logits"]
 
     # ------------------------------------------------------------------ kernel wrappers
     def _gemm(self, a_lay, b_lay, epi, A, lda, Bm, ldb, C, ldc, M, N, K, C2=None, bias=None, aux=None, acc=0):
@@ -497,11 +514,26 @@ class Engine:
                         w["Y16b"][l][:B].zero_()
         yield
         st = L.cur_stream()
-        self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop)
+        fused = bool(w["v2"] and self.fused_ce and with_loss)
+        self._fused_ce_step = fused and with_dlogits
+        self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop, project=not fused)
         if with_loss:
             if ce_count is None:
                 _call("ark_count_targets", L.ptr(seq), L.i64(ld_seq), L.i32(B), L.i32(Lq), L.ptr(self.hyper), st)
                 self._hp.pop("CE_COUNT", None)   # the device slot no longer holds what set_hyper last wrote
+        if with_loss and fused:
+            # projection + cross-entropy (+ dY of the top layer, consumed by the backward diagonals) in one sweep over V
+            _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]),
+                  L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
+                  L.ptr(w["dYa"] if with_dlogits else None), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
+            self._finalize = lambda: _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R),
+                                           L.ptr(w["kl"] if self.mt == "SAIL" else None), L.ptr(self.hyper), L.ptr(w["out4"]),
+                                           L.cur_stream())
+            if not (self._defer_finalize and with_dlogits):
+                self._finalize()
+                self._finalize = None
+        elif with_loss:
+            self._logits(w)
             d16 = w["dlog16"] if (with_dlogits and w["v2"]) else None
             # the diagonal backward takes every consumer of dlogits (dY, dW_tok, db_out) from the 16-bit copy:
             # the fp32 gradient is then never written
@@ -538,8 +570,9 @@ class Engine:
         for l in range(self.n):
             _call("ark_zproj_fwd", *zp, L.ptr(w["Y"][l]), L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(self.D), st)
 
-    def _decoder_forward_v2(self, w, seq, ld_seq, B, Lq, use_drop, save=True):
-        """fast decoder forward: token gather -> layer-diagonal GRU sweep -> tied vocabulary projection"""
+    def _decoder_forward_v2(self, w, seq, ld_seq, B, Lq, use_drop, save=True, project=True):
+        """fast decoder forward: token gather -> layer-diagonal GRU sweep -> tied vocabulary projection
+        (project=False: the caller fuses the projection into the cross-entropy)"""
         D, n, V = self.D, self.n, self.V
         R = Lq * B
         st = L.cur_stream()
@@ -549,9 +582,10 @@ class Engine:
               L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0a"]), L.ptr(w["X0b"]), L.i32(B),
               L.i32(Lq), L.i32(D), L.ptr(self.hyper if use_drop else None), st)
         self._diag_sweep(w, B, Lq, use_drop, save)
-        _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(w["Y16a"][n - 1][B:]), L.i64(D), L.ptr(self.wtok16), L.i64(D),
-              L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(p["dec.out.bias"]), L.ptr(None), L.i32(R), L.i32(V), L.i32(D),
-              L.i32(0), st)
+        if project:
+            _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(w["Y16a"][n - 1][B:]), L.i64(D), L.ptr(self.wtok16), L.i64(D),
+                  L.ptr(self._logits(w)), L.i64(self.ldl), L.ptr(p["dec.out.bias"]), L.ptr(None), L.i32(R), L.i32(V), L.i32(D),
+                  L.i32(0), st)
 
     def _diag_sweep(self, w, B, Lq, use_drop, save=True):
         """Layer-diagonal forward recurrence: cells (l, d-l) of one anti-diagonal are independent -> ONE
@@ -592,9 +626,9 @@ class Engine:
                 _call("ark_gru_diag_fwd", L.i32(pf), L.i32(pb), L.i32(len(chunk)), roles, L.ptr(self.hyper), L.i32(B),
                       L.i32(D), ctypes.byref(self.tune), L.cur_stream())
 
-    def _decoder_forward(self, w, seq, ld_seq, B, Lq, use_drop, save=True):
+    def _decoder_forward(self, w, seq, ld_seq, B, Lq, use_drop, save=True, project=True):
         if w["v2"]:
-            return self._decoder_forward_v2(w, seq, ld_seq, B, Lq, use_drop, save)
+            return self._decoder_forward_v2(w, seq, ld_seq, B, Lq, use_drop, save, project)
         D, n, V = self.D, self.n, self.V
         R = Lq * B
         st = L.cur_stream()
@@ -623,7 +657,7 @@ class Engine:
                       *common, *tail)
             xin = w["Ydrop"][l] if drop else Y[B:]
         self._xin_top = xin
-        self._gemm(KM, KM, L.EPI_BIAS, w["Y"][n - 1][B:], D, p["dec.out.weight"], D, w["logits"], self.ldl, R, V, D,
+        self._gemm(KM, KM, L.EPI_BIAS, w["Y"][n - 1][B:], D, p["dec.out.weight"], D, self._logits(w), self.ldl, R, V, D,
                    bias=p["dec.out.bias"])
 
     # ------------------------------------------------------------------ backward
@@ -778,7 +812,7 @@ class Engine:
         st = L.cur_stream()
         KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
         p, g = self.p, self.g
-        dlog = w["logits"]
+        dlog = self._logits(w)
         ytop = w["Y"][n - 1][B:]
         # tied vocabulary projection
         self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
@@ -824,7 +858,6 @@ class Engine:
         pb = self.prec_bwd
         KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
         ld_seq = seq.shape[1]
-        dlog = w["logits"]
         yb = lambda l: (w["Y16b"][l] if w["Y16b"][l] is not None else w["Y16a"][l])
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else main   # ark_overlap_wgrad=0: everything in one queue
@@ -838,23 +871,31 @@ class Engine:
             if self.mt == "SAIL":
                 w["dH0"].zero_()   # the initial-state roles add into it
             filled.record(side)
-            if getattr(self, "_dlog16_valid", False) and self._dlog16_only:
+            if self._fused_ce_step:
+                # dW_tok and db_out from the recomputed softmax (no dlogits buffer): csrc/vocab_ce.hip
+                _call("ark_vocab_ce_dw", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]),
+                      L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["lse"]), L.ptr(g["dec.out.weight"]),
+                      L.ptr(g["dec.out.bias"]), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), L.cur_stream())
+            elif getattr(self, "_dlog16_valid", False) and self._dlog16_only:
                 _call("ark_colsum16", L.i32(pb), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(g["dec.out.bias"]), L.i32(R), L.i32(V),
                       L.i32(1), L.cur_stream())
                 _call("ark_wgrad16_rows", L.i32(pb), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(yb(n - 1)[B:]), L.i64(D),
                       L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(self.Vp), L.i32(V), L.i32(D), L.i32(R), L.cur_stream())
             else:
+                dlog = self._logits(w)
                 self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
                 _call("ark_gemm_wgrad", L.i32(pb), L.ptr(dlog), L.i32(0), L.i64(self.ldl), L.ptr(yb(n - 1)[B:]), L.i32(1), L.i64(D),
                       L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(V), L.i32(D), L.i32(R), L.i32(1), L.cur_stream())
         self._side_used = side is not main
         st = L.cur_stream()
-        if getattr(self, "_dlog16_valid", False):
+        if self._fused_ce_step:
+            pass   # dY of the top layer was written by the fused forward kernel (w["dYa"], tile-native)
+        elif getattr(self, "_dlog16_valid", False):
             _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(self.wtokT16),
                   L.i64(self.Vp), L.ptr(w["dYa"]), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(self.Vp),
                   L.i32(1), st)
         else:   # external dlogits (autograd path): register-staged engine on the fp32 buffer, then re-tile
-            self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
+            self._gemm(KM, MM, L.EPI_NONE, self._logits(w), self.ldl, p["dec.out.weight"], D, w["dX0"], D, R, D, V)
             _call("ark_to_tiled", L.ptr(w["dX0"]), L.ptr(w["dYa"]), L.i32(R), L.i32(D), st)
         main.wait_event(filled)   # the cells accumulate bias gradients into the flat buffer
 

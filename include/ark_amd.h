@@ -251,6 +251,19 @@ int ark_count_targets(const int64_t* seq, int64_t ld_seq, int B, int L, float* h
 int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int64_t ld_seq, const float* hyper,
                    float* row_loss, float* dlogits, void* dlogits16, int prec16, int64_t ld16, int B, int L, int V,
                    void* stream);
+/* Tied vocabulary projection FUSED with the cross-entropy, for large vocabularies: the [B*L, V] logits and their
+ * gradient are never written (reference: logits = out(y), kgvae/model/models.py:128-134,142; F.cross_entropy with
+ * ignore_index = PAD, kgvae/experiments/ablation_study.py:65-69; and their autograd).  Rows are time-major
+ * (t, b); target of row (t, b) is seq[b, t + 1].  Y16 [B*L, D] / W16 [V, D] are 16-bit row-major in `prec`;
+ * D in {64, 128, 256, 512}.
+ *   ark_vocab_ce_fwd: row_loss[r] = lse_r - logit_r[target] (0 for PAD targets), lse[r], and (dY_t non-NULL,
+ *     B*L % 16 == 0) dY = (softmax_r W_tok - W_tok[target]) * hyper[CE_INV_COUNT] in tile-native fp32.
+ *   ark_vocab_ce_dw:  dW[V, D] += dlogits^T Y and db[V] += colsum(dlogits), dlogits recomputed from lse. */
+int ark_vocab_ce_fwd(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
+                     const float* hyper, float* row_loss, float* lse, float* dY_t /* nullable */, int B, int L, int V, int D,
+                     void* stream);
+int ark_vocab_ce_dw(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
+                    const float* hyper, const float* lse, float* dW, float* db, int B, int L, int V, int D, void* stream);
 /* out4 = {loss = ce + beta*kl, ce, kl, sum of token losses}; kl nullable (ARK) */
 int ark_loss_finalize(const float* row_loss, int n_rows, const float* kl, const float* hyper, float* out4,
                       void* stream);

@@ -137,7 +137,7 @@ class _SailFn(torch.autograd.Function):
         B, Lq = seq_in.shape
         w = eng.forward(triples, seq_in, eps, with_loss=False, L_run=Lq)
         V = eng.V
-        logits = w["logits"][:Lq * B, :V].reshape(Lq, B, V).permute(1, 0, 2).contiguous()
+        logits = eng._logits(w)[:Lq * B, :V].reshape(Lq, B, V).permute(1, 0, 2).contiguous()
         ctx.model, ctx.shape, ctx.gen = model, (B, Lq, V), eng.fwd_gen
         return logits, w["mu"].clone(), w["logv"].clone()
 
@@ -148,7 +148,7 @@ class _SailFn(torch.autograd.Function):
         _check_generation(eng, ctx)
         B, Lq, V = ctx.shape
         w = eng.ws
-        buf = w["logits"]
+        buf = eng._logits(w)
         buf.zero_()
         if dlogits is not None:
             buf[:Lq * B, :V].copy_(dlogits.permute(1, 0, 2).reshape(Lq * B, V))
@@ -173,7 +173,7 @@ class _ArkFn(torch.autograd.Function):
         w = eng.forward(None, seq_in, None, with_loss=False, L_run=Lq)
         V = eng.V
         ctx.model, ctx.shape, ctx.gen = model, (B, Lq, V), eng.fwd_gen
-        return w["logits"][:Lq * B, :V].reshape(Lq, B, V).permute(1, 0, 2).contiguous()
+        return eng._logits(w)[:Lq * B, :V].reshape(Lq, B, V).permute(1, 0, 2).contiguous()
 
     @staticmethod
     def backward(ctx, dlogits):
@@ -181,7 +181,7 @@ class _ArkFn(torch.autograd.Function):
         eng = model._eng
         _check_generation(eng, ctx)
         B, Lq, V = ctx.shape
-        buf = eng.ws["logits"]
+        buf = eng._logits(eng.ws)
         buf.zero_()
         buf[:Lq * B, :V].copy_(dlogits.permute(1, 0, 2).reshape(Lq * B, V))
         eng.backward()
@@ -271,7 +271,7 @@ class SAIL(_EngineModel):
                 eng.refresh_shadows()
             eng._decode_h0(w, z.contiguous(), B)
             eng._decoder_forward(w, seq_prefix.contiguous(), Lq, B, Lq, False, save=False)
-            return w["logits"][:Lq * B, :eng.V].reshape(Lq, B, eng.V).permute(1, 0, 2).contiguous()
+            return eng._logits(w)[:Lq * B, :eng.V].reshape(Lq, B, eng.V).permute(1, 0, 2).contiguous()
         finally:
             eng.training = was
 

@@ -234,3 +234,64 @@ def test_wgrad16_rows_guard():
     got = C.double().cpu()
     assert torch.equal(got[mv:], torch.full((M - mv, N), 5.0, dtype=torch.float64))
     assert (got[:mv] - ref[:mv]).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def _tile_native_index(rows, D):
+    r = torch.arange(rows).view(-1, 1)
+    c = torch.arange(D).view(1, -1)
+    return ((r >> 4) * (D >> 4) + (c >> 4)) * 256 + ((((r >> 2) & 3) << 4) + (c & 15)) * 4 + (r & 3)
+
+
+@pytest.mark.parametrize("prec,tol", [(L.PREC_F16, 3e-3), (L.PREC_BF16, 2e-2)])
+@pytest.mark.parametrize("B,Lq,V,D", [(16, 5, 777, 128), (16, 9, 4099, 512), (32, 7, 24101, 128), (16, 3, 60943, 512), (48, 1, 64, 64),
+                                       (16, 6, 2000, 256)])
+def test_fused_vocabulary_cross_entropy(prec, tol, B, Lq, V, D):
+    """ark_vocab_ce_fwd / ark_vocab_ce_dw (logits never materialised) against torch in fp64 on the same 16-bit-rounded
+    operands: per-row loss, log-sum-exp, dY = dlogits W, dW = dlogits^T Y, db = colsum(dlogits), with PAD targets,
+    a vocabulary that is not a multiple of the 64-token tile and a row count that is not a multiple of the 64-row tile"""
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(V + D)
+    R = B * Lq
+    dt = torch.float16 if prec == L.PREC_F16 else torch.bfloat16
+    Y = (torch.randn(R, D, generator=g) * 0.5).to(dt)
+    W = (torch.randn(V, D, generator=g) * (2.0 / D ** 0.5)).to(dt)
+    bias = torch.randn(V, generator=g) * 0.3
+    seq = torch.randint(1, V, (B, Lq + 1), generator=g)
+    seq[1, 2:] = 0                       # PAD targets are ignored
+    seq[0, 1] = V - 1                    # a target in the last (partial) tile
+    tgt = seq[:, 1:].t().reshape(-1)     # rows are time-major: row (t, b) -> seq[b, t+1]
+    count = int((tgt != 0).sum())
+    Yd, Wd = Y.double().requires_grad_(True), W.double().requires_grad_(True)
+    bd = bias.double().requires_grad_(True)
+    logits = Yd @ Wd.t() + bd
+    per_row = F.cross_entropy(logits, tgt, ignore_index=0, reduction="none")
+    (per_row.sum() / count).backward()
+    lse_ref = torch.logsumexp(logits, dim=1).detach()
+    hyper = torch.zeros(16, device=dev)
+    hyper[3], hyper[4] = 1.0 / count, count          # ARK_HP_CE_INV_COUNT, ARK_HP_CE_COUNT
+    Yg, Wg, bg, sq = Y.to(dev), W.to(dev), bias.to(dev), seq.to(dev)
+    row_loss, lse = torch.full((R,), 9.0, device=dev), torch.full((R,), 9.0, device=dev)
+    dY_t = torch.full((R * D,), 9.0, device=dev)
+    common = (L.i32(prec), L.ptr(Yg), L.ptr(Wg), L.ptr(bg), L.ptr(sq), L.i64(Lq + 1), L.ptr(hyper))
+    tail = (L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), L.cur_stream())
+    # evaluation flavour (no dY) first, then the training flavour
+    L.check(L.lib().ark_vocab_ce_fwd(*common, L.ptr(row_loss), L.ptr(lse), L.ptr(None), *tail), "ark_vocab_ce_fwd")
+    torch.cuda.synchronize()
+    ev = row_loss.double().cpu().clone()
+    L.check(L.lib().ark_vocab_ce_fwd(*common, L.ptr(row_loss), L.ptr(lse), L.ptr(dY_t), *tail), "ark_vocab_ce_fwd")
+    dW = torch.full((V, D), 0.25, device=dev)         # += semantics
+    db = torch.full((V,), 0.5, device=dev)
+    L.check(L.lib().ark_vocab_ce_dw(*common, L.ptr(lse), L.ptr(dW), L.ptr(db), *tail), "ark_vocab_ce_dw")
+    torch.cuda.synchronize()
+    got_loss = row_loss.double().cpu()
+    assert (ev - got_loss).abs().max().item() <= 1e-5     # (two instantiations: same sums, different instruction order)
+    assert (got_loss - per_row.detach()).abs().max().item() <= 2e-5 * per_row.max().item()
+    assert (lse.double().cpu() - lse_ref).abs().max().item() <= 2e-5 * lse_ref.abs().max().item()
+    assert (got_loss[tgt == 0] == 0).all()
+    idx = _tile_native_index(R, D).reshape(-1)
+    dY = dY_t.double().cpu()[idx].reshape(R, D)
+    close = lambda got, want, t: (got - want).abs().max().item() <= t * want.abs().max().item() + 1e-12
+    assert close(dY, Yd.grad, tol), (dY - Yd.grad).abs().max().item() / Yd.grad.abs().max().item()
+    assert close(dW.double().cpu() - 0.25, Wd.grad, tol), ((dW.double().cpu() - 0.25) - Wd.grad).abs().max().item() / Wd.grad.abs().max().item()
+    assert close(db.double().cpu() - 0.5, bd.grad, tol)

@@ -11,7 +11,7 @@ import sys
 
 
 def one(pat):
-    f = glob.glob(pat)
+    f = glob.glob(pat) or glob.glob(pat.replace("/*/", "/"))   # rocprofv3 -o NAME writes into the directory itself
     if not f:
         raise SystemExit(f"no file matches {pat}")
     return f[0]
