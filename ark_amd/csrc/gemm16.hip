@@ -15,6 +15,7 @@ struct Gemm16Args {
   long lda, ldb, ldc;
   int M, N, K, epi, c_tiled, tiles_n;
   void* c16a; void* c16b; int prec_a, prec_b;   // optional row-major 16-bit copies of the result (ld = ldc)
+  float* colsum;   // optional: colsum[col] += sum over rows of the value written to C (bias gradient of a dpre output)
 };
 
 template <int PREC, int BM, int BN, int NBUF>
@@ -31,13 +32,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  float csum[G::TN];
+#pragma unroll
+  for (int tn = 0; tn < G::TN; ++tn) csum[tn] = 0.f;
 #pragma unroll
   for (int tm = 0; tm < G::TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < G::TN; ++tn) {
       const int row0 = m0 + wm * G::WTM + tm * 16 + 4 * (lane >> 4);
       const int col = n0 + wn * G::WTN + tn * 16 + (lane & 15);
-      if (row0 >= M || col >= N) continue;
+      if (row0 >= M || col >= N) continue;   // (the column-sum shuffles below run outside this loop: all lanes take part)
       f32x4 v = acc[tm][tn];
       if (p.epi == ARK_EPI_BIAS) v += p.bias[col];
       if (p.c_tiled) {  // M % 16 == 0 and ldc % 16 == 0 (checked on the host): the quad is whole
@@ -45,6 +49,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
         if (p.epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
         *reinterpret_cast<f32x4*>(p.C + o) = v;
       } else {
+        float cs = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (row0 + i >= M) break;
@@ -58,12 +63,25 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
             x = gelu_erf(x);       // the 16-bit copies carry the activation
           } else {
             p.C[o] = x;
+            cs += x;
           }
           if (p.c16a) put16(p.c16a, o, x, p.prec_a);
           if (p.c16b) put16(p.c16b, o, x, p.prec_b);
         }
+        csum[tn] += cs;
       }
     }
+  if (p.colsum && !p.c_tiled) {
+    // the four lane groups of a wave hold different rows of the same columns: fold them, one atomic per column per wave
+#pragma unroll
+    for (int tn = 0; tn < G::TN; ++tn) {
+      float cs = csum[tn];
+      cs += __shfl_xor(cs, 16, 64);
+      cs += __shfl_xor(cs, 32, 64);
+      const int col = n0 + wn * G::WTN + tn * 16 + (lane & 15);
+      if ((lane >> 4) == 0 && col < N) atomicAdd(&p.colsum[col], cs);
+    }
+  }
 }
 
 template <class K>
@@ -138,26 +156,39 @@ __global__ __launch_bounds__(256) void tok_gather16_kernel(const int64_t* __rest
   }
 }
 
-// ---- one-hot rows of the decoder's input tokens: out[(t,b), v] = (v == seq[b,t]), v < Vp -------
-// Turns the embedding-gradient scatter into a product on the matrix cores:
-//   dW_tok = onehot^T x dX0 = (onehot^T x dgi_0) x W_ih_0     (0/1 are exact in every 16-bit type)
+// ---- per-token sums of a 16-bit panel: S[v, c] += sum over rows (t, b) with seq[b, t] == v of X16[(t, b), c] ----
+// With S = the token sums of layer 0's gate-gradient panel, two exact identities replace a [B*L, D] input-gradient
+// product + scatter and a whole weight-gradient product (small vocabularies, no position embedding):
+//   dW_tok  += onehot^T dX0 = S W_ih_0            (autograd embedding_backward of models.py:138)
+//   dW_ih_0 += dgi_0^T X0   = S^T W_tok           (X0 rows ARE rows of W_tok)
+// 64 columns x a chunk of rows per workgroup; the [Vp, 64] table is privatised in LDS (ds_add_f32), then one
+// global float atomic per non-zero entry.  (Round 1 formed S as onehot^T x panel on the matrix cores: 6 + 31 us and
+// a [B*L, Vp] one-hot buffer; this reads the panel once.)
 template <int PREC>
-__global__ __launch_bounds__(256) void onehot16_kernel(const int64_t* __restrict__ seq, long ld_seq, void* out_, int B, int L,
-                                                       int Vp) {
+__global__ __launch_bounds__(256) void token_sums16_kernel(const int64_t* __restrict__ seq, long ld_seq, const void* X_, long ldx,
+                                                           float* __restrict__ S, long lds_, int B, int R, int Vp, int rows_per_wg) {
   using H = typename PrecTraits<PREC>::h_t;
-  typedef H h8v __attribute__((ext_vector_type(8)));
-  const int C8 = Vp >> 3;
-  const long total = (long)B * L * C8;
-  const H one = PrecTraits<PREC>::cvt(1.0f), zero = PrecTraits<PREC>::cvt(0.0f);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C8);
-    const long row = i / C8;
-    const int t = (int)(row / B), b = (int)(row % B);
+  typedef H h4v __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) char smem_ts[];
+  float* tab = reinterpret_cast<float*>(smem_ts);   // [Vp][64]
+  const H* X = reinterpret_cast<const H*>(X_);
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+  for (int i = threadIdx.x; i < Vp * 64; i += 256) tab[i] = 0.f;
+  __syncthreads();
+  const int rsub = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;   // 16 rows per pass, 4 columns per thread
+  for (int r = r0 + rsub; r < r1; r += 16) {
+    const int t = r / B, b = r % B;
     const int tok = (int)seq[(long)b * ld_seq + t];
-    h8v v;
+    const h4v x = *reinterpret_cast<const h4v*>(X + (long)r * ldx + c0 + c4);
+    if (tok >= 0 && tok < Vp) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (8 * c + j == tok) ? one : zero;
-    reinterpret_cast<h8v*>(out_)[i] = v;
+      for (int e = 0; e < 4; ++e) atomicAdd(&tab[tok * 64 + c4 + e], (float)x[e]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Vp * 64; i += 256) {
+    const float v = tab[i];
+    if (v != 0.f) atomicAdd(&S[(long)(i >> 6) * lds_ + c0 + (i & 63)], v);
   }
 }
 
@@ -212,7 +243,7 @@ extern "C" int ark_set_gemm16_tuning(int nbuf, int tile) {
 
 static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
                        int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* c16a,
-                       void* c16b, int prec_b, void* stream) {
+                       void* c16b, int prec_b, float* colsum, void* stream) {
   using namespace ark;
   if (!A16 || !B16 || !C || M <= 0 || N <= 0 || K <= 0) return ARK_ERR_ARG;
   if (K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0) return ARK_ERR_SHAPE;
@@ -221,9 +252,10 @@ static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const vo
   if ((epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU) && !bias) return ARK_ERR_ARG;
   if ((epi == ARK_EPI_MUL_AUX || epi == ARK_EPI_MUL_DGELU) && !aux) return ARK_ERR_ARG;
   if (c_tiled && (M % 16 != 0 || ldc % 16 != 0 || N > ldc)) return ARK_ERR_SHAPE;
-  if (c_tiled && (epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_MUL_DGELU || c16a || c16b)) return ARK_ERR_ARG;
+  if (c_tiled && (epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_MUL_DGELU || c16a || c16b || colsum)) return ARK_ERR_ARG;
+  if (colsum && epi == ARK_EPI_BIAS_GELU) return ARK_ERR_ARG;
   if (c16b && prec_b != PREC_F16 && prec_b != PREC_BF16) return ARK_ERR_ARG;
-  Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0, c16a, c16b, prec, prec_b};
+  Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0, c16a, c16b, prec, prec_b, colsum};
   if (prec == PREC_F16) return launch16<PREC_F16>(p, (hipStream_t)stream);
   if (prec == PREC_BF16) return launch16<PREC_BF16>(p, (hipStream_t)stream);
   return ARK_ERR_ARG;
@@ -232,16 +264,16 @@ static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const vo
 extern "C" int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
                           int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled,
                           void* stream) {
-  return gemm16_impl(prec, epi, A16, lda, B16, ldb, C, ldc, bias, aux, M, N, K, c_tiled, nullptr, nullptr, 0, stream);
+  return gemm16_impl(prec, epi, A16, lda, B16, ldb, C, ldc, bias, aux, M, N, K, c_tiled, nullptr, nullptr, 0, nullptr, stream);
 }
 
 // same product with row-major 16-bit copies of the result written by the epilogue: c16a in `prec`,
 // c16b (nullable) in `prec_b`.  BIAS_GELU: C = pre-activation (fp32), copies = gelu(C);
-// MUL_DGELU: C = acc * gelu'(aux), copies = C.
+// MUL_DGELU: C = acc * gelu'(aux), copies = C.  colsum (nullable, not with BIAS_GELU): colsum[col] += sum_rows C.
 extern "C" int ark_gemm16_ex(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
-                             int64_t ldc, const float* bias, const float* aux, void* c16a, void* c16b, int prec_b, int M,
-                             int N, int K, void* stream) {
-  return gemm16_impl(prec, epi, A16, lda, B16, ldb, C, ldc, bias, aux, M, N, K, 0, c16a, c16b, prec_b, stream);
+                             int64_t ldc, const float* bias, const float* aux, void* c16a, void* c16b, int prec_b,
+                             float* colsum, int M, int N, int K, void* stream) {
+  return gemm16_impl(prec, epi, A16, lda, B16, ldb, C, ldc, bias, aux, M, N, K, 0, c16a, c16b, prec_b, colsum, stream);
 }
 
 extern "C" int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,
@@ -262,15 +294,21 @@ extern "C" int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int6
   return 0;
 }
 
-extern "C" int ark_onehot16(int prec, const int64_t* seq, int64_t ld_seq, void* out16, int B, int L, int Vp, void* stream) {
+extern "C" int ark_token_sums16(int prec, const int64_t* seq, int64_t ld_seq, const void* x16, int64_t ldx, float* S,
+                                int64_t ld_s, int B, int L, int Vp, int n_cols, void* stream) {
   using namespace ark;
-  if (!seq || !out16 || B <= 0 || L <= 0 || Vp <= 0) return ARK_ERR_ARG;
-  if (Vp % 8 != 0) return ARK_ERR_SHAPE;
-  const long total = (long)B * L * (Vp / 8);
-  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  if (!seq || !x16 || !S || B <= 0 || L <= 0 || Vp <= 0 || n_cols <= 0) return ARK_ERR_ARG;
+  if (n_cols % 64 != 0 || ldx % 4 != 0 || (long)Vp * 64 * 4 > 64 * 1024) return ARK_ERR_SHAPE;
+  const int R = B * L;
+  int chunks = 512 / (n_cols / 64);   // ~512 workgroups
+  if (chunks < 1) chunks = 1;
+  int rows_per_wg = ((R + chunks - 1) / chunks + 15) / 16 * 16;
+  if (rows_per_wg < 64) rows_per_wg = 64;
+  dim3 grid(n_cols / 64, (R + rows_per_wg - 1) / rows_per_wg);
+  const size_t lds = (size_t)Vp * 64 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (prec == PREC_F16) hipLaunchKernelGGL(onehot16_kernel<PREC_F16>, dim3(grid), dim3(256), 0, st, seq, (long)ld_seq, out16, B, L, Vp);
-  else if (prec == PREC_BF16) hipLaunchKernelGGL(onehot16_kernel<PREC_BF16>, dim3(grid), dim3(256), 0, st, seq, (long)ld_seq, out16, B, L, Vp);
+  if (prec == PREC_F16) hipLaunchKernelGGL(token_sums16_kernel<PREC_F16>, grid, dim3(256), lds, st, seq, (long)ld_seq, x16, (long)ldx, S, (long)ld_s, B, R, Vp, rows_per_wg);
+  else if (prec == PREC_BF16) hipLaunchKernelGGL(token_sums16_kernel<PREC_BF16>, grid, dim3(256), lds, st, seq, (long)ld_seq, x16, (long)ldx, S, (long)ld_s, B, R, Vp, rows_per_wg);
   else return ARK_ERR_ARG;
   ARK_LAUNCH_CHECK();
   return 0;

@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
                                                                const float* __restrict__ ext_dhead,
                                                                const float* __restrict__ Whead, const float* __restrict__ pre,
                                                                float* __restrict__ dhead, float* __restrict__ dA, void* dA16,
-                                                               int prec16, int B, int Z, int D, int H) {
+                                                               int prec16, float* __restrict__ dA_colsum, int B, int Z, int D,
+                                                               int H) {
   static_assert(RW == 4, "one wave per row");
   extern __shared__ __attribute__((aligned(16))) char smem_lc[];
   float* zs = reinterpret_cast<float*>(smem_lc);   // Wz^T: [Z][D + 1]
@@ -207,15 +208,18 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
     for (int k = 0; k < KC; ++k) {
       const int c = cb + 256 * k + threadIdx.x;
       if (c >= H) continue;
+      float cs = 0.f;
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
         if (row0 + r >= B) break;
         const long o = (long)(row0 + r) * H + c;
         const float v = acc4[k][r] * dgelu_erf(pre[o]);
         dA[o] = v;
+        cs += v;
         if (prec16 == 2) reinterpret_cast<_Float16*>(dA16)[o] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
         else reinterpret_cast<__bf16*>(dA16)[o] = (__bf16)v;
       }
+      if (dA_colsum) atomicAdd(&dA_colsum[c], cs);
     }
   }
 }
@@ -261,6 +265,74 @@ __global__ __launch_bounds__(256) void zproj_bwd_dw_kernel(const float* __restri
       else atomicAdd(&dbz[d], t);
     }
     __syncthreads();
+  }
+}
+
+// Both batch reductions that follow the per-row latent backward, in ONE launch (they used to be three launches --
+// z-projection weights, a column sum, a register-staged skinny product -- ~45 us on the side queue):
+//   job 0:  dWz[d, j] += sum_b dzp[b, d] z[b, j]        dbz[d] += sum_b dzp[b, d]              (models.py:139)
+//   job 1:  dWh[j, c] += sum_b dhead[b, j] act[b, c]    dbh[j] += sum_b dhead[b, j]            (models.py:43-44)
+// i.e. OUT[wide column][skinny column] = sum over the batch of WIDE[b][.] x SKINNY[b][.] with a skinny side of
+// Z / 2Z columns.  64 wide columns x 4 row groups per workgroup over a chunk of the batch; the skinny rows are staged
+// in LDS padded to ZT columns so the ZT accumulators stay in registers.
+struct LatentReduceArgs {
+  const float* dzp; const float* z; float* dWz; float* dbz;              // job 0
+  const float* dhead; const void* act16; int prec16; float* dWh; float* dbh;   // job 1
+  int B, Z, D, H, b_chunk;
+};
+
+template <int ZT>
+__global__ __launch_bounds__(256) void latent_reduce_bwd_kernel(LatentReduceArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_lr[];
+  float* zs = reinterpret_cast<float*>(smem_lr);            // [b_chunk][ZT]
+  float* red = zs + (size_t)p.b_chunk * ZT;                 // [4][64] reused per column
+  const int job = blockIdx.z;
+  const int NW = job == 0 ? p.D : p.H, NS = job == 0 ? p.Z : 2 * p.Z;
+  if ((int)blockIdx.x * 64 >= NW) return;   // block-uniform
+  const float* skinny = job == 0 ? p.z : p.dhead;
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int b0 = blockIdx.y * p.b_chunk, nb = min(p.B, b0 + p.b_chunk) - b0;
+  for (int i = threadIdx.x; i < p.b_chunk * ZT; i += 256) {
+    const int bb = i / ZT, j = i % ZT;
+    zs[i] = (bb < nb && j < NS) ? skinny[(long)(b0 + bb) * NS + j] : 0.f;
+  }
+  __syncthreads();
+  float acc[ZT];
+#pragma unroll
+  for (int j = 0; j < ZT; ++j) acc[j] = 0.f;
+  float sb = 0.f;
+  if (c < NW)
+    for (int bb = rg; bb < nb; bb += 4) {
+      float g;
+      if (job == 0) g = p.dzp[(long)(b0 + bb) * p.D + c];
+      else if (p.prec16 == PREC_F16) g = (float)reinterpret_cast<const _Float16*>(p.act16)[(long)(b0 + bb) * p.H + c];
+      else g = (float)reinterpret_cast<const __bf16*>(p.act16)[(long)(b0 + bb) * p.H + c];
+      sb += g;
+#pragma unroll
+      for (int j = 0; j < ZT; ++j) acc[j] += g * zs[bb * ZT + j];
+    }
+  // cross row-group reduction through LDS, one skinny column at a time (+ the wide column sum for job 0)
+#pragma unroll
+  for (int j = 0; j <= ZT; ++j) {
+    if (j < ZT && j >= NS) continue;          // (uniform: NS is a kernel argument)
+    if (j == ZT && job != 0) continue;
+    const float v = (j < ZT) ? acc[j < ZT ? j : 0] : sb;
+    red[rg * 64 + lane] = v;
+    __syncthreads();
+    if (rg == 0 && c < NW) {
+      const float t = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+      if (j == ZT) atomicAdd(&p.dbz[c], t);
+      else if (job == 0) atomicAdd(&p.dWz[(long)c * p.Z + j], t);
+      else atomicAdd(&p.dWh[(long)j * p.H + c], t);
+    }
+    __syncthreads();
+  }
+  // dbh[j] = column sums of the skinny operand itself: once per batch chunk, by the first column block
+  if (job == 1 && blockIdx.x == 0 && (int)threadIdx.x < NS) {
+    float t = 0.f;
+    for (int bb = 0; bb < nb; ++bb) t += zs[bb * ZT + threadIdx.x];
+    atomicAdd(&p.dbh[threadIdx.x], t);
   }
 }
 
@@ -526,7 +598,8 @@ extern "C" int ark_zproj_bwd_dw(const float* dzp, const float* z, float* d_w_z, 
 
 extern "C" int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_z, const float* head, const float* eps,
                                     const float* hyper, const float* ext_dhead, const float* w_head, const float* pre,
-                                    float* dhead, float* dA, void* dA16, int prec16, int B, int Z, int D, int H, void* stream) {
+                                    float* dhead, float* dA, void* dA16, int prec16, float* dA_colsum, int B, int Z, int D, int H,
+                                    void* stream) {
   using namespace ark;
   if (!dh0 || !h0 || !w_z || !head || !hyper || !w_head || !pre || !dhead || !dA || !dA16 || B <= 0 || Z <= 0 || D <= 0 || H <= 0)
     return ARK_ERR_ARG;
@@ -541,12 +614,36 @@ extern "C" int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), true);           \
     (void)once;                                                                                                             \
     hipLaunchKernelGGL((latent_chain_bwd_kernel<ZT, 4>), dim3((B + 3) / 4), dim3(256), lds, st, dh0, h0, w_z, head, eps,     \
-                       hyper, ext_dhead, w_head, pre, dhead, dA, dA16, prec16, B, Z, D, H);                                  \
+                       hyper, ext_dhead, w_head, pre, dhead, dA, dA16, prec16, dA_colsum, B, Z, D, H);                                  \
   }
   if (Z <= 16) ARK_LC(16)
   else if (Z <= 32) ARK_LC(32)
   else ARK_LC(64)
 #undef ARK_LC
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// the two batch reductions behind ark_latent_chain_bwd in one launch; every output ACCUMULATES (+=):
+// dWz [D,Z], dbz [D] from dzp [B,D] (the in-place output of ark_latent_chain_bwd) and z [B,Z];
+// dWh [2Z,H], dbh [2Z] from dhead [B,2Z] and the 16-bit copy act16 [B,H] of the last encoder activation
+extern "C" int ark_latent_reduce_bwd(const float* dzp, const float* z, float* d_w_z, float* d_b_z, const float* dhead,
+                                     const void* act16, int prec16, float* d_w_head, float* d_b_head, int B, int Z, int D, int H,
+                                     void* stream) {
+  using namespace ark;
+  if (!dzp || !z || !d_w_z || !d_b_z || !dhead || !act16 || !d_w_head || !d_b_head || B <= 0 || Z <= 0 || D <= 0 || H <= 0)
+    return ARK_ERR_ARG;
+  if (prec16 != PREC_F16 && prec16 != PREC_BF16) return ARK_ERR_ARG;
+  if (2 * Z > 128) return ARK_ERR_SHAPE;
+  LatentReduceArgs p{dzp, z, d_w_z, d_b_z, dhead, act16, prec16, d_w_head, d_b_head, B, Z, D, H, 32};
+  const int wide = D > H ? D : H;
+  dim3 grid((wide + 63) / 64, (B + p.b_chunk - 1) / p.b_chunk, 2);
+  hipStream_t st = (hipStream_t)stream;
+#define ARK_LR(ZT) hipLaunchKernelGGL(latent_reduce_bwd_kernel<ZT>, grid, dim3(256), (size_t)(p.b_chunk * ZT + 256) * sizeof(float), st, p)
+  if (2 * Z <= 32) ARK_LR(32);
+  else if (2 * Z <= 64) ARK_LR(64);
+  else ARK_LR(128);
+#undef ARK_LR
   ARK_LAUNCH_CHECK();
   return 0;
 }

@@ -236,7 +236,9 @@ static int launch_wg_prec(Wgrad16Group& g, hipStream_t st) {
   bool ok128 = g_wg_tile == 128;
   for (int i = 0; i < g.n; ++i) ok128 = ok128 && g.p[i].M % 128 == 0 && g.p[i].N % 128 == 0;
   if (ok128) {
-    if (g_wg_nbuf == 2) launch_wg<PREC, 128, 2>(g, st); else launch_wg<PREC, 128, 3>(g, st);
+    if (g_wg_nbuf == 2) launch_wg<PREC, 128, 2>(g, st);
+    else if (g_wg_nbuf == 3) launch_wg<PREC, 128, 3>(g, st);
+    else launch_wg<PREC, 128, 4>(g, st);
   } else {
     if (g_wg_nbuf == 2) launch_wg<PREC, 64, 2>(g, st); else launch_wg<PREC, 64, 4>(g, st);
   }

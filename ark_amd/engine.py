@@ -380,11 +380,11 @@ class Engine:
                 w["lse"] = f(R)
             else:
                 w["dlog16"] = torch.zeros(R, self.Vp, device=dev, dtype=torch.int16)   # K-padded 16-bit dlogits
-            # small vocabularies: the token-embedding gradient as (onehot^T x dgi_0) x W_ih_0 instead of
-            # input-gradient GEMM + scatter (SAIL; ARK also needs dX0 for the position embedding)
-            w["emb_gemm"] = bool(self.mt == "SAIL" and self.Vp <= 256 and R % 64 == 0 and self.emb_gemm)
+            # small vocabularies: token-embedding gradient and layer 0's input weight gradient from the per-token sums
+            # of layer 0's gate-gradient panel instead of input-gradient GEMM + scatter + a [3D,D]x[B*L] weight-gradient
+            # product (SAIL; ARK also needs dX0 for the position embedding)
+            w["emb_gemm"] = bool(self.mt == "SAIL" and self.Vp <= 256 and self.emb_gemm)
             if w["emb_gemm"]:
-                w["onehot16"] = i16(R, self.Vp)
                 w["S_tok"] = f(self.Vp, 3 * D)
             w["h0"] = f(B, D)                                                # row-major h0 (z-projection)
             w["dX0"] = f(R, D)
@@ -486,7 +486,7 @@ class Engine:
                 for i in range(n):
                     _call("ark_gemm16_ex", L.i32(pf), L.i32(L.EPI_BIAS_GELU), L.ptr(a16), L.i64(H), L.ptr(self.wm16[i]), L.i64(H),
                           L.ptr(w["pre"][i]), L.i64(H), L.ptr(p[f"enc.mlp.{2 * i}.bias"]), L.ptr(None), L.ptr(w["act16a"][i]),
-                          L.ptr(w["act16b"][i]), L.i32(pb), L.i32(B), L.i32(H), L.i32(H), st)
+                          L.ptr(w["act16b"][i]), L.i32(pb), L.ptr(None), L.i32(B), L.i32(H), L.i32(H), st)
                     a16 = w["act16a"][i]
                 _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(a16), L.i64(H), L.ptr(self.wh16), L.i64(H),
                       L.ptr(w["head"]), L.i64(2 * Z), L.ptr(p["enc.mu.bias"]), L.ptr(None), L.i32(B), L.i32(2 * Z), L.i32(H),
@@ -723,8 +723,8 @@ class Engine:
             ext = ext_dhead.contiguous() if ext_dhead is not None else None
             _call("ark_latent_chain_bwd", L.ptr(w["dH0"]), L.ptr(h0rm), L.ptr(p["dec.z_proj.weight"]), L.ptr(w["head"]),
                   L.ptr(self._eps), L.ptr(self.hyper), L.ptr(ext), L.ptr(p["enc.mu.weight"]), L.ptr(w["pre"][n - 1]),
-                  L.ptr(w["dhead"]), L.ptr(w["dA"]), L.ptr(w["dpre16"][n - 1]), L.i32(pb), L.i32(B), L.i32(Z), L.i32(D),
-                  L.i32(H), st)
+                  L.ptr(w["dhead"]), L.ptr(w["dA"]), L.ptr(w["dpre16"][n - 1]), L.i32(pb),
+                  L.ptr(g[f"enc.mlp.{2 * (n - 1)}.bias"]), L.i32(B), L.i32(Z), L.i32(D), L.i32(H), st)
             if self._fork_pending is not None:
                 self._fork_pending()
             main = torch.cuda.current_stream()
@@ -732,11 +732,9 @@ class Engine:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 ss = L.cur_stream()
-                _call("ark_zproj_bwd_dw", L.ptr(w["dH0"]), L.ptr(w["z"]), L.ptr(g["dec.z_proj.weight"]),
-                      L.ptr(g["dec.z_proj.bias"]), L.i32(B), L.i32(Z), L.i32(D), L.i32(1), ss)
-                self._colsum(w["dhead"], 2 * Z, g["enc.mu.bias"], B, 2 * Z)
-                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(w["dhead"]), L.i32(0), L.i64(2 * Z), L.ptr(a16b(n - 1)), L.i32(1),
-                      L.i64(H), L.ptr(g["enc.mu.weight"]), L.i64(H), L.i32(2 * Z), L.i32(H), L.i32(B), L.i32(1), ss)
+                _call("ark_latent_reduce_bwd", L.ptr(w["dH0"]), L.ptr(w["z"]), L.ptr(g["dec.z_proj.weight"]),
+                      L.ptr(g["dec.z_proj.bias"]), L.ptr(w["dhead"]), L.ptr(a16b(n - 1)), L.i32(pb), L.ptr(g["enc.mu.weight"]),
+                      L.ptr(g["enc.mu.bias"]), L.i32(B), L.i32(Z), L.i32(D), L.i32(H), ss)
             self._side_used = self._side_used or (side is not main)
         else:
             if self._fork_pending is not None:
@@ -763,7 +761,10 @@ class Engine:
             group = []
             for i in range(n - 1, -1, -1):
                 inp16 = a16b(i - 1) if i > 0 else g16b
-                self._colsum(dpre, H, g[f"enc.mlp.{2 * i}.bias"], B, H)
+                # bias gradient = column sums of dpre: formed by the epilogue that produced dpre (the latent kernel for
+                # the last layer, the product below for the others); only the unfused latent path still needs a pass
+                if i == n - 1 and not fused:
+                    self._colsum(dpre, H, g[f"enc.mlp.{2 * i}.bias"], B, H)
                 if B % 64 == 0:
                     group.append((w["dpre16"][i], H, inp16, H, g[f"enc.mlp.{2 * i}.weight"], H, H, H, B))
                 else:
@@ -772,7 +773,7 @@ class Engine:
                 if i > 0:
                     _call("ark_gemm16_ex", L.i32(pb), L.i32(L.EPI_MUL_DGELU), L.ptr(w["dpre16"][i]), L.i64(H), L.ptr(self.wmT16[i]),
                           L.i64(H), L.ptr(other), L.i64(H), L.ptr(None), L.ptr(w["pre"][i - 1]), L.ptr(w["dpre16"][i - 1]), L.ptr(None),
-                          L.i32(pb), L.i32(B), L.i32(H), L.i32(H), st)
+                          L.i32(pb), L.ptr(g[f"enc.mlp.{2 * (i - 1)}.bias"]), L.i32(B), L.i32(H), L.i32(H), st)
                 else:
                     _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dpre16"][0]), L.i64(H), L.ptr(self.wmT16[0]), L.i64(H),
                           L.ptr(other), L.i64(H), L.ptr(None), L.ptr(None), L.i32(B), L.i32(H), L.i32(H), L.i32(0), st)
@@ -1013,8 +1014,9 @@ class Engine:
             G16 = w["dG16"][l]
             ghh = g[f"dec.gru.weight_hh_l{l}"]
             items += [(G16, 4 * D, yb(l), D, ghh, D, 2 * D, D, R),
-                      (G16[:, 3 * D:], 4 * D, yb(l), D, ghh[2 * D:], D, D, D, R),
-                      (G16, 4 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R)]
+                      (G16[:, 3 * D:], 4 * D, yb(l), D, ghh[2 * D:], D, D, D, R)]
+            if not (l == 0 and emb and w["emb_gemm"]):   # (layer 0's dW_ih comes from the token sums below)
+                items.append((G16, 4 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R))
         if R % 64 == 0:
             for i0 in range(0, len(items), L.WGRAD_MAX_GROUP):
                 self._wgrad_group(items[i0:i0 + L.WGRAD_MAX_GROUP])
@@ -1026,16 +1028,18 @@ class Engine:
             return
         G0 = w["dG16"][0]
         if w["emb_gemm"]:
-            # dW_tok += onehot^T dX0 = (onehot^T dgi_0) W_ih_0: a [Vp,3D] reduction over the tokens on the
-            # matrix cores, then one small exact-fp32 product -- no [R,D] input gradient, no scatter
+            # S = per-token sums of layer 0's gate-gradient panel [Vp, 3D]; then two small exact-fp32 products:
+            #   dW_tok += onehot^T dX0 = S W_ih_0   (no [R,D] input gradient, no scatter)
+            #   dW_ih_0 += dgi_0^T X0 = S^T W_tok   (X0 rows are rows of W_tok: that weight-gradient product is not run)
             w["S_tok"].zero_()
-            _call("ark_onehot16", L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(w["onehot16"]), L.i32(B), L.i32(Lq),
-                  L.i32(self.Vp), ss)
-            _call("ark_wgrad16", L.i32(pb), L.ptr(w["onehot16"]), L.i64(self.Vp), L.ptr(G0), L.i64(4 * D),
-                  L.ptr(w["S_tok"]), L.i64(3 * D), L.i32(self.Vp), L.i32(3 * D), L.i32(R), ss)
+            _call("ark_token_sums16", L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(G0), L.i64(4 * D), L.ptr(w["S_tok"]),
+                  L.i64(3 * D), L.i32(B), L.i32(Lq), L.i32(self.Vp), L.i32(3 * D), ss)
             _call("ark_gemm", L.i32(L.PREC_F32), L.i32(KM), L.i32(MM), L.i32(L.EPI_NONE), L.ptr(w["S_tok"]), L.i64(3 * D),
                   L.ptr(p["dec.gru.weight_ih_l0"]), L.i64(D), L.ptr(g["dec.tok_emb.weight"]), L.i64(D), L.ptr(None),
                   L.ptr(None), L.ptr(None), L.i32(V), L.i32(D), L.i32(3 * D), L.i32(1), ss)
+            _call("ark_gemm", L.i32(L.PREC_F32), L.i32(MM), L.i32(MM), L.i32(L.EPI_NONE), L.ptr(w["S_tok"]), L.i64(3 * D),
+                  L.ptr(p["dec.tok_emb.weight"]), L.i64(D), L.ptr(g["dec.gru.weight_ih_l0"]), L.i64(D), L.ptr(None),
+                  L.ptr(None), L.ptr(None), L.i32(3 * D), L.i32(D), L.i32(V), L.i32(1), ss)
         else:
             _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(G0), L.i64(4 * D), L.ptr(self.wihT16[0]),
                   L.i64(3 * D), L.ptr(w["dX0"]), L.i64(D), L.ptr(None), L.ptr(None), L.i32(R), L.i32(D), L.i32(3 * D),

@@ -177,10 +177,12 @@ int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, vo
 int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* stream);
 /* ark_gemm16 with row-major 16-bit copies of the result (c16a in `prec`, c16b nullable in `prec_b`);
- * BIAS_GELU: C = pre-activation, copies = gelu(C); MUL_DGELU: C = acc * gelu'(aux), copies = C */
+ * BIAS_GELU: C = pre-activation, copies = gelu(C); MUL_DGELU: C = acc * gelu'(aux), copies = C;
+ * colsum (nullable, not with BIAS_GELU): colsum[col] += sum over rows of C -- the bias gradient when C is a
+ * pre-activation gradient (autograd of nn.Linear, models.py:36) */
 int ark_gemm16_ex(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
-                  const float* bias, const float* aux, void* c16a, void* c16b, int prec_b, int M, int N, int K,
-                  void* stream);
+                  const float* bias, const float* aux, void* c16a, void* c16b, int prec_b, float* colsum, int M, int N,
+                  int K, void* stream);
 /* C[M,N] = sum_k A[k,M] B[k,N]: weight gradients with fp32 or 16-bit stored operands */
 int ark_gemm_wgrad(int prec, const void* A, int a_is16, int64_t lda, const void* B, int b_is16, int64_t ldb, float* C,
                    int64_t ldc, int M, int N, int K, int accumulate, void* stream);
@@ -203,10 +205,12 @@ int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq,
 /* h0 = tanh(z_proj(z)) for all layers in every layout of the LDS-DMA path, one launch */
 int ark_zproj_fwd_v2(int prec_a, int prec_b, const float* z, const float* w_z, const float* b_z, float* h0, int n_layers,
                      float* const* y_t, void* const* y16a, void* const* y16b, int B, int Z, int D, void* stream);
-/* one-hot rows of the decoder input tokens, time-major: out16[(t*B+b), v] = (v == seq[b,t]) for v < Vp
- * (Vp % 8 == 0).  With it the embedding-gradient scatter (autograd embedding_backward of
- * models.py:138) becomes dW_tok += (onehot^T x dgi_0) x W_ih_0 on the matrix cores. */
-int ark_onehot16(int prec, const int64_t* seq, int64_t ld_seq, void* out16, int B, int L, int Vp, void* stream);
+/* per-token sums of a 16-bit panel: S[v, 0:n_cols] += sum over rows (t, b) with seq[b, t] == v of x16[(t, b), 0:n_cols]
+ * (rows time-major, v < Vp, Vp * 256 B <= 64 KB of LDS, n_cols % 64 == 0).  With x16 = layer 0's gate-gradient
+ * panel this turns the embedding-gradient scatter (autograd embedding_backward of models.py:138) into
+ * dW_tok += S W_ih_0, and layer 0's input weight gradient into dW_ih_0 += S^T W_tok. */
+int ark_token_sums16(int prec, const int64_t* seq, int64_t ld_seq, const void* x16, int64_t ldx, float* S, int64_t ld_s,
+                     int B, int L, int Vp, int n_cols, void* stream);
 int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, int accumulate, void* stream);
 int ark_cast16(int prec, const float* x, void* out, int64_t n, void* stream);
 int ark_to_tiled(const float* x, float* out, int rows, int ld, void* stream);
@@ -242,8 +246,14 @@ int ark_zproj_bwd_dw(const float* dzp, const float* z, float* d_w_z, float* d_b_
  * and its 16-bit copy.  The reductions over the batch (ark_zproj_bwd_dw, db_head, dW_head) are separate. */
 int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_z, const float* head, const float* eps,
                          const float* hyper, const float* ext_dhead /* nullable */, const float* w_head /* [2Z,H] */,
-                         const float* pre /* [B,H] */, float* dhead, float* dA, void* dA16, int prec16, int B, int Z, int D,
-                         int H, void* stream);
+                         const float* pre /* [B,H] */, float* dhead, float* dA, void* dA16, int prec16,
+                         float* dA_colsum /* nullable: [H] += column sums of dA = bias gradient of the last MLP layer */,
+                         int B, int Z, int D, int H, void* stream);
+/* the batch reductions behind ark_latent_chain_bwd in ONE launch, all outputs accumulate (+=):
+ * dWz [D,Z] / dbz [D] from dzp [B,D] (what ark_latent_chain_bwd leaves in dh0) and z; dW_head [2Z,H] / db_head [2Z]
+ * from dhead [B,2Z] and the 16-bit copy act16 [B,H] (type prec16) of the last encoder activation (models.py:43-44,139) */
+int ark_latent_reduce_bwd(const float* dzp, const float* z, float* d_w_z, float* d_b_z, const float* dhead, const void* act16,
+                          int prec16, float* d_w_head, float* d_b_head, int B, int Z, int D, int H, void* stream);
 int ark_count_targets(const int64_t* seq, int64_t ld_seq, int B, int L, float* hyper, void* stream);
 /* rows are time-major (t,b); target of row (t,b) is seq[b, t+1]; dlogits may alias logits or be NULL */
 /* dlogits16 (nullable): [B*L, ld16] copy of dlogits in 16 bits (prec16), zero beyond V; may be the ONLY gradient

@@ -110,28 +110,32 @@ def test_wgrad16_tr_read_kernel(prec, tile, nbuf, shape):
 
 
 @pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_F16])
-@pytest.mark.parametrize("B,Lq,V", [(16, 3, 55), (48, 10, 130)])
-def test_onehot16(prec, B, Lq, V):
-    """one-hot rows of the decoder input tokens, time-major, padded to a multiple of 64 columns"""
+@pytest.mark.parametrize("B,Lq,V,ncols,ld", [(16, 3, 55, 192, 256), (48, 10, 130, 384, 512), (1024, 10, 55, 1536, 2048)])
+def test_token_sums16(prec, B, Lq, V, ncols, ld):
+    """ark_token_sums16: S[v] += sum of the panel rows whose INPUT token is v (rows time-major; += semantics; columns
+    beyond n_cols of the panel untouched) against index_add_ in fp64"""
     dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(3)
+    g = torch.Generator().manual_seed(3 + B)
     seq = torch.randint(0, V, (B, Lq + 1), generator=g)
     Vp = (V + 63) // 64 * 64
-    out = torch.full((B * Lq, Vp), 7, dtype=torch.int16, device=dev)
-    seq_d = seq.to(dev)
-    L.check(L.lib().ark_onehot16(L.i32(prec), L.ptr(seq_d), L.i64(Lq + 1), L.ptr(out), L.i32(B), L.i32(Lq), L.i32(Vp),
-                                 L.cur_stream()), "ark_onehot16")
+    R = B * Lq
+    dt = torch.bfloat16 if prec == L.PREC_BF16 else torch.float16
+    X = (torch.randn(R, ld, generator=g) * 0.01).to(dt)
+    S = torch.full((Vp, ncols), 0.5, device=dev)
+    seq_d, X_d = seq.to(dev), X.to(dev)     # (named: a temporary would be freed before the launch reads it)
+    L.check(L.lib().ark_token_sums16(L.i32(prec), L.ptr(seq_d), L.i64(Lq + 1), L.ptr(X_d), L.i64(ld), L.ptr(S),
+                                     L.i64(ncols), L.i32(B), L.i32(Lq), L.i32(Vp), L.i32(ncols), L.cur_stream()), "ark_token_sums16")
     torch.cuda.synchronize()
-    got = out.view(torch.bfloat16 if prec == L.PREC_BF16 else torch.float16).float().cpu()
-    want = torch.zeros(B * Lq, Vp)
-    for t in range(Lq):
-        want[t * B + torch.arange(B), seq[:, t]] = 1.0
-    assert torch.equal(got, want)
+    tok = seq[:, :Lq].t().reshape(-1)            # row (t, b) -> seq[b, t]
+    want = torch.full((Vp, ncols), 0.5, dtype=torch.float64)
+    want.index_add_(0, tok, X[:, :ncols].double())
+    assert (S.double().cpu() - want).abs().max().item() <= 2e-6 * (Lq * B / V + 1) ** 0.5 + 1e-6
 
 
 @pytest.mark.parametrize("B,Z,D,H,with_ext", [(8, 10, 64, 192, False), (37, 10, 512, 1536, True), (64, 32, 128, 384, False)])
 def test_latent_chain_bwd_matches_autograd(B, Z, D, H, with_ext):
-    """ark_latent_chain_bwd (dh0 -> dz -> dhead -> dA in one launch) and ark_zproj_bwd_dw against torch autograd of
+    """ark_latent_chain_bwd (dh0 -> dz -> dhead -> dA in one launch, + bias gradient of the last MLP layer) and the
+    batch reductions behind it (ark_zproj_bwd_dw; ark_latent_reduce_bwd, which fuses them) against torch autograd of
     h0 = tanh(z Wz^T + bz), z = mu + eps*exp(0.5*clamp(logv)), loss = <dh0, h0> + beta*kl_norm-scaled KL (+ <ext, head>)"""
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(11)
@@ -161,18 +165,31 @@ def test_latent_chain_bwd_matches_autograd(B, Z, D, H, with_ext):
     bufs = dict(Wz=f(Wz), head=f(head), eps=f(eps), ext=f(ext), Wh=f(Whead), pre=f(pre))
     dhead, dA = torch.zeros(B, 2 * Z, device=dev), torch.zeros(B, H, device=dev)
     dA16 = torch.zeros(B, H, dtype=torch.int16, device=dev)
+    dbA = torch.full((H,), 0.5, device=dev)          # += semantics
     L.check(L.lib().ark_latent_chain_bwd(L.ptr(dh0_d), L.ptr(h0_d), L.ptr(bufs["Wz"]), L.ptr(bufs["head"]), L.ptr(bufs["eps"]),
                                          L.ptr(hyper), L.ptr(bufs["ext"] if with_ext else None), L.ptr(bufs["Wh"]),
-                                         L.ptr(bufs["pre"]), L.ptr(dhead), L.ptr(dA), L.ptr(dA16), L.i32(L.PREC_BF16), L.i32(B),
-                                         L.i32(Z), L.i32(D), L.i32(H), L.cur_stream()), "ark_latent_chain_bwd")
+                                         L.ptr(bufs["pre"]), L.ptr(dhead), L.ptr(dA), L.ptr(dA16), L.i32(L.PREC_BF16), L.ptr(dbA),
+                                         L.i32(B), L.i32(Z), L.i32(D), L.i32(H), L.cur_stream()), "ark_latent_chain_bwd")
     dWz, dbz = torch.zeros(D, Z, device=dev), torch.zeros(D, device=dev)
     L.check(L.lib().ark_zproj_bwd_dw(L.ptr(dh0_d), L.ptr(z_d), L.ptr(dWz), L.ptr(dbz), L.i32(B), L.i32(Z), L.i32(D), L.i32(0),
                                      L.cur_stream()), "ark_zproj_bwd_dw")
+    # the fused reduction: same dWz / dbz plus the head weight / bias gradients from dhead and a 16-bit activation copy
+    act16 = torch.nn.functional.gelu(pre).to(torch.bfloat16)
+    dWz2, dbz2 = torch.full((D, Z), 0.25, device=dev), torch.full((D,), 0.25, device=dev)
+    dWh, dbh = torch.full((2 * Z, H), 0.25, device=dev), torch.full((2 * Z,), 0.25, device=dev)
+    act16_d = act16.to(dev)
+    L.check(L.lib().ark_latent_reduce_bwd(L.ptr(dh0_d), L.ptr(z_d), L.ptr(dWz2), L.ptr(dbz2), L.ptr(dhead), L.ptr(act16_d),
+                                          L.i32(L.PREC_BF16), L.ptr(dWh), L.ptr(dbh), L.i32(B), L.i32(Z), L.i32(D), L.i32(H),
+                                          L.cur_stream()), "ark_latent_reduce_bwd")
     torch.cuda.synchronize()
     close = lambda got, want, tol: (got.double().cpu() - want).abs().max().item() <= tol * (want.abs().max().item() + 1e-12)
     assert close(dA, pre_t.grad, 2e-5)
     assert close(dA16.view(torch.bfloat16).float(), pre_t.grad, 1e-2)
+    assert close(dbA - 0.5, pre_t.grad.sum(0), 2e-5)
     assert close(dWz, Wz_t.grad, 2e-5) and close(dbz, bz_t.grad, 2e-5)
+    assert close(dWz2 - 0.25, Wz_t.grad, 2e-5) and close(dbz2 - 0.25, bz_t.grad, 2e-5)
+    dh = dhead.double().cpu()
+    assert close(dWh - 0.25, dh.t() @ act16.double(), 2e-5) and close(dbh - 0.25, dh.sum(0), 2e-5)
     # dhead^T gelu(pre) is the head weight gradient: checks dhead itself
     assert close(dhead.double().cpu().t() @ torch.nn.functional.gelu(pre), Wh_t.grad, 2e-5)
 
