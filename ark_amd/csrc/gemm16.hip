@@ -161,30 +161,93 @@ __global__ __launch_bounds__(256) void tok_gather16_kernel(const int64_t* __rest
 // product + scatter and a whole weight-gradient product (small vocabularies, no position embedding):
 //   dW_tok  += onehot^T dX0 = S W_ih_0            (autograd embedding_backward of models.py:138)
 //   dW_ih_0 += dgi_0^T X0   = S^T W_tok           (X0 rows ARE rows of W_tok)
-// 64 columns x a chunk of rows per workgroup; the [Vp, 64] table is privatised in LDS (ds_add_f32), then one
-// global float atomic per non-zero entry.  (Round 1 formed S as onehot^T x panel on the matrix cores: 6 + 31 us and
-// a [B*L, Vp] one-hot buffer; this reads the panel once.)
+// A tiny vocabulary means MANY rows per token (every row of step 0 is BOS; a relation slot has 3 values), so adding
+// rows into a shared table with atomics serialises.  Instead the rows of each chunk are counting-sorted by token ONCE
+// (token_sort_kernel: two passes of LDS integer atomics over <= a few hundred rows), and every (token, column) sum is
+// then a plain loop over that token's row list -- the only atomics left are one per table entry.
+__global__ __launch_bounds__(256) void token_sort_kernel(const int64_t* __restrict__ seq, long ld_seq, int B, int R, int Vp,
+                                                         int rows_per_chunk, short* __restrict__ perm, short* __restrict__ ptok,
+                                                         int* __restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) char smem_sort[];
+  int* cnt = reinterpret_cast<int*>(smem_sort);        // [Vp + 1] counts, then exclusive starts
+  int* fill = cnt + Vp + 1;                            // [Vp]
+  short* tk = reinterpret_cast<short*>(fill + Vp);     // [rows_per_chunk]
+  const int r0 = blockIdx.x * rows_per_chunk, nr = min(R, r0 + rows_per_chunk) - r0;
+  for (int i = threadIdx.x; i <= Vp; i += 256) cnt[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nr; i += 256) {
+    const int r = r0 + i, t = r / B, b = r % B;
+    int tok = (int)seq[(long)b * ld_seq + t];
+    if (tok < 0 || tok >= Vp) tok = Vp;                // out-of-range ids are dropped (list Vp is never summed)
+    tk[i] = (short)tok;
+    if (tok < Vp) atomicAdd(&cnt[tok], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {                              // Vp <= 256: a serial exclusive scan is a few hundred cycles
+    int run = 0;
+    for (int v = 0; v < Vp; ++v) { const int c = cnt[v]; cnt[v] = run; fill[v] = run; run += c; }
+    cnt[Vp] = run;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nr; i += 256) {
+    const int tok = tk[i];
+    if (tok < Vp) {
+      const int pos = atomicAdd(&fill[tok], 1);
+      perm[r0 + pos] = (short)i;
+      ptok[r0 + pos] = (short)tok;
+    }
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = cnt[Vp];   // rows of this chunk that carry a token in range
+}
+
 template <int PREC>
-__global__ __launch_bounds__(256) void token_sums16_kernel(const int64_t* __restrict__ seq, long ld_seq, const void* X_, long ldx,
-                                                           float* __restrict__ S, long lds_, int B, int R, int Vp, int rows_per_wg) {
+__global__ __launch_bounds__(256) void token_sums16_kernel(const short* __restrict__ perm, const short* __restrict__ ptok,
+                                                           const int* __restrict__ counts, const void* X_, long ldx,
+                                                           float* __restrict__ S, long lds_, int Vp, int rows_per_chunk) {
   using H = typename PrecTraits<PREC>::h_t;
   typedef H h4v __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char smem_ts[];
   float* tab = reinterpret_cast<float*>(smem_ts);   // [Vp][64]
   const H* X = reinterpret_cast<const H*>(X_);
-  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * rows_per_chunk, n = counts[blockIdx.y];
   for (int i = threadIdx.x; i < Vp * 64; i += 256) tab[i] = 0.f;
   __syncthreads();
-  const int rsub = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;   // 16 rows per pass, 4 columns per thread
-  for (int r = r0 + rsub; r < r1; r += 16) {
-    const int t = r / B, b = r % B;
-    const int tok = (int)seq[(long)b * ld_seq + t];
-    const h4v x = *reinterpret_cast<const h4v*>(X + (long)r * ldx + c0 + c4);
-    if (tok >= 0 && tok < Vp) {
+  // 16 row lanes x 16 column quads.  A row lane walks a CONTIGUOUS piece of the token-sorted row list, so it meets a
+  // handful of distinct tokens: it sums in registers and touches the LDS table only when the token changes.
+  const int rl = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+  const int per = (n + 15) / 16, lo = min(n, rl * per), hi = min(n, lo + per);
+  const short* pm = perm + r0;
+  const short* pt = ptok + r0;
+  int cur = -1;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  auto flush = [&]() {
+    if (cur >= 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(&tab[tok * 64 + c4 + e], (float)x[e]);
+      for (int e = 0; e < 4; ++e) atomicAdd(&tab[cur * 64 + c4 + e], acc[e]);
+    }
+  };
+  for (int k = lo; k < hi; k += 4) {
+    h4v x[4];
+    int tk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // four independent loads in flight per thread
+      const int kk = min(k + u, hi - 1);
+      tk[u] = pt[kk];
+      x[u] = *reinterpret_cast<const h4v*>(X + (long)(r0 + pm[kk]) * ldx + c0 + c4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (k + u >= hi) break;
+      if (tk[u] != cur) {
+        flush();
+        cur = tk[u];
+        acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += (float)x[u][e];
     }
   }
+  flush();
   __syncthreads();
   for (int i = threadIdx.x; i < Vp * 64; i += 256) {
     const float v = tab[i];
@@ -295,20 +358,30 @@ extern "C" int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int6
 }
 
 extern "C" int ark_token_sums16(int prec, const int64_t* seq, int64_t ld_seq, const void* x16, int64_t ldx, float* S,
-                                int64_t ld_s, int B, int L, int Vp, int n_cols, void* stream) {
+                                int64_t ld_s, void* scratch, int64_t scratch_bytes, int B, int L, int Vp, int n_cols,
+                                void* stream) {
   using namespace ark;
-  if (!seq || !x16 || !S || B <= 0 || L <= 0 || Vp <= 0 || n_cols <= 0) return ARK_ERR_ARG;
+  if (!seq || !x16 || !S || !scratch || B <= 0 || L <= 0 || Vp <= 0 || n_cols <= 0) return ARK_ERR_ARG;
   if (n_cols % 64 != 0 || ldx % 4 != 0 || (long)Vp * 64 * 4 > 64 * 1024) return ARK_ERR_SHAPE;
   const int R = B * L;
-  int chunks = 512 / (n_cols / 64);   // ~512 workgroups
+  int chunks = 512 / (n_cols / 64);   // ~512 workgroups in the sum kernel
   if (chunks < 1) chunks = 1;
-  int rows_per_wg = ((R + chunks - 1) / chunks + 15) / 16 * 16;
-  if (rows_per_wg < 64) rows_per_wg = 64;
-  dim3 grid(n_cols / 64, (R + rows_per_wg - 1) / rows_per_wg);
-  const size_t lds = (size_t)Vp * 64 * sizeof(float);
+  int rows_per_chunk = ((R + chunks - 1) / chunks + 15) / 16 * 16;
+  if (rows_per_chunk < 64) rows_per_chunk = 64;
+  if (rows_per_chunk > 8192) rows_per_chunk = 8192;   // (row-in-chunk indices are 16-bit; LDS holds one per row)
+  chunks = (R + rows_per_chunk - 1) / rows_per_chunk;
+  const size_t lst = ((size_t)R * sizeof(short) + 15) / 16 * 16;
+  if ((size_t)scratch_bytes < 2 * lst + (size_t)chunks * sizeof(int)) return ARK_ERR_ARG;
+  short* perm = reinterpret_cast<short*>(scratch);
+  short* ptok = reinterpret_cast<short*>(reinterpret_cast<char*>(scratch) + lst);
+  int* counts = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + 2 * lst);
   hipStream_t st = (hipStream_t)stream;
-  if (prec == PREC_F16) hipLaunchKernelGGL(token_sums16_kernel<PREC_F16>, grid, dim3(256), lds, st, seq, (long)ld_seq, x16, (long)ldx, S, (long)ld_s, B, R, Vp, rows_per_wg);
-  else if (prec == PREC_BF16) hipLaunchKernelGGL(token_sums16_kernel<PREC_BF16>, grid, dim3(256), lds, st, seq, (long)ld_seq, x16, (long)ldx, S, (long)ld_s, B, R, Vp, rows_per_wg);
+  const size_t lds = (size_t)(2 * Vp + 1) * sizeof(int) + (size_t)rows_per_chunk * sizeof(short);
+  hipLaunchKernelGGL(token_sort_kernel, dim3(chunks), dim3(256), lds, st, seq, (long)ld_seq, B, R, Vp, rows_per_chunk, perm, ptok, counts);
+  dim3 grid(n_cols / 64, chunks);
+  const size_t tlds = (size_t)Vp * 64 * sizeof(float);
+  if (prec == PREC_F16) hipLaunchKernelGGL(token_sums16_kernel<PREC_F16>, grid, dim3(256), tlds, st, perm, ptok, counts, x16, (long)ldx, S, (long)ld_s, Vp, rows_per_chunk);
+  else if (prec == PREC_BF16) hipLaunchKernelGGL(token_sums16_kernel<PREC_BF16>, grid, dim3(256), tlds, st, perm, ptok, counts, x16, (long)ldx, S, (long)ld_s, Vp, rows_per_chunk);
   else return ARK_ERR_ARG;
   ARK_LAUNCH_CHECK();
   return 0;

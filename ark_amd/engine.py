@@ -386,6 +386,7 @@ class Engine:
             w["emb_gemm"] = bool(self.mt == "SAIL" and self.Vp <= 256 and self.emb_gemm)
             if w["emb_gemm"]:
                 w["S_tok"] = f(self.Vp, 3 * D)
+                w["tok_scratch"] = torch.empty(4 * R + 32 + 4 * (R // 64 + 1), device=dev, dtype=torch.uint8)
             w["h0"] = f(B, D)                                                # row-major h0 (z-projection)
             w["dX0"] = f(R, D)
             if self.p_drop > 0:   # the dropout mask itself is regenerated in-kernel from a counter hash
@@ -1033,7 +1034,8 @@ class Engine:
             #   dW_ih_0 += dgi_0^T X0 = S^T W_tok   (X0 rows are rows of W_tok: that weight-gradient product is not run)
             w["S_tok"].zero_()
             _call("ark_token_sums16", L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(G0), L.i64(4 * D), L.ptr(w["S_tok"]),
-                  L.i64(3 * D), L.i32(B), L.i32(Lq), L.i32(self.Vp), L.i32(3 * D), ss)
+                  L.i64(3 * D), L.ptr(w["tok_scratch"]), L.i64(w["tok_scratch"].numel()), L.i32(B), L.i32(Lq), L.i32(self.Vp),
+                  L.i32(3 * D), ss)
             _call("ark_gemm", L.i32(L.PREC_F32), L.i32(KM), L.i32(MM), L.i32(L.EPI_NONE), L.ptr(w["S_tok"]), L.i64(3 * D),
                   L.ptr(p["dec.gru.weight_ih_l0"]), L.i64(D), L.ptr(g["dec.tok_emb.weight"]), L.i64(D), L.ptr(None),
                   L.ptr(None), L.ptr(None), L.i32(V), L.i32(D), L.i32(3 * D), L.i32(1), ss)

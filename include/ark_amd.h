@@ -206,11 +206,12 @@ int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq,
 int ark_zproj_fwd_v2(int prec_a, int prec_b, const float* z, const float* w_z, const float* b_z, float* h0, int n_layers,
                      float* const* y_t, void* const* y16a, void* const* y16b, int B, int Z, int D, void* stream);
 /* per-token sums of a 16-bit panel: S[v, 0:n_cols] += sum over rows (t, b) with seq[b, t] == v of x16[(t, b), 0:n_cols]
- * (rows time-major, v < Vp, Vp * 256 B <= 64 KB of LDS, n_cols % 64 == 0).  With x16 = layer 0's gate-gradient
- * panel this turns the embedding-gradient scatter (autograd embedding_backward of models.py:138) into
+ * (rows time-major, v < Vp, Vp * 256 B <= 64 KB of LDS, n_cols % 64 == 0; ids outside [0, Vp) are skipped).  `scratch`
+ * (caller-owned, >= 4*B*L + 32 + 4*ceil(B*L/64) bytes) holds the per-chunk row lists sorted by token.  With x16 = layer 0's
+ * gate-gradient panel this turns the embedding-gradient scatter (autograd embedding_backward of models.py:138) into
  * dW_tok += S W_ih_0, and layer 0's input weight gradient into dW_ih_0 += S^T W_tok. */
 int ark_token_sums16(int prec, const int64_t* seq, int64_t ld_seq, const void* x16, int64_t ldx, float* S, int64_t ld_s,
-                     int B, int L, int Vp, int n_cols, void* stream);
+                     void* scratch, int64_t scratch_bytes, int B, int L, int Vp, int n_cols, void* stream);
 int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, int accumulate, void* stream);
 int ark_cast16(int prec, const float* x, void* out, int64_t n, void* stream);
 int ark_to_tiled(const float* x, float* out, int rows, int ld, void* stream);
