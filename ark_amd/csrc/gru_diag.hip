@@ -197,6 +197,9 @@ static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t 
   }
   if (rows == 128 && units != 64) rows = 64;   // 128-row tiles exist for 64-unit tiles only
   const int MT = (p.B + rows - 1) / rows, UT = p.D / units;
+  // (measured and not kept: four ring slots instead of two for grids of at most one workgroup per CU -- wd-movies B=256,
+  //  wd-articles B=16 -- 5.9 -> 6.2 us forward, 9.9 -> 13.6 us backward per launch)
+  const bool deep = false;
   p.xcd_map = (tn.fwd_xcd && UT % 4 == 0 && MT % 2 == 0) ? 1 : 0;
   if (units == 64) {   // 8 waves
     if (rows == 128) launch_diag<PREC, PRECB, 2, 1, 128, 64>(p, st);
@@ -207,8 +210,9 @@ static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t 
     else if (tn.fwd_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 64, 32>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 64, 32>(p, st);
   } else {
-    if (ki2) launch_diag<PREC, PRECB, 2, 2, 32, 32>(p, st);
-    else if (tn.fwd_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 32, 32>(p, st);
+    if (ki2 && deep) launch_diag<PREC, PRECB, 4, 2, 32, 32>(p, st);
+    else if (ki2) launch_diag<PREC, PRECB, 2, 2, 32, 32>(p, st);
+    else if (tn.fwd_nbuf >= 4 || deep) launch_diag<PREC, PRECB, 4, 1, 32, 32>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 32, 32>(p, st);
   }
   ARK_LAUNCH_CHECK();
@@ -461,17 +465,20 @@ template <int PREC>
 static int launch_diag_bwd_cfg(GruDiagBwdArgs& p, const ArkDiagTuning& tn, hipStream_t st) {
   const bool ki2 = tn.bwd_ki == 2 && p.D % 128 == 0;   // every K-segment (3D, 2D, D) must be a whole number of stages
   {
-    const int MT = (p.B + tn.bwd_rows - 1) / tn.bwd_rows, NT = p.D / 64;
+    const int rows = tn.bwd_rows;
+    const int MT = (p.B + rows - 1) / rows, NT = p.D / 64;
     const int xm = tn.bwd_xcd_rows;
     p.xcd_m = (xm > 1 && MT % xm == 0 && NT % (8 / xm) == 0) ? xm : 1;
   }
-  if (tn.bwd_rows == 64) {
+  const bool deep = false;   // (see the forward launch)
+  if (tn.bwd_rows == 64 && !deep) {
     if (ki2) launch_diag_bwd<PREC, 2, 2, 64>(p, st);
     else if (tn.bwd_nbuf >= 4) launch_diag_bwd<PREC, 4, 1, 64>(p, st);
     else launch_diag_bwd<PREC, 2, 1, 64>(p, st);
   } else {
-    if (ki2) launch_diag_bwd<PREC, 2, 2, 32>(p, st);
-    else if (tn.bwd_nbuf >= 4) launch_diag_bwd<PREC, 4, 1, 32>(p, st);
+    if (ki2 && deep) launch_diag_bwd<PREC, 4, 2, 32>(p, st);
+    else if (ki2) launch_diag_bwd<PREC, 2, 2, 32>(p, st);
+    else if (tn.bwd_nbuf >= 4 || deep) launch_diag_bwd<PREC, 4, 1, 32>(p, st);
     else launch_diag_bwd<PREC, 2, 1, 32>(p, st);
   }
   ARK_LAUNCH_CHECK();

@@ -48,12 +48,17 @@ struct VocabCeArgs {
 constexpr int kVcImg = 64 * 128;   // one k-image: 64 rows x 128 B (64 16-bit elements of the reduction index)
 constexpr int kVcAux = 256;        // per-wave side data of a stage: 64 dwords
 
-// issue one ring stage: DCH k-images of 64 rows; row -> memory row by `rowmap`; pieces dealt over the 8 waves
-template <int DCH, class T, class RM>
+// issue one ring stage: DCH k-images of 64 rows = 8*DCH one-KB pieces, dealt round-robin over the NW waves (every wave
+// issues PPW = ceil(8*DCH / NW) instructions so that the counted vmcnt waits are the same for all; a wave whose last
+// piece does not exist repeats piece 0's bytes into piece 0 -- same data, harmless)
+template <int DCH, int NW, class T, class RM>
 __device__ __forceinline__ void vc_issue_stage(const T* src, int D, RM rowmap, char* slot, int wave, int lane) {
+  constexpr int NP = 8 * DCH, PPW = (NP + NW - 1) / NW;
 #pragma unroll
-  for (int i = 0; i < DCH; ++i) {
-    const int piece = wave + 8 * i, j = piece >> 3, pr = piece & 7;
+  for (int i = 0; i < PPW; ++i) {
+    int piece = wave + NW * i;
+    if (piece >= NP) piece = 0;
+    const int j = piece >> 3, pr = piece & 7;
     const int row = 8 * pr + (lane >> 3);
     const T* g = src + (long)rowmap(row) * D + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -80,21 +85,42 @@ __device__ __forceinline__ H8 vc_tr_frag(const char* img0, int rbase, int dt, in
 
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
+// ring depth by model width: a stage is 64 rows x D 16-bit elements (8 KB per 64 of D); narrow models afford four slots
+// -- three stages in flight per workgroup -- and need them: at D = 128 a step is ~0.3 us of matrix work behind ~1 us of
+// LDS-DMA latency with one stage in flight
+template <int DCH> constexpr int vc_slots() { return DCH <= 2 ? 4 : DCH <= 4 ? 3 : 2; }
+
+// wait until all but the youngest `k` stages (LPS LDS-DMA instructions each) of this wave have landed
+template <int LPS>
+__device__ __forceinline__ void vc_wait_stages(int k) {
+  switch (k) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory"); break;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
-template <int PREC, int DCH, bool WITH_DY>
-__global__ __launch_bounds__(512) void vocab_ce_fwd_kernel(VocabCeArgs p) {
+// RG groups of 16 rows per workgroup (2*RG waves: RG row groups x 2 token halves), chosen on the host so that the row
+// tiles fill the 256 CUs evenly (64-row tiles gave 280 workgroups at wd-movies B=256: two rounds for 1.09 rounds of work)
+template <int PREC, int DCH, int RG, bool WITH_DY>
+__global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
   using h8 = typename PT::h8;
   constexpr int D = 64 * DCH, KSTEPS = D / 32, DT = D / 16;
-  constexpr int STAGE = DCH * kVcImg, SLOT = STAGE + 8 * kVcAux, LPS = DCH + 1;
+  constexpr int NW = 2 * RG;
+  constexpr int STAGE = DCH * kVcImg, SLOT = STAGE + NW * kVcAux, LPS = (8 * DCH + NW - 1) / NW + 1;
+  constexpr int NSLOT = vc_slots<DCH>();
+  static_assert((NSLOT - 1) * LPS <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rg = wave & 3, vh = wave >> 2;
+  const int rg = wave % RG, vh = wave / RG;
   const int c = lane & 15, q = lane >> 4;
   const int R = p.R, V = p.V;
-  const int r = blockIdx.x * 64 + rg * 16 + c;
+  const int r = blockIdx.x * (16 * RG) + rg * 16 + c;
   const int rc = min(r, R - 1);
   const h_t* Y = reinterpret_cast<const h_t*>(p.Y16);
   const h_t* W = reinterpret_cast<const h_t*>(p.W16);
@@ -109,14 +135,13 @@ __global__ __launch_bounds__(512) void vocab_ce_fwd_kernel(VocabCeArgs p) {
 
   const int nsteps = (V + 63) / 64;
   auto issue = [&](int s) {
-    char* slot = smem + (s & 1) * SLOT;
+    char* slot = smem + (s % NSLOT) * SLOT;
     const int v0 = s * 64;
-    vc_issue_stage<DCH>(W, D, [=](int row) { return min(v0 + row, V - 1); }, slot, wave, lane);
+    vc_issue_stage<DCH, NW>(W, D, [=](int row) { return min(v0 + row, V - 1); }, slot, wave, lane);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + min(v0 + lane, V - 1)),
                                      (__attribute__((address_space(3))) void*)(slot + STAGE + wave * kVcAux), 4, 0, 0);
   };
-  issue(0);
-  if (nsteps > 1) issue(1);
+  for (int s = 0; s < NSLOT && s < nsteps; ++s) issue(s);
 
   float m2 = -INFINITY, lsum = 0.f, picked = 0.f;   // running max (log2 domain), this LANE's partial sum, target logit
   f32x4 U[WITH_DY ? DT : 1];
@@ -125,11 +150,10 @@ __global__ __launch_bounds__(512) void vocab_ce_fwd_kernel(VocabCeArgs p) {
     for (int dt = 0; dt < DT; ++dt) U[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vc_wait_stages<LPS>(min(NSLOT - 1, nsteps - 1 - s));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    const char* base = smem + (s & 1) * SLOT;
+    const char* base = smem + (s % NSLOT) * SLOT;
     f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -145,13 +169,22 @@ __global__ __launch_bounds__(512) void vocab_ce_fwd_kernel(VocabCeArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int vloc = vh * 32 + 16 * (j >> 2) + 4 * q + (j & 3);
-      const int v = s * 64 + vloc;
-      float x = S[j >> 2][j & 3] + bw[vloc];
-      if ((long)v == tgt) picked = x;
-      x = (v < V) ? x * kLog2e : -INFINITY;
-      sv[j] = x;
-      mt = fmaxf(mt, x);
+      sv[j] = (S[j >> 2][j & 3] + bw[vloc]) * kLog2e;
     }
+    // two rare cases, each behind a wave-uniform branch so that the common step pays nothing per element:
+    // the last tile reaches past V; some row's target token lives in this tile
+    if (s == nsteps - 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (s * 64 + vh * 32 + 16 * (j >> 2) + 4 * q + (j & 3) >= V) sv[j] = -INFINITY;
+    }
+    if (__any((int)(tgt >> 6) == s)) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if ((long)(s * 64 + vh * 32 + 16 * (j >> 2) + 4 * q + (j & 3)) == tgt) picked = sv[j];   // (log2 domain)
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mt = fmaxf(mt, sv[j]);
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float mn = fmaxf(m2, mt);
@@ -173,11 +206,11 @@ __global__ __launch_bounds__(512) void vocab_ce_fwd_kernel(VocabCeArgs p) {
       for (int dt = 0; dt < DT; ++dt) U[dt] = PT::mfma(vc_tr_frag<h8>(base, vh * 32, dt, lane), pf, U[dt]);
     }
     m2 = mn;
-    if (s + 2 < nsteps) {
+    if (s + NSLOT < nsteps) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      issue(s + 2);
+      issue(s + NSLOT);
     }
   }
   // this lane's row sum over the 4 token quarters held by the lanes c, c+16, c+32, c+48
@@ -188,9 +221,9 @@ __global__ __launch_bounds__(512) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   // combine the two token halves (waves w and w+4 share their rows) through the ring space
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  float* xs = reinterpret_cast<float*>(smem);                  // [4 row groups][DT][64 lanes] f32x4 + stats
+  float* xs = reinterpret_cast<float*>(smem);                  // [RG row groups][DT][64 lanes] f32x4 + stats
   constexpr int UW = (WITH_DY ? DT : 0) * 64 * 4;              // floats per row group
-  float* st = xs + 4 * UW;                                     // [4][3][64]
+  float* st = xs + RG * UW;                                    // [RG][3][64]
   if (vh == 1) {
     if constexpr (WITH_DY) {
 #pragma unroll
@@ -207,7 +240,7 @@ __global__ __launch_bounds__(512) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   const float fa = __builtin_amdgcn_exp2f(m2 - mm), fb = (mb == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mb - mm);
   const float l = lsum * fa + lb * fb;
   const float lse = (mm + __builtin_amdgcn_logf(l)) * kLn2;   // v_log_f32 is log2
-  const float tl = picked + pb;
+  const float tl = (picked + pb) * kLn2;   // the target logit was picked in the log2 domain
   if (q == 0 && r < R) {
     p.row_loss[r] = live ? (lse - tl) : 0.f;
     p.lse[r] = lse;
@@ -232,20 +265,24 @@ __global__ __launch_bounds__(512) void vocab_ce_fwd_kernel(VocabCeArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int PREC, int DCH>
-__global__ __launch_bounds__(512) void vocab_ce_dw_kernel(VocabCeArgs p) {
+// VG groups of 16 tokens per workgroup (2*VG waves: VG token groups x 2 row halves)
+template <int PREC, int DCH, int VG>
+__global__ __launch_bounds__(128 * VG) void vocab_ce_dw_kernel(VocabCeArgs p) {
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
   using h8 = typename PT::h8;
   constexpr int D = 64 * DCH, KSTEPS = D / 32, DT = D / 16;
-  constexpr int STAGE = DCH * kVcImg, SLOT = STAGE + 8 * 2 * kVcAux, LPS = DCH + 2;   // per wave: lse[64] + target[64]
+  constexpr int NW = 2 * VG;
+  constexpr int STAGE = DCH * kVcImg, SLOT = STAGE + NW * 2 * kVcAux, LPS = (8 * DCH + NW - 1) / NW + 2;   // per wave: lse[64] + target[64]
+  constexpr int NSLOT = vc_slots<DCH>();
+  static_assert((NSLOT - 1) * LPS <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int vg = wave & 3, rh = wave >> 2;
+  const int vg = wave % VG, rh = wave / VG;
   const int c = lane & 15, q = lane >> 4;
   const int R = p.R, V = p.V, B = p.B;
-  const int v = blockIdx.x * 64 + vg * 16 + c;
+  const int v = blockIdx.x * (16 * VG) + vg * 16 + c;
   const int vc = min(v, V - 1);
   const h_t* Y = reinterpret_cast<const h_t*>(p.Y16);
   const h_t* W = reinterpret_cast<const h_t*>(p.W16);
@@ -253,14 +290,14 @@ __global__ __launch_bounds__(512) void vocab_ce_dw_kernel(VocabCeArgs p) {
   h8 wf[KSTEPS];
 #pragma unroll
   for (int s = 0; s < KSTEPS; ++s) wf[s] = *reinterpret_cast<const h8*>(W + (long)vc * D + 32 * s + 8 * q);
-  const float bv = p.bias[vc] * kLog2e;
+  const float bv = (v < V) ? p.bias[vc] * kLog2e : -INFINITY;   // tokens past V (last tile): exp2(-inf) = 0, no target matches
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   const int nsteps = (R + 63) / 64;
   auto issue = [&](int s) {
-    char* slot = smem + (s & 1) * SLOT;
+    char* slot = smem + (s % NSLOT) * SLOT;
     const int r0 = s * 64;
-    vc_issue_stage<DCH>(Y, D, [=](int row) { return min(r0 + row, R - 1); }, slot, wave, lane);
+    vc_issue_stage<DCH, NW>(Y, D, [=](int row) { return min(r0 + row, R - 1); }, slot, wave, lane);
     // per-wave side data of the stage's 64 rows: lse and the target token (low dword of the int64)
     const int rr = min(r0 + lane, R - 1);
     const int t = rr / B, b = rr % B;
@@ -270,19 +307,17 @@ __global__ __launch_bounds__(512) void vocab_ce_dw_kernel(VocabCeArgs p) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.seq + (long)b * p.ld_seq + t + 1),
                                      (__attribute__((address_space(3))) void*)(aux + kVcAux), 4, 0, 0);
   };
-  issue(0);
-  if (nsteps > 1) issue(1);
+  for (int s = 0; s < NSLOT && s < nsteps; ++s) issue(s);
 
   f32x4 dWt[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) dWt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dbv = 0.f;
   for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vc_wait_stages<LPS>(min(NSLOT - 1, nsteps - 1 - s));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    const char* base = smem + (s & 1) * SLOT;
+    const char* base = smem + (s % NSLOT) * SLOT;
     f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -295,32 +330,45 @@ __global__ __launch_bounds__(512) void vocab_ce_dw_kernel(VocabCeArgs p) {
     const float* lw = reinterpret_cast<const float*>(base + STAGE + wave * 2 * kVcAux);
     const int* tw = reinterpret_cast<const int*>(base + STAGE + wave * 2 * kVcAux + kVcAux);
     h8 gf;
+    // per row: c_r = -lse_r (log2 domain), -inf for rows whose target is PAD (their gradient is zero) and, in the last
+    // stage only, for the clamped copies of the last row; the target of such rows is set to -1 so no token matches it
+    float cr[8];
+    int tg[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int rloc = rh * 32 + 16 * (j >> 2) + 4 * q + (j & 3);
-      const int rr = s * 64 + rloc;
-      const int tg = tw[rloc];
-      float g = __builtin_amdgcn_exp2f(S[j >> 2][j & 3] * kLog2e + bv - lw[rloc] * kLog2e) - (tg == v ? 1.0f : 0.f);
-      if (rr >= R || tg == ARK_TOK_PAD || v >= V) g = 0.f;
+      const int t0 = tw[rloc];
+      const bool dead = t0 == ARK_TOK_PAD;
+      cr[j] = dead ? -INFINITY : -lw[rloc] * kLog2e;
+      tg[j] = dead ? -1 : t0;
+    }
+    if (s == nsteps - 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (s * 64 + rh * 32 + 16 * (j >> 2) + 4 * q + (j & 3) >= R) { cr[j] = -INFINITY; tg[j] = -1; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float g = __builtin_amdgcn_exp2f(__builtin_fmaf(S[j >> 2][j & 3], kLog2e, bv + cr[j])) - (tg[j] == v ? 1.0f : 0.f);
       dbv += g;
       gf[j] = PT::cvt(g);
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dWt[dt] = PT::mfma(vc_tr_frag<h8>(base, rh * 32, dt, lane), gf, dWt[dt]);
-    if (s + 2 < nsteps) {
+    if (s + NSLOT < nsteps) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      issue(s + 2);
+      issue(s + NSLOT);
     }
   }
   dbv += __shfl_xor(dbv, 16, 64);
   dbv += __shfl_xor(dbv, 32, 64);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  float* xs = reinterpret_cast<float*>(smem);   // [4 token groups][DT][64 lanes] f32x4, then [4][64] bias partials
+  float* xs = reinterpret_cast<float*>(smem);   // [VG token groups][DT][64 lanes] f32x4, then [VG][64] bias partials
   constexpr int UW = DT * 64 * 4;
-  float* st = xs + 4 * UW;
+  float* st = xs + VG * UW;
   if (rh == 1) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(xs + vg * UW + (dt * 64 + lane) * 4) = dWt[dt];
@@ -343,37 +391,76 @@ static void vc_allow_lds(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-template <int DCH>
+template <int DCH, int NG>
 constexpr int vc_lds_bytes(int aux_per_wave) {
-  const int ring = 2 * (DCH * kVcImg + 8 * aux_per_wave);
-  const int comb = 4 * (64 * DCH / 16) * 64 * 16 + 4 * 3 * 64 * 4;
+  const int ring = vc_slots<DCH>() * (DCH * kVcImg + 2 * NG * aux_per_wave);
+  const int comb = NG * (64 * DCH / 16) * 64 * 16 + NG * 3 * 64 * 4;
   return ring > comb ? ring : comb;
+}
+
+template <int PREC, int DCH, int RG>
+static int vc_launch_fwd_rg(const VocabCeArgs& p, bool with_dy, hipStream_t st) {
+  constexpr int LDS = vc_lds_bytes<DCH, RG>(kVcAux);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  const unsigned grid = (unsigned)((p.R + 16 * RG - 1) / (16 * RG));
+  if (with_dy) {
+    static bool once = (vc_allow_lds(vocab_ce_fwd_kernel<PREC, DCH, RG, true>, LDS), true); (void)once;
+    hipLaunchKernelGGL((vocab_ce_fwd_kernel<PREC, DCH, RG, true>), dim3(grid), dim3(128 * RG), LDS, st, p);
+  } else {
+    static bool once = (vc_allow_lds(vocab_ce_fwd_kernel<PREC, DCH, RG, false>, LDS), true); (void)once;
+    hipLaunchKernelGGL((vocab_ce_fwd_kernel<PREC, DCH, RG, false>), dim3(grid), dim3(128 * RG), LDS, st, p);
+  }
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// groups of 16 (rows / tokens) per workgroup so that the tiles come out as close below a multiple of 256 CUs as possible
+static int vc_groups(int n16, int max_groups) {
+  int best = 4;
+  double best_eff = 0.0;
+  for (int g : {6, 5, 4, 3}) {   // (ties go to the larger tile: fewer sweeps over the streamed operand)
+    if (g > max_groups) continue;   // (wide models need the whole register file of a 512-thread workgroup)
+    const int wgs = (n16 + g - 1) / g;
+    const int rounds = (wgs + 255) / 256;
+    const double eff = (double)n16 / ((double)rounds * 256 * g);   // useful fraction of the CU-rounds spent
+    if (eff > best_eff + 0.02) { best_eff = eff; best = g; }
+  }
+  return best;
 }
 
 template <int PREC, int DCH>
 static int vc_launch_fwd(const VocabCeArgs& p, bool with_dy, hipStream_t st) {
-  constexpr int LDS = vc_lds_bytes<DCH>(kVcAux);
-  static_assert(LDS <= 160 * 1024, "LDS budget");
-  const unsigned grid = (unsigned)((p.R + 63) / 64);
-  if (with_dy) {
-    static bool once = (vc_allow_lds(vocab_ce_fwd_kernel<PREC, DCH, true>, LDS), true); (void)once;
-    hipLaunchKernelGGL((vocab_ce_fwd_kernel<PREC, DCH, true>), dim3(grid), dim3(512), LDS, st, p);
-  } else {
-    static bool once = (vc_allow_lds(vocab_ce_fwd_kernel<PREC, DCH, false>, LDS), true); (void)once;
-    hipLaunchKernelGGL((vocab_ce_fwd_kernel<PREC, DCH, false>), dim3(grid), dim3(512), LDS, st, p);
+  // (measured: D = 512 is register-bound -- 256 VGPRs with spills -- and slower with anything but 4 groups: 3.9 -> 7.4 ms at
+  //  wd-articles; D = 128 gains 10 % from 5 row groups at wd-movies, 280 -> 224 workgroups)
+  switch (DCH >= 8 ? 4 : vc_groups((p.R + 15) / 16, DCH <= 2 ? 6 : 5)) {
+    case 3: return vc_launch_fwd_rg<PREC, DCH, 3>(p, with_dy, st);
+    case 5: if constexpr (DCH <= 4) return vc_launch_fwd_rg<PREC, DCH, 5>(p, with_dy, st); else break;
+    case 6: if constexpr (DCH <= 2) return vc_launch_fwd_rg<PREC, DCH, 6>(p, with_dy, st); else break;
+    default: break;
   }
+  return vc_launch_fwd_rg<PREC, DCH, 4>(p, with_dy, st);
+}
+
+template <int PREC, int DCH, int VG>
+static int vc_launch_dw_vg(const VocabCeArgs& p, hipStream_t st) {
+  constexpr int LDS = vc_lds_bytes<DCH, VG>(2 * kVcAux);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool once = (vc_allow_lds(vocab_ce_dw_kernel<PREC, DCH, VG>, LDS), true); (void)once;
+  hipLaunchKernelGGL((vocab_ce_dw_kernel<PREC, DCH, VG>), dim3((unsigned)((p.V + 16 * VG - 1) / (16 * VG))), dim3(128 * VG), LDS, st, p);
   ARK_LAUNCH_CHECK();
   return 0;
 }
 
 template <int PREC, int DCH>
 static int vc_launch_dw(const VocabCeArgs& p, hipStream_t st) {
-  constexpr int LDS = vc_lds_bytes<DCH>(2 * kVcAux);
-  static_assert(LDS <= 160 * 1024, "LDS budget");
-  static bool once = (vc_allow_lds(vocab_ce_dw_kernel<PREC, DCH>, LDS), true); (void)once;
-  hipLaunchKernelGGL((vocab_ce_dw_kernel<PREC, DCH>), dim3((unsigned)((p.V + 63) / 64)), dim3(512), LDS, st, p);
-  ARK_LAUNCH_CHECK();
-  return 0;
+  // (wd-movies, V = 24 101, standalone: 547 / 551 / 924 / 507 us at 3 / 4 / 5 / 6 token groups: one full round of 252 workgroups wins)
+  switch (DCH >= 8 ? 4 : vc_groups((p.V + 15) / 16, DCH <= 2 ? 6 : 5)) {
+    case 3: return vc_launch_dw_vg<PREC, DCH, 3>(p, st);
+    case 5: if constexpr (DCH <= 4) return vc_launch_dw_vg<PREC, DCH, 5>(p, st); else break;
+    case 6: if constexpr (DCH <= 2) return vc_launch_dw_vg<PREC, DCH, 6>(p, st); else break;
+    default: break;
+  }
+  return vc_launch_dw_vg<PREC, DCH, 4>(p, st);
 }
 
 static int vc_check(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, const float* hyper, int B,

@@ -1,0 +1,25 @@
+import os, sys, torch, time
+sys.path.insert(0, "/root/repo")
+from ark_amd import _lib as L
+dev = torch.device("cuda:0")
+B, Lq, V, D = 256, 70, 24101, 128
+R = B * Lq
+g = torch.Generator().manual_seed(0)
+Y = (torch.randn(R, D, generator=g) * 0.5).half().to(dev)
+W = (torch.randn(V, D, generator=g) * 0.2).half().to(dev)
+bias = torch.zeros(V, device=dev)
+seq = torch.randint(1, V, (B, Lq + 1), generator=g).to(dev)
+hyper = torch.zeros(16, device=dev); hyper[3] = 1.0 / R
+rl, lse, dY = torch.zeros(R, device=dev), torch.zeros(R, device=dev), torch.zeros(R * D, device=dev)
+dW, db = torch.zeros(V, D, device=dev), torch.zeros(V, device=dev)
+common = (L.i32(L.PREC_F16), L.ptr(Y), L.ptr(W), L.ptr(bias), L.ptr(seq), L.i64(Lq + 1), L.ptr(hyper))
+tail = (L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), L.cur_stream())
+def fwd(): L.check(L.lib().ark_vocab_ce_fwd(*common, L.ptr(rl), L.ptr(lse), L.ptr(dY), *tail), "f")
+def dw(): L.check(L.lib().ark_vocab_ce_dw(*common, L.ptr(lse), L.ptr(dW), L.ptr(db), *tail), "d")
+for name, fn in (("fwd", fwd), ("dw", dw)):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): fn()
+    e1.record(); e1.synchronize()
+    print(os.environ.get("ARK_VC_RG"), os.environ.get("ARK_VC_VG"), name, e0.elapsed_time(e1) / 10 * 1e3, "us")
