@@ -103,6 +103,22 @@ class DiagTuning(ctypes.Structure):
                                             "bwd_nbuf", "bwd_xcd_rows")]
 
 
+class WgradTuning(ctypes.Structure):
+    """ArkWgradTuning of include/ark_amd.h"""
+    _fields_ = [(k, ctypes.c_int) for k in ("tile", "nbuf", "target_wgs", "balance")]
+
+
+def wgrad_tuning(**kw):
+    """the library's measured defaults with the given fields replaced (a ctypes byref, ready to pass)"""
+    t = WgradTuning()
+    lib().ark_wgrad_tuning_default(ctypes.byref(t))
+    for k, v in kw.items():
+        if k not in dict(WgradTuning._fields_):
+            raise KeyError(k)
+        setattr(t, k, int(v))
+    return ctypes.byref(t)
+
+
 def diag_tuning(**kw):
     """the library's measured defaults with the given fields replaced"""
     t = DiagTuning()

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void enc_scatter_fused_kernel(const int64_t* _
   }
 }
 
-int g_scatter_chunk_items = 48;
+constexpr int g_scatter_chunk_items = 48;
 
 static int launch_scatter(const ScatterArgs& p, hipStream_t st) {
   if (p.n_items <= 0) return 0;
@@ -223,12 +223,6 @@ static int launch_scatter(const ScatterArgs& p, hipStream_t st) {
 }
 
 }  // namespace ark
-
-extern "C" int ark_set_scatter_chunk(int items) {
-  if (items < 16) return ARK_ERR_ARG;
-  ark::g_scatter_chunk_items = items;
-  return 0;
-}
 
 extern "C" int ark_enc_pool_fwd(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt,
                                 int B, int T, int D, int64_t pad_rid, void* stream) {

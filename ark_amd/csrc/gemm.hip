@@ -7,8 +7,9 @@
 
 namespace ark {
 
-static int g_split_k_enabled = 1;
-static int g_wgrad_tile128 = 0;  // 1: weight-gradient products use 128x128 tiles + deeper split-K
+// (speed choices are compile-time constants: the library keeps no mutable state, include/ark_amd.h)
+constexpr bool g_split_k_enabled = true;   // long-K products reduce over workgroups with fp32 atomics
+constexpr bool g_wgrad_tile128 = false;    // 128x128 tiles + deeper split-K for weight-gradient products: measured slower
 
 struct GemmArgs {
   const float* A; const float* B; float* C; float* C2; const float* bias; const float* aux;
@@ -125,16 +126,6 @@ static int dispatch_lay(int a_lay, int b_lay, const GemmArgs& p, hipStream_t st)
 }
 
 }  // namespace ark
-
-// tuning / test knob: 0 disables split-K (bitwise run-to-run reproducible weight gradients)
-extern "C" int ark_set_split_k(int enabled) {
-  ark::g_split_k_enabled = enabled ? 1 : 0;
-  return 0;
-}
-extern "C" int ark_set_wgrad_tile128(int enabled) {
-  ark::g_wgrad_tile128 = enabled ? 1 : 0;
-  return 0;
-}
 
 extern "C" int ark_gemm(int prec, int a_lay, int b_lay, int epi, const float* A, int64_t lda, const float* B,
                         int64_t ldb, float* C, int64_t ldc, float* C2, const float* bias, const float* aux,

@@ -89,8 +89,8 @@ static void allow_lds16(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int g_g16_nbuf = 2;     // ring depth of the 128x128 tile (2 -> 64 KB LDS, two workgroups per CU)
-int g_g16_force64 = 0;  // 1: always use 64x64 tiles
+constexpr int g_g16_nbuf = 2;     // ring depth (2 -> 64 KB LDS at 128x128, two workgroups per CU)
+constexpr int g_g16_force64 = 0;  // 1: always use 64x64 tiles
 
 template <int PREC, int BM, int BN, int NBUF>
 static void launch16_cfg(Gemm16Args p, hipStream_t st) {
@@ -101,7 +101,7 @@ static void launch16_cfg(Gemm16Args p, hipStream_t st) {
   hipLaunchKernelGGL((gemm16_kernel<PREC, BM, BN, NBUF>), dim3((unsigned)tiles), dim3(256), G::LDS_BYTES, st, p);
 }
 
-int g_g16_tile = 0;   // 0: heuristic below, 1: 64x64, 2: 128x64, 3: 128x128, 4: 32x64, 5: 64x32
+constexpr int g_g16_tile = 0;   // 0: heuristic below, 1: 64x64, 2: 128x64, 3: 128x128, 4: 32x64, 5: 64x32
 
 template <int PREC>
 static int launch16(Gemm16Args p, hipStream_t st) {
@@ -280,6 +280,13 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ x
     out[i] = PrecTraits<PREC>::cvt(x[i]);
 }
 
+template <int PREC>
+__global__ __launch_bounds__(256) void uncast16_kernel(const void* x_, float* __restrict__ out, long n) {
+  using H = typename PrecTraits<PREC>::h_t;
+  const H* x = reinterpret_cast<const H*>(x_);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)x[i];
+}
+
 // row-major fp32 [rows, ld] -> tile-native fp32 (rows % 16 == 0, ld % 16 == 0)
 __global__ __launch_bounds__(256) void to_tiled_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int ld) {
   const long n4 = (long)rows * ld / 4;
@@ -295,14 +302,6 @@ __global__ __launch_bounds__(256) void to_tiled_kernel(const float* __restrict__
 }
 
 }  // namespace ark
-
-// speed-only knobs of the LDS-DMA GEMM: ring depth {2,3,4}; tile 0 auto | 1 64x64 | 2 128x64 | 3 128x128 | 4 32x64 | 5 64x32
-extern "C" int ark_set_gemm16_tuning(int nbuf, int tile) {
-  if (nbuf < 2 || nbuf > 4 || tile < 0 || tile > 5) return ARK_ERR_ARG;
-  ark::g_g16_nbuf = nbuf;
-  ark::g_g16_tile = tile;
-  return 0;
-}
 
 static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
                        int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* c16a,
@@ -414,6 +413,18 @@ extern "C" int ark_cast16(int prec, const float* x, void* out, int64_t n, void* 
   if (blocks > 2048) blocks = 2048;
   if (prec == PREC_F16) hipLaunchKernelGGL(cast16_kernel<PREC_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
   else if (prec == PREC_BF16) hipLaunchKernelGGL(cast16_kernel<PREC_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
+  else return ARK_ERR_ARG;
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_uncast16(int prec, const void* x16, float* out, int64_t n, void* stream) {
+  using namespace ark;
+  if (!x16 || !out || n <= 0) return ARK_ERR_ARG;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (prec == PREC_F16) hipLaunchKernelGGL(uncast16_kernel<PREC_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x16, out, (long)n);
+  else if (prec == PREC_BF16) hipLaunchKernelGGL(uncast16_kernel<PREC_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x16, out, (long)n);
   else return ARK_ERR_ARG;
   ARK_LAUNCH_CHECK();
   return 0;

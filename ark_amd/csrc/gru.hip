@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(GruBwdArgs p) {
 }  // namespace ark
 
 namespace ark {
-static int g_fwd_bm = 32;      // rows per forward-cell workgroup (64 | 32)
-static int g_bwd_tile = 2;     // backward-cell tile: 0 = 64x64, 1 = 32x64, 2 = 32x32
+constexpr int g_fwd_bm = 32;      // rows per forward-cell workgroup (64 | 32)
+constexpr int g_bwd_tile = 2;     // backward-cell tile: 0 = 64x64, 1 = 32x64, 2 = 32x32
 
 template <int PREC, int BM>
 static void launch_fwd(const GruFwdArgs& p, hipStream_t st) {
@@ -139,14 +139,6 @@ static int launch_bwd_any(int prec, const GruBwdArgs& p, hipStream_t st) {
   return 0;
 }
 }  // namespace ark
-
-// tuning knobs (speed only, results identical up to fp32 summation order): key 1 = forward-cell
-// rows per workgroup {64,32}; key 2 = backward-cell tile {0: 64x64, 1: 32x64, 2: 32x32}
-extern "C" int ark_set_tuning(int key, int value) {
-  if (key == 1 && (value == 64 || value == 32)) { ark::g_fwd_bm = value; return 0; }
-  if (key == 2 && value >= 0 && value <= 2) { ark::g_bwd_tile = value; return 0; }
-  return ARK_ERR_ARG;
-}
 
 extern "C" int ark_gru_cell_fwd(int prec, const float* h_prev, const float* w_hh, const float* b_hh, const float* gi,
                                 float* h_out, float* h_drop, const float* drop_mask, float* save_r, float* save_z,

@@ -194,10 +194,9 @@ static void allow_lds_w(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int g_wg_tile = 128, g_wg_nbuf = 2, g_wg_target = 300, g_wg_balance = 1;   // target: 240 whole-K tiles -> 480 half-K (same-box A/B: 1.245 -> 1.202 ms/step)
 
 template <int PREC, int BT, int NBUF>
-static void launch_wg(Wgrad16Group& g, hipStream_t st) {
+static void launch_wg(Wgrad16Group& g, const ArkWgradTuning& tn, hipStream_t st) {
   constexpr int LDS = NBUF * 2 * 64 * BT * 2;
   static bool once = (allow_lds_w(wgrad16_kernel<PREC, BT, NBUF>, LDS), true); (void)once;
   long tiles = 0;
@@ -210,7 +209,7 @@ static void launch_wg(Wgrad16Group& g, hipStream_t st) {
   }
   g.tile_start[g.n] = (int)tiles;
   int split = 1;
-  while (tiles * split < g_wg_target && kmax / (split * 2) >= 256 && split < 64) split *= 2;
+  while (tiles * split < tn.target_wgs && kmax / (split * 2) >= 256 && split < 64) split *= 2;
   for (int i = 0; i < g.n; ++i) {
     g.p[i].k_chunk = ((g.p[i].K + split - 1) / split + 63) / 64 * 64;
     g.p[i].use_atomics = split > 1;
@@ -218,7 +217,7 @@ static void launch_wg(Wgrad16Group& g, hipStream_t st) {
   g.n_long = 0;
   g.s_short = 1;
   constexpr int kCUs = 256;
-  if (g_wg_balance && split == 1 && tiles > kCUs && tiles < 2 * kCUs) {
+  if (tn.balance && split == 1 && tiles > kCUs && tiles < 2 * kCUs) {
     const int rest = (int)tiles - kCUs;
     const int s = kCUs / rest;   // slices per remaining tile: rest * s <= 256 short workgroups
     if (s >= 2 && kmax / s >= 256) {
@@ -232,15 +231,19 @@ static void launch_wg(Wgrad16Group& g, hipStream_t st) {
 }
 
 template <int PREC>
-static int launch_wg_prec(Wgrad16Group& g, hipStream_t st) {
-  bool ok128 = g_wg_tile == 128;
+static int launch_wg_prec(Wgrad16Group& g, const ArkWgradTuning* tuning, hipStream_t st) {
+  ArkWgradTuning tn;
+  ark_wgrad_tuning_default(&tn);
+  if (tuning) tn = *tuning;
+  if ((tn.tile != 64 && tn.tile != 128) || tn.nbuf < 2 || tn.nbuf > 4 || tn.target_wgs < 1) return ARK_ERR_ARG;
+  bool ok128 = tn.tile == 128;
   for (int i = 0; i < g.n; ++i) ok128 = ok128 && g.p[i].M % 128 == 0 && g.p[i].N % 128 == 0;
   if (ok128) {
-    if (g_wg_nbuf == 2) launch_wg<PREC, 128, 2>(g, st);
-    else if (g_wg_nbuf == 3) launch_wg<PREC, 128, 3>(g, st);
-    else launch_wg<PREC, 128, 4>(g, st);
+    if (tn.nbuf == 2) launch_wg<PREC, 128, 2>(g, tn, st);
+    else if (tn.nbuf == 3) launch_wg<PREC, 128, 3>(g, tn, st);
+    else launch_wg<PREC, 128, 4>(g, tn, st);
   } else {
-    if (g_wg_nbuf == 2) launch_wg<PREC, 64, 2>(g, st); else launch_wg<PREC, 64, 4>(g, st);
+    if (tn.nbuf == 2) launch_wg<PREC, 64, 2>(g, tn, st); else launch_wg<PREC, 64, 4>(g, tn, st);
   }
   ARK_LAUNCH_CHECK();
   return 0;
@@ -248,13 +251,11 @@ static int launch_wg_prec(Wgrad16Group& g, hipStream_t st) {
 
 }  // namespace ark
 
-// speed-only knobs: tile (64|128), ring depth, target workgroup count for the split-K heuristic
-extern "C" int ark_set_wgrad16_balance(int enabled) { ark::g_wg_balance = enabled ? 1 : 0; return 0; }
-
-extern "C" int ark_set_wgrad16_tuning(int tile, int nbuf, int target_wgs) {
-  if ((tile != 64 && tile != 128) || nbuf < 2 || nbuf > 4 || target_wgs < 1) return ARK_ERR_ARG;
-  ark::g_wg_tile = tile; ark::g_wg_nbuf = nbuf; ark::g_wg_target = target_wgs;
-  return 0;
+// measured defaults (MI355X, syn-paths B=1024): 128x128 tiles, two ring slots, split K until >= 300 workgroups
+// (240 whole-K tiles -> 480 half-K: same-box A/B 1.245 -> 1.202 ms/step), even dealing of 257..511 tiles over the CUs
+extern "C" void ark_wgrad_tuning_default(ArkWgradTuning* t) {
+  if (!t) return;
+  t->tile = 128; t->nbuf = 2; t->target_wgs = 300; t->balance = 1;
 }
 
 static int check_one(const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int M, int N, int K) {
@@ -266,22 +267,22 @@ static int check_one(const void* A16, int64_t lda, const void* B16, int64_t ldb,
 
 // C[M,N] += A16[K,M]^T B16[K,N]; requires M % 64 == N % 64 == K % 64 == 0, 16-byte aligned rows.
 extern "C" int ark_wgrad16(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
-                           int M, int N, int K, void* stream) {
+                           int M, int N, int K, const ArkWgradTuning* tuning, void* stream) {
   using namespace ark;
   int rc = check_one(A16, lda, B16, ldb, C, M, N, K);
   if (rc) return rc;
   Wgrad16Group g{};
   g.n = 1;
   g.p[0] = Wgrad16Args{A16, B16, C, (long)lda, (long)ldb, (long)ldc, M, N, K, K, 1, 0, M};
-  if (prec == PREC_F16) return launch_wg_prec<PREC_F16>(g, (hipStream_t)stream);
-  if (prec == PREC_BF16) return launch_wg_prec<PREC_BF16>(g, (hipStream_t)stream);
+  if (prec == PREC_F16) return launch_wg_prec<PREC_F16>(g, tuning, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch_wg_prec<PREC_BF16>(g, tuning, (hipStream_t)stream);
   return ARK_ERR_ARG;
 }
 
 // n (<= ARK_WGRAD_MAX_GROUP) independent products of the kind above in ONE launch
 extern "C" int ark_wgrad16_group(int prec, int n, const void* const* A16, const int64_t* lda, const void* const* B16,
                                  const int64_t* ldb, float* const* C, const int64_t* ldc, const int* M, const int* N,
-                                 const int* K, void* stream) {
+                                 const int* K, const ArkWgradTuning* tuning, void* stream) {
   using namespace ark;
   if (n <= 0 || n > kMaxGroup || !A16 || !B16 || !C || !lda || !ldb || !ldc || !M || !N || !K) return ARK_ERR_ARG;
   Wgrad16Group g{};
@@ -291,15 +292,15 @@ extern "C" int ark_wgrad16_group(int prec, int n, const void* const* A16, const 
     if (rc) return rc;
     g.p[i] = Wgrad16Args{A16[i], B16[i], C[i], (long)lda[i], (long)ldb[i], (long)ldc[i], M[i], N[i], K[i], K[i], 1, 0, M[i]};
   }
-  if (prec == PREC_F16) return launch_wg_prec<PREC_F16>(g, (hipStream_t)stream);
-  if (prec == PREC_BF16) return launch_wg_prec<PREC_BF16>(g, (hipStream_t)stream);
+  if (prec == PREC_F16) return launch_wg_prec<PREC_F16>(g, tuning, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch_wg_prec<PREC_BF16>(g, tuning, (hipStream_t)stream);
   return ARK_ERR_ARG;
 }
 
 // as ark_wgrad16, for an A operand whose M columns are padded to a tile multiple while C has only m_valid rows
 // (e.g. the K-padded 16-bit dlogits against the [V,D] vocabulary gradient): rows >= m_valid are not written
 extern "C" int ark_wgrad16_rows(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
-                                int M, int m_valid, int N, int K, void* stream) {
+                                int M, int m_valid, int N, int K, const ArkWgradTuning* tuning, void* stream) {
   using namespace ark;
   int rc = check_one(A16, lda, B16, ldb, C, M, N, K);
   if (rc) return rc;
@@ -307,7 +308,7 @@ extern "C" int ark_wgrad16_rows(int prec, const void* A16, int64_t lda, const vo
   Wgrad16Group g{};
   g.n = 1;
   g.p[0] = Wgrad16Args{A16, B16, C, (long)lda, (long)ldb, (long)ldc, M, N, K, K, 1, 0, m_valid};
-  if (prec == PREC_F16) return launch_wg_prec<PREC_F16>(g, (hipStream_t)stream);
-  if (prec == PREC_BF16) return launch_wg_prec<PREC_BF16>(g, (hipStream_t)stream);
+  if (prec == PREC_F16) return launch_wg_prec<PREC_F16>(g, tuning, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch_wg_prec<PREC_BF16>(g, tuning, (hipStream_t)stream);
   return ARK_ERR_ARG;
 }

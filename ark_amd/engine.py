@@ -146,6 +146,7 @@ class Engine:
         self.use_dma = (self.prec_fwd != L.PREC_F32 and self.prec_bwd != L.PREC_F32 and self.D % 64 == 0
                         and not cfg.get("ark_no_dma", False))
         self.tune = L.diag_tuning(**dict(cfg.get("ark_diag_tuning") or {})) if self.use_dma else None
+        self.wg_tune = L.wgrad_tuning(**dict(cfg.get("ark_wgrad_tuning") or {})) if self.use_dma else None
         if self.use_dma:
             D, V = self.D, self.V
             i16 = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.int16)
@@ -882,7 +883,7 @@ class Engine:
                 _call("ark_colsum16", L.i32(pb), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(g["dec.out.bias"]), L.i32(R), L.i32(V),
                       L.i32(1), L.cur_stream())
                 _call("ark_wgrad16_rows", L.i32(pb), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(yb(n - 1)[B:]), L.i64(D),
-                      L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(self.Vp), L.i32(V), L.i32(D), L.i32(R), L.cur_stream())
+                      L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(self.Vp), L.i32(V), L.i32(D), L.i32(R), self.wg_tune, L.cur_stream())
             else:
                 dlog = self._logits(w)
                 self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
@@ -1063,7 +1064,7 @@ class Engine:
         i64 = lambda k: (ctypes.c_int64 * n)(*[it[k] for it in items])
         i32 = lambda k: (ctypes.c_int * n)(*[it[k] for it in items])
         _call("ark_wgrad16_group", L.i32(self.prec_bwd), L.i32(n), vp(0), i64(1), vp(2), i64(3), vp(4), i64(5), i32(6), i32(7),
-              i32(8), L.cur_stream())
+              i32(8), self.wg_tune, L.cur_stream())
 
     # ------------------------------------------------------------------ optimiser
     def adam(self):
@@ -1078,9 +1079,13 @@ class Engine:
         """Adam (+ shadows) of ONE gradient bucket (pipelined data parallel): `enc` = [0, dec_grad_offset)
         comes first and ticks the step counter, `dec` = [dec_grad_offset, total) follows with the same
         step scalars -- together exactly adam()."""
+        off, tot = self.layout.dec_grad_offset, self.layout.total
         if which == "enc":
             _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
             self.adam_steps += 1
+            self._dp_unpack(0, off)
+        else:
+            self._dp_unpack(off, tot)
         self._adam_launch(which)
 
     def dp_flush(self):
@@ -1125,9 +1130,11 @@ class Engine:
         if not (self.mt == "SAIL" and w["v2"]):
             more = self.backward_decoder()
             self._join_side()
+            self._dp_pack(off, tot)
             yield (off, tot)
             if more:
                 self.backward_encoder()
+                self._dp_pack(0, off)
                 yield (0, off)
             return
         self._defer_wgrads = True
@@ -1136,9 +1143,28 @@ class Engine:
         finally:
             self._defer_wgrads = False
         self.backward_encoder()   # (joins the side queue)
+        self._dp_pack(0, off)
         yield (0, off)
         self._gru_wgrads(w, self._B, self._Lrun, self._seq, self.training and self.p_drop > 0, range(self.n), emb=True)
+        self._dp_pack(off, tot)
         yield (off, tot)
+
+    # optional 16-bit transport of the gradient buckets (`ark_dp_bf16`): the all-reduce moves bf16 copies -- half the
+    # bytes over xGMI -- and the reduced values return to the fp32 gradient buffer before Adam (fp32 master weights,
+    # fp32 moments).  Off by default: the sums are formed in bf16 by the collective.
+    def _dp_pack(self, lo, hi):
+        if self.dp_bf16:
+            if getattr(self, "_Gh", None) is None:
+                self._Gh = torch.empty(self.layout.total, device=self.device, dtype=torch.bfloat16)
+            _call("ark_cast16", L.i32(L.PREC_BF16), L.ptr(self.G[lo:]), L.ptr(self._Gh[lo:]), L.i64(hi - lo), L.cur_stream())
+
+    def _dp_unpack(self, lo, hi):
+        if self.dp_bf16:
+            _call("ark_uncast16", L.i32(L.PREC_BF16), L.ptr(self._Gh[lo:]), L.ptr(self.G[lo:]), L.i64(hi - lo), L.cur_stream())
+
+    def dp_bucket(self, lo, hi):
+        """the tensor to all-reduce for gradient bucket [lo, hi)"""
+        return self._Gh[lo:hi] if self.dp_bf16 else self.G[lo:hi]
 
     def train_step(self, triples, seq, eps=None, grad_sync=None, ce_count=None, dp=False):
         """forward + ELBO + backward (+ gradient all-reduce) + Adam.  Returns the device tensor
@@ -1157,7 +1183,7 @@ class Engine:
                 if item == "seam":
                     self.dp_flush()
                     continue
-                handles[item] = dist.all_reduce(self.G[item[0]:item[1]], op=dist.ReduceOp.SUM, async_op=True)
+                handles[item] = dist.all_reduce(self.dp_bucket(*item), op=dist.ReduceOp.SUM, async_op=True)
             self._dp_nseg = nseg
             off, tot = self.layout.dec_grad_offset, self.layout.total
             if self.dp_pipeline and grad_sync is None and set(handles) == {(0, off), (off, tot)}:
@@ -1169,6 +1195,8 @@ class Engine:
                 return self.ws["out4"]
             for h in handles.values():
                 h.wait()
+            for item in handles:
+                self._dp_unpack(*item)
         else:
             self._defer_finalize = True
             try:
@@ -1243,7 +1271,12 @@ class Engine:
                 gc = cap(lambda: self._adam_part("enc"))
                 self._dp_flush_graph = cap(lambda: self._adam_part("dec"))
             else:
-                gc = cap(self.adam)
+                def unpack_adam():
+                    for _, it in segs:
+                        if it != "seam":
+                            self._dp_unpack(*it)
+                    self.adam()
+                gc = cap(unpack_adam)
         elif grad_sync is not None:
             def a():
                 self.forward(triples, seq, eps, ce_count=ce_count)
@@ -1282,7 +1315,7 @@ class Engine:
                         if item == "seam":
                             self.dp_flush()   # previous step's decoder bucket: wait for its reduction, replay its Adam
                         else:
-                            handles[item] = dist.all_reduce(self.G[item[0]:item[1]], op=dist.ReduceOp.SUM, async_op=True)
+                            handles[item] = dist.all_reduce(self.dp_bucket(*item), op=dist.ReduceOp.SUM, async_op=True)
                     if pipelined:
                         handles[(0, off)].wait()
                         gc.replay()

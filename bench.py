@@ -188,14 +188,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
-    ap.add_argument("--tuning", default="", help="speed-only kernel knobs of the exact-fp32 cells, e.g. '1=32,2=1' (ark_set_tuning)")
-    ap.add_argument("--no-splitk", action="store_true")
     ap.add_argument("--cfg", default="", help="extra engine config ints, e.g. ark_overlap_wgrad=0,ark_fork_after=0")
     ap.add_argument("--diag", default="", help="diagonal-kernel tiles, e.g. fwd_rows=64,fwd_units=32,bwd_rows=32,bwd_ki=2")
     ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path even with one rank")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (the measured configuration); gloo = functional rehearsal, ranks may share a GPU")
-    ap.add_argument("--knobs", default="", help="speed-only knobs: g16=NBUF:TILE,wg128=0|1,wg16=TILE:NBUF:TARGET,sc=N,wgbal=0|1")
+    ap.add_argument("--wgrad", default="", help="weight-gradient kernel choices, e.g. tile=128,nbuf=2,target_wgs=300,balance=1")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -223,25 +221,14 @@ def main():
     from ark_amd.engine import Engine
     from ark_amd import initlib
 
-    from ark_amd import _lib as L
-    for kv in filter(None, args.tuning.split(",")):
-        k, v = kv.split("=")
-        L.check(L.lib().ark_set_tuning(int(k), int(v)), "ark_set_tuning")
-    if args.no_splitk:
-        L.lib().ark_set_split_k(0)
-    for kv in filter(None, args.knobs.split(",")):   # e.g. g16=2:0,wg128=1
-        k, v = kv.split("=")
-        vals = [int(x) for x in v.split(":")]
-        fn = {"g16": L.lib().ark_set_gemm16_tuning, "wg128": L.lib().ark_set_wgrad_tile128, "wg16": L.lib().ark_set_wgrad16_tuning,
-              "sc": L.lib().ark_set_scatter_chunk, "wgbal": L.lib().ark_set_wgrad16_balance}[k]
-        L.check(fn(*vals), k)
-
     cfg = build_cfg(args.dropout, args.workload)
     for kv in filter(None, args.cfg.split(",")):   # engine options, e.g. ark_overlap_wgrad=0
         k, v = kv.split("=")
         cfg[k] = int(v)
     if args.diag:
         cfg["ark_diag_tuning"] = {k: int(v) for k, v in (kv.split("=") for kv in args.diag.split(","))}
+    if args.wgrad:
+        cfg["ark_wgrad_tuning"] = {k: int(v) for k, v in (kv.split("=") for kv in args.wgrad.split(","))}
     B = args.batch or cfg["batch"]
     Bg = B * world
     eng = Engine(cfg, dev, precision=args.precision, world_size=world, rank=rank)

@@ -9,7 +9,9 @@
  *     (kgvae/model/utils.py:131-146);
  *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream);
  *   - return 0 on success, a positive hipError_t if a launch failed, a negative ARK_ERR_* for
- *     bad arguments.  Calls are asynchronous and stateless (thread-safe).
+ *     bad arguments.  Calls are asynchronous and STATELESS (thread-safe): the library has no mutable globals;
+ *     the few speed-only choices that are not compile-time constants travel in per-call structs
+ *     (ArkDiagTuning, ArkWgradTuning; NULL = measured defaults).
  *   - decoder activations are TIME-MAJOR: row (t, b) = t * B + b.
  */
 #ifndef ARK_AMD_H
@@ -40,10 +42,6 @@ int ark_gemm(int prec, int a_lay, int b_lay, int epi, const float* A, int64_t ld
              float* C, int64_t ldc, float* C2, const float* bias, const float* aux, int M, int N, int K,
              int accumulate, void* stream);
 
-/* 0 disables split-K (atomic) reduction of long-K products: bitwise reproducible, slower */
-int ark_set_split_k(int enabled);
-/* speed-only tuning knobs of the GRU cell kernels (see ark_amd/csrc/gru.hip) */
-int ark_set_tuning(int key, int value);
 
 /* ---- device-resident step scalars ("hyper" array, ARK_HP_COUNT floats) -------------------------
  * Everything that changes between steps lives in device memory so a captured hipGraph of the
@@ -166,9 +164,6 @@ typedef struct {
 } ArkGruDiagBwdRole;
 int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* roles, const float* hyper, int B, int D,
                      const ArkDiagTuning* tuning, void* stream);
-int ark_set_scatter_chunk(int items_per_workgroup);
-int ark_set_gemm16_tuning(int nbuf, int tile);
-int ark_set_wgrad_tile128(int enabled);
 /* up to 12 jobs in one launch: dst[i] = cast(src[i] [R,C]) in prec[i]; dstT[i] = cast(src[i]^T) in precT[i],
  * rows of dstT ldT[i] apart (ldT NULL or 0: dense, = R) */
 int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, void* const* dstT, const int* R,
@@ -188,17 +183,23 @@ int ark_gemm_wgrad(int prec, const void* A, int a_is16, int64_t lda, const void*
                    int64_t ldc, int M, int N, int K, int accumulate, void* stream);
 /* same product on the LDS-DMA ring with ds_read_b64_tr_b16 fragment reads; C += (accumulates);
  * needs M, N, K multiples of 64 and both operands 16-bit */
+/* speed-only choices of the weight-gradient kernel, passed per call (NULL = ark_wgrad_tuning_default) */
+typedef struct {
+  int tile;        /* 64 | 128 (square output tile; 128 needs M, N multiples of 128)                         */
+  int nbuf;        /* LDS-DMA ring slots: 2..4                                                               */
+  int target_wgs;  /* split K over workgroups (fp32 atomics) until at least this many workgroups exist        */
+  int balance;     /* 257..511 whole-K tiles: 256 whole tiles + the rest cut into k-slices, 1.x tiles per CU  */
+} ArkWgradTuning;
+void ark_wgrad_tuning_default(ArkWgradTuning* t);
 int ark_wgrad16(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc, int M,
-                int N, int K, void* stream);
+                int N, int K, const ArkWgradTuning* tuning, void* stream);
 /* ark_wgrad16 for an A operand column-padded to a tile multiple (M) while C has only m_valid rows */
 int ark_wgrad16_rows(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc, int M,
-                     int m_valid, int N, int K, void* stream);
+                     int m_valid, int N, int K, const ArkWgradTuning* tuning, void* stream);
 #define ARK_WGRAD_MAX_GROUP 12
 int ark_wgrad16_group(int prec, int n, const void* const* A16, const int64_t* lda, const void* const* B16,
                       const int64_t* ldb, float* const* C, const int64_t* ldc, const int* M, const int* N, const int* K,
-                      void* stream);
-int ark_set_wgrad16_tuning(int tile, int nbuf, int target_wgs);
-int ark_set_wgrad16_balance(int enabled);   /* whole tiles on every CU + k-slices of the remainder (default on) */
+                      const ArkWgradTuning* tuning, void* stream);
 /* hyper_tick (nullable): training forward -> ++hyper[ARK_HP_DROP_STEP] (fresh dropout masks for this step) */
 int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,
                      const float* w_pos, void* x16a, void* x16b, int B, int L, int D, float* hyper_tick, void* stream);
@@ -214,6 +215,8 @@ int ark_token_sums16(int prec, const int64_t* seq, int64_t ld_seq, const void* x
                      void* scratch, int64_t scratch_bytes, int B, int L, int Vp, int n_cols, void* stream);
 int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, int accumulate, void* stream);
 int ark_cast16(int prec, const float* x, void* out, int64_t n, void* stream);
+/* out[i] = (float)x16[i]: data-parallel gradient buckets reduced in 16 bits go back into the fp32 gradient buffer */
+int ark_uncast16(int prec, const void* x16, float* out, int64_t n, void* stream);
 int ark_to_tiled(const float* x, float* out, int rows, int ld, void* stream);
 
 /* ---- embeddings (reference: models.py:47-58 encoder gather+concat+masked mean; :138,:343

@@ -12,7 +12,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def main(rank, world, port, out_path, graph, steps):
+def main(rank, world, port, out_path, graph, steps, bf16=False):
     from oracle import sail_oracle as O
     from tests.parity_util import load_golden, synth_batch
     from ark_amd.engine import Engine
@@ -22,7 +22,7 @@ def main(rank, world, port, out_path, graph, steps):
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     _, cfg = load_golden("sail_synpaths_b32_s0")
-    cfg = dict(cfg, dec_dropout=0.0, learning_rate=1e-3)
+    cfg = dict(cfg, dec_dropout=0.0, learning_rate=1e-3, ark_dp_bf16=bf16)
     P = O.init_params(cfg, 0)
     B = 128
     eng = Engine(cfg, dev, precision="mixed", world_size=world, rank=rank)
@@ -67,4 +67,5 @@ def main(rank, world, port, out_path, graph, steps):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5] == "1", int(sys.argv[6]))
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5] == "1", int(sys.argv[6]),
+         len(sys.argv) > 7 and sys.argv[7] == "1")

@@ -23,8 +23,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_two_process_data_parallel_matches_single_process(tmp_path, graph):
+@pytest.mark.parametrize("graph,bf16", [(False, False), (True, False), (True, True)])
+def test_two_process_data_parallel_matches_single_process(tmp_path, graph, bf16):
     from oracle import sail_oracle as O
     from ark_amd.engine import Engine
     steps, B = 3, 128
@@ -32,7 +32,7 @@ def test_two_process_data_parallel_matches_single_process(tmp_path, graph):
     port = _free_port()
     env = dict(os.environ, PYTHONPATH=ROOT)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), "2", str(port), out,
-                               "1" if graph else "0", str(steps)], env=env, cwd=ROOT) for r in range(2)]
+                               "1" if graph else "0", str(steps), "1" if bf16 else "0"], env=env, cwd=ROOT) for r in range(2)]
     try:
         rcs = [p.wait(timeout=420) for p in procs]
     finally:
@@ -60,9 +60,11 @@ def test_two_process_data_parallel_matches_single_process(tmp_path, graph):
     ref = eng.P.detach().cpu()
     moved = (ref - O_flat(eng, O.init_params(cfg, 0))).abs().max().item()
     assert moved > 1e-3                  # the weights did train
-    # Adam normalises the update, so per-step differences are bounded by ~lr where a gradient is ~0 in bf16
-    assert (P0 - ref).abs().max().item() <= 2.5e-3
-    assert (P0 - ref).abs().mean().item() <= 2e-5
+    # Adam normalises the update: where a gradient is ~0 its rounded sign decides a full +-lr step, so the worst single
+    # weight may differ by up to ~lr per step (3 steps x 1e-3); the mean below is the meaningful bar
+    assert (P0 - ref).abs().max().item() <= steps * 1e-3 * 1.05
+    # (bf16 transport of the gradient buckets, `ark_dp_bf16`: the reduced gradients carry 8 significant bits)
+    assert (P0 - ref).abs().mean().item() <= (1e-4 if bf16 else 2e-5)
 
 
 def O_flat(eng, P):

@@ -99,11 +99,10 @@ def test_wgrad16_tr_read_kernel(prec, tile, nbuf, shape):
     C0 = torch.randn(M, N, generator=g)
     dev = torch.device("cuda:0")
     Ad, Bd, C = A.to(dev), B.to(dev), C0.to(dev).clone()
-    L.check(L.lib().ark_set_wgrad16_tuning(L.i32(tile), L.i32(nbuf), L.i32(512)), "tune")
+    tn = L.wgrad_tuning(tile=tile, nbuf=nbuf, target_wgs=512)
     L.check(L.lib().ark_wgrad16(L.i32(prec), L.ptr(Ad), L.i64(M), L.ptr(Bd), L.i64(N), L.ptr(C), L.i64(N), L.i32(M), L.i32(N),
-                                L.i32(K), L.cur_stream()), "ark_wgrad16")
+                                L.i32(K), tn, L.cur_stream()), "ark_wgrad16")
     torch.cuda.synchronize()
-    L.check(L.lib().ark_set_wgrad16_tuning(L.i32(128), L.i32(2), L.i32(300)), "tune")
     ref = C0.double() + A.double().t() @ B.double()
     err = (C.cpu().double() - ref).abs().max().item()
     assert err <= 3e-5 * (K ** 0.5) + 1e-4, err
@@ -249,7 +248,7 @@ def test_wgrad16_rows_guard():
     Ad, Xd = A.to(dev).to(torch.bfloat16), X.to(dev).to(torch.bfloat16)
     C = torch.full((M, N), 5.0, device=dev)          # rows >= mv are "somebody else's memory"
     L.check(L.lib().ark_wgrad16_rows(L.i32(L.PREC_BF16), L.ptr(Ad), L.i64(M), L.ptr(Xd), L.i64(N), L.ptr(C), L.i64(N), L.i32(M),
-                                     L.i32(mv), L.i32(N), L.i32(K), L.cur_stream()), "ark_wgrad16_rows")
+                                     L.i32(mv), L.i32(N), L.i32(K), None, L.cur_stream()), "ark_wgrad16_rows")
     torch.cuda.synchronize()
     ref = 5.0 + Ad.float().t().double().cpu() @ Xd.float().double().cpu()
     got = C.double().cpu()

@@ -32,7 +32,10 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_argument_errors_are_negative_codes_without_touching_the_gpu():
     lib = ctypes.CDLL(os.path.join(ROOT, "ark_amd", "lib", "libark_amd.so"))
-    assert lib.ark_set_tuning(99, 0) < 0
+    wt = (ctypes.c_int * 4)(96, 2, 300, 1)                    # ArkWgradTuning with a tile size that does not exist
+    one = ctypes.c_void_p(256)                                # never dereferenced: the argument check comes first
+    assert lib.ark_wgrad16(2, one, ctypes.c_int64(128), one, ctypes.c_int64(128), one, ctypes.c_int64(128), 128, 128, 256, wt,
+                           ctypes.c_void_p(0)) < 0
     bad = (ctypes.c_int * 9)(48, 1, 2, 1, 32, 32, 2, 2, 4)   # ArkDiagTuning with a forward row count that does not exist
     role = (ctypes.c_char * 256)()
     assert lib.ark_gru_diag_fwd(2, 1, 1, role, ctypes.c_void_p(0), 64, 128, bad, ctypes.c_void_p(0)) < 0

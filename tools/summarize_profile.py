@@ -2,6 +2,8 @@
 
     python tools/summarize_profile.py stats  gpurun_out/profX  profiles/r01_kernel_stats.csv  [steps_in_run]
     python tools/summarize_profile.py pmc    gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_SQ profiles/r01_pmc_summary.json
+    python tools/summarize_profile.py mix    gpurun_out/pmc_mix profiles/r02_diag_sq_counters.json
+(the gpurun_out directories are written by tools/profile_round.sh on the GPU box)
 """
 import collections
 import csv
@@ -51,8 +53,30 @@ def pmc(fetch_dir, write_dir, sq_dir, dst):
     print("wrote", dst, len(res), "kernels")
 
 
+def mix(src, dst):
+    """per kernel, per launch: the SQ instruction-mix counters of one --pmc pass (all counters of the pass)"""
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(one(src + "/*/*_counter_collection.csv"))):
+        out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {}
+    for k, c in out.items():
+        if "ark::" not in k and "ark" not in k:
+            continue
+        e = {n: sum(v) / len(v) for n, v in c.items()}
+        e["launches"] = max(len(v) for v in c.values())
+        if e.get("SQ_WAVES"):
+            for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
+                if n in e:
+                    e[n + "_per_wave"] = e[n] / e["SQ_WAVES"]
+        res[k] = e
+    json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
+    print("wrote", dst, len(res), "kernels")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "mix":
+        mix(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 1.0)
     else:
         pmc(*sys.argv[2:6])
