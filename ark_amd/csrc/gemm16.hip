@@ -89,7 +89,13 @@ static void allow_lds16(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-constexpr int g_g16_nbuf = 2;     // ring depth (2 -> 64 KB LDS at 128x128, two workgroups per CU)
+#ifndef ARK_G16_NBUF
+#define ARK_G16_NBUF 2
+#endif
+#ifndef ARK_G16_TILE
+#define ARK_G16_TILE 0
+#endif
+constexpr int g_g16_nbuf = ARK_G16_NBUF;     // ring depth (2 -> 64 KB LDS at 128x128, two workgroups per CU)
 constexpr int g_g16_force64 = 0;  // 1: always use 64x64 tiles
 
 template <int PREC, int BM, int BN, int NBUF>
@@ -101,7 +107,7 @@ static void launch16_cfg(Gemm16Args p, hipStream_t st) {
   hipLaunchKernelGGL((gemm16_kernel<PREC, BM, BN, NBUF>), dim3((unsigned)tiles), dim3(256), G::LDS_BYTES, st, p);
 }
 
-constexpr int g_g16_tile = 0;   // 0: heuristic below, 1: 64x64, 2: 128x64, 3: 128x128, 4: 32x64, 5: 64x32
+constexpr int g_g16_tile = ARK_G16_TILE;   // 0: heuristic below, 1: 64x64, 2: 128x64, 3: 128x128, 4: 32x64, 5: 64x32
 
 template <int PREC>
 static int launch16(Gemm16Args p, hipStream_t st) {
