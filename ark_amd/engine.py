@@ -168,6 +168,8 @@ class Engine:
                                "dec": self._build_adam_jobs(off, tot)}
         self._shadow_ok = False
         self._side = None
+        self._pad_bufs = {}
+        self._n_valid = 0
         self._side_used = False
         self._dp_pending = None      # data parallel: the decoder bucket's reduction + Adam still owed (see dp_flush)
         self._dp_flush_graph = None
@@ -349,12 +351,13 @@ class Engine:
             w["pre"] = [f(B, H) for _ in range(n)]
             w["act"] = [f(B, H) for _ in range(n)]
             w["head"] = f(B, 2 * Z)
-            w["mu"], w["logv"], w["z"] = f(B, Z), f(B, Z), f(B, Z)
+            z0 = lambda *sh: torch.zeros(*sh, device=dev)   # (rows of a padded batch are never written: they must read 0)
+            w["mu"], w["logv"], w["z"] = z0(B, Z), z0(B, Z), z0(B, Z)
             w["kl"] = torch.zeros(1, device=dev)
             w["eps0"] = torch.zeros(B, Z, device=dev)
-            w["dz"], w["dhead"] = f(B, Z), f(B, 2 * Z)
+            w["dz"], w["dhead"] = z0(B, Z), z0(B, 2 * Z)
             w["dH0"] = f(B, D)
-            w["dA"], w["dB"] = f(B, H), f(B, H)
+            w["dA"], w["dB"] = z0(B, H), z0(B, H)
         # fast path: 16-bit operands + layer-diagonal GRU kernels.  (Batches that are not a multiple of 16 rows run
         # the register-staged kernels: same results, several times slower -- pad the batch instead.)
         v2 = self.use_dma and B % 16 == 0
@@ -366,7 +369,7 @@ class Engine:
             w["g16a"], w["g16b"] = i16(B, H), (i16(B, H) if two else None)
             w["act16a"] = [i16(B, H) for _ in range(n)]
             w["act16b"] = [i16(B, H) if two else None for _ in range(n)]
-            w["dpre16"] = [i16(B, H) for _ in range(n)]
+            w["dpre16"] = [torch.zeros(B, H, device=dev, dtype=torch.int16) for _ in range(n)]
         if v2:
             # "16": row-major 16-bit copies (a: forward type, b: backward type); "_t": tile-native
             w["X0a"] = i16(R, D)
@@ -458,6 +461,14 @@ class Engine:
         if not self._shadow_ok:
             self.refresh_shadows()
         B = seq.shape[0]
+        nv = B
+        if with_loss and self.use_dma and B % 16 != 0:
+            # the layer-diagonal kernels work on 16-row tiles: a ragged batch (the last one of an epoch) is padded with
+            # all-PAD rows -- no target, no KL term (the latent kernels run on the real rows only), so every gradient they
+            # contribute is exactly zero -- instead of dropping to the register-staged path
+            triples, seq, eps = self._pad_batch(triples, seq, eps)
+            B = seq.shape[0]
+        self._n_valid = nv
         T = triples.shape[1] if (self.mt == "SAIL" and triples is not None) else 0
         w = self._workspace(B, T)
         D, n, V, Z = self.D, self.n, self.V, self.Z
@@ -505,7 +516,7 @@ class Engine:
                 eps = w["eps0"].normal_()
             self._eps = eps
             _call("ark_latent_fwd", L.ptr(w["head"]), L.ptr(eps), L.ptr(w["mu"]), L.ptr(w["logv"]), L.ptr(w["z"]),
-                  L.ptr(w["kl"]), L.i32(B), L.i32(Z), st)
+                  L.ptr(w["kl"]), L.i32(nv), L.i32(Z), st)   # (padding rows: z stays 0, no KL term)
             self._decode_h0(w, w["z"], B)
         else:
             for l in range(n):
@@ -712,6 +723,7 @@ class Engine:
         st = L.cur_stream()
         KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
         p, g = self.p, self.g
+        nv = self._n_valid   # real rows (< B when a ragged batch was padded: those rows of dhead / dA stay zero)
         # latent path
         H = 3 * D
         h0rm = w["h0"] if w["v2"] else w["Y"][0]   # row-major h0 (the v2 state buffers are tile-native)
@@ -726,7 +738,7 @@ class Engine:
             _call("ark_latent_chain_bwd", L.ptr(w["dH0"]), L.ptr(h0rm), L.ptr(p["dec.z_proj.weight"]), L.ptr(w["head"]),
                   L.ptr(self._eps), L.ptr(self.hyper), L.ptr(ext), L.ptr(p["enc.mu.weight"]), L.ptr(w["pre"][n - 1]),
                   L.ptr(w["dhead"]), L.ptr(w["dA"]), L.ptr(w["dpre16"][n - 1]), L.i32(pb),
-                  L.ptr(g[f"enc.mlp.{2 * (n - 1)}.bias"]), L.i32(B), L.i32(Z), L.i32(D), L.i32(H), st)
+                  L.ptr(g[f"enc.mlp.{2 * (n - 1)}.bias"]), L.i32(nv), L.i32(Z), L.i32(D), L.i32(H), st)
             if self._fork_pending is not None:
                 self._fork_pending()
             main = torch.cuda.current_stream()
@@ -736,7 +748,7 @@ class Engine:
                 ss = L.cur_stream()
                 _call("ark_latent_reduce_bwd", L.ptr(w["dH0"]), L.ptr(w["z"]), L.ptr(g["dec.z_proj.weight"]),
                       L.ptr(g["dec.z_proj.bias"]), L.ptr(w["dhead"]), L.ptr(a16b(n - 1)), L.i32(pb), L.ptr(g["enc.mu.weight"]),
-                      L.ptr(g["enc.mu.bias"]), L.i32(B), L.i32(Z), L.i32(D), L.i32(H), ss)
+                      L.ptr(g["enc.mu.bias"]), L.i32(nv), L.i32(Z), L.i32(D), L.i32(H), ss)
             self._side_used = self._side_used or (side is not main)
         else:
             if self._fork_pending is not None:
@@ -1103,6 +1115,27 @@ class Engine:
             self._adam_part("dec")
 
     # ------------------------------------------------------------------ whole step
+    def _pad_batch(self, triples, seq, eps):
+        """copies of the inputs with the batch padded to a multiple of 16 rows (token 0 = PAD everywhere, eps 0);
+        persistent buffers, so the copies can be captured into a hipGraph"""
+        B = seq.shape[0]
+        Bp = (B + 15) // 16 * 16
+        key = (B, tuple(seq.shape[1:]), None if triples is None else tuple(triples.shape[1:]), eps is not None)
+        bufs = self._pad_bufs.get(key)
+        if bufs is None:
+            dev = self.device
+            bufs = (None if triples is None else torch.zeros((Bp,) + tuple(triples.shape[1:]), dtype=torch.int64, device=dev),
+                    torch.zeros((Bp,) + tuple(seq.shape[1:]), dtype=torch.int64, device=dev),
+                    None if eps is None else torch.zeros(Bp, self.Z, device=dev))
+            self._pad_bufs[key] = bufs
+        tp, sp, ep = bufs
+        if tp is not None:
+            tp[:B].copy_(triples)
+        sp[:B].copy_(seq)
+        if ep is not None:
+            ep[:B].copy_(eps)
+        return tp, sp, ep
+
     def _default_norms(self, B):
         if self.mt == "SAIL":
             self.set_hyper(kl_norm=1.0 / (B * self.world_size * self.Z))

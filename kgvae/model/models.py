@@ -322,8 +322,9 @@ class SAIL(_EngineModel):
                 B = seq.shape[0]
                 e = torch.randn(B, eng.Z, device=device) if eps is None else eps[i0:i0 + B].to(device, dtype=torch.float32).contiguous()
                 w = eng.forward(tri, seq, e, with_dlogits=False)
-                ar = (w["row_loss"][:eng.L * B].reshape(eng.L, B).sum(0) / ln2).cpu().numpy()
-                mu, logv = w["mu"], w["logv"]
+                Bp = eng._B   # (a ragged batch is padded to 16 rows inside the engine)
+                ar = (w["row_loss"][:eng.L * Bp].reshape(eng.L, Bp)[:, :B].sum(0) / ln2).cpu().numpy()
+                mu, logv = w["mu"][:B], w["logv"][:B]
                 kl = (-0.5 * torch.sum(1 + logv - mu.pow(2) - logv.exp(), dim=1) / ln2).cpu().numpy()
                 records += [{"ar_bits": float(a), "kl_bits": float(k), "total_bits": float(a + k)} for a, k in zip(ar, kl)]
         finally:
@@ -419,7 +420,8 @@ class ARK(_EngineModel):
                 seq = seq.to(device)
                 B = seq.shape[0]
                 w = eng.forward(None, seq, None, with_dlogits=False)
-                ar = (w["row_loss"][:eng.L * B].reshape(eng.L, B).sum(0) / ln2).cpu().numpy()
+                Bp = eng._B
+                ar = (w["row_loss"][:eng.L * Bp].reshape(eng.L, Bp)[:, :B].sum(0) / ln2).cpu().numpy()
                 records += [{"ar_bits": float(a), "kl_bits": 0.0, "total_bits": float(a)} for a in ar]
         finally:
             eng.training = was

@@ -172,6 +172,109 @@ def test_gradients_match_oracle_fast_path(precision, rel, cos):
     assert checked >= 20
 
 
+def _trained_weights(cfg, steps, lr, scale):
+    """weights off the initialisation: `steps` Adam steps of the CPU oracle (B=128, the usual synthetic batches), then every
+    GRU / MLP / projection matrix multiplied by `scale` (pre-activations well outside the init's +-1: fp16 operand
+    range, saturating gates)"""
+    from oracle import sail_oracle as O
+    P = O._detach_tied(O.init_params(cfg, 0), True)
+    state = O.adam_init(O.leaf_params(P))
+    for s_ in range(steps):
+        tri, seq = synth_batch(cfg, 128, seed=200 + s_ % 4)
+        torch.manual_seed(300 + s_)
+        O.train_step(P, state, (tri, seq), cfg, lr, beta=0.3, eps=torch.randn(128, cfg["d_latent"]))
+    P = {k: v.detach().clone() for k, v in P.items()}
+    if scale != 1.0:
+        for k in P:
+            if P[k].dim() == 2 and ("gru.weight" in k or "mlp" in k or "z_proj" in k):
+                P[k] = P[k] * scale
+    return P
+
+
+@pytest.mark.parametrize("steps,lr,scale,tol,grel", [(40, 1e-3, 1.0, 1e-4, 1.5e-2), (10, 1e-3, 4.0, 2e-4, 2.5e-2)])
+def test_mixed_precision_parity_on_trained_and_scaled_weights(steps, lr, scale, tol, grel):
+    """the shipped mixed mode (fp16 forward / bf16 backward operands) away from the initialisation: weights after 40
+    oracle Adam steps at lr 1e-3 (the loss has dropped by > 0.5), and weights with every hidden matrix scaled x4 (gate
+    pre-activations of +-10 and more).  ELBO within north_star's 1e-4 (2e-4 for the scaled case) of the fp32 oracle and
+    per-tensor gradients within the bf16 operand rounding, dropout off (same batch / eps)."""
+    from oracle import sail_oracle as O
+    cfg = dict(_big_cfg(), dec_dropout=0.0)
+    P0 = O.init_params(cfg, 0)
+    P = _trained_weights(cfg, steps, lr, scale)
+    moved = max((P[k] - P0[k]).abs().max().item() for k in P if k in P0 and P[k].shape == P0[k].shape)
+    assert moved > 5e-3
+    B = 256
+    triples, seq = synth_batch(cfg, B, seed=9)
+    torch.manual_seed(19)
+    eps = torch.randn(B, cfg["d_latent"])
+    eng = make_engine(cfg, P, "mixed")
+    dev = eng.device
+    eng.set_hyper(beta=0.3)
+    eng._default_norms(B)
+    eng.forward(triples.to(dev), seq.to(dev), eps.to(dev))
+    eng.backward()
+    torch.cuda.synchronize()
+    val = float(eng.ws["out4"].cpu()[0])
+    got = {k: v.detach().double().cpu().clone() for k, v in eng.g.items()}
+    Pc = O._detach_tied(P, True)
+    leaves = O.leaf_params(Pc)
+    for _, t in leaves:
+        t.requires_grad_(True)
+    loss, *_ = O.sail_elbo(Pc, triples, seq, eps, 0.3, cfg)
+    loss.backward()
+    assert rel_err(val, float(loss)) < tol, (val, float(loss))
+    worst = 0.0
+    for k, t in leaves:
+        want = t.grad.double()
+        nw = want.norm().item()
+        if nw < 1e-12:
+            continue
+        e = (got[k] - want).norm().item() / nw
+        worst = max(worst, e)
+        assert e <= grel, (k, e)
+    assert worst > 0
+
+
+@pytest.mark.parametrize("B", [100, 7])
+def test_ragged_batch_is_padded_onto_the_fast_path(B):
+    """a batch that is not a multiple of 16 rows (the last batch of an epoch) runs the layer-diagonal fast path on
+    all-PAD padding rows instead of the register-staged path: ELBO and every gradient against the CPU oracle on the
+    real rows only (padding rows carry no target and no KL term)"""
+    from oracle import sail_oracle as O
+    cfg = dict(_big_cfg(), dec_dropout=0.0)
+    P = O.init_params(cfg, 0)
+    triples, seq = synth_batch(cfg, B, seed=11)
+    torch.manual_seed(13)
+    eps = torch.randn(B, cfg["d_latent"])
+    eng = make_engine(cfg, P, "mixed")
+    dev = eng.device
+    eng.set_hyper(beta=0.5)
+    eng._default_norms(B)
+    eng.forward(triples.to(dev), seq.to(dev), eps.to(dev))
+    assert eng.ws["v2"] and eng._B % 16 == 0 and eng._n_valid == B
+    eng.backward()
+    torch.cuda.synchronize()
+    val = eng.ws["out4"].cpu().numpy().copy()
+    got = {k: v.detach().double().cpu().clone() for k, v in eng.g.items()}
+    Pc = O._detach_tied(P, True)
+    leaves = O.leaf_params(Pc)
+    for _, t in leaves:
+        t.requires_grad_(True)
+    loss, ce, kl, *_ = O.sail_elbo(Pc, triples, seq, eps, 0.5, cfg)
+    loss.backward()
+    assert rel_err(float(val[0]), float(loss)) < 1e-4, (val, float(loss))
+    assert rel_err(float(val[2]), float(kl)) < 1e-3, (val, float(kl))   # (a KL of 3e-4 nats: fp16 operand noise)
+    for k, t in leaves:
+        want = t.grad.double()
+        nw = want.norm().item()
+        if nw < 1e-12:
+            continue
+        assert (got[k] - want).norm().item() <= 1.5e-2 * nw, (k, (got[k] - want).norm().item() / nw)
+    # evaluation entry point on the same ragged batch
+    out = eng.eval_loss(triples.to(dev), seq.to(dev), eps.to(dev)).cpu().numpy()
+    assert rel_err(float(out[0]), float(loss)) < 1e-4
+
+
 def test_loss_trajectory_matches_oracle_fast_path():
     """12 consecutive optimiser steps of the shipped fast path (captured hipGraph, mixed precision, diagonal
     kernels, 16-bit shadows refreshed after every Adam) against the fp32 CPU oracle on the same batches and
