@@ -142,7 +142,12 @@ __global__ __launch_bounds__(256) void scatter_global_kernel(ScatterArgs p) {
     if (!scatter_item(p, i, id, srow, sc)) continue;
     const float* s = p.src + srow * p.ld_src + p.col_off;
     float* d = p.dst + id * p.D;
-    for (int c = lane; c < p.D; c += 64) atomicAdd(&d[c], sc * s[c]);
+    // exact zeros are skipped: the rows behind PAD inputs (half of a padded batch) have an all-zero gradient and all
+    // hit ONE table row -- same-address atomics serialise (wd-movies trace: 228 us for 2.3 M adds before, see DESIGN)
+    for (int c = lane; c < p.D; c += 64) {
+      const float v = sc * s[c];
+      if (v != 0.f) atomicAdd(&d[c], v);
+    }
   }
 }
 

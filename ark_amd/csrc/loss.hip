@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void zproj_bwd_dz_kernel(float* __restrict__ d
 // of dA with every W_head element loaded once per workgroup.  Round 1 used 2 rows per workgroup with half of
 // the waves idle in the first phase and scalar, strided Wz reads: 39 us alone (104 us beside the weight
 // gradients) for 31 MFLOP; this one is bound by its ~15 MB of HBM traffic.
-template <int ZT, int RW>
+template <int ZT, int RW, bool BATCHED>
 __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict__ dh0, const float* __restrict__ h0,
                                                                const float* __restrict__ Wz, const float* __restrict__ head,
                                                                const float* __restrict__ eps, const float* __restrict__ hyper,
@@ -136,7 +136,36 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
   __shared__ float sh[RW][2 * ZT];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int DS = D + 1;
-  for (int i = threadIdx.x; i < D * Z; i += 256) zs[(i % Z) * DS + i / Z] = Wz[i];   // coalesced read, stride-(D+1) write
+  // BATCHED: every loop keeps a batch of loads in flight before it touches the results (with 4 waves per CU nobody
+  // else hides a load's latency).  It costs registers (255 VGPRs against ~100), which matters where the kernel has to
+  // squeeze in beside the weight-gradient launch: measured in situ, same box, alternating rounds -- wd-movies
+  // (Z = 64, 64 workgroups) 2.50 -> 2.44 ms/step, syn-types (Z = 24) equal, syn-paths (Z = 10, 256 workgroups beside
+  // 480 weight-gradient workgroups) 1.28 -> 1.30 ms/step.  So: batched for Z > 32 only.
+  if constexpr (!BATCHED) {
+    for (int i = threadIdx.x; i < D * Z; i += 256) zs[(i % Z) * DS + i / Z] = Wz[i];   // coalesced read, stride-(D+1) write
+  } else {
+    const int N4 = (D * Z) >> 2;   // D % 4 == 0 (host check) -> whole float4s; parameter blocks are 16-byte aligned
+    const f32x4* W4 = reinterpret_cast<const f32x4*>(Wz);
+    for (int base = threadIdx.x; base < N4; base += 256 * 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = base + 256 * u;
+        v[u] = q < N4 ? W4[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = base + 256 * u;
+        if (q < N4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * q + e;
+            zs[(i % Z) * DS + i / Z] = v[u][e];   // row stride D+1: conflict-free fill and reads
+          }
+        }
+      }
+    }
+  }
   const int b = blockIdx.x * RW + wave;
   const bool valid = b < B;
   const int bb = valid ? b : B - 1;
@@ -144,14 +173,26 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
   float acc[ZT];
 #pragma unroll
   for (int j = 0; j < ZT; ++j) acc[j] = 0.f;
-  for (int d = lane; d < D; d += 64) {
-    const long i = (long)bb * D + d;
-    const float h = h0[i];
-    const float g = dh0[i] * (1.0f - h * h);
-    if (valid) dh0[i] = g;
+  constexpr int DU = BATCHED ? 8 : 1;
+  for (int d0 = lane; d0 < D; d0 += 64 * DU) {
+    float hv[DU], gv[DU];
 #pragma unroll
-    for (int j = 0; j < ZT; ++j)
-      if (j < Z) acc[j] += g * zs[j * DS + d];
+    for (int u = 0; u < DU; ++u) {
+      const int d = d0 + 64 * u;
+      hv[u] = d < D ? h0[(long)bb * D + d] : 0.f;
+      gv[u] = d < D ? dh0[(long)bb * D + d] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int d = d0 + 64 * u;
+      if (d < D) {
+        const float g = gv[u] * (1.0f - hv[u] * hv[u]);
+        if (valid) dh0[(long)bb * D + d] = g;
+#pragma unroll
+        for (int j = 0; j < ZT; ++j)
+          if (j < Z) acc[j] += g * zs[j * DS + d];
+      }
+    }
   }
   float mydz = 0.f;
 #pragma unroll
@@ -180,46 +221,104 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
     }
   }
   __syncthreads();
-  // dA for the workgroup's RW rows: thread -> KC columns at a time (every W_head element is loaded once per
-  // workgroup and used for all rows; each dhead value is one LDS broadcast per KC columns)
-  const int row0 = blockIdx.x * RW;
-  constexpr int KC = 3;
-  for (int cb = 0; cb < H; cb += 256 * KC) {
-    float acc4[KC][RW];
-#pragma unroll
-    for (int k = 0; k < KC; ++k)
-#pragma unroll
-      for (int r = 0; r < RW; ++r) acc4[k][r] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 2 * ZT; ++j)
-      if (j < 2 * Z) {
-        float dj[RW];
-#pragma unroll
-        for (int r = 0; r < RW; ++r) dj[r] = sh[r][j];
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
+  if constexpr (!BATCHED) {
+    // dA for the workgroup's RW rows: thread -> KC columns at a time (every W_head element is loaded once per
+    // workgroup and used for all rows; each dhead value is one LDS broadcast per KC columns)
+    const int row0 = blockIdx.x * RW;
+    constexpr int KC = 3;
+    for (int cb = 0; cb < H; cb += 256 * KC) {
+      float acc4[KC][RW];
+  #pragma unroll
+      for (int k = 0; k < KC; ++k)
+  #pragma unroll
+        for (int r = 0; r < RW; ++r) acc4[k][r] = 0.f;
+  #pragma unroll
+      for (int j = 0; j < 2 * ZT; ++j)
+        if (j < 2 * Z) {
+          float dj[RW];
+  #pragma unroll
+          for (int r = 0; r < RW; ++r) dj[r] = sh[r][j];
+  #pragma unroll
+          for (int k = 0; k < KC; ++k) {
+            const int c = cb + 256 * k + threadIdx.x;
+            const float wv = (c < H) ? Whead[(long)j * H + c] : 0.f;
+  #pragma unroll
+            for (int r = 0; r < RW; ++r) acc4[k][r] += dj[r] * wv;
+          }
+        }
+  #pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        const int c = cb + 256 * k + threadIdx.x;
+        if (c >= H) continue;
+        float cs = 0.f;
+  #pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          if (row0 + r >= B) break;
+          const long o = (long)(row0 + r) * H + c;
+          const float v = acc4[k][r] * dgelu_erf(pre[o]);
+          dA[o] = v;
+          cs += v;
+          if (prec16 == 2) reinterpret_cast<_Float16*>(dA16)[o] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+          else reinterpret_cast<__bf16*>(dA16)[o] = (__bf16)v;
+        }
+        if (dA_colsum) atomicAdd(&dA_colsum[c], cs);
+      }
+    }
+  } else {
+    // dA for the workgroup's RW rows: thread -> KC columns at a time (every W_head element is loaded once per
+    // workgroup and used for all rows; each dhead value is one LDS broadcast per KC columns); W_head in batches of
+    // JC x KC loads, the pre-activations of the epilogue fetched before the products
+    const int row0 = blockIdx.x * RW;
+    constexpr int KC = 3, JC = 16;
+    static_assert((2 * ZT) % JC == 0, "batches of head rows");
+    for (int cb = 0; cb < H; cb += 256 * KC) {
+      float acc4[KC][RW], pv[KC][RW];
+  #pragma unroll
+      for (int k = 0; k < KC; ++k)
+  #pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          acc4[k][r] = 0.f;
           const int c = cb + 256 * k + threadIdx.x;
-          const float wv = (c < H) ? Whead[(long)j * H + c] : 0.f;
-#pragma unroll
-          for (int r = 0; r < RW; ++r) acc4[k][r] += dj[r] * wv;
+          pv[k][r] = (c < H && row0 + r < B) ? pre[(long)(row0 + r) * H + c] : 0.f;
+        }
+  #pragma unroll 1
+      for (int j0 = 0; j0 < 2 * Z; j0 += JC) {
+        float wv[JC][KC];
+  #pragma unroll
+        for (int jj = 0; jj < JC; ++jj)
+  #pragma unroll
+          for (int k = 0; k < KC; ++k) {
+            const int c = cb + 256 * k + threadIdx.x;
+            wv[jj][k] = (j0 + jj < 2 * Z && c < H) ? Whead[(long)(j0 + jj) * H + c] : 0.f;
+          }
+  #pragma unroll
+        for (int jj = 0; jj < JC; ++jj) {
+          float dj[RW];
+  #pragma unroll
+          for (int r = 0; r < RW; ++r) dj[r] = (j0 + jj < 2 * Z) ? sh[r][j0 + jj] : 0.f;
+  #pragma unroll
+          for (int k = 0; k < KC; ++k)
+  #pragma unroll
+            for (int r = 0; r < RW; ++r) acc4[k][r] += dj[r] * wv[jj][k];
         }
       }
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      const int c = cb + 256 * k + threadIdx.x;
-      if (c >= H) continue;
-      float cs = 0.f;
-#pragma unroll
-      for (int r = 0; r < RW; ++r) {
-        if (row0 + r >= B) break;
-        const long o = (long)(row0 + r) * H + c;
-        const float v = acc4[k][r] * dgelu_erf(pre[o]);
-        dA[o] = v;
-        cs += v;
-        if (prec16 == 2) reinterpret_cast<_Float16*>(dA16)[o] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-        else reinterpret_cast<__bf16*>(dA16)[o] = (__bf16)v;
+  #pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        const int c = cb + 256 * k + threadIdx.x;
+        if (c >= H) continue;
+        float cs = 0.f;
+  #pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          if (row0 + r >= B) break;
+          const long o = (long)(row0 + r) * H + c;
+          const float v = acc4[k][r] * dgelu_erf(pv[k][r]);
+          dA[o] = v;
+          cs += v;
+          if (prec16 == 2) reinterpret_cast<_Float16*>(dA16)[o] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+          else reinterpret_cast<__bf16*>(dA16)[o] = (__bf16)v;
+        }
+        if (dA_colsum) atomicAdd(&dA_colsum[c], cs);
       }
-      if (dA_colsum) atomicAdd(&dA_colsum[c], cs);
     }
   }
 }
@@ -610,10 +709,10 @@ extern "C" int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_
   if (lds > 150 * 1024) return ARK_ERR_SHAPE;
 #define ARK_LC(ZT)                                                                                                          \
   {                                                                                                                         \
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_bwd_kernel<ZT, 4>),            \
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_bwd_kernel<ZT, 4, (ZT > 32)>),            \
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), true);           \
     (void)once;                                                                                                             \
-    hipLaunchKernelGGL((latent_chain_bwd_kernel<ZT, 4>), dim3((B + 3) / 4), dim3(256), lds, st, dh0, h0, w_z, head, eps,     \
+    hipLaunchKernelGGL((latent_chain_bwd_kernel<ZT, 4, (ZT > 32)>), dim3((B + 3) / 4), dim3(256), lds, st, dh0, h0, w_z, head, eps,     \
                        hyper, ext_dhead, w_head, pre, dhead, dA, dA16, prec16, dA_colsum, B, Z, D, H);                                  \
   }
   if (Z <= 16) ARK_LC(16)
