@@ -472,6 +472,88 @@ __global__ __launch_bounds__(256) void zproj_fwd_v2_kernel(const float* __restri
 }
 }  // namespace ark
 
+namespace ark {
+// reparameterisation + z-projection in ONE launch (they were a single-workgroup kernel and a per-element kernel on the
+// dependent chain between the encoder heads and the first GRU diagonal): a workgroup = one batch row x 256 hidden
+// units; its first Z threads form mu, clamped logv, z = mu + eps * exp(logv / 2) and the row's KL terms (written by the
+// row's first workgroup; the per-row sums are added up in fixed order by ark_loss_finalize: deterministic), every
+// thread then forms h0[b, d] = tanh(bz[d] + z . Wz[d, :]) in all layouts the GRU path reads.  Rows >= n_valid (padding
+// of a ragged batch) get z = 0 and no KL term.  Reference: models.py:61-63, 139, 199-200.
+template <int PA, int PB2>
+__global__ __launch_bounds__(256) void latent_zproj_fwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
+                                                               float* __restrict__ mu, float* __restrict__ logv,
+                                                               float* __restrict__ z, float* __restrict__ kl_rows,
+                                                               const float* __restrict__ Wz, const float* __restrict__ bz,
+                                                               float* __restrict__ h0, ZprojOut o, int B, int n_valid, int Z,
+                                                               int D, int DC) {
+  __shared__ float zs[128], ts[128];
+  const int b = blockIdx.x / DC, dc = blockIdx.x % DC, tid = threadIdx.x;
+  if (tid < Z) {
+    float zz = 0.f, term = 0.f;
+    if (b < n_valid) {
+      const float m = head[(long)b * 2 * Z + tid];
+      const float lv = fminf(fmaxf(head[(long)b * 2 * Z + Z + tid], -10.0f), 10.0f);
+      zz = m + (eps ? eps[(long)b * Z + tid] : 0.f) * expf(0.5f * lv);
+      term = 1.0f + lv - m * m - expf(lv);
+      if (dc == 0) {
+        mu[(long)b * Z + tid] = m;
+        logv[(long)b * Z + tid] = lv;
+        z[(long)b * Z + tid] = zz;
+      }
+    }
+    zs[tid] = zz;
+    ts[tid] = term;
+  }
+  __syncthreads();
+  if (dc == 0 && tid == 0 && b < n_valid) {
+    float s = 0.f;
+    for (int j = 0; j < Z; ++j) s += ts[j];
+    kl_rows[b] = s;
+  }
+  const int d = dc * 256 + tid;
+  if (d >= D) return;
+  float a = bz[d];
+  for (int j = 0; j < Z; ++j) a += zs[j] * Wz[(long)d * Z + j];
+  const float h = tanhf(a);
+  const long i = (long)b * D + d;
+  h0[i] = h;
+  const long ot = tile_native_off(b, d, D);
+  for (int l = 0; l < o.n; ++l) {
+    o.y_t[l][ot] = h;
+    reinterpret_cast<typename PrecTraits<PA>::h_t*>(o.y16a[l])[i] = PrecTraits<PA>::cvt(h);
+    if (o.y16b[l]) reinterpret_cast<typename PrecTraits<PB2>::h_t*>(o.y16b[l])[i] = PrecTraits<PB2>::cvt(h);
+  }
+}
+}  // namespace ark
+
+extern "C" int ark_latent_zproj_fwd(int prec_a, int prec_b, const float* head, const float* eps, float* mu, float* logv,
+                                    float* z, float* kl_rows, const float* w_z, const float* b_z, float* h0, int n_layers,
+                                    float* const* y_t, void* const* y16a, void* const* y16b, int B, int n_valid, int Z, int D,
+                                    void* stream) {
+  using namespace ark;
+  if (!head || !mu || !logv || !z || !kl_rows || !w_z || !b_z || !h0 || !y_t || !y16a || n_layers <= 0 || n_layers > 8 ||
+      B <= 0 || n_valid <= 0 || n_valid > B || Z <= 0 || D <= 0)
+    return ARK_ERR_ARG;
+  if (B % 16 != 0 || D % 16 != 0 || Z > 128) return ARK_ERR_SHAPE;
+  ZprojOut o{};
+  o.n = n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    if (!y_t[l] || !y16a[l]) return ARK_ERR_ARG;
+    o.y_t[l] = y_t[l]; o.y16a[l] = y16a[l]; o.y16b[l] = y16b ? y16b[l] : nullptr;
+  }
+  const int DC = (D + 255) / 256;
+  dim3 grid((unsigned)((long)B * DC));
+  hipStream_t st = (hipStream_t)stream;
+#define ARK_LZ(PA, PB2) hipLaunchKernelGGL((latent_zproj_fwd_kernel<PA, PB2>), grid, dim3(256), 0, st, head, eps, mu, logv, z, kl_rows, w_z, b_z, h0, o, B, n_valid, Z, D, DC)
+  if (prec_a == PREC_F16 && prec_b == PREC_BF16) ARK_LZ(PREC_F16, PREC_BF16);
+  else if (prec_a == PREC_F16 && prec_b == PREC_F16) ARK_LZ(PREC_F16, PREC_F16);
+  else if (prec_a == PREC_BF16 && prec_b == PREC_BF16) ARK_LZ(PREC_BF16, PREC_BF16);
+  else return ARK_ERR_ARG;
+#undef ARK_LZ
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ark_zproj_fwd_v2(int prec_a, int prec_b, const float* z, const float* w_z, const float* b_z, float* h0,
                                 int n_layers, float* const* y_t, void* const* y16a, void* const* y16b, int B, int Z, int D,
                                 void* stream) {

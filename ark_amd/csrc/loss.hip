@@ -568,15 +568,22 @@ __global__ __launch_bounds__(1024) void count_targets_kernel(const int64_t* __re
 
 // out[0] = loss = ce + beta*kl, out[1] = ce, out[2] = kl.  Deterministic single-workgroup sum.
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float* __restrict__ row_loss, int n_rows,
-                                                             const float* __restrict__ kl, const float* __restrict__ hyper,
-                                                             float* __restrict__ out) {
+                                                             const float* __restrict__ kl, int n_kl, float kl_scale,
+                                                             const float* __restrict__ hyper, float* __restrict__ out) {
   __shared__ float red[16];
   float s = 0.f;
   for (int i = threadIdx.x; i < n_rows; i += blockDim.x) s += row_loss[i];
   const float tot = block_sum_1024(s, red);
+  float ks = 0.f;
+  if (kl && n_kl > 1) {   // per-row KL sums (ark_latent_zproj_fwd): fixed-order reduction, deterministic
+    __syncthreads();      // (red[] is reused)
+    float t = 0.f;
+    for (int i = threadIdx.x; i < n_kl; i += blockDim.x) t += kl[i];
+    ks = block_sum_1024(t, red) * kl_scale;
+  }
   if (threadIdx.x == 0) {
     const float ce = tot * hyper[ARK_HP_CE_INV_COUNT];
-    const float k = kl ? kl[0] : 0.f;
+    const float k = !kl ? 0.f : (n_kl > 1 ? ks : kl[0] * kl_scale);
     out[0] = ce + hyper[ARK_HP_BETA] * k;
     out[1] = ce;
     out[2] = k;
@@ -790,7 +797,19 @@ extern "C" int ark_loss_finalize(const float* row_loss, int n_rows, const float*
                                  void* stream) {
   using namespace ark;
   if (!row_loss || !hyper || !out4 || n_rows <= 0) return ARK_ERR_ARG;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, n_rows, kl, hyper, out4);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, n_rows, kl, 1, 1.0f, hyper,
+                     out4);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same with kl = kl_scale * sum(kl_rows[0:n_kl]) (per-row KL terms of ark_latent_zproj_fwd; kl_scale = -0.5 / (rows * Z))
+extern "C" int ark_loss_finalize_rows(const float* row_loss, int n_rows, const float* kl_rows, int n_kl, float kl_scale,
+                                      const float* hyper, float* out4, void* stream) {
+  using namespace ark;
+  if (!row_loss || !hyper || !out4 || !kl_rows || n_rows <= 0 || n_kl <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, n_rows, kl_rows, n_kl, kl_scale, hyper,
+                     out4);
   ARK_LAUNCH_CHECK();
   return 0;
 }

@@ -184,6 +184,7 @@ class Engine:
         self._defer_finalize = False   # set by train_step / _dp_steps around forward(): backward follows at once
         self.fork_after = int(cfg.get("ark_fork_after", 1))   # measured: 0 -> 1.281, 1 -> 1.266, 2 -> 1.296 ms/step
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
+        self.fused_latent = bool(cfg.get("ark_fused_latent", True))   # reparameterisation + z-projection as one launch
         self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))
         # large vocabularies: tied projection fused with the cross-entropy -- [B*L, V] logits / dlogits never exist
         # (csrc/vocab_ce.hip); small ones keep the three short launches (W_tok is a few KB there)
@@ -354,6 +355,7 @@ class Engine:
             z0 = lambda *sh: torch.zeros(*sh, device=dev)   # (rows of a padded batch are never written: they must read 0)
             w["mu"], w["logv"], w["z"] = z0(B, Z), z0(B, Z), z0(B, Z)
             w["kl"] = torch.zeros(1, device=dev)
+            w["kl_rows"] = torch.zeros(B, device=dev)
             w["eps0"] = torch.zeros(B, Z, device=dev)
             w["dz"], w["dhead"] = z0(B, Z), z0(B, 2 * Z)
             w["dH0"] = f(B, D)
@@ -515,9 +517,20 @@ class Engine:
             if eps is None:   # z = mu + N(0,1) * std, drawn on the device (reference models.py:63)
                 eps = w["eps0"].normal_()
             self._eps = eps
-            _call("ark_latent_fwd", L.ptr(w["head"]), L.ptr(eps), L.ptr(w["mu"]), L.ptr(w["logv"]), L.ptr(w["z"]),
-                  L.ptr(w["kl"]), L.i32(nv), L.i32(Z), st)   # (padding rows: z stays 0, no KL term)
-            self._decode_h0(w, w["z"], B)
+            self._kl_rows = bool(w["v2"] and Z <= 128 and self.fused_latent)
+            if self._kl_rows:
+                # reparameterisation + z-projection as ONE launch; per-row KL terms, summed by the loss finalisation
+                import ctypes
+                yt = (ctypes.c_void_p * n)(*[w["Y"][l].data_ptr() for l in range(n)])
+                ya = (ctypes.c_void_p * n)(*[w["Y16a"][l].data_ptr() for l in range(n)])
+                yb = (ctypes.c_void_p * n)(*[(w["Y16b"][l].data_ptr() if w["Y16b"][l] is not None else 0) for l in range(n)])
+                _call("ark_latent_zproj_fwd", L.i32(self.prec_fwd), L.i32(self.prec_bwd), L.ptr(w["head"]), L.ptr(eps), L.ptr(w["mu"]),
+                      L.ptr(w["logv"]), L.ptr(w["z"]), L.ptr(w["kl_rows"]), L.ptr(p["dec.z_proj.weight"]), L.ptr(p["dec.z_proj.bias"]),
+                      L.ptr(w["h0"]), L.i32(n), yt, ya, yb, L.i32(B), L.i32(nv), L.i32(Z), L.i32(D), st)
+            else:
+                _call("ark_latent_fwd", L.ptr(w["head"]), L.ptr(eps), L.ptr(w["mu"]), L.ptr(w["logv"]), L.ptr(w["z"]),
+                      L.ptr(w["kl"]), L.i32(nv), L.i32(Z), st)   # (padding rows: z stays 0, no KL term)
+                self._decode_h0(w, w["z"], B)
         else:
             for l in range(n):
                 w["Y"][l][:B].zero_()
@@ -539,9 +552,7 @@ class Engine:
             _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]),
                   L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
                   L.ptr(w["dYa"] if with_dlogits else None), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
-            self._finalize = lambda: _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R),
-                                           L.ptr(w["kl"] if self.mt == "SAIL" else None), L.ptr(self.hyper), L.ptr(w["out4"]),
-                                           L.cur_stream())
+            self._finalize = self._make_finalize(w, R, B)
             if not (self._defer_finalize and with_dlogits):
                 self._finalize()
                 self._finalize = None
@@ -557,14 +568,22 @@ class Engine:
                   L.i32(V), st)
             self._dlog16_valid = d16 is not None
             self._dlog16_only = bool(only16)
-            self._finalize = lambda: _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R),
-                                           L.ptr(w["kl"] if self.mt == "SAIL" else None), L.ptr(self.hyper), L.ptr(w["out4"]),
-                                           L.cur_stream())
+            self._finalize = self._make_finalize(w, R, B)
             if not (self._defer_finalize and with_dlogits and w["v2"]):
                 self._finalize()
                 self._finalize = None
             # (else: the two-queue backward launches it on its side queue -- the loss scalars are not on the
             #  dependent chain)
+
+    def _make_finalize(self, w, R, B):
+        """the launch that turns per-row losses (and the KL terms) into out4 = [loss, ce, kl, token-loss sum]"""
+        if self.mt == "SAIL" and getattr(self, "_kl_rows", False):
+            nv = self._n_valid
+            scale = -0.5 / (nv * self.Z)
+            return lambda: _call("ark_loss_finalize_rows", L.ptr(w["row_loss"]), L.i32(R), L.ptr(w["kl_rows"]), L.i32(nv),
+                                 L.f32(scale), L.ptr(self.hyper), L.ptr(w["out4"]), L.cur_stream())
+        return lambda: _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R), L.ptr(w["kl"] if self.mt == "SAIL" else None),
+                             L.ptr(self.hyper), L.ptr(w["out4"]), L.cur_stream())
 
     def _decode_h0(self, w, z, B):
         p = self.p

@@ -206,6 +206,13 @@ int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq,
 /* h0 = tanh(z_proj(z)) for all layers in every layout of the LDS-DMA path, one launch */
 int ark_zproj_fwd_v2(int prec_a, int prec_b, const float* z, const float* w_z, const float* b_z, float* h0, int n_layers,
                      float* const* y_t, void* const* y16a, void* const* y16b, int B, int Z, int D, void* stream);
+/* reparameterisation + z-projection in one launch (fast path): mu, clamped logv, z = mu + eps * exp(logv / 2) for rows
+ * < n_valid (rows beyond: z = 0, nothing written), kl_rows[b] = sum_j (1 + logv - mu^2 - exp(logv)), and
+ * h0 = tanh(z_proj(z)) for all layers in every layout of the LDS-DMA path.  B % 16 == 0, Z <= 128.
+ * Replaces ark_latent_fwd + ark_zproj_fwd_v2 (models.py:61-63,139,199-200). */
+int ark_latent_zproj_fwd(int prec_a, int prec_b, const float* head, const float* eps, float* mu, float* logv, float* z,
+                         float* kl_rows, const float* w_z, const float* b_z, float* h0, int n_layers, float* const* y_t,
+                         void* const* y16a, void* const* y16b, int B, int n_valid, int Z, int D, void* stream);
 /* per-token sums of a 16-bit panel: S[v, 0:n_cols] += sum over rows (t, b) with seq[b, t] == v of x16[(t, b), 0:n_cols]
  * (rows time-major, v < Vp, Vp * 256 B <= 64 KB of LDS, n_cols % 64 == 0; ids outside [0, Vp) are skipped).  `scratch`
  * (caller-owned, >= 4*B*L + 32 + 4*ceil(B*L/64) bytes) holds the per-chunk row lists sorted by token.  With x16 = layer 0's
@@ -281,6 +288,10 @@ int ark_vocab_ce_dw(int prec, const void* Y16, const void* W16, const float* bia
 /* out4 = {loss = ce + beta*kl, ce, kl, sum of token losses}; kl nullable (ARK) */
 int ark_loss_finalize(const float* row_loss, int n_rows, const float* kl, const float* hyper, float* out4,
                       void* stream);
+/* the same with kl = kl_scale * sum(kl_rows[0:n_kl]): per-row KL terms of ark_latent_zproj_fwd, kl_scale = -0.5 / (rows * Z);
+ * summed in a fixed order (deterministic) */
+int ark_loss_finalize_rows(const float* row_loss, int n_rows, const float* kl_rows, int n_kl, float kl_scale,
+                           const float* hyper, float* out4, void* stream);
 int ark_argmax_rows(const float* x, int64_t ld, int64_t* out, int rows, int V, void* stream);
 
 /* ---- optimiser and reductions (reference: optim.Adam, ablation_study.py:571,76) ---------------- */

@@ -315,3 +315,58 @@ def test_fused_vocabulary_cross_entropy(prec, tol, B, Lq, V, D):
     assert close(dY, Yd.grad, tol), (dY - Yd.grad).abs().max().item() / Yd.grad.abs().max().item()
     assert close(dW.double().cpu() - 0.25, Wd.grad, tol), ((dW.double().cpu() - 0.25) - Wd.grad).abs().max().item() / Wd.grad.abs().max().item()
     assert close(db.double().cpu() - 0.5, bd.grad, tol)
+
+
+@pytest.mark.parametrize("B,nv,Z,D,n", [(32, 32, 10, 512, 3), (16, 7, 64, 384, 2), (48, 48, 128, 320, 1)])
+def test_latent_zproj_fwd_and_rowwise_kl(B, nv, Z, D, n):
+    """ark_latent_zproj_fwd (reparameterisation + z-projection in one launch) against torch: mu, clamped logv, z, the KL
+    through ark_loss_finalize_rows, h0 = tanh(z Wz^T + bz) in the row-major, tile-native and 16-bit layouts of every
+    layer; rows >= n_valid (padding of a ragged batch) get z = 0, are not written and carry no KL term"""
+    import ctypes
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + Z)
+    head = torch.randn(B, 2 * Z, generator=g) * 3.0
+    head[0, Z] = 14.0          # clamped high
+    head[1, Z + 1] = -12.0     # clamped low
+    eps = torch.randn(B, Z, generator=g)
+    Wz = torch.randn(D, Z, generator=g) * 0.3
+    bz = torch.randn(D, generator=g) * 0.1
+    mu_ref = head[:nv, :Z].double()
+    lv_ref = head[:nv, Z:].double().clamp(-10, 10)
+    z_ref = mu_ref + eps[:nv].double() * (0.5 * lv_ref).exp()
+    kl_ref = (-0.5 * (1 + lv_ref - mu_ref ** 2 - lv_ref.exp())).mean().item()
+    z_full = torch.zeros(B, Z, dtype=torch.float64)
+    z_full[:nv] = z_ref
+    h_ref = torch.tanh(z_full @ Wz.double().t() + bz.double())
+    t = lambda x: x.to(dev)
+    mu, logv, z = (torch.full((B, Z), 7.0, device=dev) for _ in range(3))
+    kl_rows = torch.full((B,), 7.0, device=dev)
+    h0 = torch.zeros(B, D, device=dev)
+    yt = [torch.zeros(2 * B * D, device=dev) for _ in range(n)]
+    ya = [torch.zeros(2 * B * D, device=dev, dtype=torch.float16) for _ in range(n)]
+    yb = [torch.zeros(2 * B * D, device=dev, dtype=torch.bfloat16) for _ in range(n)]
+    arr = lambda ts: (ctypes.c_void_p * n)(*[x.data_ptr() for x in ts])
+    hd, ed, Wd, bd = t(head), t(eps), t(Wz), t(bz)
+    L.check(L.lib().ark_latent_zproj_fwd(L.i32(L.PREC_F16), L.i32(L.PREC_BF16), L.ptr(hd), L.ptr(ed), L.ptr(mu), L.ptr(logv),
+                                         L.ptr(z), L.ptr(kl_rows), L.ptr(Wd), L.ptr(bd), L.ptr(h0), L.i32(n), arr(yt), arr(ya),
+                                         arr(yb), L.i32(B), L.i32(nv), L.i32(Z), L.i32(D), L.cur_stream()), "ark_latent_zproj_fwd")
+    row_loss = torch.tensor([1.0, 2.0, 3.5], device=dev)
+    hyper = torch.zeros(16, device=dev)
+    hyper[3], hyper[1] = 0.5, 0.25        # ARK_HP_CE_INV_COUNT, ARK_HP_BETA
+    out4 = torch.zeros(4, device=dev)
+    L.check(L.lib().ark_loss_finalize_rows(L.ptr(row_loss), L.i32(3), L.ptr(kl_rows), L.i32(nv), L.f32(-0.5 / (nv * Z)),
+                                           L.ptr(hyper), L.ptr(out4), L.cur_stream()), "ark_loss_finalize_rows")
+    torch.cuda.synchronize()
+    assert (mu[:nv].double().cpu() - mu_ref).abs().max().item() == 0
+    assert (logv[:nv].double().cpu() - lv_ref).abs().max().item() <= 1e-6
+    assert (z[:nv].double().cpu() - z_ref).abs().max().item() <= 1e-4 * z_ref.abs().max().item()
+    assert (mu[nv:] == 7.0).all() and (z[nv:] == 7.0).all() and (kl_rows[nv:] == 7.0).all()      # padding rows: untouched
+    o = out4.cpu().double()
+    assert abs(o[2].item() - kl_ref) <= 1e-5 * abs(kl_ref)
+    assert abs(o[1].item() - 3.25) < 1e-6 and abs(o[0].item() - (3.25 + 0.25 * o[2].item())) < 1e-5
+    assert (h0.double().cpu() - h_ref).abs().max().item() <= 2e-5
+    idx = _tile_native_index(B, D).reshape(-1)
+    for l in range(n):
+        assert torch.equal(yt[l][:B * D].cpu()[idx].reshape(B, D), h0.cpu())
+        assert torch.equal(ya[l][:B * D].cpu().reshape(B, D), h0.cpu().to(torch.float16))
+        assert torch.equal(yb[l][:B * D].cpu().reshape(B, D), h0.cpu().to(torch.bfloat16))
