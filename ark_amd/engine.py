@@ -184,7 +184,9 @@ class Engine:
         self._defer_finalize = False   # set by train_step / _dp_steps around forward(): backward follows at once
         self.fork_after = int(cfg.get("ark_fork_after", 1))   # measured: 0 -> 1.281, 1 -> 1.266, 2 -> 1.296 ms/step
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
-        self.fused_latent = bool(cfg.get("ark_fused_latent", True))   # reparameterisation + z-projection as one launch
+        self.fused_latent = bool(cfg.get("ark_fused_latent", True))
+        # small vocabularies (one 64-token tile): projection + cross-entropy + dY(top) + 16-bit dlogits in one launch
+        self.fused_ce_small = bool(cfg.get("ark_fused_ce_small", self.use_dma and self.V <= 64 and self.D in (64, 128, 256, 512)))   # reparameterisation + z-projection as one launch
         self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))
         # large vocabularies: tied projection fused with the cross-entropy -- [B*L, V] logits / dlogits never exist
         # (csrc/vocab_ce.hip); small ones keep the three short launches (W_tok is a few KB there)
@@ -386,6 +388,8 @@ class Engine:
                 w["lse"] = f(R)
             else:
                 w["dlog16"] = torch.zeros(R, self.Vp, device=dev, dtype=torch.int16)   # K-padded 16-bit dlogits
+                if self.fused_ce_small:
+                    w["lse"] = f(R)
             # small vocabularies: token-embedding gradient and layer 0's input weight gradient from the per-token sums
             # of layer 0's gate-gradient panel instead of input-gradient GEMM + scatter + a [3D,D]x[B*L] weight-gradient
             # product (SAIL; ARK also needs dX0 for the position embedding)
@@ -541,8 +545,11 @@ class Engine:
         yield
         st = L.cur_stream()
         fused = bool(w["v2"] and self.fused_ce and with_loss)
+        small = bool(w["v2"] and self.fused_ce_small and not self.fused_ce and with_loss and R % 64 == 0 and self.dlog16_only
+                     and self.Vp >= 64)
         self._fused_ce_step = fused and with_dlogits
-        self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop, project=not fused)
+        self._dy_ready = False
+        self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop, project=not (fused or small))
         if with_loss:
             if ce_count is None:
                 _call("ark_count_targets", L.ptr(seq), L.i64(ld_seq), L.i32(B), L.i32(Lq), L.ptr(self.hyper), st)
@@ -552,6 +559,21 @@ class Engine:
             _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]),
                   L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
                   L.ptr(w["dYa"] if with_dlogits else None), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
+            self._finalize = self._make_finalize(w, R, B)
+            if not (self._defer_finalize and with_dlogits):
+                self._finalize()
+                self._finalize = None
+        elif with_loss and small:
+            if with_dlogits:
+                _call("ark_vocab_ce_fwd_small", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16),
+                      L.ptr(p["dec.out.bias"]), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
+                      L.ptr(w["dYa"]), L.ptr(w["dlog16"]), L.i32(self.prec_bwd), L.i64(self.Vp), L.i32(B), L.i32(Lq), L.i32(V),
+                      L.i32(D), st)
+                self._dlog16_valid, self._dlog16_only, self._dy_ready = True, True, True
+            else:
+                _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16),
+                      L.ptr(p["dec.out.bias"]), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
+                      L.ptr(None), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
             self._finalize = self._make_finalize(w, R, B)
             if not (self._defer_finalize and with_dlogits):
                 self._finalize()
@@ -922,7 +944,7 @@ class Engine:
                       L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(V), L.i32(D), L.i32(R), L.i32(1), L.cur_stream())
         self._side_used = side is not main
         st = L.cur_stream()
-        if self._fused_ce_step:
+        if self._fused_ce_step or getattr(self, "_dy_ready", False):
             pass   # dY of the top layer was written by the fused forward kernel (w["dYa"], tile-native)
         elif getattr(self, "_dlog16_valid", False):
             _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(self.wtokT16),
