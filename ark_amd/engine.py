@@ -920,13 +920,13 @@ class Engine:
         side.wait_stream(main)
         filled = torch.cuda.Event()
         with torch.cuda.stream(side):
-            if self._finalize is not None:   # loss scalars of this step (deferred by forward)
-                self._finalize()
-                self._finalize = None
             self.G.zero_()   # ONE fill; every reduction of the step accumulates into it
             if self.mt == "SAIL":
                 w["dH0"].zero_()   # the initial-state roles add into it
-            filled.record(side)
+            filled.record(side)   # (the first backward diagonal waits for this: nothing else goes in front of it)
+            if self._finalize is not None:   # loss scalars of this step (deferred by forward)
+                self._finalize()
+                self._finalize = None
             if self._fused_ce_step:
                 # dW_tok and db_out from the recomputed softmax (no dlogits buffer): csrc/vocab_ce.hip
                 _call("ark_vocab_ce_dw", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]),
