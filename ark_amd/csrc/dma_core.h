@@ -63,8 +63,8 @@ template <int PREC, int BM, int BN, int NBUF, int WGM, int WGN, int KI = 1>
 struct DmaTile {
   static_assert(PREC == PREC_F16 || PREC == PREC_BF16, "LDS-DMA engine takes 16-bit operands");
   static_assert(BM % 32 == 0 && BN % 32 == 0, "tile shape");
-  static constexpr int NW = WGM * WGN;   // waves per workgroup (4, or 8 for 512-thread workgroups)
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static constexpr int NW = WGM * WGN;   // waves per workgroup (4; 8 or 16 for 512- / 1024-thread workgroups)
+  static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
   using h8 = typename PT::h8;
@@ -75,10 +75,12 @@ struct DmaTile {
   static constexpr int STAGE_BYTES = A_STAGE + B_STAGE;
   static constexpr int LDS_BYTES = NBUF * STAGE_BYTES;
   // a stage of one operand is KI * R/8 one-KB pieces (8 rows x 128 B each), dealt round-robin to the waves
+  // Pieces that do not divide evenly (24 weight pieces over 16 waves) leave the high waves one piece short: those waves
+  // simply count fewer LDS-DMA instructions per stage in their s_waitcnt (wave-uniform, see lps_of / wait_stage).
   static constexpr int PA = KI * BM / 8, PB = KI * BN / 8;
-  static_assert(PA % NW == 0 && PB % NW == 0, "pieces per stage must divide evenly over the waves");
-  static constexpr int NPA = PA / NW, NPB = PB / NW;   // pieces per stage per wave
-  static constexpr int LPS = NPA + NPB;                // LDS-DMA instructions per stage per wave
+  static constexpr int NPA = (PA + NW - 1) / NW, NPB = (PB + NW - 1) / NW;   // pieces per stage per wave (at most)
+  static constexpr int LPS = NPA + NPB;                // LDS-DMA instructions per stage per wave (at most)
+  static constexpr bool EVEN_A = PA % NW == 0, EVEN_B = PB % NW == 0;
   static_assert((NBUF - 1) * LPS <= 63, "in-flight stages must fit the 6-bit vmcnt");
   static_assert(NBUF >= 2 && NBUF <= 8, "ring depth");
   static constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -87,6 +89,20 @@ struct DmaTile {
   template <int N>
   static __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  }
+  // this wave's LDS-DMA instructions per stage: LPS, or one / two fewer where the pieces run out (wave-uniform)
+  static __device__ __forceinline__ int lps_of(int wave) {
+    return LPS - ((EVEN_A || wave < PA % NW) ? 0 : 1) - ((EVEN_B || wave < PB % NW) ? 0 : 1);
+  }
+  // all but the youngest NBUF-1 stages of this wave have landed
+  static __device__ __forceinline__ void wait_stage(int lps) {
+    if constexpr (EVEN_A && EVEN_B) {
+      wait_vmcnt<(NBUF - 1) * LPS>();
+    } else {
+      if (lps == LPS) wait_vmcnt<(NBUF - 1) * LPS>();
+      else if (lps == LPS - 1) wait_vmcnt<(NBUF - 1) * (LPS - 1)>();
+      else wait_vmcnt<(NBUF - 1) * (LPS > 2 ? LPS - 2 : 0)>();
+    }
   }
 
   // K-segments of one product: acc(seg) += A[seg] x B[seg]^T over K[seg] (K % KS == 0, 0 allowed);
@@ -112,13 +128,13 @@ struct DmaTile {
     long ao[NPA], bo[NPB];
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
-      const int q = wave + NW * i, j = q / (BM / 8), pr = q % (BM / 8);
+      const int q = min(wave + NW * i, PA - 1), j = q / (BM / 8), pr = q % (BM / 8);
       const int row = 8 * pr + (lane >> 3);
       ao[i] = rma(row) * lda + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
-      const int q = wave + NW * i, j = q / (BN / 8), pr = q % (BN / 8);
+      const int q = min(wave + NW * i, PB - 1), j = q / (BN / 8), pr = q % (BN / 8);
       const int row = 8 * pr + (lane >> 3);
       bo[i] = rmb(row) * ldb + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
     }
@@ -151,12 +167,14 @@ struct DmaTile {
       char* base = lds + islot * STAGE_BYTES;
 #pragma unroll
       for (int i = 0; i < NPA; ++i)   // piece q lands at byte q*1024 of the operand's stage (images are contiguous)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ap + ao[i]),
-                                         (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
+        if (EVEN_A || i + 1 < NPA || wave + NW * i < PA)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ap + ao[i]),
+                                           (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
 #pragma unroll
       for (int i = 0; i < NPB; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bp + bo[i]),
-                                         (__attribute__((address_space(3))) void*)(base + A_STAGE + (wave + NW * i) * 1024), 16, 0, 0);
+        if (EVEN_B || i + 1 < NPB || wave + NW * i < PB)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bp + bo[i]),
+                                           (__attribute__((address_space(3))) void*)(base + A_STAGE + (wave + NW * i) * 1024), 16, 0, 0);
       ++gi;
       islot = (islot + 1 == NBUF) ? 0 : islot + 1;
       --left;
@@ -166,12 +184,13 @@ struct DmaTile {
       for (int s = 0; s < pre; ++s) issue_next();
     }
     int cslot = 0;
+    const int lps = lps_of(wave);
     static_for<NSEG>([&](auto segc) {
       const int ns = sg.K[decltype(segc)::value] / KS;
       for (int s = 0; s < ns; ++s) {
         // min(NBUF, remaining) stages are in flight; the oldest must have landed.  (Ring tails deeper than two
         // slots drain completely: exact counting there bought nothing measurable.)
-        if (remaining >= NBUF) wait_vmcnt<(NBUF - 1) * LPS>();
+        if (remaining >= NBUF) wait_stage(lps);
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);

@@ -27,11 +27,11 @@ struct GruDiagArgs {
   int n_roles, B, D, xcd_map;
 };
 
-// BM rows x BU hidden units (x 3 gates) per workgroup, 2 x (BU/16) waves; wave tile (BM/2) x 48 = 16 units x 3 gates.
-template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU>
-__global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagArgs p) {
-  constexpr int BN = 3 * BU, WGN = BU / 16, NTHR = 128 * WGN;
-  using G = DmaTile<PREC, BM, BN, NBUF, 2, WGN, KI>;
+// BM rows x BU hidden units (x 3 gates) per workgroup, WGM x (BU/16) waves; wave tile (BM/WGM) x 48 = 16 units x 3 gates.
+template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU, int WGM = 2>
+__global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruDiagArgs p) {
+  constexpr int BN = 3 * BU, WGN = BU / 16, NTHR = 64 * WGM * WGN;
+  using G = DmaTile<PREC, BM, BN, NBUF, WGM, WGN, KI>;
   constexpr int TM = G::TM, TN = G::TN;
   static_assert(TN == 3, "wave tile = 16 units x (r, z, n)");
   using h_t = typename G::h_t;
@@ -171,17 +171,17 @@ __global__ __launch_bounds__(128 * (BU / 16)) void gru_diag_fwd_kernel(GruDiagAr
   }
 }
 
-template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU>
+template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU, int WGM = 2>
 static void launch_diag(const GruDiagArgs& p, hipStream_t st) {
-  using G = DmaTile<PREC, BM, 3 * BU, NBUF, 2, BU / 16, KI>;
+  using G = DmaTile<PREC, BM, 3 * BU, NBUF, WGM, BU / 16, KI>;
   constexpr int MINL = 4 * BM * (BU + 8) * 2;
   constexpr int LDS = G::LDS_BYTES > MINL ? G::LDS_BYTES : MINL;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = gru_diag_fwd_kernel<PREC, PRECB, NBUF, KI, BM, BU>;
+  auto kern = gru_diag_fwd_kernel<PREC, PRECB, NBUF, KI, BM, BU, WGM>;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
   (void)once;
   const unsigned grid = (unsigned)(p.n_roles * ((p.B + BM - 1) / BM) * (p.D / BU));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * (BU / 16)), LDS, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WGM * (BU / 16)), LDS, st, p);
 }
 
 template <int PREC, int PRECB>
@@ -201,8 +201,12 @@ static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t 
   //  wd-articles B=16 -- 5.9 -> 6.2 us forward, 9.9 -> 13.6 us backward per launch)
   const bool deep = false;
   p.xcd_map = (tn.fwd_xcd && UT % 4 == 0 && MT % 2 == 0) ? 1 : 0;
-  if (units == 64) {   // 8 waves
-    if (rows == 128) launch_diag<PREC, PRECB, 2, 1, 128, 64>(p, st);
+  if (units == 64) {   // 8 waves (16 for the 128-row tile on request: wave tile 32 x 48 as in the default kernel)
+    // (measured, syn-paths B=1024: 23.6 us per launch against 18.7 for the default 64 x 32 tiles although a CU streams a
+    //  third fewer bytes -- and the same with four ring slots: ONE workgroup per CU runs its LDS-DMA issue, fragment-read
+    //  and MFMA phases one after the other behind its barriers, three small workgroups overlap them)
+    if (rows == 128 && tn.fwd_waves == 16) launch_diag<PREC, PRECB, 2, 1, 128, 64, 4>(p, st);
+    else if (rows == 128) launch_diag<PREC, PRECB, 2, 1, 128, 64>(p, st);
     else if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 64>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 64, 64>(p, st);
   } else if (rows == 64) {
@@ -223,7 +227,8 @@ static bool diag_tuning_ok(const ArkDiagTuning& t) {
   return (t.fwd_rows == 32 || t.fwd_rows == 64 || t.fwd_rows == 128) && (t.fwd_ki == 1 || t.fwd_ki == 2) &&
          (t.fwd_nbuf == 2 || t.fwd_nbuf == 4) && (t.fwd_units == 32 || t.fwd_units == 64) &&
          (t.bwd_rows == 32 || t.bwd_rows == 64) && (t.bwd_ki == 1 || t.bwd_ki == 2) && (t.bwd_nbuf == 2 || t.bwd_nbuf == 4) &&
-         (t.bwd_xcd_rows == 1 || t.bwd_xcd_rows == 2 || t.bwd_xcd_rows == 4 || t.bwd_xcd_rows == 8);
+         (t.bwd_xcd_rows == 1 || t.bwd_xcd_rows == 2 || t.bwd_xcd_rows == 4 || t.bwd_xcd_rows == 8) &&
+         (t.fwd_waves == 0 || t.fwd_waves == 16);
 }
 
 }  // namespace ark
@@ -233,6 +238,7 @@ extern "C" void ark_diag_tuning_default(ArkDiagTuning* t) {
   if (!t) return;
   t->fwd_rows = 64; t->fwd_ki = 1; t->fwd_nbuf = 2; t->fwd_xcd = 1; t->fwd_units = 32;
   t->bwd_rows = 32; t->bwd_ki = 2; t->bwd_nbuf = 2; t->bwd_xcd_rows = 4;
+  t->fwd_waves = 0;
 }
 
 extern "C" int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruDiagRole* roles, const float* hyper, int B, int D,
