@@ -159,8 +159,16 @@ def diag_byte_models(eng, B):
         dy = 4 * D if l == n - 1 else 0
         b_impl += Lq * (B * (up + 3 * D * 2 + dy + 4 * D + 4 * D + 8 * D + 4 * D * 2 + 4 * D) + wbytes)
     fl = cells * 2.0 * B * D * 6 * D
-    return {"gru_diag_fwd_kernel": dict(min=f_min, impl=f_impl, flops=fl),
-            "gru_diag_bwd_kernel": dict(min=b_min, impl=b_impl, flops=fl)}
+    # operand bytes the workgroups pull from L2 into LDS by LDS-DMA (default tiles: forward 64 rows x 32 units = 96 weight
+    # rows over K = 2D; backward 32 rows x 64 columns over K = 3D from the layer above + 3D recurrent), summed over the step
+    f_dma = cells * ((B + 63) // 64) * (D // 32) * (64 + 96) * (2 * D) * 2
+    b_dma = 0
+    for l in range(n):
+        for t in range(Lq):
+            K = (3 * D if l < n - 1 else 0) + (3 * D if t < Lq - 1 else 0)
+            b_dma += ((B + 31) // 32) * (D // 64) * (32 + 64) * K * 2
+    return {"gru_diag_fwd_kernel": dict(min=f_min, impl=f_impl, flops=fl, dma=f_dma),
+            "gru_diag_bwd_kernel": dict(min=b_min, impl=b_impl, flops=fl, dma=b_dma)}
 
 
 def self_launch(args, argv):
@@ -333,7 +341,13 @@ def main():
                               "achieved": m["impl"] / launches / kt / 1e9, "frac": m["impl"] / launches / kt / 1e9 / 8000.0,
                               "frac_min_8d": m["min"] / launches / kt / 1e9 / 8000.0, "traffic": traffic.get(name),
                               "flops_per_launch": m["flops"] / launches,
-                              "mfma_frac": m["flops"] / launches / kt / 1e12 / mfma_peak}
+                              "mfma_frac": m["flops"] / launches / kt / 1e12 / mfma_peak,
+                              # what actually bounds these kernels: the per-CU L2 -> LDS operand stream.
+                              # ceiling = 110 GB/s per CU, measured with a consumer-less LDS-DMA ring (tools/l2_stream_bench.hip)
+                              "l2_to_lds": {"bytes_per_cu_per_launch": m["dma"] / launches / 256,
+                                            "achieved_gbs_per_cu": m["dma"] / launches / 256 / kt / 1e9,
+                                            "measured_ceiling_gbs_per_cu": 110.0,
+                                            "frac": m["dma"] / launches / 256 / kt / 1e9 / 110.0}}
                 log(f'{name}: {kt * 1e6:.2f} us/launch x {launches}')
             dom = max(kern, key=lambda k: kern[k]["us_per_step"])   # dominant = most time per step
             d = kern[dom]
