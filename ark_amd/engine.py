@@ -1524,3 +1524,44 @@ class Engine:
         hit = torch.nonzero(done)
         stop = int(hit[0]) + 1 if hit.numel() else Lmax
         return toks[:, :stop + 1].clone()
+
+    @torch.no_grad()
+    def beam_decode(self, z, beam, max_len=None):
+        """token sequences of SAIL.decode_latent(z, beam > 1) (reference models.py:282-300: a batch-shared beam,
+        candidates ranked by the batch-MEAN log-probability, stable descending sort).  The reference re-runs the decoder
+        on every beam's whole prefix per generated token; here every beam keeps its GRU state (beam x B rows of one
+        incremental decode), advances ONE token per step, and the surviving beams' states are gathered block-wise.
+        Exact-fp32 kernels.  One host synchronisation per step for the reference's stopping rule."""
+        assert self.mt == "SAIL" and beam >= 1
+        B = z.shape[0]
+        Lmax = (self.seq_len - 1) if max_len is None else max_len
+        Bt = beam * B
+        zr = z.to(self.device, dtype=torch.float32).repeat(beam, 1)
+        d = self.decode_begin(Bt, zr)
+        dev = self.device
+        toks = torch.full((beam, B, Lmax + 1), 2, dtype=torch.int64, device=dev)
+        toks[:, :, 0] = 1
+        scores = torch.zeros(beam, B, device=dev)
+        active = 1          # distinct beams so far (all blocks start as copies of the single BOS beam)
+        length = 1
+        for t in range(Lmax):
+            logits = self.decode_step(d, toks[:, :, t].reshape(-1).contiguous(), t)
+            logp = torch.log_softmax(logits.float(), dim=-1).view(beam, B, -1)
+            top_lp, ids = logp.topk(beam, dim=-1)                         # [beam, B, beam]
+            cand = (scores[:, :, None] + top_lp)[:active]                 # candidate (j, k) = beam j extended by its k-th token
+            order = torch.sort(cand.mean(dim=1).reshape(-1), descending=True, stable=True).indices[:beam]
+            j, k = order // beam, order % beam
+            new_tok = ids[j, :, k]                                        # [beam, B]
+            scores = scores[j] + top_lp[j, :, k]
+            toks = toks[j]
+            toks[:, :, t + 1] = new_tok
+            half = (t + 1) % 2                                            # decode_step left the new state in this half
+            for l in range(self.n):
+                y = d["Y"][l].view(2, beam, B, self.D)
+                y[half].copy_(y[half].index_select(0, j))
+            active = beam
+            length = t + 2
+            if bool((new_tok == 2).all()):                                # every beam's last token is EOS
+                break
+        return toks[0, :, :length].clone()
+

@@ -238,42 +238,10 @@ class SAIL(_EngineModel):
             # the device instead of re-running the whole prefix
             best = eng.greedy_decode(z, max_len=seq_len - 1).cpu()
             return [seq_to_triples(row, special_tokens, ent_base, rel_base) for row in best]
-        # beam > 1: the reference's batch-shared beam (candidates ranked by the batch-MEAN log-prob)
-        B = z.shape[0]
-        dev = z.device
-        start = torch.full((B, 1), special_tokens["BOS"], dtype=torch.long, device=dev)
-        beams = [(start, torch.zeros(B, device=dev))]
-        for _ in range(seq_len - 1):
-            cand = []
-            for s, lp in beams:
-                logp = torch.log_softmax(self._decoder_logits(z, s)[:, -1], dim=-1)
-                top_lp, ids = logp.topk(beam, dim=-1)
-                for k in range(beam):
-                    cand.append((torch.cat([s, ids[:, k:k + 1]], 1), lp + top_lp[:, k]))
-            cand.sort(key=lambda c: c[1].mean().item(), reverse=True)
-            beams = cand[:beam]
-            if all(bool((s[:, -1] == special_tokens["EOS"]).all()) for s, _ in beams):
-                break
-        best = beams[0][0].cpu()
+        # beam > 1: the reference's batch-shared beam (candidates ranked by the batch-MEAN log-prob); every beam keeps its
+        # GRU state on the device and advances one token per step (Engine.beam_decode)
+        best = eng.beam_decode(z, beam, max_len=seq_len - 1).cpu()
         return [seq_to_triples(row, special_tokens, ent_base, rel_base) for row in best]
-
-    @torch.no_grad()
-    def _decoder_logits(self, z, seq_prefix):
-        """logits [B, len, V] of the decoder run on a prefix with latent z (the reference's self.dec(z, s))"""
-        eng = self.engine()
-        was = eng.training
-        eng.training = False
-        try:
-            B, Lq = seq_prefix.shape
-            w = eng._workspace(B, 0)
-            eng.prec = eng.prec_fwd
-            if not eng._shadow_ok:
-                eng.refresh_shadows()
-            eng._decode_h0(w, z.contiguous(), B)
-            eng._decoder_forward(w, seq_prefix.contiguous(), Lq, B, Lq, False, save=False)
-            return eng._logits(w)[:Lq * B, :eng.V].reshape(Lq, B, eng.V).permute(1, 0, 2).contiguous()
-        finally:
-            eng.training = was
 
     @torch.no_grad()
     def count_unique_graphs(self, latent_dim, decode_latent_fn, num_samples=1000, beam=1):

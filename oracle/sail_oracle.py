@@ -20,6 +20,7 @@ Reference call sites restated (paths relative to the reference repo):
   ELBO assembly (ce + b*kl) ................ kgvae/experiments/ablation_study.py:59-73
   Adam step ................................ kgvae/experiments/ablation_study.py:571,76
   greedy decode (beam=1) ................... kgvae/model/models.py:262-266, 282-300
+  beam decode (batch-shared beam) .......... kgvae/model/models.py:282-300
   compression bits (AR + KL) ............... kgvae/model/models.py:202-260 (SAIL), 473-520 (ARK)
   next-token sampling distribution ......... kgvae/model/models.py:431-456 (inline in ARK.generate: not
                                              callable on its own, so this one restatement is pinned by its
@@ -279,6 +280,28 @@ def greedy_decode(P, z, cfg):
         if bool((s[:, -1] == EOS).all()):
             break
     return s
+
+
+@torch.no_grad()
+def beam_decode(P, z, cfg, beam):
+    """token sequences of SAIL.decode_latent(z, beam > 1), restated from models.py:282-300: ONE beam shared by the whole
+    batch; every step re-runs the decoder on each beam's prefix, extends it by its `beam` best tokens per row, ranks
+    the candidates by the MEAN over the batch of their accumulated log-probabilities (stable descending sort) and
+    keeps the first `beam`; stops when every row of every kept beam ends in EOS; returns the best beam's sequences."""
+    B = z.shape[0]
+    beams = [(torch.full((B, 1), BOS, dtype=torch.long), torch.zeros(B))]
+    for _ in range(cfg["seq_len"] - 1):
+        cand = []
+        for s, lp in beams:
+            logp = F.log_softmax(decoder_forward(P, z, s, cfg)[:, -1], dim=-1)
+            top_lp, ids = logp.topk(beam, dim=-1)
+            for k in range(beam):
+                cand.append((torch.cat([s, ids[:, k:k + 1]], 1), lp + top_lp[:, k]))
+        cand.sort(key=lambda c: c[1].mean().item(), reverse=True)
+        beams = cand[:beam]
+        if all(bool((s[:, -1] == EOS).all()) for s, _ in beams):
+            break
+    return beams[0][0]
 
 
 @torch.no_grad()

@@ -95,6 +95,25 @@ def test_decode_latent_and_beam():
     assert 1 <= len(uniq) <= 32
 
 
+@pytest.mark.parametrize("name,beam", [("sail_small", 3), ("sail_small_pad", 2), ("sail_tiny", 4)])
+def test_beam_decode_matches_the_reference_beam(name, beam):
+    """SAIL.decode_latent(beam > 1) on per-beam incremental GRU states (Engine.beam_decode) against the oracle's
+    restatement of the reference's prefix-re-running, batch-shared beam (models.py:282-300): identical token sequences"""
+    from oracle import sail_oracle as O
+    from kgvae.model.utils import seq_to_triples
+    model, z, cfg = _model(name)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in ((f[3:], z[f]) for f in z.files if f.startswith(f"w{len(z['losses'])}/"))}
+    model.load_state_dict(sd)
+    zs = torch.from_numpy(z["dec_z"])
+    want = O.beam_decode(sd, zs, cfg, beam)
+    eng = model.engine()
+    got = eng.beam_decode(zs.to(eng.device), beam, max_len=cfg["seq_len"] - 1).cpu()
+    assert got.shape == want.shape and torch.equal(got, want), (got, want)
+    st = cfg["special_tokens"]
+    tri = model.decode_latent(zs, cfg["seq_len"], st, seq_to_triples, cfg["ENT_BASE"], cfg["REL_BASE"], beam=beam)
+    assert tri == [seq_to_triples(row, st, cfg["ENT_BASE"], cfg["REL_BASE"]) for row in want]
+
+
 def test_posterior_bits_is_the_teacher_forced_nll():
     """ARK.posterior_bits (single pass) equals the oracle's per-sequence token NLL in bits"""
     from oracle import sail_oracle as O
