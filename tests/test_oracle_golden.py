@@ -195,3 +195,19 @@ def test_sampling_distribution_properties():
         assert float(sp[:n - 1].sum()) <= 0.6 < float(sp[:n].sum())
     pt = O.sampling_distribution(logits, temperature=0.5)
     assert torch.allclose(pt, torch.softmax(logits / 0.5, -1), atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["sail_tiny", "sail_small", "sail_small_pad"])
+@pytest.mark.parametrize("beam", [2, 3, 4])
+def test_beam_decode_matches_reference_goldens(name, beam):
+    """the oracle's restatement of the batch-shared beam (models.py:282-300) against triples decoded by the REAL
+    reference's SAIL.decode_latent(z, beam) on the stored trained weights (tests/golden/beam_decode.npz, written by
+    tools/make_golden_beam.py)"""
+    z, cfg = load(name)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "beam_decode.npz"))
+    P = OrderedDictFrom(z, f"w{len(z['losses'])}/")
+    seqs = O.beam_decode(P, torch.from_numpy(z["dec_z"]), cfg, beam)
+    want, n = g[f"{name}/beam{beam}/triples"], g[f"{name}/beam{beam}/n"]
+    for i in range(seqs.shape[0]):
+        got = O.seq_to_triples(seqs[i].tolist(), cfg["ENT_BASE"], cfg["REL_BASE"])
+        assert [list(t) for t in got] == want[i, :int(n[i])].tolist(), (i, got)
