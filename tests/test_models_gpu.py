@@ -423,3 +423,30 @@ def test_reference_yaml_key_set_runs_verbatim(tmp_path):
     ck = torch.load(tmp_path / "ck" / run / "syn-paths_ARK_best_model.pt", weights_only=True)
     assert ck["epoch"] == 1 and ck["model_state_dict"]["dec.gru.weight_ih_l0"].shape == (1536, 512)
     assert ck["scheduler_state_dict"]["last_epoch"] == 1 and math.isfinite(ck["val_loss"])
+
+
+def test_reference_style_loop_draws_fresh_dropout_masks_every_forward():
+    """nn.GRU(dropout=p) draws a new mask per training forward; the engine-backed module does too in the reference-style
+    loop (model(...) twice without an engine Adam step in between), on different ranks, and not at all in eval mode"""
+    from kgvae.model.models import SAIL
+    z, cfg = load_golden("sail_small")
+    cfg = dict(cfg, dec_dropout=0.3, precision="mixed")
+    torch.manual_seed(0)
+    model = SAIL(cfg).to("cuda")
+    triples, seq = torch.from_numpy(z["triples"]).to("cuda"), torch.from_numpy(z["seq"]).to("cuda")
+    eps = torch.from_numpy(z["eps0"]).to("cuda")
+    model.train()
+    with torch.no_grad():
+        a = model(triples, seq[:, :-1], eps=eps)[0].clone()
+        b = model(triples, seq[:, :-1], eps=eps)[0].clone()
+    assert (a - b).abs().max().item() > 1e-3          # a different mask
+    model.eval()
+    with torch.no_grad():
+        c = model(triples, seq[:, :-1], eps=eps)[0].clone()
+        d = model(triples, seq[:, :-1], eps=eps)[0].clone()
+    assert torch.equal(c, d)
+    eng = model.engine()
+    s0 = eng._layer_seed(0)
+    eng.rank = 1
+    assert eng._layer_seed(0) != s0                    # shards of a data-parallel batch draw different masks
+    eng.rank = 0
