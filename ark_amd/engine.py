@@ -185,6 +185,9 @@ class Engine:
         self.fork_after = int(cfg.get("ark_fork_after", 1))   # measured: 0 -> 1.281, 1 -> 1.266, 2 -> 1.296 ms/step
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
         self.fused_latent = bool(cfg.get("ark_fused_latent", True))
+        self.early_dec_adam = bool(cfg.get("ark_early_dec_adam", True))
+        self._adam_dec_early = False
+        self._adam_dec_done = False
         # small vocabularies (one 64-token tile): projection + cross-entropy + dY(top) + 16-bit dlogits in one launch
         self.fused_ce_small = bool(cfg.get("ark_fused_ce_small", self.use_dma and self.V <= 64 and self.D in (64, 128, 256, 512)))   # reparameterisation + z-projection as one launch
         self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))
@@ -963,6 +966,12 @@ class Engine:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self._gru_wgrads(w, B, Lq, seq, use_drop, range(n), emb=True)
+                if self._adam_dec_early:
+                    # every gradient of the decoder bucket [dec_grad_offset, total) is now queued: its Adam (+ shadows,
+                    # 40 % of the parameters, HBM-bound) runs here, underneath the latent / encoder backward chain
+                    _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
+                    self._adam_launch("dec")
+                    self._adam_dec_done = True
             self._side_used = side is not main
             self._fork_pending = None
 
@@ -1272,17 +1281,32 @@ class Engine:
             for item in handles:
                 self._dp_unpack(*item)
         else:
-            self._defer_finalize = True
-            try:
-                self.forward(triples, seq, eps, ce_count=ce_count)
-            finally:
-                self._defer_finalize = False
+            self._local_step(triples, seq, eps, ce_count, grad_sync)
+        return self.ws["out4"]
+
+    def _local_step(self, triples, seq, eps, ce_count, grad_sync=None):
+        """forward + backward + Adam of ONE process (also the body of the captured single-process graph).  The decoder
+        bucket's Adam is launched on the side queue as soon as its gradients are queued (see _backward_decoder_diag)."""
+        self._defer_finalize = True
+        self._adam_dec_early = bool(self.early_dec_adam and grad_sync is None and self.use_dma and self.overlap_wgrad
+                                    and self.mt == "SAIL")
+        self._adam_dec_done = False
+        try:
+            self.forward(triples, seq, eps, ce_count=ce_count)
             if self.backward_decoder():
                 self.backward_encoder()
+        finally:
+            self._defer_finalize = False
+            self._adam_dec_early = False
         if grad_sync is not None:
             grad_sync(self.G)
-        self.adam()
-        return self.ws["out4"]
+        if self._adam_dec_done:   # the decoder bucket was updated on the side queue (which ticked the step): the rest
+            self._adam_dec_done = False
+            self._adam_launch("enc")
+            self.adam_steps += 1
+            self._shadow_ok = True
+        else:
+            self.adam()
 
     def eval_loss(self, triples, seq, eps=None):
         self._default_norms(seq.shape[0])
@@ -1359,15 +1383,7 @@ class Engine:
             gb = None
             gc = cap(self.adam)
         else:
-            def a():
-                self._defer_finalize = True
-                try:
-                    self.forward(triples, seq, eps, ce_count=ce_count)
-                finally:
-                    self._defer_finalize = False
-                self.backward()
-                self.adam()
-            ga, gb, gc = cap(a), None, None
+            ga, gb, gc = cap(lambda: self._local_step(triples, seq, eps, ce_count)), None, None
         self.adam_steps = steps0  # capture does not execute
         out4 = self.ws["out4"]
         gstream = torch.cuda.Stream(device=self.device)
