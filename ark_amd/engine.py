@@ -166,6 +166,10 @@ class Engine:
             off, tot = self.layout.dec_grad_offset, self.layout.total
             self._adam_jobs = {"all": self._build_adam_jobs(0, tot), "enc": self._build_adam_jobs(0, off),
                                "dec": self._build_adam_jobs(off, tot)}
+            if self.mt == "SAIL":   # the encoder bucket = embeddings | MLP (99 % of it) | heads + z-projection
+                m0, m1 = self.layout.entries["enc.mlp.0.weight"][0], self.layout.entries["enc.mu.weight"][0]
+                self._adam_jobs["mlp"] = self._build_adam_jobs(m0, m1)
+                self._adam_jobs["enc_rest"] = self._build_adam_jobs(0, m0) + self._build_adam_jobs(m1, off)
         self._shadow_ok = False
         self._side = None
         self._pad_bufs = {}
@@ -186,8 +190,10 @@ class Engine:
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
         self.fused_latent = bool(cfg.get("ark_fused_latent", True))
         self.early_dec_adam = bool(cfg.get("ark_early_dec_adam", True))
+        self.early_mlp_adam = bool(cfg.get("ark_early_mlp_adam", True))
         self._adam_dec_early = False
         self._adam_dec_done = False
+        self._adam_mlp_done = False
         # small vocabularies (one 64-token tile): projection + cross-entropy + dY(top) + 16-bit dlogits in one launch
         self.fused_ce_small = bool(cfg.get("ark_fused_ce_small", self.use_dma and self.V <= 64 and self.D in (64, 128, 256, 512)))   # reparameterisation + z-projection as one launch
         self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))
@@ -838,6 +844,15 @@ class Engine:
                 dpre, other = other, dpre
             for i0 in range(0, len(group), 8):
                 self._wgrad_group(group[i0:i0 + 8])
+            if self._adam_dec_early and self._adam_dec_done and self._side is not None and self.early_mlp_adam:
+                # the MLP block of the encoder bucket (99 % of it) is complete: its Adam runs on the side queue (which
+                # already ticked the step for the decoder bucket) underneath the embedding scatter
+                main = torch.cuda.current_stream()
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    self._adam_launch("mlp")
+                self._adam_mlp_done = True
+                self._side_used = True
         else:
             self._gemm(MM, MM, L.EPI_NONE, w["dhead"], 2 * Z, w["act"][n - 1], H, g["enc.mu.weight"], H, 2 * Z, H, B, acc=1)
             self._gemm(KM, MM, L.EPI_MUL_DGELU, w["dhead"], 2 * Z, p["enc.mu.weight"], H, w["dA"], H, B, H, 2 * Z,
@@ -1291,6 +1306,7 @@ class Engine:
         self._adam_dec_early = bool(self.early_dec_adam and grad_sync is None and self.use_dma and self.overlap_wgrad
                                     and self.mt == "SAIL")
         self._adam_dec_done = False
+        self._adam_mlp_done = False
         try:
             self.forward(triples, seq, eps, ce_count=ce_count)
             if self.backward_decoder():
@@ -1302,7 +1318,8 @@ class Engine:
             grad_sync(self.G)
         if self._adam_dec_done:   # the decoder bucket was updated on the side queue (which ticked the step): the rest
             self._adam_dec_done = False
-            self._adam_launch("enc")
+            self._adam_launch("enc_rest" if self._adam_mlp_done else "enc")
+            self._adam_mlp_done = False
             self.adam_steps += 1
             self._shadow_ok = True
         else:
