@@ -1,5 +1,5 @@
 """Print the kernel timeline of the last complete train step from a rocprofv3 --kernel-trace CSV
-(start offset from the previous step's Adam, duration, queue, workgroups, kernel name).
+(start offset from the step's first kernel, duration, queue, workgroups, kernel name).
 
     python tools/step_timeline.py gpurun_out/<dir>/<prefix>_kernel_trace.csv
 """
@@ -8,9 +8,11 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adam_shadow" in r["Kernel_Name"] or "adam_kernel" in r["Kernel_Name"]]
+# a step starts at the encoder pool (SAIL) / the token gather (ARK): print the last complete one
+anchor = "enc_pool_fwd" if any("enc_pool_fwd" in r["Kernel_Name"] for r in rows) else "tok_gather"
+idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
 a, b = idx[-2], idx[-1]
-t0 = int(rows[a]["End_Timestamp"])
-for r in rows[a + 1:b + 1]:
+t0 = int(rows[a]["Start_Timestamp"])
+for r in rows[a:b]:
     wg = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(1, int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]))
     print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f} q{r['Queue_Id']} wg{wg:<6d} {r['Kernel_Name'][:70]}")
