@@ -34,12 +34,21 @@ __global__ __launch_bounds__(256) void enc_pool_fwd_kernel(const int64_t* __rest
   const int D4 = D >> 2;
   for (int c = threadIdx.x; c < 3 * D4; c += blockDim.x) {
     const int part = c / D4, d4 = c % D4;
+    const float* tab = (part == 1) ? R : E;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < T; ++t) {
-      if (pad_rid >= 0 && tr[t * 3 + 1] == pad_rid) continue;
-      const long id = tr[t * 3 + part];
-      const float* tab = (part == 1) ? R : E;
-      s += *reinterpret_cast<const f32x4*>(tab + id * D + 4 * d4);
+    // batches of 8 row loads in flight: one workgroup per graph walks its T triples alone, and a load-add chain of
+    // T = 212 (wd-articles) cost 307 us of pure latency; the summation order is unchanged
+    for (int t0 = 0; t0 < T; t0 += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u;
+        const bool ok = t < T && !(pad_rid >= 0 && tr[t * 3 + 1] == pad_rid);
+        const long id = ok ? tr[t * 3 + part] : 0;
+        v[u] = ok ? *reinterpret_cast<const f32x4*>(tab + id * D + 4 * d4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
     }
     const f32x4 r = s * w;
     *reinterpret_cast<f32x4*>(g + (long)b * 3 * D + 4 * c) = r;
