@@ -1,5 +1,7 @@
+"""Standalone timing of the fused vocabulary projection + cross-entropy kernels (ark_vocab_ce_fwd / ark_vocab_ce_dw) at the
+wd-movies shape: python tools/vc_time.py (GPU)."""
 import os, sys, torch, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ark_amd import _lib as L
 dev = torch.device("cuda:0")
 B, Lq, V, D = 256, 70, 24101, 128
