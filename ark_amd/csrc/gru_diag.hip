@@ -228,7 +228,7 @@ static bool diag_tuning_ok(const ArkDiagTuning& t) {
          (t.fwd_nbuf == 2 || t.fwd_nbuf == 4) && (t.fwd_units == 32 || t.fwd_units == 64) &&
          (t.bwd_rows == 32 || t.bwd_rows == 64) && (t.bwd_ki == 1 || t.bwd_ki == 2) && (t.bwd_nbuf == 2 || t.bwd_nbuf == 4) &&
          (t.bwd_xcd_rows == 1 || t.bwd_xcd_rows == 2 || t.bwd_xcd_rows == 4 || t.bwd_xcd_rows == 8) &&
-         (t.fwd_waves == 0 || t.fwd_waves == 16);
+         (t.fwd_waves == 0 || t.fwd_waves == 16) && (t.bwd_cols == 0 || t.bwd_cols == 32 || t.bwd_cols == 64);
 }
 
 }  // namespace ark
@@ -238,7 +238,7 @@ extern "C" void ark_diag_tuning_default(ArkDiagTuning* t) {
   if (!t) return;
   t->fwd_rows = 64; t->fwd_ki = 1; t->fwd_nbuf = 2; t->fwd_xcd = 1; t->fwd_units = 32;
   t->bwd_rows = 32; t->bwd_ki = 2; t->bwd_nbuf = 2; t->bwd_xcd_rows = 4;
-  t->fwd_waves = 0;
+  t->fwd_waves = 0; t->bwd_cols = 0;
 }
 
 extern "C" int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruDiagRole* roles, const float* hyper, int B, int D,
@@ -289,10 +289,10 @@ struct GruDiagBwdArgs {
   int n_roles, B, D, xcd_m;
 };
 
-template <int PREC, int NBUF, int KI, int BM>
+template <int PREC, int NBUF, int KI, int BM, int BN = 64>
 __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
-  constexpr int BN = 64;
-  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;   // wave tile (BM/2) x 32
+  static_assert(BN == 64 || BN == 32, "64 output columns per workgroup, or 32 for grids that would leave most CUs empty");
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;   // wave tile (BM/2) x (BN/2)
   constexpr int TM = G::TM, TN = G::TN, WN = BN / 2;
   using h_t = typename G::h_t;
   using h8 = typename G::h8;
@@ -426,15 +426,16 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
     }
   }
   __syncthreads();
-  // 4 parts x BM rows x 128 B: thread t -> (row, 16-byte chunk) for each part, 32 rows per pass
+  // 4 parts x BM rows x (2 BN) B: thread t -> (row, 16-byte chunk) for each part, 256 / CPR rows per pass
   const int t = threadIdx.x;
-  constexpr int CPR = BN / 8;   // 8 chunks per row -> 32 rows per 256 threads
+  constexpr int CPR = BN / 8;   // chunks per row: 8 -> 32 rows per 256 threads, 4 -> 64
+  constexpr int RPASS = 256 / CPR;
   h_t* g16 = reinterpret_cast<h_t*>(R.dg16);
 #pragma unroll
-  for (int r0 = 0; r0 < BM; r0 += 32) {
+  for (int r0 = 0; r0 < BM; r0 += RPASS) {
     const int rr = r0 + t / CPR, ch = t % CPR;
     const int row = m0 + rr;
-    if (row < B) {
+    if (rr < BM && row < B) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const long go = (long)row * 4 * D + (long)g * D + n0 + ch * 8;
@@ -444,8 +445,8 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
   }
   // bias gradients: column sums of this tile straight from LDS, one atomic per (gate, unit):
   // db_ih = colsum [dr | dz | dn], db_hh = colsum [dr | dz | dn*r]
-  if (R.db_ih) {
-    const int g = t / BN, ul = t % BN;   // 256 threads = 4 parts x 64 units
+  if (R.db_ih && t < 4 * BN) {
+    const int g = t / BN, ul = t % BN;   // 4 parts x BN units (all 256 threads at BN = 64)
     const int nrows = min(BM, B - m0);
     float s = 0.f;
     for (int r2 = 0; r2 < nrows; ++r2) s += (float)tg[g * BM * TS + r2 * TS + ul];
@@ -455,26 +456,36 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
   }
 }
 
-template <int PREC, int NBUF, int KI, int BM>
+template <int PREC, int NBUF, int KI, int BM, int BN = 64>
 static void launch_diag_bwd(const GruDiagBwdArgs& p, hipStream_t st) {
-  using G = DmaTile<PREC, BM, 64, NBUF, 2, 2, KI>;
-  constexpr int MINL = 4 * BM * (64 + 8) * 2;
+  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;
+  constexpr int MINL = 4 * BM * (BN + 8) * 2;
   constexpr int LDS = G::LDS_BYTES > MINL ? G::LDS_BYTES : MINL;
-  auto kern = gru_diag_bwd_kernel<PREC, NBUF, KI, BM>;
+  auto kern = gru_diag_bwd_kernel<PREC, NBUF, KI, BM, BN>;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
   (void)once;
-  const unsigned grid = (unsigned)(p.n_roles * ((p.B + BM - 1) / BM) * (p.D / 64));
+  const unsigned grid = (unsigned)(p.n_roles * ((p.B + BM - 1) / BM) * (p.D / BN));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, p);
 }
 
 template <int PREC>
 static int launch_diag_bwd_cfg(GruDiagBwdArgs& p, const ArkDiagTuning& tn, hipStream_t st) {
   const bool ki2 = tn.bwd_ki == 2 && p.D % 128 == 0;   // every K-segment (3D, 2D, D) must be a whole number of stages
+  // small batch x width (wd-articles B = 16: 24 workgroups of 32 x 64): a launch is bound by what ONE CU can stream, so
+  // halve the column tile and use twice the CUs (each streams (32 + 32) instead of (32 + 64) rows of K)
+  const bool narrow = tn.bwd_cols == 32 ||
+                      (tn.bwd_cols == 0 && tn.bwd_rows == 32 && (long)p.n_roles * ((p.B + 31) / 32) * (p.D / 64) <= 96);
   {
     const int rows = tn.bwd_rows;
-    const int MT = (p.B + rows - 1) / rows, NT = p.D / 64;
+    const int MT = (p.B + rows - 1) / rows, NT = p.D / (narrow ? 32 : 64);
     const int xm = tn.bwd_xcd_rows;
     p.xcd_m = (xm > 1 && MT % xm == 0 && NT % (8 / xm) == 0) ? xm : 1;
+  }
+  if (narrow) {
+    if (ki2) launch_diag_bwd<PREC, 2, 2, 32, 32>(p, st);
+    else launch_diag_bwd<PREC, 2, 1, 32, 32>(p, st);
+    ARK_LAUNCH_CHECK();
+    return 0;
   }
   const bool deep = false;   // (see the forward launch)
   if (tn.bwd_rows == 64 && !deep) {

@@ -128,6 +128,7 @@ typedef struct {
   int bwd_nbuf;      /* 2 | 4                                                                   */
   int bwd_xcd_rows;  /* row-tile classes per XCD octet: 1 (plain order) | 2 | 4 | 8             */
   int fwd_waves;     /* 0 = by tile shape | 16 (128-row x 64-unit tile on a 1024-thread workgroup) */
+  int bwd_cols;      /* output columns per backward workgroup: 0 = by grid size | 32 | 64        */
 } ArkDiagTuning;
 void ark_diag_tuning_default(ArkDiagTuning* t);
 int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruDiagRole* roles, const float* hyper, int B, int D,

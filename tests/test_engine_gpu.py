@@ -525,11 +525,12 @@ def test_dropout_on_fast_path_matches_oracle_with_the_same_masks(B):
     assert checked >= 20
 
 
-@pytest.mark.parametrize("rows,ki,nbuf,xcd,units,waves", [(32, 2, 2, 0, 32, 0), (64, 1, 2, 0, 32, 0), (64, 2, 2, 1, 32, 0), (32, 1, 4, 1, 32, 0),
-                                                         (128, 1, 2, 1, 64, 0), (64, 1, 2, 0, 64, 0), (64, 2, 2, 1, 64, 0),
-                                                         (128, 1, 2, 1, 64, 16), (128, 1, 2, 0, 64, 16)])
+@pytest.mark.parametrize("rows,ki,nbuf,xcd,units,waves,bcols", [(32, 2, 2, 0, 32, 0, 0), (64, 1, 2, 0, 32, 0, 64), (64, 2, 2, 1, 32, 0, 0),
+                                                               (32, 1, 4, 1, 32, 0, 64), (128, 1, 2, 1, 64, 0, 0), (64, 1, 2, 0, 64, 0, 0),
+                                                               (64, 2, 2, 1, 64, 0, 0), (128, 1, 2, 1, 64, 16, 0), (128, 1, 2, 0, 64, 16, 0),
+                                                               (32, 2, 2, 1, 32, 0, 32), (32, 1, 2, 0, 32, 0, 32)])
 @pytest.mark.parametrize("drop", [0.0, 0.1])
-def test_diagonal_tilings_agree(rows, ki, nbuf, xcd, units, waves, drop):
+def test_diagonal_tilings_agree(rows, ki, nbuf, xcd, units, waves, bcols, drop):
     """every tile / ring configuration of the two diagonal kernels (ArkDiagTuning, passed per call) computes the
     same states, losses and gradients as the default one, and the same ELBO as the CPU oracle within north_star's
     tolerance"""
@@ -541,7 +542,7 @@ def test_diagonal_tilings_agree(rows, ki, nbuf, xcd, units, waves, drop):
     torch.manual_seed(5)
     eps = torch.randn(B, cfg["d_latent"])
     tun = dict(fwd_rows=rows, fwd_ki=ki, fwd_nbuf=nbuf, fwd_xcd=xcd, fwd_units=units, bwd_rows=min(rows, 64), bwd_ki=ki,
-               bwd_nbuf=nbuf, bwd_xcd_rows=4 if xcd else 1, fwd_waves=waves)
+               bwd_nbuf=nbuf, bwd_xcd_rows=4 if xcd else 1, fwd_waves=waves, bwd_cols=bcols)
     a = make_engine(cfg, P, "mixed")
     b = make_engine(dict(cfg, ark_diag_tuning=tun), P, "mixed")
     dev = a.device

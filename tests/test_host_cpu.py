@@ -36,7 +36,7 @@ def test_argument_errors_are_negative_codes_without_touching_the_gpu():
     one = ctypes.c_void_p(256)                                # never dereferenced: the argument check comes first
     assert lib.ark_wgrad16(2, one, ctypes.c_int64(128), one, ctypes.c_int64(128), one, ctypes.c_int64(128), 128, 128, 256, wt,
                            ctypes.c_void_p(0)) < 0
-    bad = (ctypes.c_int * 10)(48, 1, 2, 1, 32, 32, 2, 2, 4, 0)   # ArkDiagTuning with a forward row count that does not exist
+    bad = (ctypes.c_int * 11)(48, 1, 2, 1, 32, 32, 2, 2, 4, 0, 0)   # ArkDiagTuning with a forward row count that does not exist
     role = (ctypes.c_char * 256)()
     assert lib.ark_gru_diag_fwd(2, 1, 1, role, ctypes.c_void_p(0), 64, 128, bad, ctypes.c_void_p(0)) < 0
     null = ctypes.c_void_p(0)
