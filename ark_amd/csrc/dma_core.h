@@ -62,9 +62,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int PREC, int BM, int BN, int NBUF, int WGM, int WGN, int KI = 1>
 struct DmaTile {
   static_assert(PREC == PREC_F16 || PREC == PREC_BF16, "LDS-DMA engine takes 16-bit operands");
-  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile shape");
-  static constexpr int NW = WGM * WGN;   // waves per workgroup (4; 8 or 16 for 512- / 1024-thread workgroups)
-  static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
+  static_assert(BM % (16 * WGM) == 0 && BN % (16 * WGN) == 0, "tile shape: whole 16 x 16 MFMA tiles per wave");
+  static constexpr int NW = WGM * WGN;   // waves per workgroup (4; 2 for narrow tiles; 8 or 16 for 512- / 1024-thread workgroups)
+  static_assert(NW == 2 || NW == 4 || NW == 8 || NW == 16, "2, 4, 8 or 16 waves");
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
   using h8 = typename PT::h8;

@@ -188,13 +188,17 @@ template <int PREC, int PRECB>
 static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t st) {
   bool ki2 = tn.fwd_ki == 2 && p.D % 128 == 0;
   int rows = tn.fwd_rows;
-  const int units = (tn.fwd_units == 64 && p.D % 64 == 0) ? 64 : 32;
+  int units = (tn.fwd_units == 64 && p.D % 64 == 0) ? 64 : 32;
   if (rows == 64 && units == 32 && (long)p.n_roles * ((p.B + 63) / 64) * (p.D / 32) < 256) {
     // small batch x width (e.g. B = 256, D = 128): 64-row tiles leave most CUs empty -> 32-row tiles, two k-images per
     // stage (measured on the wd-movies shape: 4.33 -> 4.12 ms/step)
     rows = 32;
     ki2 = p.D % 128 == 0;
+    // ... and when even that fills at most 96 CUs (wd-articles B = 16, wd-movies B = 256 x D = 128): 16-unit tiles on
+    // 128-thread workgroups, twice the workgroups, each streaming (32 + 48) instead of (32 + 96) rows of K
+    if (tn.fwd_units == 0 && (long)p.n_roles * ((p.B + 31) / 32) * (p.D / 32) <= 96) units = 16;
   }
+  if (tn.fwd_units == 16) { units = 16; rows = 32; ki2 = tn.fwd_ki == 2 && p.D % 128 == 0; }
   if (rows == 128 && units != 64) rows = 64;   // 128-row tiles exist for 64-unit tiles only
   const int MT = (p.B + rows - 1) / rows, UT = p.D / units;
   // (measured and not kept: four ring slots instead of two for grids of at most one workgroup per CU -- wd-movies B=256,
@@ -209,6 +213,9 @@ static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t 
     else if (rows == 128) launch_diag<PREC, PRECB, 2, 1, 128, 64>(p, st);
     else if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 64>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 64, 64>(p, st);
+  } else if (units == 16) {   // 2 waves
+    if (ki2) launch_diag<PREC, PRECB, 2, 2, 32, 16>(p, st);
+    else launch_diag<PREC, PRECB, 2, 1, 32, 16>(p, st);
   } else if (rows == 64) {
     if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 32>(p, st);
     else if (tn.fwd_nbuf >= 4) launch_diag<PREC, PRECB, 4, 1, 64, 32>(p, st);
@@ -225,7 +232,7 @@ static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t 
 
 static bool diag_tuning_ok(const ArkDiagTuning& t) {
   return (t.fwd_rows == 32 || t.fwd_rows == 64 || t.fwd_rows == 128) && (t.fwd_ki == 1 || t.fwd_ki == 2) &&
-         (t.fwd_nbuf == 2 || t.fwd_nbuf == 4) && (t.fwd_units == 32 || t.fwd_units == 64) &&
+         (t.fwd_nbuf == 2 || t.fwd_nbuf == 4) && (t.fwd_units == 0 || t.fwd_units == 16 || t.fwd_units == 32 || t.fwd_units == 64) &&
          (t.bwd_rows == 32 || t.bwd_rows == 64) && (t.bwd_ki == 1 || t.bwd_ki == 2) && (t.bwd_nbuf == 2 || t.bwd_nbuf == 4) &&
          (t.bwd_xcd_rows == 1 || t.bwd_xcd_rows == 2 || t.bwd_xcd_rows == 4 || t.bwd_xcd_rows == 8) &&
          (t.fwd_waves == 0 || t.fwd_waves == 16) && (t.bwd_cols == 0 || t.bwd_cols == 32 || t.bwd_cols == 64);
@@ -236,7 +243,7 @@ static bool diag_tuning_ok(const ArkDiagTuning& t) {
 // measured on MI355X (syn-paths, B=1024): see DESIGN.md section 6
 extern "C" void ark_diag_tuning_default(ArkDiagTuning* t) {
   if (!t) return;
-  t->fwd_rows = 64; t->fwd_ki = 1; t->fwd_nbuf = 2; t->fwd_xcd = 1; t->fwd_units = 32;
+  t->fwd_rows = 64; t->fwd_ki = 1; t->fwd_nbuf = 2; t->fwd_xcd = 1; t->fwd_units = 0;
   t->bwd_rows = 32; t->bwd_ki = 2; t->bwd_nbuf = 2; t->bwd_xcd_rows = 4;
   t->fwd_waves = 0; t->bwd_cols = 0;
 }

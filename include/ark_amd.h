@@ -122,7 +122,7 @@ typedef struct {
   int fwd_ki;        /* 64-wide k-images per ring stage: 1 | 2                                  */
   int fwd_nbuf;      /* ring slots: 2 | 4                                                       */
   int fwd_xcd;       /* XCD-aware tile order: 0 | 1                                             */
-  int fwd_units;     /* hidden units per forward workgroup: 32 (4 waves) | 64 (8 waves)         */
+  int fwd_units;     /* hidden units per forward workgroup: 0 = by grid size | 16 (2 waves) | 32 (4) | 64 (8) */
   int bwd_rows;      /* 32 | 64                                                                 */
   int bwd_ki;        /* 1 | 2                                                                   */
   int bwd_nbuf;      /* 2 | 4                                                                   */

@@ -528,7 +528,7 @@ def test_dropout_on_fast_path_matches_oracle_with_the_same_masks(B):
 @pytest.mark.parametrize("rows,ki,nbuf,xcd,units,waves,bcols", [(32, 2, 2, 0, 32, 0, 0), (64, 1, 2, 0, 32, 0, 64), (64, 2, 2, 1, 32, 0, 0),
                                                                (32, 1, 4, 1, 32, 0, 64), (128, 1, 2, 1, 64, 0, 0), (64, 1, 2, 0, 64, 0, 0),
                                                                (64, 2, 2, 1, 64, 0, 0), (128, 1, 2, 1, 64, 16, 0), (128, 1, 2, 0, 64, 16, 0),
-                                                               (32, 2, 2, 1, 32, 0, 32), (32, 1, 2, 0, 32, 0, 32)])
+                                                               (32, 2, 2, 1, 32, 0, 32), (32, 1, 2, 0, 32, 0, 32), (32, 2, 2, 1, 16, 0, 32), (32, 1, 2, 0, 16, 0, 0)])
 @pytest.mark.parametrize("drop", [0.0, 0.1])
 def test_diagonal_tilings_agree(rows, ki, nbuf, xcd, units, waves, bcols, drop):
     """every tile / ring configuration of the two diagonal kernels (ArkDiagTuning, passed per call) computes the
