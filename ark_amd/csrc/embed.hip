@@ -20,11 +20,10 @@ __device__ __forceinline__ void put16x4(void* base, long idx4, f32x4 v, int prec
   }
 }
 
-__global__ __launch_bounds__(256) void enc_pool_fwd_kernel(const int64_t* __restrict__ triples, const float* __restrict__ E,
+__device__ __forceinline__ void enc_pool_fwd_body(int b, const int64_t* __restrict__ triples, const float* __restrict__ E,
                                                            const float* __restrict__ R, float* __restrict__ g,
                                                            float* __restrict__ inv_cnt, int T, int D, long pad_rid,
                                                            void* g16a, int prec_a, void* g16b, int prec_b) {
-  const int b = blockIdx.x;
   const int64_t* tr = triples + (long)b * T * 3;
   int cnt = 0;
   for (int t = 0; t < T; ++t) cnt += (pad_rid < 0 || tr[t * 3 + 1] != pad_rid) ? 1 : 0;
@@ -54,6 +53,42 @@ __global__ __launch_bounds__(256) void enc_pool_fwd_kernel(const int64_t* __rest
     *reinterpret_cast<f32x4*>(g + (long)b * 3 * D + 4 * c) = r;
     if (g16a) put16x4(g16a, (long)b * 3 * D4 + c, r, prec_a);   // 16-bit operand copies for the MLP products
     if (g16b) put16x4(g16b, (long)b * 3 * D4 + c, r, prec_b);
+  }
+}
+
+__global__ __launch_bounds__(256) void enc_pool_fwd_kernel(const int64_t* __restrict__ triples, const float* __restrict__ E,
+                                                           const float* __restrict__ R, float* __restrict__ g,
+                                                           float* __restrict__ inv_cnt, int T, int D, long pad_rid,
+                                                           void* g16a, int prec_a, void* g16b, int prec_b) {
+  enc_pool_fwd_body(blockIdx.x, triples, E, R, g, inv_cnt, T, D, pad_rid, g16a, prec_a, g16b, prec_b);
+}
+
+// The first launch of a SAIL step: the encoder pool (blocks [0, B)) and the decoder's token gather (the blocks after
+// them) have nothing to do with each other except that both only need the batch indices, so they share one launch
+// instead of two dependent ones.  The gather role also bumps the dropout draw counter (see tok_gather16_kernel).
+struct PoolGatherArgs {
+  const int64_t* triples; const float* E; const float* R; float* g; float* inv_cnt; void* g16a; void* g16b;
+  const int64_t* seq; const float* Wt; void* xa; void* xb; float* hyper_tick;
+  long pad_rid, ld_seq;
+  int B, T, D, Dd, L, prec_a, prec_b;
+};
+__global__ __launch_bounds__(256) void pool_gather_fwd_kernel(PoolGatherArgs p) {
+  if ((int)blockIdx.x < p.B) {
+    enc_pool_fwd_body(blockIdx.x, p.triples, p.E, p.R, p.g, p.inv_cnt, p.T, p.D, p.pad_rid, p.g16a, p.prec_a, p.g16b, p.prec_b);
+    return;
+  }
+  const int blk = blockIdx.x - p.B, nblk = gridDim.x - p.B;
+  if (p.hyper_tick && blk == 0 && threadIdx.x == 0) reinterpret_cast<uint32_t*>(p.hyper_tick)[kHpDropStep] += 1u;
+  const int D4 = p.Dd >> 2;
+  const long total = (long)p.B * p.L * D4;
+  for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblk * 256) {
+    const int d4 = (int)(i % D4);
+    const long row = i / D4;
+    const int t = (int)(row / p.B), b = (int)(row % p.B);
+    const long tok = p.seq[(long)b * p.ld_seq + t];
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p.Wt + tok * p.Dd + 4 * d4);
+    put16x4(p.xa, row * D4 + d4, v, p.prec_a);
+    if (p.xb) put16x4(p.xb, row * D4 + d4, v, p.prec_b);
   }
 }
 
@@ -259,6 +294,27 @@ extern "C" int ark_enc_pool_fwd16(const int64_t* triples, const float* E, const 
   if ((prec_a != PREC_F16 && prec_a != PREC_BF16) || (g16b && prec_b != PREC_F16 && prec_b != PREC_BF16)) return ARK_ERR_ARG;
   hipLaunchKernelGGL(enc_pool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, triples, E, R, g, inv_cnt, T, D,
                      (long)pad_rid, g16a, prec_a, g16b, prec_b);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// encoder pool (as ark_enc_pool_fwd16) and decoder token gather (as ark_tok_gather16 without a position table) in ONE
+// launch: x16a/x16b[(t, b), :] = cast(W_tok[seq[b, t]]), t < L, rows time-major, D_dec columns
+extern "C" int ark_pool_gather_fwd16(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt,
+                                     void* g16a, int prec_a, void* g16b, int prec_b, int B, int T, int D, int64_t pad_rid,
+                                     const int64_t* seq, int64_t ld_seq, const float* w_tok, void* x16a, void* x16b, int L,
+                                     int D_dec, float* hyper_tick, void* stream) {
+  using namespace ark;
+  if (!triples || !E || !R || !g || !g16a || !seq || !w_tok || !x16a || B <= 0 || T <= 0 || D <= 0 || L <= 0 || D_dec <= 0)
+    return ARK_ERR_ARG;
+  if (D % 4 != 0 || D_dec % 4 != 0) return ARK_ERR_SHAPE;
+  if ((prec_a != PREC_F16 && prec_a != PREC_BF16) || (g16b && prec_b != PREC_F16 && prec_b != PREC_BF16)) return ARK_ERR_ARG;
+  if ((g16b == nullptr) != (x16b == nullptr)) return ARK_ERR_ARG;   // one backward type for both (or none)
+  PoolGatherArgs p{triples, E, R, g, inv_cnt, g16a, g16b, seq, w_tok, x16a, x16b, hyper_tick, (long)pad_rid, (long)ld_seq,
+                   B, T, D, D_dec, L, prec_a, prec_b};
+  const long total = (long)B * L * (D_dec / 4);
+  long gb = (total + 255) / 256; if (gb > 4096) gb = 4096; if (gb < 1) gb = 1;
+  hipLaunchKernelGGL(pool_gather_fwd_kernel, dim3((unsigned)(B + gb)), dim3(256), 0, (hipStream_t)stream, p);
   ARK_LAUNCH_CHECK();
   return 0;
 }

@@ -189,6 +189,8 @@ class Engine:
         self.fork_after = int(cfg.get("ark_fork_after", 1))   # measured: 0 -> 1.281, 1 -> 1.266, 2 -> 1.296 ms/step
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
         self.fused_latent = bool(cfg.get("ark_fused_latent", True))
+        self.fused_prologue = bool(cfg.get("ark_fused_prologue", True))   # encoder pool + token gather as one launch
+        self._x0_ready = False
         self.early_dec_adam = bool(cfg.get("ark_early_dec_adam", True))
         self.early_mlp_adam = bool(cfg.get("ark_early_mlp_adam", True))
         self._adam_dec_early = False
@@ -502,9 +504,19 @@ class Engine:
             H = 3 * D
             if w["v2"]:
                 pf, pb = self.prec_fwd, self.prec_bwd
-                _call("ark_enc_pool_fwd16", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
-                      L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.ptr(w["g16a"]), L.i32(pf), L.ptr(w["g16b"]), L.i32(pb), L.i32(B),
-                      L.i32(T), L.i32(D), L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
+                if self._dp_pending is None and self.fused_prologue:
+                    # the decoder's token gather shares the encoder pool's launch (both only need the batch indices); not
+                    # while a pipelined data-parallel update of the token table is still owed (it lands at the seam)
+                    _call("ark_pool_gather_fwd16", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
+                          L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.ptr(w["g16a"]), L.i32(pf), L.ptr(w["g16b"]), L.i32(pb), L.i32(B),
+                          L.i32(T), L.i32(D), L.i64(-1 if self.pad_rid is None else self.pad_rid), L.ptr(seq), L.i64(ld_seq),
+                          L.ptr(p["dec.tok_emb.weight"]), L.ptr(w["X0a"]), L.ptr(w["X0b"]), L.i32(Lq), L.i32(D),
+                          L.ptr(self.hyper if use_drop else None), st)
+                    self._x0_ready = True
+                else:
+                    _call("ark_enc_pool_fwd16", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
+                          L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.ptr(w["g16a"]), L.i32(pf), L.ptr(w["g16b"]), L.i32(pb), L.i32(B),
+                          L.i32(T), L.i32(D), L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
             else:
                 _call("ark_enc_pool_fwd", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
                       L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.i32(B), L.i32(T), L.i32(D),
@@ -641,9 +653,12 @@ class Engine:
         st = L.cur_stream()
         p = self.p
         pf, pb = self.prec_fwd, self.prec_bwd
-        _call("ark_tok_gather16", L.i32(pf), L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(p["dec.tok_emb.weight"]),
-              L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0a"]), L.ptr(w["X0b"]), L.i32(B),
-              L.i32(Lq), L.i32(D), L.ptr(self.hyper if use_drop else None), st)
+        if self._x0_ready:   # (gathered by the step's first launch, beside the encoder pool)
+            self._x0_ready = False
+        else:
+            _call("ark_tok_gather16", L.i32(pf), L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(p["dec.tok_emb.weight"]),
+                  L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0a"]), L.ptr(w["X0b"]), L.i32(B),
+                  L.i32(Lq), L.i32(D), L.ptr(self.hyper if use_drop else None), st)
         self._diag_sweep(w, B, Lq, use_drop, save)
         if project:
             _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(w["Y16a"][n - 1][B:]), L.i64(D), L.ptr(self.wtok16), L.i64(D),

@@ -239,6 +239,12 @@ int ark_enc_pool_bwd(const int64_t* triples, const float* dg, const float* inv_c
                      int T, int D, int n_ent, int n_rel, int64_t pad_eid, int64_t pad_rid, void* stream);
 int ark_tok_gather(const int64_t* seq, int64_t ld_seq, const float* w_tok, const float* w_pos /* nullable */,
                    float* x, int B, int L, int D, float* hyper_tick /* nullable, as ark_tok_gather16 */, void* stream);
+/* encoder pool (ark_enc_pool_fwd16) + decoder token gather (ark_tok_gather16, no position table) in ONE launch: the two
+ * first kernels of a SAIL step only need the batch indices.  x16a/x16b[(t, b), :] = cast(W_tok[seq[b, t]]), t < L. */
+int ark_pool_gather_fwd16(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt, void* g16a,
+                          int prec_a, void* g16b, int prec_b, int B, int T, int D, int64_t pad_rid, const int64_t* seq,
+                          int64_t ld_seq, const float* w_tok, void* x16a, void* x16b, int L, int D_dec, float* hyper_tick,
+                          void* stream);
 int ark_tok_scatter(const int64_t* seq, int64_t ld_seq, const float* dx, float* d_w_tok, int B, int L, int D,
                     int vocab, void* stream);
 
