@@ -381,10 +381,14 @@ class Engine:
         two = self.prec_fwd != self.prec_bwd   # separate backward-type copies of the activations
         if v2 and self.mt == "SAIL":
             H = 3 * D
-            w["g16a"], w["g16b"] = i16(B, H), (i16(B, H) if two else None)
-            w["act16a"] = [i16(B, H) for _ in range(n)]
-            w["act16b"] = [i16(B, H) if two else None for _ in range(n)]
-            w["dpre16"] = [torch.zeros(B, H, device=dev, dtype=torch.int16) for _ in range(n)]
+            # rows padded to a multiple of 64 and zero-initialised: the grouped weight-gradient launch reduces over whole
+            # 64-row stages, and rows >= B are never written (they add exact zeros)
+            Bk = _rup(B, 64)
+            z16 = lambda: torch.zeros(Bk, H, device=dev, dtype=torch.int16)
+            w["g16a"], w["g16b"] = z16(), (z16() if two else None)
+            w["act16a"] = [z16() for _ in range(n)]
+            w["act16b"] = [z16() if two else None for _ in range(n)]
+            w["dpre16"] = [z16() for _ in range(n)]
         if v2:
             # "16": row-major 16-bit copies (a: forward type, b: backward type); "_t": tile-native
             w["X0a"] = i16(R, D)
@@ -844,11 +848,7 @@ class Engine:
                 # the last layer, the product below for the others); only the unfused latent path still needs a pass
                 if i == n - 1 and not fused:
                     self._colsum(dpre, H, g[f"enc.mlp.{2 * i}.bias"], B, H)
-                if B % 64 == 0:
-                    group.append((w["dpre16"][i], H, inp16, H, g[f"enc.mlp.{2 * i}.weight"], H, H, H, B))
-                else:
-                    _call("ark_gemm_wgrad", L.i32(pb), L.ptr(w["dpre16"][i]), L.i32(1), L.i64(H), L.ptr(inp16), L.i32(1), L.i64(H),
-                          L.ptr(g[f"enc.mlp.{2 * i}.weight"]), L.i64(H), L.i32(H), L.i32(H), L.i32(B), L.i32(1), st)
+                group.append((w["dpre16"][i], H, inp16, H, g[f"enc.mlp.{2 * i}.weight"], H, H, H, _rup(B, 64)))
                 if i > 0:
                     _call("ark_gemm16_ex", L.i32(pb), L.i32(L.EPI_MUL_DGELU), L.ptr(w["dpre16"][i]), L.i64(H), L.ptr(self.wmT16[i]),
                           L.i64(H), L.ptr(other), L.i64(H), L.ptr(None), L.ptr(w["pre"][i - 1]), L.ptr(w["dpre16"][i - 1]), L.ptr(None),
