@@ -391,14 +391,19 @@ class Engine:
             w["dpre16"] = [z16() for _ in range(n)]
         if v2:
             # "16": row-major 16-bit copies (a: forward type, b: backward type); "_t": tile-native
-            w["X0a"] = i16(R, D)
-            w["X0b"] = i16(R, D) if two else None
+            # the weight-gradient launch reduces over whole 64-row stages: its operands carry zeroed rows up to the next
+            # multiple of 64 (rows >= R of the gate-gradient panels are never written, so whatever the other operand holds
+            # there is multiplied by exact zeros -- and it is finite: zero-initialised, written by real cells only)
+            Rp = _rup(R, 64)
+            z16r = lambda rows, cols: torch.zeros(rows, cols, device=dev, dtype=torch.int16)
+            w["X0a"] = z16r(Rp, D)
+            w["X0b"] = z16r(Rp, D) if two else None
             w["Y"] = [torch.zeros((Lq + 1) * B, D, device=dev) for _ in range(n)]   # tile-native fp32 state
-            w["Y16a"] = [torch.zeros((Lq + 1) * B, D, device=dev, dtype=torch.int16) for _ in range(n)]
-            w["Y16b"] = [torch.zeros((Lq + 1) * B, D, device=dev, dtype=torch.int16) if two else None for _ in range(n)]
+            w["Y16a"] = [z16r((Lq + 1) * B + 64, D) for _ in range(n)]
+            w["Y16b"] = [z16r((Lq + 1) * B + 64, D) if two else None for _ in range(n)]
             for nm in ("SR", "SZ", "SN", "SHN"):
                 w[nm] = [i16(R, D) for _ in range(n)]                        # tile-native fp16 saves
-            w["dG16"] = [i16(R, 4 * D) for _ in range(n)]                    # gate-gradient panels [dr | dz | dn | dn*r]
+            w["dG16"] = [z16r(Rp, 4 * D) for _ in range(n)]                  # gate-gradient panels [dr | dz | dn | dn*r]
             if self.fused_ce:
                 w["lse"] = f(R)
             else:
@@ -415,8 +420,8 @@ class Engine:
             w["h0"] = f(B, D)                                                # row-major h0 (z-projection)
             w["dX0"] = f(R, D)
             if self.p_drop > 0:   # the dropout mask itself is regenerated in-kernel from a counter hash
-                w["Yd16a"] = [i16(R, D) for _ in range(n - 1)]
-                w["Yd16b"] = [i16(R, D) if two else None for _ in range(n - 1)]
+                w["Yd16a"] = [z16r(Rp, D) for _ in range(n - 1)]
+                w["Yd16b"] = [z16r(Rp, D) if two else None for _ in range(n - 1)]
             w["carry_l"] = [f(B, D) for _ in range(n)]   # the diagonal BPTT keeps one carry per layer
         else:
             w["X0"] = f(R, D)
@@ -1107,17 +1112,16 @@ class Engine:
                 xin = yb(l - 1)[B:]
             G16 = w["dG16"][l]
             ghh = g[f"dec.gru.weight_hh_l{l}"]
-            items += [(G16, 4 * D, yb(l), D, ghh, D, 2 * D, D, R),
-                      (G16[:, 3 * D:], 4 * D, yb(l), D, ghh[2 * D:], D, D, D, R)]
+            Rp = _rup(R, 64)   # (whole 64-row stages: the operands are allocated with zeroed rows up to there)
+            items += [(G16, 4 * D, yb(l), D, ghh, D, 2 * D, D, Rp),
+                      (G16[:, 3 * D:], 4 * D, yb(l), D, ghh[2 * D:], D, D, D, Rp)]
             if not (l == 0 and emb and w["emb_gemm"]):   # (layer 0's dW_ih comes from the token sums below)
-                items.append((G16, 4 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, R))
-        if R % 64 == 0:
-            for i0 in range(0, len(items), L.WGRAD_MAX_GROUP):
-                self._wgrad_group(items[i0:i0 + L.WGRAD_MAX_GROUP])
-        else:
-            for (a, lda, x, ldx, out, ldo, M, N, K) in items:
-                _call("ark_gemm_wgrad", L.i32(pb), L.ptr(a), L.i32(1), L.i64(lda), L.ptr(x), L.i32(1), L.i64(ldx), L.ptr(out),
-                      L.i64(ldo), L.i32(M), L.i32(N), L.i32(K), L.i32(1), ss)
+                items.append((G16, 4 * D, xin, D, g[f"dec.gru.weight_ih_l{l}"], D, 3 * D, D, Rp))
+        if R % 64 != 0 and R < w["_R"]:   # a run shorter than the allocation: the tail rows may hold an earlier run's panel
+            for l in layers:
+                w["dG16"][l][R:_rup(R, 64)].zero_()
+        for i0 in range(0, len(items), L.WGRAD_MAX_GROUP):
+            self._wgrad_group(items[i0:i0 + L.WGRAD_MAX_GROUP])
         if not emb:
             return
         G0 = w["dG16"][0]

@@ -464,8 +464,8 @@ def test_in_kernel_dropout_matches_the_materialised_mask():
     masks = _row_major_masks(eng, B, eng.L)
     kept = []
     for l in range(eng.n - 1):
-        y = w["Y16a"][l][B:].view(torch.float16).float().view(eng.L, B, eng.D).permute(1, 0, 2).cpu()
-        yd = w["Yd16a"][l].view(torch.float16).float().view(eng.L, B, eng.D).permute(1, 0, 2).cpu()
+        y = w["Y16a"][l][B:B + eng.L * B].view(torch.float16).float().view(eng.L, B, eng.D).permute(1, 0, 2).cpu()
+        yd = w["Yd16a"][l][:eng.L * B].view(torch.float16).float().view(eng.L, B, eng.D).permute(1, 0, 2).cpu()
         m = masks[l]
         assert set(m.unique().tolist()) == {0.0, 2.0} and 0.45 < (m == 0).float().mean().item() < 0.55
         assert torch.allclose(yd, y * m, rtol=2e-3, atol=1e-4)
