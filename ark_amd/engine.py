@@ -169,7 +169,7 @@ class Engine:
             if self.mt == "SAIL":   # the encoder bucket = embeddings | MLP (99 % of it) | heads + z-projection
                 m0, m1 = self.layout.entries["enc.mlp.0.weight"][0], self.layout.entries["enc.mu.weight"][0]
                 self._adam_jobs["mlp"] = self._build_adam_jobs(m0, m1)
-                self._adam_jobs["enc_rest"] = self._build_adam_jobs(0, m0) + self._build_adam_jobs(m1, off)
+                self._adam_jobs["enc_rest"] = self._build_adam_jobs((0, m0), (m1, off))   # (one launch)
         self._shadow_ok = False
         self._side = None
         self._pad_bufs = {}
@@ -259,10 +259,29 @@ class Engine:
                 _call("ark_weight_shadows", L.i32(n), src, dst, dstT, R, C, pf, pb, ldT, L.cur_stream())
         self._shadow_ok = True
 
-    def _build_adam_jobs(self, lo, hi):
-        """job table of ark_adam_step_shadows for the flat range [lo, hi): one MATRIX job per shadowed weight (its
-        16-bit shadows are written from the updated values), LINEAR jobs for everything between them"""
+    def _build_adam_jobs(self, *ranges):
+        """job tables of ark_adam_step_shadows for the flat ranges [lo, hi), ... : one MATRIX job per shadowed weight (its
+        16-bit shadows are written from the updated values), LINEAR jobs for everything between them; all ranges share
+        launches (ARK_ADAM_MAX_JOBS jobs each)"""
         import ctypes
+        if len(ranges) == 2 and not isinstance(ranges[0], (tuple, list)):
+            ranges = (ranges,)
+        jobs = []
+        for lo, hi in ranges:
+            jobs += self._adam_job_list(lo, hi)
+        chunks = []
+        for c0 in range(0, len(jobs), L.ADAM_MAX_JOBS):
+            ch = jobs[c0:c0 + L.ADAM_MAX_JOBS]
+            n = len(ch)
+            chunks.append((n, (ctypes.c_int64 * n)(*[j[0] for j in ch]), (ctypes.c_int * n)(*[j[1] for j in ch]),
+                           (ctypes.c_int * n)(*[j[2] for j in ch]),
+                           (ctypes.c_void_p * n)(*[(j[3].data_ptr() if j[3] is not None else 0) for j in ch]),
+                           (ctypes.c_void_p * n)(*[(j[4].data_ptr() if j[4] is not None else 0) for j in ch]),
+                           (ctypes.c_int * n)(*[self.prec_fwd] * n), (ctypes.c_int * n)(*[self.prec_bwd] * n),
+                           (ctypes.c_int * n)(*[j[5] for j in ch])))
+        return chunks
+
+    def _adam_job_list(self, lo, hi):
         shadows = {}   # parameter name -> (dst, dstT, ldT)
         for l in range(self.n):
             shadows[f"dec.gru.weight_ih_l{l}"] = (self.wih16[l], self.wihT16[l], 0)
@@ -292,17 +311,7 @@ class Engine:
                 cur = mat[0] + mat[1] * mat[2]
             k += 1
         linear(cur, hi)
-        chunks = []
-        for c0 in range(0, len(jobs), L.ADAM_MAX_JOBS):
-            ch = jobs[c0:c0 + L.ADAM_MAX_JOBS]
-            n = len(ch)
-            chunks.append((n, (ctypes.c_int64 * n)(*[j[0] for j in ch]), (ctypes.c_int * n)(*[j[1] for j in ch]),
-                           (ctypes.c_int * n)(*[j[2] for j in ch]),
-                           (ctypes.c_void_p * n)(*[(j[3].data_ptr() if j[3] is not None else 0) for j in ch]),
-                           (ctypes.c_void_p * n)(*[(j[4].data_ptr() if j[4] is not None else 0) for j in ch]),
-                           (ctypes.c_int * n)(*[self.prec_fwd] * n), (ctypes.c_int * n)(*[self.prec_bwd] * n),
-                           (ctypes.c_int * n)(*[j[5] for j in ch])))
-        return chunks
+        return jobs
 
     def _adam_launch(self, which):
         st = L.cur_stream()
