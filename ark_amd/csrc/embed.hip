@@ -31,28 +31,39 @@ __device__ __forceinline__ void enc_pool_fwd_body(int b, const int64_t* __restri
   const float w = 1.0f / (float)(pad_rid < 0 ? T : (cnt > 0 ? cnt : 1));
   if (threadIdx.x == 0 && inv_cnt) inv_cnt[b] = w;
   const int D4 = D >> 2;
-  for (int c = threadIdx.x; c < 3 * D4; c += blockDim.x) {
-    const int part = c / D4, d4 = c % D4;
-    const float* tab = (part == 1) ? R : E;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    // batches of 8 row loads in flight: one workgroup per graph walks its T triples alone, and a load-add chain of
-    // T = 212 (wd-articles) cost 307 us of pure latency; the summation order is unchanged
+  // One workgroup per graph walks its T triples alone: what it costs is load latency (the entity table of the wd-* sets
+  // is HBM-resident, rows are random).  Every thread therefore owns TWO float4 columns at a time and keeps 2 x 8 row
+  // loads in flight (a load-add chain of T = 212 was 307 us; 8 in flight 210 us).  Summation order per column: t ascending.
+  for (int c0 = threadIdx.x; c0 < 3 * D4; c0 += 2 * blockDim.x) {
+    const int c1 = c0 + blockDim.x;
+    const bool two = c1 < 3 * D4;
+    const int part0 = c0 / D4, d40 = c0 % D4;
+    const int part1 = two ? c1 / D4 : part0, d41 = two ? c1 % D4 : d40;
+    const float* tab0 = (part0 == 1) ? R : E;
+    const float* tab1 = (part1 == 1) ? R : E;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     for (int t0 = 0; t0 < T; t0 += 8) {
-      f32x4 v[8];
+      f32x4 v0[8], v1[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int t = t0 + u;
         const bool ok = t < T && !(pad_rid >= 0 && tr[t * 3 + 1] == pad_rid);
-        const long id = ok ? tr[t * 3 + part] : 0;
-        v[u] = ok ? *reinterpret_cast<const f32x4*>(tab + id * D + 4 * d4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const long id0 = ok ? tr[t * 3 + part0] : 0, id1 = ok ? tr[t * 3 + part1] : 0;
+        v0[u] = ok ? *reinterpret_cast<const f32x4*>(tab0 + id0 * D + 4 * d40) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v1[u] = (ok && two) ? *reinterpret_cast<const f32x4*>(tab1 + id1 * D + 4 * d41) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u) { s0 += v0[u]; s1 += v1[u]; }
     }
-    const f32x4 r = s * w;
-    *reinterpret_cast<f32x4*>(g + (long)b * 3 * D + 4 * c) = r;
-    if (g16a) put16x4(g16a, (long)b * 3 * D4 + c, r, prec_a);   // 16-bit operand copies for the MLP products
-    if (g16b) put16x4(g16b, (long)b * 3 * D4 + c, r, prec_b);
+    const f32x4 r0 = s0 * w, r1 = s1 * w;
+    *reinterpret_cast<f32x4*>(g + (long)b * 3 * D + 4 * c0) = r0;
+    if (g16a) put16x4(g16a, (long)b * 3 * D4 + c0, r0, prec_a);   // 16-bit operand copies for the MLP products
+    if (g16b) put16x4(g16b, (long)b * 3 * D4 + c0, r0, prec_b);
+    if (two) {
+      *reinterpret_cast<f32x4*>(g + (long)b * 3 * D + 4 * c1) = r1;
+      if (g16a) put16x4(g16a, (long)b * 3 * D4 + c1, r1, prec_a);
+      if (g16b) put16x4(g16b, (long)b * 3 * D4 + c1, r1, prec_b);
+    }
   }
 }
 
