@@ -115,7 +115,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     prints ONE JSON line with n_gpus 2 and the global batch"""
     import json
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
-                          "--warmup", "1", "--batch", "128", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True,
+                          "--warmup", "1", "--settle", "0", "--batch", "128", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True,
                          timeout=600, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
