@@ -197,7 +197,10 @@ class Engine:
         self._adam_dec_done = False
         self._adam_mlp_done = False
         # small vocabularies (one 64-token tile): projection + cross-entropy + dY(top) + 16-bit dlogits in one launch
-        self.fused_ce_small = bool(cfg.get("ark_fused_ce_small", self.use_dma and self.V <= 64 and self.D in (64, 128, 256, 512)))   # reparameterisation + z-projection as one launch
+        # (opt-in: at D = 512 the fused kernel measures 22 us against 7.8 + 6.4 + 13.3 us for the three launches it replaces,
+        #  and in steady state the step is 9 us SLOWER with it -- 1.168 vs 1.158 ms, 4 of 4 alternating rounds; it won only
+        #  while the device was still ramping up after the capture)
+        self.fused_ce_small = bool(cfg.get("ark_fused_ce_small", False)) and self.use_dma and self.V <= 64 and self.D in (64, 128, 256, 512)   # reparameterisation + z-projection as one launch
         self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))
         # large vocabularies: tied projection fused with the cross-entropy -- [B*L, V] logits / dlogits never exist
         # (csrc/vocab_ce.hip); small ones keep the three short launches (W_tok is a few KB there)
