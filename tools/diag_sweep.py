@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--workload", default="syn-paths")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("settings", nargs="*", default=[""])
     args = ap.parse_args()
     from ark_amd import initlib
@@ -47,6 +47,11 @@ def main():
         with torch.cuda.stream(st):
             step = eng.capture_train_step(tri, seq, eps, ce_count=cnt)
         engines.append((s, eng, step, st))
+    for s, eng, step, st in engines:   # settle: the first ~300 replays after a capture run slower
+        with torch.cuda.stream(st):
+            for _ in range(300):
+                step()
+    torch.cuda.synchronize()
     res = {s: {"fwd": [], "bwd": [], "step": []} for s in args.settings}
     for _ in range(args.rounds):
         for s, eng, step, st in engines:

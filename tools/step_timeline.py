@@ -9,7 +9,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step starts at the encoder pool (SAIL) / the token gather (ARK): print the last complete one
-anchor = "enc_pool_fwd" if any("enc_pool_fwd" in r["Kernel_Name"] for r in rows) else "tok_gather"
+anchor = next((a for a in ("pool_gather_fwd", "enc_pool_fwd", "tok_gather") if any(a in r["Kernel_Name"] for r in rows)), "tok_gather")
 idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]["Start_Timestamp"])
