@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1, help="dec_dropout (reference default 0.1)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--cfg", default="", help="extra engine config ints, e.g. ark_overlap_wgrad=0,ark_fork_after=0")
     ap.add_argument("--diag", default="", help="diagonal-kernel tiles, e.g. fwd_rows=64,fwd_units=32,bwd_rows=32,bwd_ki=2")
     ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path even with one rank")
