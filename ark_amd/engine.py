@@ -1233,6 +1233,9 @@ class Engine:
         return tp, sp, ep
 
     def _default_norms(self, B):
+        # KL_NORM scales the KL GRADIENT only (loss.hip: latent_bwd / latent_chain_bwd); the reported KL value is always
+        # the mean over THIS process's rows (kl_scale = -0.5 / (rows * Z) in the loss finalisation), so evaluation of
+        # whole batches on one rank of a data-parallel job reports the same KL as a single process
         if self.mt == "SAIL":
             self.set_hyper(kl_norm=1.0 / (B * self.world_size * self.Z))
 
@@ -1326,6 +1329,10 @@ class Engine:
                 h.wait()
             for item in handles:
                 self._dp_unpack(*item)
+            # (unpipelined: ARK's single bucket, `ark_dp_pipeline: false`, or a caller-supplied grad_sync on top)
+            if grad_sync is not None:
+                grad_sync(self.G)
+            self.adam()
         else:
             self._local_step(triples, seq, eps, ce_count, grad_sync)
         return self.ws["out4"]
@@ -1334,8 +1341,9 @@ class Engine:
         """forward + backward + Adam of ONE process (also the body of the captured single-process graph).  The decoder
         bucket's Adam is launched on the side queue as soon as its gradients are queued (see _backward_decoder_diag)."""
         self._defer_finalize = True
+        # (fork_after = 0 would launch that Adam -- which rewrites the W_hh^T shadows -- beside the h0 roles that read them)
         self._adam_dec_early = bool(self.early_dec_adam and grad_sync is None and self.use_dma and self.overlap_wgrad
-                                    and self.mt == "SAIL")
+                                    and self.mt == "SAIL" and self.fork_after >= 1)
         self._adam_dec_done = False
         self._adam_mlp_done = False
         try:
@@ -1565,7 +1573,7 @@ class Engine:
         return d["logits"][:, :V]
 
     @torch.no_grad()
-    def greedy_decode(self, z, max_len=None):
+    def greedy_decode(self, z, max_len=None, bos=1, eos=2):
         """token sequences of SAIL.decode_latent(z, beam=1) (reference models.py:282-300): the decoder is a causal
         GRU, so instead of re-running the whole prefix we advance one step per token.  Exact-fp32 kernels on
         persistent buffers; every step is queued without a host round trip and the reference's stopping rule
@@ -1576,21 +1584,21 @@ class Engine:
         Lmax = (self.seq_len - 1) if max_len is None else max_len
         d = self.decode_begin(B, z)
         toks = d["toks"]
-        toks.fill_(2)
-        toks[:, 0] = 1
+        toks.fill_(eos)
+        toks[:, 0] = bos
         st = L.cur_stream()
         ldl = d["logits"].shape[1]
         for t in range(Lmax):
             self.decode_step(d, toks[:, t].contiguous() if t == 0 else d["nxt"], t)
             _call("ark_argmax_rows", L.ptr(d["logits"]), L.i64(ldl), L.ptr(d["nxt"]), L.i32(B), L.i32(self.V), st)
             toks[:, t + 1] = d["nxt"]
-        done = (toks[:, 1:Lmax + 1] == 2).all(dim=0)          # ONE synchronisation, after the last step
+        done = (toks[:, 1:Lmax + 1] == eos).all(dim=0)          # ONE synchronisation, after the last step
         hit = torch.nonzero(done)
         stop = int(hit[0]) + 1 if hit.numel() else Lmax
         return toks[:, :stop + 1].clone()
 
     @torch.no_grad()
-    def beam_decode(self, z, beam, max_len=None):
+    def beam_decode(self, z, beam, max_len=None, bos=1, eos=2):
         """token sequences of SAIL.decode_latent(z, beam > 1) (reference models.py:282-300: a batch-shared beam,
         candidates ranked by the batch-MEAN log-probability, stable descending sort).  The reference re-runs the decoder
         on every beam's whole prefix per generated token; here every beam keeps its GRU state (beam x B rows of one
@@ -1603,8 +1611,8 @@ class Engine:
         zr = z.to(self.device, dtype=torch.float32).repeat(beam, 1)
         d = self.decode_begin(Bt, zr)
         dev = self.device
-        toks = torch.full((beam, B, Lmax + 1), 2, dtype=torch.int64, device=dev)
-        toks[:, :, 0] = 1
+        toks = torch.full((beam, B, Lmax + 1), eos, dtype=torch.int64, device=dev)
+        toks[:, :, 0] = bos
         scores = torch.zeros(beam, B, device=dev)
         active = 1          # distinct beams so far (all blocks start as copies of the single BOS beam)
         length = 1
@@ -1625,7 +1633,7 @@ class Engine:
                 y[half].copy_(y[half].index_select(0, j))
             active = beam
             length = t + 2
-            if bool((new_tok == 2).all()):                                # every beam's last token is EOS
+            if bool((new_tok == eos).all()):                                # every beam's last token is EOS
                 break
         return toks[0, :, :length].clone()
 

@@ -376,6 +376,11 @@ def main(argv=None):
         if model_type == "SAIL":
             b = config["beta0"] + (config["beta1"] - config["beta0"]) * epoch / num_epochs
         lr = cosine_lr(base_lr, epoch, num_epochs, eta_min) if use_sched else base_lr
+        if nranks > 1:
+            # the latent noise is drawn on the device inside the step: every rank needs its OWN stream (the same seed on
+            # every rank would repeat one rank's noise nranks times across the global batch), re-derived from
+            # (seed, epoch, rank) so that a resumed run -- which loads rank 0's generator state -- splits again
+            torch.cuda.manual_seed((seed * 1000003 + epoch) * 8191 + rank)
         t0 = time.time()
         train_loss, train_recon, train_kl, _ = train_epoch(model, train_ds, config, device, b, lr, (rank, nranks),
                                                            config.get("max_steps_per_epoch"),
@@ -443,6 +448,8 @@ def main(argv=None):
     if config.get("dump_final_params"):   # test hook: every rank's flat parameter buffer
         eng.dp_flush()
         torch.save(eng.P.detach().cpu(), f"{config['dump_final_params']}.rank{rank}.pt")
+        if model_type == "SAIL" and eng.ws is not None and "eps0" in eng.ws:   # the last step's device-drawn latent noise
+            torch.save(eng.ws["eps0"].detach().cpu(), f"{config['dump_final_params']}.eps.rank{rank}.pt")
     if nranks > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -236,11 +236,11 @@ class SAIL(_EngineModel):
         if beam == 1:
             # beam 1 == greedy argmax per row; the causal GRU is advanced one token per step on
             # the device instead of re-running the whole prefix
-            best = eng.greedy_decode(z, max_len=seq_len - 1).cpu()
+            best = eng.greedy_decode(z, max_len=seq_len - 1, bos=special_tokens["BOS"], eos=special_tokens["EOS"]).cpu()
             return [seq_to_triples(row, special_tokens, ent_base, rel_base) for row in best]
         # beam > 1: the reference's batch-shared beam (candidates ranked by the batch-MEAN log-prob); every beam keeps its
         # GRU state on the device and advances one token per step (Engine.beam_decode)
-        best = eng.beam_decode(z, beam, max_len=seq_len - 1).cpu()
+        best = eng.beam_decode(z, beam, max_len=seq_len - 1, bos=special_tokens["BOS"], eos=special_tokens["EOS"]).cpu()
         return [seq_to_triples(row, special_tokens, ent_base, rel_base) for row in best]
 
     @torch.no_grad()
@@ -323,10 +323,10 @@ class ARK(_EngineModel):
         return _ArkFn.apply(self, seq.contiguous(), *prm)
 
     @staticmethod
-    def filtered_probs(logits, temperature=1.0, top_p=0.0, top_k=0):
-        """the distribution the reference samples the next token from (models.py:431-456), as dense probabilities
-        over the vocabulary: softmax(logits / temperature) -> keep the top_k -> keep the nucleus (the sorted prefix
-        up to AND including the token that crosses top_p) -> renormalise after each cut."""
+    def _filter(logits, temperature=1.0, top_p=0.0, top_k=0):
+        """next-token filtering of the reference's sampler (models.py:431-449): softmax(logits / temperature) -> keep the
+        top_k -> nucleus in SORTED space (the sorted prefix up to AND including the token that crosses top_p), each cut
+        followed by a renormalisation.  -> (probs, sorted_probs, sorted_idx), the last two None without a nucleus."""
         if temperature and temperature != 1.0:
             logits = logits / float(temperature)
         probs = torch.softmax(logits, dim=-1)
@@ -334,38 +334,59 @@ class ARK(_EngineModel):
             _, keep = probs.topk(top_k, dim=-1)
             probs = probs * torch.zeros_like(probs).scatter_(-1, keep, 1.0)
             probs = probs / probs.sum(dim=-1, keepdim=True).clamp_min(1e-12)
-        if top_p and 0.0 < top_p < 1.0:
-            sp, si = probs.sort(dim=-1, descending=True)
-            cut = sp.cumsum(dim=-1) > top_p
-            cut[..., 1:] = cut[..., :-1].clone()   # always keep the token that crosses top_p
-            cut[..., 0] = False
-            sp = sp.masked_fill(cut, 0.0)
-            sp = sp / sp.sum(dim=-1, keepdim=True).clamp_min(1e-12)
-            probs = torch.zeros_like(probs).scatter_(-1, si, sp)
-        return probs
+        if not (top_p and 0.0 < top_p < 1.0):
+            return probs, None, None
+        sp, si = probs.sort(dim=-1, descending=True)
+        cut = sp.cumsum(dim=-1) > top_p
+        cut[..., 1:] = cut[..., :-1].clone()   # always keep the token that crosses top_p
+        cut[..., 0] = False
+        sp = sp.masked_fill(cut, 0.0)
+        sp = sp / sp.sum(dim=-1, keepdim=True).clamp_min(1e-12)
+        return probs, sp, si
+
+    @staticmethod
+    def filtered_probs(logits, temperature=1.0, top_p=0.0, top_k=0):
+        """the distribution the next token is sampled from, as dense probabilities over the vocabulary"""
+        probs, sp, si = ARK._filter(logits, temperature, top_p, top_k)
+        return probs if sp is None else torch.zeros_like(probs).scatter_(-1, si, sp)
 
     @torch.no_grad()
     def generate(self, seq_len, special_tokens, device=None, batch_size=1, beam=1, sample=False, temperature=1.0,
-                 top_p=0.0, top_k=0):
+                 top_p=0.0, top_k=0, host_draws=False):
         """autoregressive generation with the reference's sampling rules (models.py:407-471): greedy, or
-        temperature / top-k / nucleus sampling drawn with torch.multinomial.  The causal GRU advances ONE token per
-        step on the engine (Engine.decode_step) instead of re-running the whole prefix."""
+        temperature / top-k / nucleus sampling.  The causal GRU advances ONE token per step on the engine
+        (Engine.decode_step, exact-fp32 kernels) instead of re-running the whole prefix.
+
+        Draws: with a nucleus the reference draws in SORTED space, one torch.multinomial per row, and maps the drawn
+        position back through the sort; otherwise one batched multinomial over the dense distribution.  By default the
+        draws are made on the device (one batched multinomial per step, in sorted space under a nucleus: the same
+        distribution, the device generator's stream).  `host_draws=True` copies each step's logits to the host and makes
+        the reference's draws there, call for call, from torch's global CPU generator: under the same torch.manual_seed
+        the sampled tokens are then the reference's CPU path's, token for token (tests/golden/ark_sampling.npz)."""
         device = device or next(self.parameters()).device
         B = batch_size
+        bos, eos = special_tokens["BOS"], special_tokens["EOS"]
         eng = self.engine()
         d = eng.decode_begin(B)
-        seq = torch.full((B, 1), special_tokens["BOS"], dtype=torch.long, device=device)
+        seq = torch.full((B, 1), bos, dtype=torch.long, device=device)
         for t in range(seq_len - 1):
             logits = eng.decode_step(d, seq[:, -1].contiguous(), t)
             if not sample:
                 nxt = logits.argmax(dim=-1, keepdim=True)
             else:
-                nxt = torch.multinomial(self.filtered_probs(logits, temperature, top_p, top_k), 1)
+                probs, sp, si = self._filter(logits.cpu() if host_draws else logits, temperature, top_p, top_k)
+                if sp is None:
+                    nxt = torch.multinomial(probs, 1)
+                elif host_draws:
+                    nxt = torch.stack([si[b, torch.multinomial(sp[b], 1)] for b in range(B)])
+                else:
+                    nxt = si.gather(-1, torch.multinomial(sp, 1))
+                nxt = nxt.to(device)
             seq = torch.cat([seq, nxt], dim=1)
-            if bool((seq[:, -1] == special_tokens["EOS"]).all()):
+            if bool((seq[:, -1] == eos).all()):
                 break
         if seq.size(1) < seq_len:
-            fill = torch.full((B, seq_len - seq.size(1)), special_tokens["EOS"], dtype=torch.long, device=device)
+            fill = torch.full((B, seq_len - seq.size(1)), eos, dtype=torch.long, device=device)
             seq = torch.cat([seq, fill], dim=1)
         return seq[:, :seq_len]
 

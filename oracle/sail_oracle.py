@@ -22,9 +22,8 @@ Reference call sites restated (paths relative to the reference repo):
   greedy decode (beam=1) ................... kgvae/model/models.py:262-266, 282-300
   beam decode (batch-shared beam) .......... kgvae/model/models.py:282-300
   compression bits (AR + KL) ............... kgvae/model/models.py:202-260 (SAIL), 473-520 (ARK)
-  next-token sampling distribution ......... kgvae/model/models.py:431-456 (inline in ARK.generate: not
-                                             callable on its own, so this one restatement is pinned by its
-                                             own properties only -- see tests/test_oracle_golden.py)
+  ARK.generate (greedy / temperature / top-k / nucleus sampling, draw order) ... kgvae/model/models.py:407-471
+                                             (pinned by token sequences the reference sampled under fixed seeds)
   sequence codec ........................... kgvae/model/utils.py:70-78, 102-108
 """
 import math
@@ -268,28 +267,28 @@ def train_step(P, state, batch, cfg, lr, beta=1.0, eps=None, drop_masks=None):
 # decode + codec
 # --------------------------------------------------------------------------------------------
 @torch.no_grad()
-def greedy_decode(P, z, cfg):
+def greedy_decode(P, z, cfg, bos=BOS, eos=EOS):
     """token sequences of SAIL.decode_latent(z, beam=1): start at BOS, re-run the decoder on the
     whole prefix, take argmax of the last position, stop when every row ends in EOS
     (models.py:282-300 with beam=1; log_softmax is monotone so argmax(logits) == topk(1))."""
     B = z.shape[0]
-    s = torch.full((B, 1), BOS, dtype=torch.long)
+    s = torch.full((B, 1), bos, dtype=torch.long)
     for _ in range(cfg["seq_len"] - 1):
         nxt = decoder_forward(P, z, s, cfg)[:, -1].argmax(dim=-1, keepdim=True)
         s = torch.cat([s, nxt], dim=1)
-        if bool((s[:, -1] == EOS).all()):
+        if bool((s[:, -1] == eos).all()):
             break
     return s
 
 
 @torch.no_grad()
-def beam_decode(P, z, cfg, beam):
+def beam_decode(P, z, cfg, beam, bos=BOS, eos=EOS):
     """token sequences of SAIL.decode_latent(z, beam > 1), restated from models.py:282-300: ONE beam shared by the whole
     batch; every step re-runs the decoder on each beam's prefix, extends it by its `beam` best tokens per row, ranks
     the candidates by the MEAN over the batch of their accumulated log-probabilities (stable descending sort) and
     keeps the first `beam`; stops when every row of every kept beam ends in EOS; returns the best beam's sequences."""
     B = z.shape[0]
-    beams = [(torch.full((B, 1), BOS, dtype=torch.long), torch.zeros(B))]
+    beams = [(torch.full((B, 1), bos, dtype=torch.long), torch.zeros(B))]
     for _ in range(cfg["seq_len"] - 1):
         cand = []
         for s, lp in beams:
@@ -299,7 +298,7 @@ def beam_decode(P, z, cfg, beam):
                 cand.append((torch.cat([s, ids[:, k:k + 1]], 1), lp + top_lp[:, k]))
         cand.sort(key=lambda c: c[1].mean().item(), reverse=True)
         beams = cand[:beam]
-        if all(bool((s[:, -1] == EOS).all()) for s, _ in beams):
+        if all(bool((s[:, -1] == eos).all()) for s, _ in beams):
             break
     return beams[0][0]
 
@@ -326,11 +325,86 @@ def posterior_bits(P, triples, seq, eps, cfg):
     return ar, kl
 
 
+def next_token_filter(logits, temperature=1.0, top_p=0.0, top_k=0):
+    """the filtering half of ARK.generate(sample=True) (models.py:431-449) on a batch of last-position logits:
+    temperature, softmax, top-k mask + renormalise; with a nucleus: descending sort, every sorted position whose
+    PREDECESSOR's cumulative mass already exceeds top_p is zeroed (so the token that crosses top_p stays in), renormalise.
+    -> (probs, sorted_probs, sorted_idx); the last two are None without a nucleus.  Pinned through ark_generate by the
+    token sequences the reference sampled (tests/golden/ark_sampling.npz)."""
+    if temperature and temperature != 1.0:
+        logits = logits / float(temperature)
+    probs = F.softmax(logits, dim=-1)
+    if top_k and top_k > 0:
+        keep = probs.topk(top_k, dim=-1).indices
+        probs = probs * torch.zeros_like(probs).scatter_(-1, keep, 1.0)
+        probs = probs / probs.sum(dim=-1, keepdim=True).clamp_min(1e-12)
+    if not (top_p and 0.0 < top_p < 1.0):
+        return probs, None, None
+    sp, si = probs.sort(dim=-1, descending=True)
+    over = sp.cumsum(dim=-1) > top_p
+    cut = torch.zeros_like(over)
+    cut[..., 1:] = over[..., :-1]
+    sp = sp.masked_fill(cut, 0.0)
+    sp = sp / sp.sum(dim=-1, keepdim=True).clamp_min(1e-12)
+    return probs, sp, si
+
+
 @torch.no_grad()
 def sampling_distribution(logits, temperature=1.0, top_p=0.0, top_k=0):
-    """dense next-token probabilities of ARK.generate(sample=True) (models.py:431-456), row by row with explicit
-    loops: temperature, softmax, top-k mask + renormalise, nucleus over the descending sort (the token that crosses
-    top_p stays in) + renormalise."""
+    """dense next-token probabilities of ARK.generate(sample=True): next_token_filter scattered back to vocabulary order"""
+    probs, sp, si = next_token_filter(logits, temperature, top_p, top_k)
+    return probs if sp is None else torch.zeros_like(probs).scatter_(-1, si, sp)
+
+
+@torch.no_grad()
+def ark_generate(P, cfg, batch_size, sample=False, temperature=1.0, top_p=0.0, top_k=0, bos=BOS, eos=EOS):
+    """token sequences of ARK.generate (models.py:407-471): the decoder is re-run on the whole prefix, the next token is
+    the argmax or a draw from next_token_filter's distribution, generation stops once EVERY row's last token is EOS and
+    the result is padded with EOS to seq_len.  The draws consume torch's GLOBAL generator in the reference's pattern:
+    with a nucleus ONE torch.multinomial PER ROW over the sorted distribution (the drawn position is mapped back
+    through the sort), otherwise one batched torch.multinomial over the dense distribution."""
+    B, seq_len = batch_size, cfg["seq_len"]
+    s = torch.full((B, 1), bos, dtype=torch.long)
+    for _ in range(seq_len - 1):
+        logits = ark_forward(P, s, cfg)[:, -1]
+        if not sample:
+            nxt = logits.argmax(dim=-1, keepdim=True)
+        else:
+            probs, sp, si = next_token_filter(logits, temperature, top_p, top_k)
+            if sp is None:
+                nxt = torch.multinomial(probs, 1)
+            else:
+                nxt = torch.stack([si[b, torch.multinomial(sp[b], 1)] for b in range(B)])
+        s = torch.cat([s, nxt], dim=1)
+        if bool((s[:, -1] == eos).all()):
+            break
+    if s.shape[1] < seq_len:
+        s = torch.cat([s, torch.full((B, seq_len - s.shape[1]), eos, dtype=torch.long)], dim=1)
+    return s[:, :seq_len]
+
+
+@torch.no_grad()
+def ark_posterior_bits(P, seq, cfg):
+    """per-sequence AR bits of ARK.posterior_bits / bits_per_sequence (models.py:473-520): sum over target positions
+    t >= 1, up to the first PAD target, of -log2 softmax(dec(seq[:t])[-1])[seq[t]], one decoder run per prefix."""
+    ln2 = math.log(2)
+    out = []
+    for b in range(seq.shape[0]):
+        total = 0.0
+        for t in range(1, seq.shape[1]):
+            tgt = int(seq[b, t])
+            if tgt == PAD:
+                break
+            logits = ark_forward(P, seq[b:b + 1, :t], cfg)[:, -1]
+            total += -float(F.log_softmax(logits, dim=-1)[0, tgt]) / ln2
+        out.append(total)
+    return out
+
+
+@torch.no_grad()
+def sampling_distribution_loops(logits, temperature=1.0, top_p=0.0, top_k=0):
+    """the same distribution as sampling_distribution, written row by row with explicit Python loops (an independent
+    second statement of models.py:431-449 the vectorised one is cross-checked against)"""
     if temperature and temperature != 1.0:
         logits = logits / float(temperature)
     probs = F.softmax(logits, dim=-1)

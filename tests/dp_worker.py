@@ -12,7 +12,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def main(rank, world, port, out_path, graph, steps, bf16=False):
+def main(rank, world, port, out_path, graph, steps, bf16=False, variant="sail"):
     from oracle import sail_oracle as O
     from tests.parity_util import load_golden, synth_batch
     from ark_amd.engine import Engine
@@ -21,8 +21,10 @@ def main(rank, world, port, out_path, graph, steps, bf16=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    _, cfg = load_golden("sail_synpaths_b32_s0")
-    cfg = dict(cfg, dec_dropout=0.0, learning_rate=1e-3, ark_dp_bf16=bf16)
+    # variants: "sail" (pipelined two-bucket schedule), "nopipe" (ark_dp_pipeline: false), "ark" (decoder-only: one bucket)
+    _, cfg = load_golden("ark_synpaths_b32_s0" if variant == "ark" else "sail_synpaths_b32_s0")
+    cfg = dict(cfg, dec_dropout=0.0, learning_rate=1e-3, ark_dp_bf16=bf16, ark_dp_pipeline=(variant != "nopipe"))
+    sail = cfg["model_type"] == "SAIL"
     P = O.init_params(cfg, 0)
     B = 128
     eng = Engine(cfg, dev, precision="mixed", world_size=world, rank=rank)
@@ -36,9 +38,9 @@ def main(rank, world, port, out_path, graph, steps, bf16=False):
         torch.manual_seed(40 + s)
         eps = torch.randn(B, cfg["d_latent"])
         batches.append((tri, seq, eps, int((seq[:, 1:] != 0).sum())))
-    tri_in = batches[0][0][sl].contiguous().to(dev)
+    tri_in = batches[0][0][sl].contiguous().to(dev) if sail else None
     seq_in = batches[0][1][sl].contiguous().to(dev)
-    eps_in = batches[0][2][sl].contiguous().to(dev)
+    eps_in = batches[0][2][sl].contiguous().to(dev) if sail else None
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         eng._default_norms(Bl)
@@ -52,7 +54,9 @@ def main(rank, world, port, out_path, graph, steps, bf16=False):
             def step():
                 return eng.train_step(tri_in, seq_in, eps_in, ce_count=eng._hp["CE_COUNT"], dp=True)
         for (tri, seq, eps, cnt) in batches:
-            tri_in.copy_(tri[sl].to(dev)); seq_in.copy_(seq[sl].to(dev)); eps_in.copy_(eps[sl].to(dev))
+            seq_in.copy_(seq[sl].to(dev))
+            if sail:
+                tri_in.copy_(tri[sl].to(dev)); eps_in.copy_(eps[sl].to(dev))
             eng.set_hyper(ce_count=cnt)
             step()
         eng.dp_flush()
@@ -68,4 +72,4 @@ def main(rank, world, port, out_path, graph, steps, bf16=False):
 
 if __name__ == "__main__":
     main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5] == "1", int(sys.argv[6]),
-         len(sys.argv) > 7 and sys.argv[7] == "1")
+         len(sys.argv) > 7 and sys.argv[7] == "1", sys.argv[8] if len(sys.argv) > 8 else "sail")

@@ -21,8 +21,8 @@ def _cfg(D, Z, nE, nR, T, padded, n_layers=3):
 
 SHAPES = {
     # name: (cfg, batch)            reference YAML                     what it exercises
-    "syn-types": (_cfg(1024, 24, 30, 3, 3, False), 32),          # configs/autoreg_syn-types.yaml: D=1024 tiles, Z=24
-    "wd-movies": (_cfg(128, 64, 24093, 3, 23, True), 32),         # autoreg_wd-movies.yaml: V=24101, padding, L=70
+    "syn-types": (_cfg(1024, 24, 30, 3, 3, False), 256),         # configs/autoreg_syn-types.yaml: D=1024 tiles, Z=24, B=256
+    "wd-movies": (_cfg(128, 64, 24093, 3, 23, True), 256),        # autoreg_wd-movies.yaml: V=24101, padding, L=70, B=256
     "wd-articles": (_cfg(512, 128, 60932, 6, 40, True), 16),      # autoreg_wd-articles.yaml: V=60943, B=16 (T cut to 40)
     # the same at the dataset's REAL length: T = 212 padded triples, L = 637 decoder steps, [B*L, V] = 10 192 x 60 943
     "wd-articles-full": (_cfg(512, 128, 60932, 6, 212, True), 16),

@@ -23,8 +23,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("graph,bf16", [(False, False), (True, False), (True, True)])
-def test_two_process_data_parallel_matches_single_process(tmp_path, graph, bf16):
+@pytest.mark.parametrize("graph,bf16,variant", [(False, False, "sail"), (True, False, "sail"), (True, True, "sail"),
+                                                (False, False, "nopipe"), (True, False, "nopipe"),
+                                                (False, False, "ark"), (True, False, "ark")])
+def test_two_process_data_parallel_matches_single_process(tmp_path, graph, bf16, variant):
+    """variants: the pipelined two-bucket SAIL schedule; the same with `ark_dp_pipeline: false` and decoder-only ARK (one
+    bucket) -- both take the UNPIPELINED tail of Engine.train_step (wait, unpack, Adam), eager and captured"""
     from oracle import sail_oracle as O
     from ark_amd.engine import Engine
     steps, B = 3, 128
@@ -32,7 +36,8 @@ def test_two_process_data_parallel_matches_single_process(tmp_path, graph, bf16)
     port = _free_port()
     env = dict(os.environ, PYTHONPATH=ROOT)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), "2", str(port), out,
-                               "1" if graph else "0", str(steps), "1" if bf16 else "0"], env=env, cwd=ROOT) for r in range(2)]
+                               "1" if graph else "0", str(steps), "1" if bf16 else "0", variant], env=env, cwd=ROOT)
+             for r in range(2)]
     try:
         rcs = [p.wait(timeout=420) for p in procs]
     finally:
@@ -45,8 +50,9 @@ def test_two_process_data_parallel_matches_single_process(tmp_path, graph, bf16)
     assert res["adam_steps"] == steps
     assert torch.equal(P0, P1)          # identical Adam on identical reduced gradients
     # single process, full batch
-    _, cfg = load_golden("sail_synpaths_b32_s0")
+    _, cfg = load_golden("ark_synpaths_b32_s0" if variant == "ark" else "sail_synpaths_b32_s0")
     cfg = dict(cfg, dec_dropout=0.0, learning_rate=1e-3)
+    sail = cfg["model_type"] == "SAIL"
     eng = Engine(cfg, "cuda:0", precision="mixed")
     eng.load_params(O.init_params(cfg, 0))
     eng.set_hyper(lr=1e-3, beta=0.5)
@@ -55,7 +61,8 @@ def test_two_process_data_parallel_matches_single_process(tmp_path, graph, bf16)
         tri, seq = synth_batch(cfg, B, seed=20 + s)
         torch.manual_seed(40 + s)
         eps = torch.randn(B, cfg["d_latent"])
-        eng.train_step(tri.to(dev), seq.to(dev), eps.to(dev), ce_count=int((seq[:, 1:] != 0).sum()))
+        eng.train_step(tri.to(dev) if sail else None, seq.to(dev), eps.to(dev) if sail else None,
+                       ce_count=int((seq[:, 1:] != 0).sum()))
     torch.cuda.synchronize()
     ref = eng.P.detach().cpu()
     moved = (ref - O_flat(eng, O.init_params(cfg, 0))).abs().max().item()
@@ -108,6 +115,10 @@ def test_train_entry_point_two_ranks_start_and_stay_equal(tmp_path):
     P1 = torch.load(str(tmp_path / "P.rank1.pt"), weights_only=True)
     assert torch.equal(P0, P1)
     assert torch.isfinite(P0).all()
+    # ... while every rank draws its OWN latent noise (the device generator is reseeded per (seed, epoch, rank))
+    e0 = torch.load(str(tmp_path / "P.eps.rank0.pt"), weights_only=True)
+    e1 = torch.load(str(tmp_path / "P.eps.rank1.pt"), weights_only=True)
+    assert e0.shape == e1.shape and not torch.equal(e0, e1) and float(e0.std()) > 0.5
 
 
 def test_bench_launches_its_own_ranks(tmp_path):

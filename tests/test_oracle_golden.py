@@ -211,3 +211,83 @@ def test_beam_decode_matches_reference_goldens(name, beam):
     for i in range(seqs.shape[0]):
         got = O.seq_to_triples(seqs[i].tolist(), cfg["ENT_BASE"], cfg["REL_BASE"])
         assert [list(t) for t in got] == want[i, :int(n[i])].tolist(), (i, got)
+
+
+def _npz(name):
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name), allow_pickle=False)
+
+
+def _case_cfg(g, name):
+    import json
+    return json.loads(str(g[f"{name}/cfg_json"]))
+
+
+@pytest.mark.parametrize("name,beams", [("synpaths_d512", (1, 2, 4)), ("wdmovies_pad", (1, 2))])
+def test_decode_at_baseline_sizes_from_seed_weights(name, beams):
+    """greedy and beam decode at BASELINE sizes (D = 512 syn-paths; padded V = 24 101 / T = 23 wd-movies shape) against the
+    REAL reference's decode_latent on seed-initialised weights (tests/golden/decode_init.npz, tools/make_golden_r3.py)"""
+    g = _npz("decode_init.npz")
+    cfg = _case_cfg(g, name)
+    torch.set_num_threads(8)
+    P = O.init_params(cfg, int(g[f"{name}/seed"]))
+    zs = torch.from_numpy(g[f"{name}/z"])
+    toks = O.greedy_decode(P, zs, cfg)
+    assert np.array_equal(toks.numpy(), g[f"{name}/greedy_tokens"])
+    for b in beams:
+        seqs = toks if b == 1 else O.beam_decode(P, zs, cfg, b)
+        want, n = g[f"{name}/beam{b}/triples"], g[f"{name}/beam{b}/n"]
+        for i in range(seqs.shape[0]):
+            got = O.seq_to_triples(seqs[i].tolist(), cfg["ENT_BASE"], cfg["REL_BASE"])
+            assert [list(t) for t in got] == want[i, :int(n[i])].tolist(), (b, i)
+
+
+@pytest.mark.parametrize("name", ["ark_tiny", "ark_synpaths"])
+def test_ark_generate_reproduces_the_reference_samples(name):
+    """ARK.generate's filtering AND draw order (models.py:407-471), token for token: the oracle under the seeds the
+    golden script used against the sequences the REAL reference sampled (tests/golden/ark_sampling.npz)"""
+    g = _npz("ark_sampling.npz")
+    cfg = _case_cfg(g, name)
+    P = O.init_params(cfg, int(g[f"{name}/seed"]))
+    B = g[f"{name}/greedy"].shape[0]
+    assert np.array_equal(O.ark_generate(P, cfg, B).numpy(), g[f"{name}/greedy"])
+    for i, (temp, top_p, top_k) in enumerate(g[f"{name}/combos"]):
+        torch.manual_seed(500 + i)
+        got = O.ark_generate(P, cfg, B, sample=True, temperature=float(temp), top_p=float(top_p), top_k=int(top_k))
+        assert np.array_equal(got.numpy(), g[f"{name}/seq{i}"]), (name, i, temp, top_p, top_k)
+
+
+def test_sampling_distribution_two_statements_agree():
+    """the vectorised filter that ark_generate draws from (pinned by the reference's samples above) against the
+    loop-by-loop second statement of the same rules"""
+    torch.manual_seed(1)
+    logits = torch.randn(7, 31) * 2.5
+    for temp, top_p, top_k in [(1.0, 0.0, 0), (0.6, 0.0, 0), (1.0, 0.85, 0), (1.0, 0.0, 6), (0.9, 0.7, 9), (1.4, 0.4, 0)]:
+        a = O.sampling_distribution(logits, temp, top_p, top_k)
+        b = O.sampling_distribution_loops(logits, temp, top_p, top_k)
+        assert torch.allclose(a, b, atol=1e-6), (temp, top_p, top_k)
+
+
+@pytest.mark.parametrize("name", ["sail_small", "sail_pad"])
+def test_sail_posterior_bits_match_the_reference_records(name):
+    """the oracle's restatement of SAIL.posterior_bits / bits_per_sequence against the per-item records the REAL
+    reference produced (models.py:202-260), fed the latent noise the reference drew (tests/golden/posterior_bits.npz)"""
+    g = _npz("posterior_bits.npz")
+    cfg = _case_cfg(g, name)
+    P = O.init_params(cfg, int(g[f"{name}/seed"]))
+    n = len(g[f"{name}/ar_bits"])
+    tri, seq = torch.from_numpy(g[f"{name}/triples"])[:n], torch.from_numpy(g[f"{name}/seq"])[:n]
+    ar, kl = O.posterior_bits(P, tri, seq, torch.from_numpy(g[f"{name}/eps"]), cfg)
+    np.testing.assert_allclose(ar, g[f"{name}/ar_bits"], rtol=2e-5)
+    np.testing.assert_allclose(kl, g[f"{name}/kl_bits"], rtol=1e-4, atol=1e-7)
+    tot = np.array(ar) + np.array(kl)
+    np.testing.assert_allclose([tot.mean(), np.mean(ar), np.mean(kl), tot.min(), tot.max()], g[f"{name}/summary"], rtol=2e-5)
+
+
+def test_ark_posterior_bits_match_the_reference_records():
+    g = _npz("posterior_bits.npz")
+    cfg = _case_cfg(g, "ark_tiny")
+    P = O.init_params(cfg, int(g["ark_tiny/seed"]))
+    n = len(g["ark_tiny/ar_bits"])
+    ar = O.ark_posterior_bits(P, torch.from_numpy(g["ark_tiny/seq"])[:n], cfg)
+    np.testing.assert_allclose(ar, g["ark_tiny/ar_bits"], rtol=2e-5)
+    assert np.all(g["ark_tiny/kl_bits"] == 0)

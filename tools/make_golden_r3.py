@@ -1,0 +1,158 @@
+"""Round-3 golden fixtures from the REAL reference (build container only; same import recipe as make_golden.py):
+
+  tests/golden/decode_init.npz     greedy / beam decode_latent outputs at BASELINE sizes (D = 512 syn-paths; a padded
+                                   wd-movies-shaped vocabulary, V = 24 101, T = 23) from SEED-INITIALISED weights, which
+                                   the GPU box regenerates bit for bit (oracle.init_params), plus the smallest top-2 logit
+                                   margin met on the greedy path (how far the argmax is from a tie)
+  tests/golden/ark_sampling.npz    token sequences of the reference's ARK.generate(sample=True, temperature, top_p,
+                                   top_k) under fixed torch seeds (models.py:407-471)
+  tests/golden/posterior_bits.npz  per-item records of the reference's own SAIL.posterior_bits / ARK.posterior_bits
+                                   (models.py:202-260, 473-520) with the latent noise they drew
+
+    python tools/make_golden_r3.py
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from tools.make_golden import OUT, REF, import_reference, make_batch, make_cfg
+
+
+def quiet_model(cls, cfg):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return cls(dict(cfg))
+
+
+def triples_array(trip):
+    L = max([len(t) for t in trip] + [1])
+    arr = -np.ones((len(trip), L, 3), dtype=np.int64)
+    for i, tl in enumerate(trip):
+        for j, t3 in enumerate(tl):
+            arr[i, j] = t3
+    return arr, np.array([len(t) for t in trip])
+
+
+def decode_case(M, U, out, name, D, Z, n, nE, nR, T, padded, seed, beams, nz=8):
+    cfg = make_cfg("SAIL", D, Z, n, nE, nR, T, padded)
+    torch.manual_seed(seed)
+    model = quiet_model(M.SAIL, cfg)
+    model.eval()
+    zs = torch.randn(nz, Z, generator=torch.Generator().manual_seed(seed + 7))
+    out[f"{name}/cfg_json"] = np.array(json.dumps(cfg))
+    out[f"{name}/seed"] = np.array(seed)
+    out[f"{name}/z"] = zs.numpy()
+    st = cfg["special_tokens"]
+    for b in beams:
+        with torch.no_grad():
+            trip = model.decode_latent(zs, cfg["seq_len"], st, U.seq_to_triples, cfg["ENT_BASE"], cfg["REL_BASE"], beam=b)
+        arr, cnt = triples_array(trip)
+        out[f"{name}/beam{b}/triples"], out[f"{name}/beam{b}/n"] = arr, cnt
+        print(name, "beam", b, cnt.tolist())
+    # the greedy path once more, token by token, for the raw token sequences and the top-2 margin of every argmax
+    with torch.no_grad():
+        s = torch.full((nz, 1), st["BOS"], dtype=torch.long)
+        margin = []
+        for _ in range(cfg["seq_len"] - 1):
+            logits = model.dec(zs, s)[:, -1]
+            top2 = logits.topk(2, dim=-1).values
+            margin.append((top2[:, 0] - top2[:, 1]).numpy())
+            s = torch.cat([s, logits.argmax(dim=-1, keepdim=True)], 1)
+            if bool((s[:, -1] == st["EOS"]).all()):
+                break
+    want = [U.seq_to_triples(row, st, cfg["ENT_BASE"], cfg["REL_BASE"]) for row in s]
+    got = [[tuple(int(v) for v in t3) for t3 in out[f"{name}/beam1/triples"][i][:out[f"{name}/beam1/n"][i]]] for i in range(nz)]
+    assert want == got, "token-by-token greedy replay differs from decode_latent(beam=1)"
+    out[f"{name}/greedy_tokens"] = s.numpy()
+    out[f"{name}/greedy_margin"] = np.stack(margin, 1)   # [nz, steps]
+    print(name, "greedy steps", s.shape[1] - 1, "min top-2 margin", float(np.min(out[f"{name}/greedy_margin"])))
+
+
+SAMPLING = [(1.0, 0.0, 0), (0.7, 0.0, 0), (1.0, 0.9, 0), (1.0, 0.0, 5), (0.8, 0.9, 10), (1.3, 0.5, 0), (1.0, 0.3, 3)]
+
+
+def sampling_case(M, out, name, D, n, nE, nR, T, seed, B):
+    cfg = make_cfg("ARK", D, 4, n, nE, nR, T, False)
+    torch.manual_seed(seed)
+    model = quiet_model(M.ARK, cfg)
+    model.eval()
+    out[f"{name}/cfg_json"] = np.array(json.dumps(cfg))
+    out[f"{name}/seed"] = np.array(seed)
+    out[f"{name}/combos"] = np.array(SAMPLING, dtype=np.float64)
+    for i, (temp, top_p, top_k) in enumerate(SAMPLING):
+        torch.manual_seed(500 + i)
+        seq = model.generate(cfg["seq_len"], cfg["special_tokens"], device="cpu", batch_size=B, sample=True,
+                             temperature=temp, top_p=top_p, top_k=int(top_k))
+        out[f"{name}/seq{i}"] = seq.numpy()
+        print(name, (temp, top_p, top_k), seq[0].tolist())
+    seq = model.generate(cfg["seq_len"], cfg["special_tokens"], device="cpu", batch_size=B, sample=False)
+    out[f"{name}/greedy"] = seq.numpy()
+
+
+def dataset_of(U, cfg, B, seed, padded):
+    triples, seq, graphs = make_batch(U, cfg, B, seed, padded)
+    ds = U.GraphSeqDataset(graphs, None, None, triple_order="keep", permute=False, use_padding=padded,
+                           pad_eid=cfg["pad_eid"], pad_rid=cfg["pad_rid"], max_triples=cfg["max_triples"],
+                           special_tokens=cfg["special_tokens"], ent_base=cfg["ENT_BASE"], rel_base=cfg["REL_BASE"],
+                           seq_len=cfg["seq_len"])
+    return ds, triples, seq
+
+
+def bits_case(M, U, out, name, model_type, D, Z, n, nE, nR, T, padded, seed, N, frac):
+    cfg = make_cfg(model_type, D, Z, n, nE, nR, T, padded)
+    torch.manual_seed(seed)
+    model = quiet_model(M.SAIL if model_type == "SAIL" else M.ARK, cfg)
+    model.eval()
+    ds, triples, seq = dataset_of(U, cfg, N, seed + 100, padded)
+    torch.manual_seed(900 + seed)
+    with contextlib.redirect_stderr(io.StringIO()):
+        stats = model.posterior_bits(ds, "cpu", pad_id=0, sample_frac=frac)
+    n_items = len(stats["records"])
+    out[f"{name}/cfg_json"] = np.array(json.dumps(cfg))
+    out[f"{name}/seed"] = np.array(seed)
+    out[f"{name}/triples"], out[f"{name}/seq"] = triples.numpy(), seq.numpy()
+    out[f"{name}/frac"] = np.array(frac)
+    out[f"{name}/ar_bits"] = np.array([r["ar_bits"] for r in stats["records"]])
+    out[f"{name}/kl_bits"] = np.array([r["kl_bits"] for r in stats["records"]])
+    out[f"{name}/summary"] = np.array([stats[k] for k in ("avg_total_bits", "avg_ar_bits", "avg_kl_bits", "min_total_bits",
+                                                          "max_total_bits")])
+    if model_type == "SAIL":
+        # the noise those calls drew: the DataLoader iterator takes ONE int64 from the global generator when it is created
+        # (torch/utils/data/dataloader.py, _BaseDataLoaderIter: base seed), then every item's encoder draws randn_like(mu)
+        torch.manual_seed(900 + seed)
+        torch.empty((), dtype=torch.int64).random_()
+        out[f"{name}/eps"] = torch.cat([torch.randn(1, Z) for _ in range(n_items)]).numpy()
+    print(name, n_items, "items", out[f"{name}/summary"].tolist())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    M, U = import_reference()
+    out = {}
+    decode_case(M, U, out, "synpaths_d512", D=512, Z=10, n=3, nE=49, nR=3, T=3, padded=False, seed=0, beams=(1, 2, 4))
+    decode_case(M, U, out, "wdmovies_pad", D=128, Z=64, n=3, nE=24093, nR=3, T=23, padded=True, seed=0, beams=(1, 2))
+    np.savez_compressed(os.path.join(OUT, "decode_init.npz"), **out)
+    out = {}
+    sampling_case(M, out, "ark_tiny", D=32, n=3, nE=20, nR=3, T=3, seed=2, B=6)
+    sampling_case(M, out, "ark_synpaths", D=512, n=3, nE=49, nR=3, T=3, seed=0, B=4)
+    np.savez_compressed(os.path.join(OUT, "ark_sampling.npz"), **out)
+    out = {}
+    bits_case(M, U, out, "sail_small", "SAIL", D=64, Z=10, n=3, nE=49, nR=3, T=3, padded=False, seed=3, N=12, frac=1.0)
+    bits_case(M, U, out, "sail_pad", "SAIL", D=32, Z=8, n=2, nE=70, nR=5, T=7, padded=True, seed=4, N=20, frac=0.5)
+    bits_case(M, U, out, "ark_tiny", "ARK", D=32, Z=4, n=3, nE=20, nR=3, T=3, padded=False, seed=2, N=10, frac=1.0)
+    np.savez_compressed(os.path.join(OUT, "posterior_bits.npz"), **out)
+    assert not any(d == "__pycache__" for _, ds, _ in os.walk(REF) for d in ds), "bytecode leaked into reference"
+
+
+if __name__ == "__main__":
+    main()
