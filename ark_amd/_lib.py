@@ -100,7 +100,7 @@ class GruDiagBwdRole(ctypes.Structure):
 class DiagTuning(ctypes.Structure):
     """ArkDiagTuning of include/ark_amd.h (speed-only tile / ring choices, passed per call)"""
     _fields_ = [(k, ctypes.c_int) for k in ("fwd_rows", "fwd_ki", "fwd_nbuf", "fwd_xcd", "fwd_units", "bwd_rows", "bwd_ki",
-                                            "bwd_nbuf", "bwd_xcd_rows", "fwd_waves", "bwd_cols")]
+                                            "bwd_nbuf", "bwd_xcd_rows", "bwd_cols")]
 
 
 class WgradTuning(ctypes.Structure):

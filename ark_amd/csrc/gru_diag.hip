@@ -17,9 +17,52 @@
 #include "dma_core.h"
 #include "../../include/ark_amd.h"
 
+// cache policy of the forward operands' LDS-DMA loads (experiment switches)
+#ifndef ARK_FWD_AUXA
+#define ARK_FWD_AUXA 0
+#endif
+#ifndef ARK_FWD_AUXB
+#define ARK_FWD_AUXB 0
+#endif
+
 namespace ark {
 
 typedef _Float16 dhalf4_t __attribute__((ext_vector_type(4)));
+
+// epilogue stores / loads of once-touched state: nontemporal in the ARK_FWD_NT_ST experiment build
+#ifdef ARK_FWD_NT_ST
+template <class T> __device__ __forceinline__ void st_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
+template <class T> __device__ __forceinline__ T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
+#else
+template <class T> __device__ __forceinline__ void st_stream(T* p, T v) { *p = v; }
+template <class T> __device__ __forceinline__ T ld_stream(const T* p) { return *p; }
+#endif
+
+// Diagnostic build only (-DARK_STAMPS, tools/stamp_probe.py): shader-clock stamps per workgroup -- kernel entry, main loop
+// start / end, epilogue math end, kernel end -- into a buffer of their own; the shipped library contains none of this.
+#ifdef ARK_STAMPS
+__device__ unsigned long long ark_stamp_buf[8192 * 8];
+#define ARK_STAMP(i)                                                                       \
+  do {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    if (threadIdx.x == 0) stamp_[i] = __builtin_amdgcn_s_memtime();                        \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  } while (0)
+#define ARK_STAMP_DECL unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime()
+#define ARK_STAMP_FLUSH()                                                                  \
+  do {                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {                                           \
+      stamp_[5] = rt0_; stamp_[6] = __builtin_amdgcn_s_memrealtime();                      \
+      unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));     \
+      stamp_[7] = xcc & 15;                                                                \
+      for (int i_ = 0; i_ < 8; ++i_) ark_stamp_buf[blockIdx.x * 8 + i_] = stamp_[i_];      \
+    }                                                                                      \
+  } while (0)
+#else
+#define ARK_STAMP(i) do {} while (0)
+#define ARK_STAMP_DECL do {} while (0)
+#define ARK_STAMP_FLUSH() do {} while (0)
+#endif
 
 struct GruDiagArgs {
   ArkGruDiagRole role[ARK_DIAG_MAX_ROLES];
@@ -28,7 +71,9 @@ struct GruDiagArgs {
 };
 
 // BM rows x BU hidden units (x 3 gates) per workgroup, WGM x (BU/16) waves; wave tile (BM/WGM) x 48 = 16 units x 3 gates.
-template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU, int WGM = 2>
+// MODE: 0 = two-barrier ring (small tiles, several workgroups per CU), 2 = ping-pong halves (ONE 8-wave workgroup per CU;
+// dma_core.h run_pp); 1 = single-barrier ring (run_segs<.., true>: measured, no instantiation shipped)
+template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU, int WGM = 2, int MODE = 0>
 __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruDiagArgs p) {
   constexpr int BN = 3 * BU, WGN = BU / 16, NTHR = 64 * WGM * WGN;
   using G = DmaTile<PREC, BM, BN, NBUF, WGM, WGN, KI>;
@@ -38,6 +83,8 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
   using h8 = typename G::h8;
   using hb_t = typename PrecTraits<PRECB>::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  ARK_STAMP_DECL;
+  ARK_STAMP(0);
   const int B = p.B, D = p.D;
   const int UT = D / BU, MT = (B + BM - 1) / BM;
   int role, mt, ut;
@@ -65,7 +112,7 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
   const int u = u0 + ul;
   // epilogue operands first: older than every LDS-DMA op in the vmcnt queue -> they land underneath the
   // products.  (Tall tiles keep only the addresses: 4 x 16 rows of prefetched state would spill.)
-  constexpr bool PRE = TM <= 2;
+  constexpr bool PRE = TM <= 2 || MODE != 0;   // (the 8-wave lone workgroup has 256 registers per lane)
   int rl[TM];
   long o[TM];
   f32x4 hp[PRE ? TM : 1];
@@ -77,7 +124,7 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
     rl[tm] = wm * G::WTM + tm * 16 + 4 * (lane >> 4);
     const int rowc = min(m0 + rl[tm], B - 4);   // B % 16 == 0: clamped quads stay in bounds
     o[tm] = tile_native_off(rowc, u, D);
-    if constexpr (PRE) hp[tm] = *reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]);
+    if constexpr (PRE) hp[tm] = ld_stream(reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]));
   }
   const float br = R.b_ih[u] + R.b_hh[u], bz = R.b_ih[D + u] + R.b_hh[D + u];
   const float bin = R.b_ih[2 * D + u], bhn = R.b_hh[2 * D + u];
@@ -91,18 +138,21 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
   typename G::template Segs<2> sg{{reinterpret_cast<const h_t*>(R.x16), reinterpret_cast<const h_t*>(R.h_prev16)},
                                   {reinterpret_cast<const h_t*>(R.w_ih16), reinterpret_cast<const h_t*>(R.w_hh16)},
                                   {D, D}};
-  G::template run_segs<2>(
-      sg, (long)D, (long)D, [=](int r) -> long { return (long)min(m0 + r, B - 1); },
-      [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); }, smem,
-      [&](auto seg, const h8 (&a)[TM], const h8 (&b)[TN]) {
-        constexpr int NCOL = decltype(seg)::value == 0 ? TN - 1 : TN;   // accumulator of the candidate-gate block
+  auto rma = [=](int r) -> long { return (long)min(m0 + r, B - 1); };
+  auto rmb = [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); };
+  auto mm = [&](auto seg, const h8 (&a)[TM], const h8 (&b)[TN]) {
+    constexpr int NCOL = decltype(seg)::value == 0 ? TN - 1 : TN;   // accumulator of the candidate-gate block
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          acc[tm][0] = G::PT::mfma(a[tm], b[0], acc[tm][0]);
-          acc[tm][1] = G::PT::mfma(a[tm], b[1], acc[tm][1]);
-          acc[tm][NCOL] = G::PT::mfma(a[tm], b[2], acc[tm][NCOL]);
-        }
-      });
+    for (int tm = 0; tm < TM; ++tm) {
+      acc[tm][0] = G::PT::mfma(a[tm], b[0], acc[tm][0]);
+      acc[tm][1] = G::PT::mfma(a[tm], b[1], acc[tm][1]);
+      acc[tm][NCOL] = G::PT::mfma(a[tm], b[2], acc[tm][NCOL]);
+    }
+  };
+  ARK_STAMP(1);
+  if constexpr (MODE == 2) G::template run_pp<2>(sg, (long)D, (long)D, rma, rmb, smem, mm);
+  else G::template run_segs<2, MODE == 1, ARK_FWD_AUXA, ARK_FWD_AUXB>(sg, (long)D, (long)D, rma, rmb, smem, mm);
+  ARK_STAMP(2);
 
   __syncthreads();   // ring is free: reuse it to assemble row-major 16-bit rows [BM][BU+pad]
   constexpr int TS = BU + 8;   // row stride in elements: 16-B aligned rows, spreads banks
@@ -120,7 +170,7 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
     if (m0 + rl[tm] >= B) continue;
     f32x4 hpv;
     if constexpr (PRE) hpv = hp[tm];
-    else hpv = *reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]);
+    else hpv = ld_stream(reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]));
     f32x4 r, z, n, hn, h;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -130,12 +180,12 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
       n[i] = fast_tanh(acc[tm][2][i] + bin + r[i] * hn[i]);
       h[i] = n[i] + z[i] * (hpv[i] - n[i]);   // (1-z) n + z h_prev
     }
-    *reinterpret_cast<f32x4*>(R.y_out_t + o[tm]) = h;
+    st_stream(reinterpret_cast<f32x4*>(R.y_out_t + o[tm]), h);
     if (sr) {
-      *reinterpret_cast<dhalf4_t*>(sr + o[tm]) = dhalf4_t{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
-      *reinterpret_cast<dhalf4_t*>(sz + o[tm]) = dhalf4_t{(_Float16)z[0], (_Float16)z[1], (_Float16)z[2], (_Float16)z[3]};
-      *reinterpret_cast<dhalf4_t*>(sn + o[tm]) = dhalf4_t{(_Float16)n[0], (_Float16)n[1], (_Float16)n[2], (_Float16)n[3]};
-      *reinterpret_cast<dhalf4_t*>(shn + o[tm]) = dhalf4_t{(_Float16)hn[0], (_Float16)hn[1], (_Float16)hn[2], (_Float16)hn[3]};
+      st_stream(reinterpret_cast<dhalf4_t*>(sr + o[tm]), dhalf4_t{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]});
+      st_stream(reinterpret_cast<dhalf4_t*>(sz + o[tm]), dhalf4_t{(_Float16)z[0], (_Float16)z[1], (_Float16)z[2], (_Float16)z[3]});
+      st_stream(reinterpret_cast<dhalf4_t*>(sn + o[tm]), dhalf4_t{(_Float16)n[0], (_Float16)n[1], (_Float16)n[2], (_Float16)n[3]});
+      st_stream(reinterpret_cast<dhalf4_t*>(shn + o[tm]), dhalf4_t{(_Float16)hn[0], (_Float16)hn[1], (_Float16)hn[2], (_Float16)hn[3]});
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -152,6 +202,7 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
     }
   }
   __syncthreads();
+  ARK_STAMP(3);
   // BM rows x (2*BU) B per array: thread t -> row t / CPR, 16-byte chunk t % CPR, NTHR / CPR rows per pass
   const int t = threadIdx.x;
   constexpr int CPR = BU / 8, RPP = NTHR / CPR;
@@ -161,23 +212,29 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
     const int row = m0 + rr;
     if (rr < BM && row < B) {
       const long go = (long)row * D + u0 + ch * 8;
-      *reinterpret_cast<uint4*>(reinterpret_cast<h_t*>(R.y16a) + go) = *reinterpret_cast<const uint4*>(ta + rr * TS + ch * 8);
-      if (R.y16b) *reinterpret_cast<uint4*>(reinterpret_cast<hb_t*>(R.y16b) + go) = *reinterpret_cast<const uint4*>(tb + rr * TS + ch * 8);
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      st_stream(reinterpret_cast<u32x4*>(reinterpret_cast<h_t*>(R.y16a) + go), *reinterpret_cast<const u32x4*>(ta + rr * TS + ch * 8));
+      if (R.y16b) st_stream(reinterpret_cast<u32x4*>(reinterpret_cast<hb_t*>(R.y16b) + go), *reinterpret_cast<const u32x4*>(tb + rr * TS + ch * 8));
       if (drop) {
-        *reinterpret_cast<uint4*>(reinterpret_cast<h_t*>(R.yd16a) + go) = *reinterpret_cast<const uint4*>(tda + rr * TS + ch * 8);
-        if (R.yd16b) *reinterpret_cast<uint4*>(reinterpret_cast<hb_t*>(R.yd16b) + go) = *reinterpret_cast<const uint4*>(tdb + rr * TS + ch * 8);
+        st_stream(reinterpret_cast<u32x4*>(reinterpret_cast<h_t*>(R.yd16a) + go), *reinterpret_cast<const u32x4*>(tda + rr * TS + ch * 8));
+        if (R.yd16b) st_stream(reinterpret_cast<u32x4*>(reinterpret_cast<hb_t*>(R.yd16b) + go), *reinterpret_cast<const u32x4*>(tdb + rr * TS + ch * 8));
       }
     }
   }
+#ifdef ARK_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (diagnostic build: the stores have left the wave)
+#endif
+  ARK_STAMP(4);
+  ARK_STAMP_FLUSH();
 }
 
-template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU, int WGM = 2>
+template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU, int WGM = 2, int MODE = 0>
 static void launch_diag(const GruDiagArgs& p, hipStream_t st) {
   using G = DmaTile<PREC, BM, 3 * BU, NBUF, WGM, BU / 16, KI>;
   constexpr int MINL = 4 * BM * (BU + 8) * 2;
   constexpr int LDS = G::LDS_BYTES > MINL ? G::LDS_BYTES : MINL;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = gru_diag_fwd_kernel<PREC, PRECB, NBUF, KI, BM, BU, WGM>;
+  auto kern = gru_diag_fwd_kernel<PREC, PRECB, NBUF, KI, BM, BU, WGM, MODE>;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
   (void)once;
   const unsigned grid = (unsigned)(p.n_roles * ((p.B + BM - 1) / BM) * (p.D / BU));
@@ -205,12 +262,13 @@ static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t 
   //  wd-articles B=16 -- 5.9 -> 6.2 us forward, 9.9 -> 13.6 us backward per launch)
   const bool deep = false;
   p.xcd_map = (tn.fwd_xcd && UT % 4 == 0 && MT % 2 == 0) ? 1 : 0;
-  if (units == 64) {   // 8 waves (16 for the 128-row tile on request: wave tile 32 x 48 as in the default kernel)
-    // (measured, syn-paths B=1024: 23.6 us per launch against 18.7 for the default 64 x 32 tiles although a CU streams a
-    //  third fewer bytes -- and the same with four ring slots: ONE workgroup per CU runs its LDS-DMA issue, fragment-read
-    //  and MFMA phases one after the other behind its barriers, three small workgroups overlap them)
-    if (rows == 128 && tn.fwd_waves == 16) launch_diag<PREC, PRECB, 2, 1, 128, 64, 4>(p, st);
-    else if (rows == 128) launch_diag<PREC, PRECB, 2, 1, 128, 64>(p, st);
+  if (units == 64) {   // 8 waves
+    // 128 x 64 on 8 waves, ONE workgroup per CU: single-barrier ring, 3 or 4 slots of 40 KB (fwd_nbuf), refill before consume
+    // 128 x 64 on 8 waves, ONE workgroup per CU, ping-pong halves over a 4-slot ring (dma_core.h run_pp).  Measured on
+    // MI355X (syn-paths B = 1024, per launch): 21.8 us against 19.1-19.6 for the default three 64 x 32 workgroups per CU;
+    // the same tile on a single-barrier ring 22.8, on the two-barrier ring 24.6 -- kept selectable as the reference point
+    // of DESIGN.md section 6, not a default.
+    if (rows == 128) launch_diag<PREC, PRECB, 4, 1, 128, 64, 2, 2>(p, st);
     else if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 64>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 64, 64>(p, st);
   } else if (units == 16) {   // 2 waves
@@ -235,7 +293,7 @@ static bool diag_tuning_ok(const ArkDiagTuning& t) {
          (t.fwd_nbuf == 2 || t.fwd_nbuf == 4) && (t.fwd_units == 0 || t.fwd_units == 16 || t.fwd_units == 32 || t.fwd_units == 64) &&
          (t.bwd_rows == 32 || t.bwd_rows == 64) && (t.bwd_ki == 1 || t.bwd_ki == 2) && (t.bwd_nbuf == 2 || t.bwd_nbuf == 4) &&
          (t.bwd_xcd_rows == 1 || t.bwd_xcd_rows == 2 || t.bwd_xcd_rows == 4 || t.bwd_xcd_rows == 8) &&
-         (t.fwd_waves == 0 || t.fwd_waves == 16) && (t.bwd_cols == 0 || t.bwd_cols == 32 || t.bwd_cols == 64);
+         (t.bwd_cols == 0 || t.bwd_cols == 32 || t.bwd_cols == 64);
 }
 
 }  // namespace ark
@@ -245,7 +303,7 @@ extern "C" void ark_diag_tuning_default(ArkDiagTuning* t) {
   if (!t) return;
   t->fwd_rows = 64; t->fwd_ki = 1; t->fwd_nbuf = 2; t->fwd_xcd = 1; t->fwd_units = 0;
   t->bwd_rows = 32; t->bwd_ki = 2; t->bwd_nbuf = 2; t->bwd_xcd_rows = 4;
-  t->fwd_waves = 0; t->bwd_cols = 0;
+  t->bwd_cols = 0;
 }
 
 extern "C" int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruDiagRole* roles, const float* hyper, int B, int D,
@@ -296,11 +354,11 @@ struct GruDiagBwdArgs {
   int n_roles, B, D, xcd_m;
 };
 
-template <int PREC, int NBUF, int KI, int BM, int BN = 64>
-__global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
+template <int PREC, int NBUF, int KI, int BM, int BN = 64, int WGM = 2, bool ONEBAR = false>
+__global__ __launch_bounds__(128 * WGM) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
   static_assert(BN == 64 || BN == 32, "64 output columns per workgroup, or 32 for grids that would leave most CUs empty");
-  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;   // wave tile (BM/2) x (BN/2)
-  constexpr int TM = G::TM, TN = G::TN, WN = BN / 2;
+  using G = DmaTile<PREC, BM, BN, NBUF, WGM, 2, KI>;   // wave tile (BM/WGM) x (BN/2); WGM = 4: 128 x 64 on 8 waves
+  constexpr int TM = G::TM, TN = G::TN, WN = BN / 2, NTHR = 128 * WGM;
   using h_t = typename G::h_t;
   using h8 = typename G::h8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -372,7 +430,7 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
   typename G::template Segs<3> sg{{gup, gnx, gnx + 3 * D},
                                   {reinterpret_cast<const h_t*>(R.w_ihT_up16), whT, whT + 2 * D},
                                   {top ? 0 : 3 * D, rec ? 2 * D : 0, rec ? D : 0}};
-  G::template run_segs<3>(
+  G::template run_segs<3, ONEBAR>(
       sg, 4L * D, 3L * D, [=](int r) -> long { return (long)min(m0 + r, B - 1); }, [=](int r) -> long { return (long)(n0 + r); },
       smem, [&](auto seg, const h8 (&a)[TM], const h8 (&b)[TN]) {
 #pragma unroll
@@ -433,10 +491,10 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
     }
   }
   __syncthreads();
-  // 4 parts x BM rows x (2 BN) B: thread t -> (row, 16-byte chunk) for each part, 256 / CPR rows per pass
+  // 4 parts x BM rows x (2 BN) B: thread t -> (row, 16-byte chunk) for each part, NTHR / CPR rows per pass
   const int t = threadIdx.x;
   constexpr int CPR = BN / 8;   // chunks per row: 8 -> 32 rows per 256 threads, 4 -> 64
-  constexpr int RPASS = 256 / CPR;
+  constexpr int RPASS = NTHR / CPR;
   h_t* g16 = reinterpret_cast<h_t*>(R.dg16);
 #pragma unroll
   for (int r0 = 0; r0 < BM; r0 += RPASS) {
@@ -452,27 +510,30 @@ __global__ __launch_bounds__(256) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
   }
   // bias gradients: column sums of this tile straight from LDS, one atomic per (gate, unit):
   // db_ih = colsum [dr | dz | dn], db_hh = colsum [dr | dz | dn*r]
-  if (R.db_ih && t < 4 * BN) {
-    const int g = t / BN, ul = t % BN;   // 4 parts x BN units (all 256 threads at BN = 64)
+  constexpr int NSPL = NTHR / (4 * BN) > 0 ? NTHR / (4 * BN) : 1;   // row groups per column (2 on the 8-wave tile)
+  if (R.db_ih && t < 4 * BN * NSPL) {
+    const int sp = t / (4 * BN), g = (t / BN) & 3, ul = t % BN;   // 4 parts x BN units x NSPL row groups
     const int nrows = min(BM, B - m0);
+    const int r_lo = sp * (BM / NSPL), r_hi = min(nrows, (sp + 1) * (BM / NSPL));
     float s = 0.f;
-    for (int r2 = 0; r2 < nrows; ++r2) s += (float)tg[g * BM * TS + r2 * TS + ul];
+    for (int r2 = r_lo; r2 < r_hi; ++r2) s += (float)tg[g * BM * TS + r2 * TS + ul];
     if (g < 3) atomicAdd(&R.db_ih[(long)g * D + n0 + ul], s);
     if (g < 2) atomicAdd(&R.db_hh[(long)g * D + n0 + ul], s);
     if (g == 3) atomicAdd(&R.db_hh[2L * D + n0 + ul], s);
   }
 }
 
-template <int PREC, int NBUF, int KI, int BM, int BN = 64>
+template <int PREC, int NBUF, int KI, int BM, int BN = 64, int WGM = 2, bool ONEBAR = false>
 static void launch_diag_bwd(const GruDiagBwdArgs& p, hipStream_t st) {
-  using G = DmaTile<PREC, BM, BN, NBUF, 2, 2, KI>;
+  using G = DmaTile<PREC, BM, BN, NBUF, WGM, 2, KI>;
   constexpr int MINL = 4 * BM * (BN + 8) * 2;
   constexpr int LDS = G::LDS_BYTES > MINL ? G::LDS_BYTES : MINL;
-  auto kern = gru_diag_bwd_kernel<PREC, NBUF, KI, BM, BN>;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  auto kern = gru_diag_bwd_kernel<PREC, NBUF, KI, BM, BN, WGM, ONEBAR>;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
   (void)once;
   const unsigned grid = (unsigned)(p.n_roles * ((p.B + BM - 1) / BM) * (p.D / BN));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WGM), LDS, st, p);
 }
 
 template <int PREC>
@@ -494,6 +555,8 @@ static int launch_diag_bwd_cfg(GruDiagBwdArgs& p, const ArkDiagTuning& tn, hipSt
     ARK_LAUNCH_CHECK();
     return 0;
   }
+  // (measured and not shipped: 128 x 64 backward tiles on 8 waves with the single-barrier ring, one workgroup per CU --
+  //  27.5 us (three 48-KB slots) / 30.3 us (five 24-KB slots) per launch against 23.2 for the default 32 x 64 tiles)
   const bool deep = false;   // (see the forward launch)
   if (tn.bwd_rows == 64 && !deep) {
     if (ki2) launch_diag_bwd<PREC, 2, 2, 64>(p, st);
@@ -548,3 +611,9 @@ extern "C" int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* 
   if (prec == PREC_BF16) return launch_diag_bwd_cfg<PREC_BF16>(p, tn, (hipStream_t)stream);
   return ARK_ERR_ARG;
 }
+
+#ifdef ARK_STAMPS
+extern "C" int ark_debug_stamps(unsigned long long* host, int n_blocks) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ark::ark_stamp_buf), sizeof(unsigned long long) * 8 * (size_t)n_blocks);
+}
+#endif

@@ -172,6 +172,9 @@ class Engine:
                 self._adam_jobs["enc_rest"] = self._build_adam_jobs((0, m0), (m1, off))   # (one launch)
         self._shadow_ok = False
         self._side = None
+        self._chain_streams = []
+        # (measured on MI355X, syn-paths B = 1024: see DESIGN.md; 1 = the single dependent chain of rounds 1-2)
+        self.diag_chains = max(1, int(cfg.get("ark_diag_chains", 2)))
         self._pad_bufs = {}
         self._n_valid = 0
         self._side_used = False
@@ -686,14 +689,59 @@ class Engine:
                   L.ptr(self._logits(w)), L.i64(self.ldl), L.ptr(p["dec.out.bias"]), L.ptr(None), L.i32(R), L.i32(V), L.i32(D),
                   L.i32(0), st)
 
+    def _chains(self, B):
+        """Row-block chains of the diagonal sweeps.  A cell's rows depend only on the SAME rows of its two predecessor
+        cells (the recurrence couples units, never graphs), so the batch splits into independent chains of dependent
+        launches.  Run on parallel queues they fill each other's launch boundaries, ramps and tails: one chain's launch
+        drains while the other's is in its main loop (`ark_diag_chains`; every chain keeps >= 256 rows of 64-row tiles)."""
+        n = self.diag_chains
+        while n > 1 and (B % (64 * n) != 0 or B // n < 256):
+            n -= 1
+        return [(c * (B // n), B // n) for c in range(n)]
+
+    def _chain_stream(self, c):
+        while len(self._chain_streams) < c:
+            self._chain_streams.append(torch.cuda.Stream(device=self.device))
+        return self._chain_streams[c - 1]
+
+    def _run_chains(self, B, body):
+        """body(b0, Bc) once per chain: chain 0 on the current queue, the others on their own queues, forked and joined
+        with events (capturable)"""
+        chains = self._chains(B)
+        if len(chains) == 1:
+            body(0, B)
+            return
+        main = torch.cuda.current_stream()
+        used = []
+        for c, (b0, Bc) in enumerate(chains):
+            if c == 0:
+                continue
+            st = self._chain_stream(c)
+            st.wait_stream(main)
+            used.append(st)
+        for c, (b0, Bc) in enumerate(chains):
+            if c == 0:
+                body(b0, Bc)
+            else:
+                with torch.cuda.stream(used[c - 1]):
+                    body(b0, Bc)
+        for st in used:
+            main.wait_stream(st)
+
     def _diag_sweep(self, w, B, Lq, use_drop, save=True):
         """Layer-diagonal forward recurrence: cells (l, d-l) of one anti-diagonal are independent -> ONE
         launch per diagonal (one per ARK_DIAG_MAX_ROLES cells for deeper stacks), each role doing its own input
-        projection (no gi buffers, no per-layer input GEMM): L+n-1 dependent launches instead of n*L + n."""
+        projection (no gi buffers, no per-layer input GEMM): L+n-1 dependent launches instead of n*L + n.
+        The batch is split into independent row-block chains on parallel queues (_chains)."""
+        self._run_chains(B, lambda b0, Bc: self._diag_chain(w, B, b0, Bc, Lq, use_drop, save))
+
+    def _diag_chain(self, w, B, b0, Bc, Lq, use_drop, save=True, diagonals=None):
+        """the forward diagonals of rows [b0, b0 + Bc) of every timestep (row (t, b) = t*B + b); `diagonals`: a subset
+        (profiling tools re-issue single launches)"""
         import ctypes
         D, n, p = self.D, self.n, self.p
         pf, pb = self.prec_fwd, self.prec_bwd
-        for d in range(Lq + n - 1):
+        for d in (range(Lq + n - 1) if diagonals is None else diagonals):
             cells = [l for l in range(n) if 0 <= d - l < Lq]
             for c0 in range(0, len(cells), L.DIAG_MAX_ROLES):
                 roles = (L.GruDiagRole * L.DIAG_MAX_ROLES)()
@@ -702,8 +750,8 @@ class Engine:
                     t = d - l
                     drop = use_drop and l < n - 1
                     Y, Ya, Yb = w["Y"][l], w["Y16a"][l], w["Y16b"][l]
-                    sl = slice(t * B, (t + 1) * B)
-                    nx = slice((t + 1) * B, (t + 2) * B)
+                    sl = slice(t * B + b0, t * B + b0 + Bc)
+                    nx = slice((t + 1) * B + b0, (t + 1) * B + b0 + Bc)
                     if l == 0:
                         x = w["X0a"][sl]
                     else:
@@ -720,9 +768,9 @@ class Engine:
                         r.save_r, r.save_z = L.dptr(w["SR"][l][sl]), L.dptr(w["SZ"][l][sl])
                         r.save_n, r.save_hn = L.dptr(w["SN"][l][sl]), L.dptr(w["SHN"][l][sl])
                     r.drop_seed = self._layer_seed(l)
-                    r.drop_base = t * B * D
+                    r.drop_base = (t * B + b0) * D
                     r.drop_p = self.p_drop if drop else 0.0
-                _call("ark_gru_diag_fwd", L.i32(pf), L.i32(pb), L.i32(len(chunk)), roles, L.ptr(self.hyper), L.i32(B),
+                _call("ark_gru_diag_fwd", L.i32(pf), L.i32(pb), L.i32(len(chunk)), roles, L.ptr(self.hyper), L.i32(Bc),
                       L.i32(D), ctypes.byref(self.tune), L.cur_stream())
 
     def _decoder_forward(self, w, seq, ld_seq, B, Lq, use_drop, save=True, project=True):
@@ -1037,14 +1085,34 @@ class Engine:
 
     def _diag_bwd_sweep(self, w, B, Lq, use_drop, after_cells=None):
         """the dependent chain of the decoder backward: one launch per backward anti-diagonal, then (SAIL) the
-        initial-state roles.  Needs dY of the top layer in w["dYa"] and a zeroed w["dH0"]."""
+        initial-state roles.  Needs dY of the top layer in w["dYa"] and a zeroed w["dH0"].  Independent row-block
+        chains run on parallel queues (_chains); `after_cells` runs once every chain's cells are queued and joined."""
+        h0_done = {}
+        self._run_chains(B, lambda b0, Bc: h0_done.setdefault(b0, self._diag_bwd_chain(w, B, b0, Bc, Lq, use_drop)))
+        if after_cells is not None:
+            after_cells()
+        if self.mt == "SAIL":   # continues on the main stream into the encoder half
+            # dH0 = sum over layers of (carry + dgh_0 W_hh): all remaining layers as roles of one more launch
+            import ctypes
+            done = set.intersection(*h0_done.values()) if h0_done else set()
+            rest = [l for l in range(self.n) if l not in done]
+            for c0 in range(0, len(rest), L.DIAG_MAX_ROLES):
+                roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
+                chunk = rest[c0:c0 + L.DIAG_MAX_ROLES]
+                for k, l in enumerate(chunk):
+                    self._h0_role(roles[k], w, l, 0)
+                _call("ark_gru_diag_bwd", L.i32(self.prec_bwd), L.i32(len(chunk)), roles, L.ptr(self.hyper), L.i32(B),
+                      L.i32(self.D), ctypes.byref(self.tune), L.cur_stream())
+
+    def _diag_bwd_chain(self, w, B, b0, Bc, Lq, use_drop):
+        """the backward diagonals of rows [b0, b0 + Bc); returns the layers whose initial-state role rode a diagonal"""
         import ctypes
         D, n, g = self.D, self.n, self.g
         pb = self.prec_bwd
         tune = ctypes.byref(self.tune)
 
         def launch(roles, k):
-            _call("ark_gru_diag_bwd", L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(B), L.i32(D), tune, L.cur_stream())
+            _call("ark_gru_diag_bwd", L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(Bc), L.i32(D), tune, L.cur_stream())
 
         h0_done = set()
         for e in range(Lq + n - 1):
@@ -1055,7 +1123,7 @@ class Engine:
                 k = 0
                 for l in chunk:
                     t = Lq - 1 - (e - (n - 1 - l))
-                    sl = slice(t * B, (t + 1) * B)
+                    sl = slice(t * B + b0, t * B + b0 + Bc)
                     r = roles[k]
                     top = l == n - 1
                     if top:
@@ -1063,9 +1131,9 @@ class Engine:
                     else:
                         r.dgi_up16, r.w_ihT_up16 = L.dptr(w["dG16"][l + 1][sl]), L.dptr(self.wihT16[l + 1])
                     r.first = 1 if t == Lq - 1 else 0
-                    r.dg_next16 = 0 if r.first else L.dptr(w["dG16"][l][(t + 1) * B:])
+                    r.dg_next16 = 0 if r.first else L.dptr(w["dG16"][l][(t + 1) * B + b0:])
                     r.w_hhT16 = L.dptr(self.whhT16[l])
-                    r.carry_t = L.dptr(w["carry_l"][l])
+                    r.carry_t = L.dptr(w["carry_l"][l][b0:])
                     r.save_r, r.save_z = L.dptr(w["SR"][l][sl]), L.dptr(w["SZ"][l][sl])
                     r.save_n, r.save_hn = L.dptr(w["SN"][l][sl]), L.dptr(w["SHN"][l][sl])
                     r.y_prev_t = L.dptr(w["Y"][l][sl])
@@ -1073,7 +1141,7 @@ class Engine:
                     r.db_ih, r.db_hh = L.dptr(g[f"dec.gru.bias_ih_l{l}"]), L.dptr(g[f"dec.gru.bias_hh_l{l}"])
                     drop = use_drop and not top
                     r.drop_seed = self._layer_seed(l)
-                    r.drop_base = t * B * D
+                    r.drop_base = (t * B + b0) * D
                     r.drop_p = self.p_drop if drop else 0.0
                     k += 1
                 if self.mt == "SAIL" and self.h0_ride and c0 + L.DIAG_MAX_ROLES >= len(cells):
@@ -1081,25 +1149,15 @@ class Engine:
                     # that finished its step 0; layers >= 1 fit into the under-filled last diagonals
                     for l in range(n - 1, 0, -1):
                         if e == (n - 1 - l) + Lq and k < L.DIAG_MAX_ROLES:
-                            self._h0_role(roles[k], w, l)
+                            self._h0_role(roles[k], w, l, b0)
                             h0_done.add(l)
                             k += 1
                 launch(roles, k)
-        if after_cells is not None:
-            after_cells()
-        if self.mt == "SAIL":   # continues on the main stream into the encoder half
-            # dH0 = sum over layers of (carry + dgh_0 W_hh): all remaining layers as roles of one more launch
-            rest = [l for l in range(n) if l not in h0_done]
-            for c0 in range(0, len(rest), L.DIAG_MAX_ROLES):
-                roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()
-                chunk = rest[c0:c0 + L.DIAG_MAX_ROLES]
-                for k, l in enumerate(chunk):
-                    self._h0_role(roles[k], w, l)
-                launch(roles, len(chunk))
+        return h0_done
 
-    def _h0_role(self, r, w, l):
-        r.dg_next16, r.w_hhT16 = L.dptr(w["dG16"][l]), L.dptr(self.whhT16[l])
-        r.carry_t, r.dh0 = L.dptr(w["carry_l"][l]), L.dptr(w["dH0"])
+    def _h0_role(self, r, w, l, b0):
+        r.dg_next16, r.w_hhT16 = L.dptr(w["dG16"][l][b0:]), L.dptr(self.whhT16[l])
+        r.carry_t, r.dh0 = L.dptr(w["carry_l"][l][b0:]), L.dptr(w["dH0"][b0:])
 
     def _gru_wgrads(self, w, B, Lq, seq, use_drop, layers, emb):
         """weight gradients of the given GRU layers as ONE grouped launch on the current stream, plus

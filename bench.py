@@ -60,6 +60,9 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("ARK_CPU_THREADS", "16"))))
 
 
+PMC_FILE = "profiles/r03_pmc_summary.json"   # committed PMC passes of this command (tools/profile_round.sh)
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
@@ -171,6 +174,126 @@ def diag_byte_models(eng, B):
             "gru_diag_bwd_kernel": dict(min=b_min, impl=b_impl, flops=fl, dma=b_dma)}
 
 
+def time_workload(dev, workload, precision, dropout, batch, steps, warmup, settle, extra_cfg=None, world=1, rank=0, dist=None,
+                  use_dp=False, no_graph=False):
+    """K timed train steps of one workload preset on this rank's GPU (the contract's timed region: barrier + synchronize on
+    both sides, max over ranks); returns the engine and the timing."""
+    import torch
+    from ark_amd.engine import Engine
+    from ark_amd import initlib
+    cfg = build_cfg(dropout, workload)
+    cfg.update(extra_cfg or {})
+    B = batch or cfg["batch"]
+    Bg = B * world
+    eng = Engine(cfg, dev, precision=precision, world_size=world, rank=rank)
+    eng.load_params(initlib.init_state(cfg, seed=0))
+    eng.set_hyper(lr=cfg["learning_rate"], beta=cfg["beta"])
+
+    # synthetic data ring in PINNED HOST memory.  Each batch is ONE packed byte buffer [triples int64 | seq int64 |
+    # eps f32]; the step's fixed-address device inputs are views of one staging buffer, so the per-step host->device
+    # transfer (SURVEY 8d: part of the metric) is a single asynchronous copy inside the timed region.
+    NB = 8
+    T = cfg["max_triples"]
+    n_tri, n_seq, n_eps = B * T * 3 * 8, B * cfg["seq_len"] * 8, B * cfg["d_latent"] * 4
+
+    def views(buf):
+        tri = buf[:n_tri].view(torch.int64).view(B, T, 3)
+        sq = buf[n_tri:n_tri + n_seq].view(torch.int64).view(B, cfg["seq_len"])
+        ep = buf[n_tri + n_seq:n_tri + n_seq + n_eps].view(torch.float32).view(B, cfg["d_latent"])
+        return tri, sq, ep
+
+    ring = []
+    ce_counts = []
+    for i in range(NB):
+        tr, sq = synth_global_batch(cfg, Bg, seed=1 + i)
+        torch.manual_seed(1000 + i)
+        eps = torch.randn(Bg, cfg["d_latent"])
+        sl = slice(rank * B, (rank + 1) * B)
+        buf = torch.empty(n_tri + n_seq + n_eps, dtype=torch.uint8).pin_memory()
+        a_, b_, c_ = views(buf)
+        a_.copy_(tr[sl]); b_.copy_(sq[sl]); c_.copy_(eps[sl])
+        ring.append(buf)
+        ce_counts.append(float((sq[:, 1:] != 0).sum()))   # non-PAD targets of the GLOBAL batch
+    ce_count = ce_counts[0]
+    stage = ring[0].to(dev)
+    tri_in, seq_in, eps_in = views(stage)
+
+    def feed(i):
+        eng.set_hyper(ce_count=ce_counts[i % NB])   # device-side scalar; a no-op while the count is unchanged
+        stage.copy_(ring[i % NB], non_blocking=True)   # pinned host -> device, on the run stream
+
+    # everything (input H2D copies, graph replays, collectives) runs on ONE explicit stream:
+    # ordering between plain copies on the legacy null stream and hipGraphLaunch is not relied on
+    run_stream = torch.cuda.Stream(device=dev)
+    run_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(run_stream):
+        if no_graph:
+            def step():
+                return eng.train_step(tri_in, seq_in, eps_in, ce_count=ce_count, dp=use_dp)
+        else:
+            step = eng.capture_train_step(tri_in, seq_in, eps_in, ce_count=ce_count, dp=use_dp)
+
+        # steady state: the first ~300 replays after capture run 3-4 % slower than the rest (same box: 1.21 ms/step timed
+        # after 20 untimed steps, 1.16 after 300 or more, independent of the number of timed steps), so a fixed number of
+        # untimed settle steps runs in front of the W warm-up steps the caller asked for
+        log(f'{workload}: captured/ready; settle + warmup')
+        for i in range(settle):
+            feed(i)
+            step()
+        for i in range(warmup):
+            feed(i)
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            feed(warmup + i)
+            out4 = step()
+        eng.dp_flush()   # pipelined data parallel: the last step's decoder-bucket update is part of the K steps
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return {"eng": eng, "cfg": cfg, "B": B, "Bg": Bg, "dt": dt, "loss": [float(x) for x in out4.cpu()],
+            "h2d_bytes": n_tri + n_seq + n_eps, "steps": steps}
+
+
+def other_workloads(dev, precision, dropout, mfma_peak):
+    """the other BASELINE.json configurations at their YAML batch sizes, a few dozen captured steps each (development
+    numbers in front of the driver: same kernels, same step definition as the headline)"""
+    import torch
+    out = {}
+    for name, steps in (("syn-types", 100), ("wd-movies", 100), ("wd-articles", 30)):
+        try:
+            r = time_workload(dev, name, precision, dropout, 0, steps, 10, 40)
+            eng, cfg, B, dt = r["eng"], r["cfg"], r["B"], r["dt"]
+            gps = B * steps / dt
+            fl = flops_per_graph(cfg)
+            ent = {"batch": B, "d_model": cfg["d_model"], "seq_len": cfg["seq_len"], "vocab": cfg["vocab_size"], "steps": steps,
+                   "ms_per_step": dt / steps * 1e3, "graphs_per_s": gps, "model_tflops": gps * fl / 1e12,
+                   "model_mfma_frac": gps * fl / 1e12 / mfma_peak, "final_loss": r["loss"][0]}
+            if eng.ws["v2"]:
+                times = time_diag_kernels(eng, B, reps=3)
+                ent["diag_kernels"] = {k: {"kernel_avg_us": kt * 1e6, "launches_per_step": n, "us_per_step": kt * 1e6 * n}
+                                       for k, (kt, n) in times.items()}
+                ent["diag_share_of_step"] = sum(v["us_per_step"] for v in ent["diag_kernels"].values()) / (dt / steps * 1e6)
+            ent["kernel_profile"] = f"profiles/r03_{name}_kernel_stats.csv"
+            out[name] = ent
+            log(f'{name}: {ent["ms_per_step"]:.3f} ms/step, {gps:.0f} graphs/s')
+            del eng, r
+            torch.cuda.empty_cache()
+        except Exception as e:   # a development leg must never take the headline line down
+            out[name] = {"error": repr(e)}
+    return out
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) as children of this process --
     which has not touched the GPU -- and relay their exit code; rank 0's JSON line goes to our stdout."""
@@ -196,7 +319,8 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1, help="dec_dropout (reference default 0.1)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--no-other", action="store_true", help="skip the other BASELINE workloads (development legs)")
     ap.add_argument("--cfg", default="", help="extra engine config ints, e.g. ark_overlap_wgrad=0,ark_fork_after=0")
     ap.add_argument("--diag", default="", help="diagonal-kernel tiles, e.g. fwd_rows=64,fwd_units=32,bwd_rows=32,bwd_ki=2")
     ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path even with one rank")
@@ -227,100 +351,18 @@ def main():
         else:   # rehearsal of the multi-rank script on fewer GPUs than ranks (collectives staged through the host)
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from ark_amd.engine import Engine
-    from ark_amd import initlib
-
-    cfg = build_cfg(args.dropout, args.workload)
+    extra = {}
     for kv in filter(None, args.cfg.split(",")):   # engine options, e.g. ark_overlap_wgrad=0
         k, v = kv.split("=")
-        cfg[k] = int(v)
+        extra[k] = int(v)
     if args.diag:
-        cfg["ark_diag_tuning"] = {k: int(v) for k, v in (kv.split("=") for kv in args.diag.split(","))}
+        extra["ark_diag_tuning"] = {k: int(v) for k, v in (kv.split("=") for kv in args.diag.split(","))}
     if args.wgrad:
-        cfg["ark_wgrad_tuning"] = {k: int(v) for k, v in (kv.split("=") for kv in args.wgrad.split(","))}
-    B = args.batch or cfg["batch"]
-    Bg = B * world
-    eng = Engine(cfg, dev, precision=args.precision, world_size=world, rank=rank)
-    eng.load_params(initlib.init_state(cfg, seed=0))
-    eng.set_hyper(lr=cfg["learning_rate"], beta=cfg["beta"])
-    Lq = cfg["seq_len"] - 1
-
-    # synthetic data ring in PINNED HOST memory.  Each batch is ONE packed byte buffer [triples int64 | seq int64 |
-    # eps f32]; the step's fixed-address device inputs are views of one staging buffer, so the per-step host->device
-    # transfer (part of the metric) is a single asynchronous copy inside the timed region.
-    NB = 8
-    T = cfg["max_triples"]
-    n_tri, n_seq, n_eps = B * T * 3 * 8, B * cfg["seq_len"] * 8, B * cfg["d_latent"] * 4
-
-    def views(buf):
-        tri = buf[:n_tri].view(torch.int64).view(B, T, 3)
-        sq = buf[n_tri:n_tri + n_seq].view(torch.int64).view(B, cfg["seq_len"])
-        ep = buf[n_tri + n_seq:n_tri + n_seq + n_eps].view(torch.float32).view(B, cfg["d_latent"])
-        return tri, sq, ep
-
-    ring = []
-    ce_counts = []
-    for i in range(NB):
-        tr, sq = synth_global_batch(cfg, Bg, seed=1 + i)
-        torch.manual_seed(1000 + i)
-        eps = torch.randn(Bg, cfg["d_latent"])
-        sl = slice(rank * B, (rank + 1) * B)
-        buf = torch.empty(n_tri + n_seq + n_eps, dtype=torch.uint8).pin_memory()
-        a_, b_, c_ = views(buf)
-        a_.copy_(tr[sl]); b_.copy_(sq[sl]); c_.copy_(eps[sl])
-        ring.append(buf)
-        ce_counts.append(float((sq[:, 1:] != 0).sum()))   # non-PAD targets of the GLOBAL batch
-    ce_count = ce_counts[0]
-    stage = ring[0].to(dev)
-    tri_in, seq_in, eps_in = views(stage)
-    h2d_bytes = n_tri + n_seq + n_eps
-
+        extra["ark_wgrad_tuning"] = {k: int(v) for k, v in (kv.split("=") for kv in args.wgrad.split(","))}
     use_dp = world > 1 or args.force_dist
-
-    def feed(i):
-        eng.set_hyper(ce_count=ce_counts[i % NB])   # device-side scalar; a no-op while the count is unchanged
-        stage.copy_(ring[i % NB], non_blocking=True)   # pinned host -> device, on the run stream
-
-    # everything (input H2D copies, graph replays, collectives) runs on ONE explicit stream:
-    # ordering between plain copies on the legacy null stream and hipGraphLaunch is not relied on
-    run_stream = torch.cuda.Stream(device=dev)
-    run_stream.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(run_stream):
-        if args.no_graph:
-            def step():
-                return eng.train_step(tri_in, seq_in, eps_in, ce_count=ce_count, dp=use_dp)
-        else:
-            step = eng.capture_train_step(tri_in, seq_in, eps_in, ce_count=ce_count, dp=use_dp)
-
-        # steady state: the first ~300 replays after capture run 3-4 % slower than the rest (same box: 1.21 ms/step timed
-        # after 20 untimed steps, 1.16 after 300 or more, independent of the number of timed steps), so a fixed number of
-        # untimed settle steps runs in front of the W warm-up steps the caller asked for
-        log('captured/ready; settle + warmup')
-        for i in range(args.settle):
-            feed(i)
-            step()
-        for i in range(args.warmup):
-            feed(i)
-            step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            feed(args.warmup + i)
-            out4 = step()
-        eng.dp_flush()   # pipelined data parallel: the last step's decoder-bucket update is part of the K steps
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    loss = [float(x) for x in out4.cpu()]
+    run = time_workload(dev, args.workload, args.precision, args.dropout, args.batch, args.steps, args.warmup, args.settle, extra,
+                        world=world, rank=rank, dist=dist, use_dp=use_dp, no_graph=args.no_graph)
+    eng, cfg, B, Bg, dt, loss, h2d_bytes = (run[k] for k in ("eng", "cfg", "B", "Bg", "dt", "loss", "h2d_bytes"))
     log(f'timed {args.steps} steps in {dt:.3f}s loss={loss[0]:.4f}')
 
     if rank == 0:
@@ -333,7 +375,7 @@ def main():
             models = diag_byte_models(eng, B)
             traffic = {}
             try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE x2 + WRITE_SIZE)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+                pm = json.load(open(os.path.join(ROOT, PMC_FILE)))
                 for k, v in pm.items():
                     for name in times:
                         if name in k:
@@ -359,11 +401,14 @@ def main():
             dom = max(kern, key=lambda k: kern[k]["us_per_step"])   # dominant = most time per step
             d = kern[dom]
             # both kernels sit below the chip's ~310 FLOP/B balance point, so the HBM roofline bounds them
-            roof = {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": d["frac"],
-                    "traffic": d["traffic"], "traffic_source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc passes of this command)",
+            # headline fraction = SURVEY 8d's ALGORITHMIC bytes (the per-cell minimum); what the implementation's layout moves
+            # (fp32 state, both 16-bit types, dropped copies) is the secondary figure
+            roof = {"bound": "hbm", "kernel": dom, "achieved": d["bytes_per_launch_min_8d"] / (d["kernel_avg_us"] * 1e-6) / 1e9,
+                    "peak": 8000.0, "unit": "GB/s", "frac": d["frac_min_8d"],
+                    "traffic": d["traffic"], "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this command)",
                     "kernel_avg_us": d["kernel_avg_us"], "launches_per_step": d["launches_per_step"],
-                    "bytes_per_launch": d["bytes_per_launch"], "bytes_per_launch_min_8d": d["bytes_per_launch_min_8d"],
-                    "frac_min_8d": d["frac_min_8d"],
+                    "bytes_per_launch": d["bytes_per_launch_min_8d"], "bytes_per_launch_impl": d["bytes_per_launch"],
+                    "achieved_impl": d["achieved"], "frac_impl": d["frac"],
                     "mfma": {"achieved": d["flops_per_launch"] / (d["kernel_avg_us"] * 1e-6) / 1e12, "peak": mfma_peak,
                              "unit": "TFLOP/s", "frac": d["mfma_frac"]},
                     "kernels": kern}
@@ -384,8 +429,16 @@ def main():
             "model_mfma_frac": gps * fl / 1e12 / mfma_peak,
             "roofline": roof,
         }
+        if not args.no_other and world == 1 and args.workload == "syn-paths" and not args.force_dist:
+            del eng
+            torch.cuda.empty_cache()
+            res["other_workloads"] = other_workloads(dev, args.precision, args.dropout, mfma_peak)
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(cfg, B, steps=args.cpu_steps)
+            res["cpu_baseline"] = cpu_baseline(cfg, B, steps=args.cpu_steps, warmup=5)
+            if B == 1024:   # the plumbing batch and the YAML batch beside it
+                for b2 in (32, 256):
+                    c2 = cpu_baseline(cfg, b2, steps=20, warmup=5)
+                    res["cpu_baseline"][f"batch_{b2}"] = {"value": c2["value"], "sample": c2["sample"]}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()   # leave together: rank 0 is still timing its kernels while the others are done

@@ -118,7 +118,7 @@ typedef struct {
 /* speed-only tile / ring choices of the two diagonal kernels; passed per call (NULL = the measured defaults of
  * ark_diag_tuning_default), so the library keeps no mutable state */
 typedef struct {
-  int fwd_rows;      /* 32 | 64 | 128 (128: 64-unit tiles only)                                 */
+  int fwd_rows;      /* 32 | 64 | 128 (128: 64-unit tiles only: ONE 8-wave workgroup per CU, ping-pong halves on a 4-slot ring) */
   int fwd_ki;        /* 64-wide k-images per ring stage: 1 | 2                                  */
   int fwd_nbuf;      /* ring slots: 2 | 4                                                       */
   int fwd_xcd;       /* XCD-aware tile order: 0 | 1                                             */
@@ -127,7 +127,6 @@ typedef struct {
   int bwd_ki;        /* 1 | 2                                                                   */
   int bwd_nbuf;      /* 2 | 4                                                                   */
   int bwd_xcd_rows;  /* row-tile classes per XCD octet: 1 (plain order) | 2 | 4 | 8             */
-  int fwd_waves;     /* 0 = by tile shape | 16 (128-row x 64-unit tile on a 1024-thread workgroup) */
   int bwd_cols;      /* output columns per backward workgroup: 0 = by grid size | 32 | 64        */
 } ArkDiagTuning;
 void ark_diag_tuning_default(ArkDiagTuning* t);

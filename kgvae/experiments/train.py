@@ -448,8 +448,9 @@ def main(argv=None):
     if config.get("dump_final_params"):   # test hook: every rank's flat parameter buffer
         eng.dp_flush()
         torch.save(eng.P.detach().cpu(), f"{config['dump_final_params']}.rank{rank}.pt")
-        if model_type == "SAIL" and eng.ws is not None and "eps0" in eng.ws:   # the last step's device-drawn latent noise
-            torch.save(eng.ws["eps0"].detach().cpu(), f"{config['dump_final_params']}.eps.rank{rank}.pt")
+        wtrain = eng._ws_cache.get(config["batch_size"] // nranks)   # (workspace of this rank's training batches)
+        if model_type == "SAIL" and wtrain is not None:   # the last training step's device-drawn latent noise
+            torch.save(wtrain["eps0"].detach().cpu(), f"{config['dump_final_params']}.eps.rank{rank}.pt")
     if nranks > 1:
         import torch.distributed as dist
         dist.barrier()

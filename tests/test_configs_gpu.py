@@ -58,7 +58,9 @@ def _oracle(name):
     return _ORACLE[name]
 
 
-@pytest.mark.parametrize("precision,ltol,gtol", [("f32", 2e-5, 2e-3), ("mixed", 5e-4, 6e-2)])
+# mixed (the shipped mode: fp16 forward / bf16 backward MFMA operands) is held to north_star's 1e-4 on the ELBO at the YAML
+# batch sizes (measured on MI355X: syn-types 3.2e-5, wd-movies 2.6e-6, wd-articles 1.5e-6 / 1.1e-6)
+@pytest.mark.parametrize("precision,ltol,gtol", [("f32", 2e-5, 2e-3), ("mixed", 1e-4, 6e-2)])
 @pytest.mark.parametrize("name", list(SHAPES))
 def test_other_configs_match_oracle(name, precision, ltol, gtol):
     cfg, B = SHAPES[name]

@@ -83,8 +83,8 @@ def test_fullsize_synpaths_scalars(name, precision, tol):
         eps = torch.from_numpy(z[f"eps{s}"]).to(dev) if sail else None
         eng.set_hyper(beta=float(z["betas"][s]))
         out4 = eng.train_step(triples if sail else None, seq, eps).cpu().numpy()
-        if precision == "f32" or s == 0:
-            assert rel_err(float(out4[0]), z["losses"][s][0]) < tol * (1 + 4 * s), (s, out4, z["losses"][s])
+        # every step in every precision (steps 1, 2 follow Adam updates made in that precision)
+        assert rel_err(float(out4[0]), z["losses"][s][0]) < tol * (1 + 4 * s), (s, out4, z["losses"][s])
         if s == 0 and precision == "f32":
             for k in [f[7:] for f in z.files if f.startswith("g0norm/")]:
                 n = float(eng.g[k].double().norm())
@@ -555,12 +555,12 @@ def test_dropout_on_fast_path_matches_oracle_with_the_same_masks(B):
     assert checked >= 20
 
 
-@pytest.mark.parametrize("rows,ki,nbuf,xcd,units,waves,bcols", [(32, 2, 2, 0, 32, 0, 0), (64, 1, 2, 0, 32, 0, 64), (64, 2, 2, 1, 32, 0, 0),
-                                                               (32, 1, 4, 1, 32, 0, 64), (128, 1, 2, 1, 64, 0, 0), (64, 1, 2, 0, 64, 0, 0),
-                                                               (64, 2, 2, 1, 64, 0, 0), (128, 1, 2, 1, 64, 16, 0), (128, 1, 2, 0, 64, 16, 0),
-                                                               (32, 2, 2, 1, 32, 0, 32), (32, 1, 2, 0, 32, 0, 32), (32, 2, 2, 1, 16, 0, 32), (32, 1, 2, 0, 16, 0, 0)])
+@pytest.mark.parametrize("rows,ki,nbuf,xcd,units,bcols", [(32, 2, 2, 0, 32, 0), (64, 1, 2, 0, 32, 64), (64, 2, 2, 1, 32, 0),
+                                                         (32, 1, 4, 1, 32, 64), (64, 1, 2, 0, 64, 0),
+                                                         (64, 2, 2, 1, 64, 0), (128, 1, 4, 0, 64, 0), (128, 1, 4, 1, 64, 0),
+                                                         (32, 2, 2, 1, 32, 32), (32, 1, 2, 0, 32, 32), (32, 2, 2, 1, 16, 32), (32, 1, 2, 0, 16, 0)])
 @pytest.mark.parametrize("drop", [0.0, 0.1])
-def test_diagonal_tilings_agree(rows, ki, nbuf, xcd, units, waves, bcols, drop):
+def test_diagonal_tilings_agree(rows, ki, nbuf, xcd, units, bcols, drop):
     """every tile / ring configuration of the two diagonal kernels (ArkDiagTuning, passed per call) computes the
     same states, losses and gradients as the default one, and the same ELBO as the CPU oracle within north_star's
     tolerance"""
@@ -571,8 +571,8 @@ def test_diagonal_tilings_agree(rows, ki, nbuf, xcd, units, waves, bcols, drop):
     triples, seq = synth_batch(cfg, B, seed=3)
     torch.manual_seed(5)
     eps = torch.randn(B, cfg["d_latent"])
-    tun = dict(fwd_rows=rows, fwd_ki=ki, fwd_nbuf=nbuf, fwd_xcd=xcd, fwd_units=units, bwd_rows=min(rows, 64), bwd_ki=ki,
-               bwd_nbuf=nbuf, bwd_xcd_rows=4 if xcd else 1, fwd_waves=waves, bwd_cols=bcols)
+    tun = dict(fwd_rows=rows, fwd_ki=ki, fwd_nbuf=nbuf, fwd_xcd=xcd, fwd_units=units, bwd_rows=min(rows, 64),
+               bwd_ki=1 if rows == 128 else ki, bwd_nbuf=2 if rows == 128 else nbuf, bwd_xcd_rows=4 if xcd else 1, bwd_cols=bcols)
     a = make_engine(cfg, P, "mixed")
     b = make_engine(dict(cfg, ark_diag_tuning=tun), P, "mixed")
     dev = a.device
@@ -597,6 +597,50 @@ def test_diagonal_tilings_agree(rows, ki, nbuf, xcd, units, waves, bcols, drop):
     for k in a.g:   # every parameter's gradient, relative to its own norm
         da, db = a.g[k].float(), b.g[k].float()
         assert (da - db).norm().item() <= 3e-3 * da.norm().item() + 1e-9, k
+
+
+@pytest.mark.parametrize("chains", [2, 4])
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_row_block_chains_agree_with_one_chain(chains, drop):
+    """the diagonal sweeps split into independent row-block chains on parallel queues (Engine._chains) compute exactly what
+    the single chain of dependent launches computes: same states bit for bit (the per-row arithmetic does not change),
+    same loss, same gradients up to the order of the bias-gradient atomics; eager and inside a captured graph"""
+    from oracle import sail_oracle as O
+    cfg = dict(_big_cfg(), dec_dropout=drop)
+    P = O.init_params(cfg, 0)
+    B = 1024
+    triples, seq = synth_batch(cfg, B, seed=3)
+    torch.manual_seed(5)
+    eps = torch.randn(B, cfg["d_latent"])
+    a = make_engine(dict(cfg, ark_diag_chains=1), P, "mixed")
+    b = make_engine(dict(cfg, ark_diag_chains=chains), P, "mixed")
+    assert len(a._chains(B)) == 1 and len(b._chains(B)) == chains
+    dev = a.device
+    args = (triples.to(dev), seq.to(dev), eps.to(dev))
+    for eng in (a, b):
+        eng.set_hyper(beta=0.1)
+    a.drop_seed = b.drop_seed = 1234
+    oa = a.train_step(*args).cpu().numpy()
+    ob = b.train_step(*args).cpu().numpy()
+    torch.cuda.synchronize()
+    assert rel_err(float(ob[0]), float(oa[0])) < 1e-6, (oa, ob)
+    for l in range(cfg["n_layers"]):
+        assert torch.equal(a.ws["Y"][l], b.ws["Y"][l]), l
+        assert torch.equal(a.ws["dG16"][l][:B * (cfg["seq_len"] - 1)], b.ws["dG16"][l][:B * (cfg["seq_len"] - 1)]), l
+    for k in a.g:
+        da, db = a.g[k].float(), b.g[k].float()
+        assert (da - db).norm().item() <= 1e-4 * da.norm().item() + 1e-9, k
+    # captured: replays of the forked / joined graph keep reproducing the eager step
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        step = b.capture_train_step(*args)
+        b.load_params(P)
+        b.reset_optimizer()
+        b.refresh_shadows()
+        b.set_dropout_draws(0)
+        og = step().cpu().numpy()
+    torch.cuda.synchronize()
+    assert rel_err(float(og[0]), float(oa[0])) < 1e-6, (oa, og)
 
 
 @pytest.mark.parametrize("B,D,n_roles", [(64, 128, 1), (48, 256, 3)])

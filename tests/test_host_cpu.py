@@ -189,3 +189,22 @@ def test_sample_perms_is_random_sample_bit_for_bit():
             assert (ref == got).all(), (T, seed)
             assert random.getstate() == after, (T, seed)
     assert sample_perms(0, 3).shape == (0, 3) and sample_perms(4, 1).tolist() == [[0]] * 4
+
+
+def test_shipped_configs_are_the_reference_yamls_with_model_type_overridden():
+    """the benchmark configs are 'the shipped YAML with model_type overridden'.  Every key of the
+    reference's five YAMLs (tests/golden/reference_yaml_values.json, parsed by tools/make_golden_r3.py) has the same value
+    in configs/sail_<dataset>.yaml, except the model type, the run's own names / paths and the added `precision`"""
+    import json
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = json.load(open(os.path.join(root, "tests", "golden", "reference_yaml_values.json")))
+    own = {"model_type", "checkpoint_path", "experiment_name"}
+    assert set(ref) == {"syn-paths", "syn-types", "syn-tipr", "wd-movies", "wd-articles"}
+    for name, want in ref.items():
+        got = yaml.safe_load(open(os.path.join(root, "configs", f"sail_{name}.yaml")))
+        assert set(got) - set(want) <= {"precision"}, (name, set(got) - set(want))
+        for k, v in want.items():
+            if k not in own:
+                assert got[k] == v, (name, k, got[k], v)
+        assert got["model_type"] == "SAIL"

@@ -6,7 +6,7 @@ for r in $(seq 1 "$rounds"); do
   i=0
   for a in "$@"; do
     i=$((i + 1))
-    python bench.py --no-cpu-baseline $a > "$out/cfg$i.$r.json" 2> "$out/cfg$i.$r.err" || { echo "[$a] failed"; tail -3 "$out/cfg$i.$r.err"; }
+    python bench.py --no-cpu-baseline --no-other $a > "$out/cfg$i.$r.json" 2> "$out/cfg$i.$r.err" || { echo "[$a] failed"; tail -3 "$out/cfg$i.$r.err"; }
     echo "[$a] round $r: $(grep -o '"ms_per_step": [0-9.]*' "$out/cfg$i.$r.json")"
   done
 done

@@ -9,7 +9,7 @@ mkdir -p "$out"
 for r in $(seq 1 "$rounds"); do
   for v in "$@"; do
     if [ "$v" = default ]; then unset ARK_AMD_LIB; else export ARK_AMD_LIB=$PWD/ark_amd/lib/variants/$v/libark_amd.so; fi
-    python bench.py --no-cpu-baseline "${args[@]}" > "$out/$v.$r.json" 2> "$out/$v.$r.err" || { echo "$v failed"; tail -3 "$out/$v.$r.err"; }
+    python bench.py --no-cpu-baseline --no-other "${args[@]}" > "$out/$v.$r.json" 2> "$out/$v.$r.err" || { echo "$v failed"; tail -3 "$out/$v.$r.err"; }
     echo "$v round $r: $(grep -o '"ms_per_step": [0-9.]*' "$out/$v.$r.json")"
   done
 done

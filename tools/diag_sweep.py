@@ -38,8 +38,12 @@ def main():
     engines = []
     for s in args.settings:
         cfg = dict(cfg0)
-        if s:
-            cfg["ark_diag_tuning"] = {k: int(v) for k, v in (kv.split("=") for kv in s.split(","))}
+        if s:   # `ark_*` keys are engine options (e.g. ark_diag_chains=1), the rest are ArkDiagTuning fields
+            kv = {k: int(v) for k, v in (kv.split("=") for kv in s.split(","))}
+            cfg.update({k: v for k, v in kv.items() if k.startswith("ark_")})
+            tun = {k: v for k, v in kv.items() if not k.startswith("ark_")}
+            if tun:
+                cfg["ark_diag_tuning"] = tun
         eng = Engine(cfg, dev, precision="mixed")
         eng.load_params(initlib.init_state(cfg, seed=0))
         eng.set_hyper(lr=cfg["learning_rate"], beta=cfg["beta"])

@@ -151,6 +151,15 @@ def main():
     bits_case(M, U, out, "sail_pad", "SAIL", D=32, Z=8, n=2, nE=70, nR=5, T=7, padded=True, seed=4, N=20, frac=0.5)
     bits_case(M, U, out, "ark_tiny", "ARK", D=32, Z=4, n=3, nE=20, nR=3, T=3, padded=False, seed=2, N=10, frac=1.0)
     np.savez_compressed(os.path.join(OUT, "posterior_bits.npz"), **out)
+    # the reference's five YAML configurations as parsed values (configs/sail_*.yaml must equal them key for key except
+    # model_type, checkpoint_path, experiment_name and the added `precision`; tests/test_host_cpu.py)
+    import yaml
+    vals = {}
+    for f in sorted(os.listdir(os.path.join(REF, "configs"))):
+        if f.endswith(".yaml"):
+            vals[f[len("autoreg_"):-len(".yaml")]] = yaml.safe_load(open(os.path.join(REF, "configs", f)))
+    with open(os.path.join(OUT, "reference_yaml_values.json"), "w") as fh:
+        json.dump(vals, fh, indent=1, sort_keys=True)
     assert not any(d == "__pycache__" for _, ds, _ in os.walk(REF) for d in ds), "bytecode leaked into reference"
 
 
