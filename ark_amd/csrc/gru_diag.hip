@@ -272,7 +272,8 @@ static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t 
     else if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 64>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 64, 64>(p, st);
   } else if (units == 16) {   // 2 waves
-    if (ki2) launch_diag<PREC, PRECB, 2, 2, 32, 16>(p, st);
+    if (ki2 && tn.fwd_nbuf >= 4) launch_diag<PREC, PRECB, 6, 2, 32, 16>(p, st);   // deep ring: 12 k-images in flight (120 KB)
+    else if (ki2) launch_diag<PREC, PRECB, 2, 2, 32, 16>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 32, 16>(p, st);
   } else if (rows == 64) {
     if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 32>(p, st);
@@ -550,7 +551,8 @@ static int launch_diag_bwd_cfg(GruDiagBwdArgs& p, const ArkDiagTuning& tn, hipSt
     p.xcd_m = (xm > 1 && MT % xm == 0 && NT % (8 / xm) == 0) ? xm : 1;
   }
   if (narrow) {
-    if (ki2) launch_diag_bwd<PREC, 2, 2, 32, 32>(p, st);
+    if (ki2 && tn.bwd_nbuf >= 4) launch_diag_bwd<PREC, 8, 2, 32, 32>(p, st);   // deep ring: 16 k-images in flight (128 KB)
+    else if (ki2) launch_diag_bwd<PREC, 2, 2, 32, 32>(p, st);
     else launch_diag_bwd<PREC, 2, 1, 32, 32>(p, st);
     ARK_LAUNCH_CHECK();
     return 0;

@@ -271,6 +271,45 @@ extern "C" int ark_weight_shadows(int n_jobs, const float* const* src, void* con
   return 0;
 }
 
+namespace ark {
+// N(0,1) by Box-Muller on two counter hashes per PAIR of elements (common.h fmix32); one workgroup, so the draw counter
+// can be read by everybody before thread 0 bumps it
+__global__ __launch_bounds__(1024) void normal_fill_kernel(float* __restrict__ out, long n, uint32_t s0, uint32_t s1,
+                                                           float* __restrict__ hyper) {
+  uint32_t* ctr = reinterpret_cast<uint32_t*>(hyper) + ARK_HP_NOISE_STEP;
+  const uint32_t step = *ctr;
+  __syncthreads();
+  const long pairs = (n + 1) >> 1;
+  for (long i = threadIdx.x; i < pairs; i += blockDim.x) {
+    uint32_t a = fmix32((uint32_t)i * 0x9E3779B1u + step * 0x85EBCA77u + s0);
+    a = fmix32(a ^ ((uint32_t)(i >> 32) * 0xC2B2AE3Du + s1));
+    const uint32_t b = fmix32(a + 0x6C8E9CF5u);
+    const float u1 = (float)((a >> 8) + 1u) * 5.9604644775390625e-8f;   // (0, 1]: 24 bits
+    const float u2 = (float)(b >> 8) * 5.9604644775390625e-8f;          // [0, 1)
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    out[2 * i] = r * cs;
+    if (2 * i + 1 < n) out[2 * i + 1] = r * sn;
+  }
+  if (threadIdx.x == 0) *ctr = step + 1u;
+}
+}  // namespace ark
+
+extern "C" int ark_normal_fill(float* out, int64_t n, uint64_t seed, float* hyper, void* stream) {
+  if (!out || !hyper || n <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(ark::normal_fill_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, out, (long)n, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), hyper);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_zero(void* ptr, int64_t nbytes, void* stream) {
+  if (!ptr || nbytes < 0) return ARK_ERR_ARG;
+  if (nbytes == 0) return 0;
+  return (int)hipMemsetAsync(ptr, 0, (size_t)nbytes, (hipStream_t)stream);
+}
+
 extern "C" int ark_adam_tick(float* hyper, void* stream) {
   if (!hyper) return ARK_ERR_ARG;
   hipLaunchKernelGGL(ark::adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper);

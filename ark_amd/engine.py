@@ -25,7 +25,7 @@ import torch
 from . import _lib as L
 
 HP = dict(LR=0, BETA=1, KL_NORM=2, CE_INV_COUNT=3, CE_COUNT=4, ADAM_STEP=5, ADAM_BC1=6, ADAM_BC2=7, ADAM_B1=8,
-          ADAM_B2=9, ADAM_EPS=10, GRAD_SCALE=11, DROP_STEP=12, COUNT=16)
+          ADAM_B2=9, ADAM_EPS=10, GRAD_SCALE=11, DROP_STEP=12, NOISE_STEP=13, COUNT=16)
 
 # precision policy -> (forward products, backward products)
 #   "mixed": fp16 operands forward (3 more mantissa bits than bf16 at the same MFMA rate keeps the
@@ -135,6 +135,7 @@ class Engine:
         self.ws_key = None
         self.training = True
         self.drop_seed = int(cfg.get("dropout_seed", 0x5A11))
+        self.noise_seed = int(cfg.get("noise_seed", cfg.get("seed", 0)))
         self._graphs = {}
         self._ws_cache = {}
         self._pinned_B = set()
@@ -209,6 +210,21 @@ class Engine:
         # (csrc/vocab_ce.hip); small ones keep the three short launches (W_tok is a few KB there)
         self.fused_ce = bool(cfg.get("ark_fused_ce", self.use_dma and self.V >= 2048 and self.D in (64, 128, 256, 512)))
         self._fused_ce_step = False
+
+    def _noise_seed(self):
+        """seed of this rank's latent-noise stream (the draw counter lives in the device scalar array)"""
+        return (self.noise_seed * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03 * (self.rank + 1)) & 0xFFFFFFFFFFFFFFFF
+
+    def noise_draws(self):
+        """latent-noise draws so far (device uint32; synchronises)"""
+        return int(self.hyper.view(torch.int32)[HP["NOISE_STEP"]].item()) & 0xFFFFFFFF
+
+    def set_noise_draws(self, n):
+        self.hyper.view(torch.int32)[HP["NOISE_STEP"]:HP["NOISE_STEP"] + 1].fill_(int(n) - (1 << 32) if int(n) >= (1 << 31) else int(n))
+
+    def _zero(self, t):
+        """zero a contiguous device tensor on the current queue (library call; a memset node inside a captured graph)"""
+        _call("ark_zero", L.ptr(t), L.i64(t.numel() * t.element_size()), L.cur_stream())
 
     def _layer_seed(self, l):
         """dropout stream of layer l's output on this rank (hashed with the draw counter and the element index)"""
@@ -563,8 +579,9 @@ class Engine:
                     a = w["act"][i]
                 self._gemm(KM, KM, L.EPI_BIAS, a, H, p["enc.mu.weight"], H, w["head"], 2 * Z, B, 2 * Z, H,
                            bias=p["enc.mu.bias"])
-            if eps is None:   # z = mu + N(0,1) * std, drawn on the device (reference models.py:63)
-                eps = w["eps0"].normal_()
+            if eps is None:   # z = mu + N(0,1) * std, drawn on the device (reference models.py:63) by the library's own
+                eps = w["eps0"]   # counter-based generator: fresh every launch / replay, a stream of its own per rank
+                _call("ark_normal_fill", L.ptr(eps), L.i64(eps.numel()), L.u64(self._noise_seed()), L.ptr(self.hyper), st)
             self._eps = eps
             self._kl_rows = bool(w["v2"] and Z <= 128 and self.fused_latent)
             if self._kl_rows:
@@ -582,11 +599,11 @@ class Engine:
                 self._decode_h0(w, w["z"], B)
         else:
             for l in range(n):
-                w["Y"][l][:B].zero_()
+                self._zero(w["Y"][l][:B])
                 if w["v2"]:
-                    w["Y16a"][l][:B].zero_()
+                    self._zero(w["Y16a"][l][:B])
                     if w["Y16b"][l] is not None:
-                        w["Y16b"][l][:B].zero_()
+                        self._zero(w["Y16b"][l][:B])
         yield
         st = L.cur_stream()
         fused = bool(w["v2"] and self.fused_ce and with_loss)
@@ -837,7 +854,7 @@ class Engine:
         if self._finalize is not None:   # (deferred by forward for the two-queue backward only)
             self._finalize()
             self._finalize = None
-        self.G.zero_()
+        self._zero(self.G)
         dX0 = self._backward_decoder_v1(w, B, Lq, seq, use_drop)
         _call("ark_tok_scatter", L.ptr(seq), L.i64(ld_seq), L.ptr(dX0), L.ptr(g["dec.tok_emb.weight"]), L.i32(B), L.i32(Lq),
               L.i32(D), L.i32(V), st)
@@ -1018,9 +1035,9 @@ class Engine:
         side.wait_stream(main)
         filled = torch.cuda.Event()
         with torch.cuda.stream(side):
-            self.G.zero_()   # ONE fill; every reduction of the step accumulates into it
+            self._zero(self.G)   # ONE fill; every reduction of the step accumulates into it
             if self.mt == "SAIL":
-                w["dH0"].zero_()   # the initial-state roles add into it
+                self._zero(w["dH0"])   # the initial-state roles add into it
             filled.record(side)   # (the first backward diagonal waits for this: nothing else goes in front of it)
             if self._finalize is not None:   # loss scalars of this step (deferred by forward)
                 self._finalize()
@@ -1199,7 +1216,7 @@ class Engine:
             # S = per-token sums of layer 0's gate-gradient panel [Vp, 3D]; then two small exact-fp32 products:
             #   dW_tok += onehot^T dX0 = S W_ih_0   (no [R,D] input gradient, no scatter)
             #   dW_ih_0 += dgi_0^T X0 = S^T W_tok   (X0 rows are rows of W_tok: that weight-gradient product is not run)
-            w["S_tok"].zero_()
+            self._zero(w["S_tok"])
             _call("ark_token_sums16", L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(G0), L.i64(4 * D), L.ptr(w["S_tok"]),
                   L.i64(3 * D), L.ptr(w["tok_scratch"]), L.i64(w["tok_scratch"].numel()), L.i32(B), L.i32(Lq), L.i32(self.Vp),
                   L.i32(3 * D), ss)

@@ -62,6 +62,7 @@ int ark_gemm(int prec, int a_lay, int b_lay, int epi, const float* A, int64_t ld
                                   ark_tok_gather / ark_tok_gather16 once per TRAINING forward; the GRU cells hash
                                   (seed, this counter, element index) -> forward and backward of one step agree,
                                   consecutive forwards differ (reference: nn.GRU(dropout=p), models.py:121-127)  */
+#define ARK_HP_NOISE_STEP 13   /* uint32: latent-noise draw counter, bumped by every ark_normal_fill launch        */
 #define ARK_HP_COUNT 16
 
 #define ARK_TOK_PAD 0 /* special_tokens["PAD"], the ignore_index of the reference's cross-entropy */
@@ -307,6 +308,13 @@ int ark_loss_finalize_rows(const float* row_loss, int n_rows, const float* kl_ro
                            const float* hyper, float* out4, void* stream);
 int ark_argmax_rows(const float* x, int64_t ld, int64_t* out, int rows, int V, void* stream);
 
+/* out[0:n] = N(0,1) draws for the reparameterisation noise (reference: torch.randn_like(mu), kgvae/model/models.py:63):
+ * counter-based -- element i of draw number hyper[ARK_HP_NOISE_STEP] under `seed` is a pure function of (seed, draw, i)
+ * (two 32-bit hashes -> Box-Muller) -- so a captured graph replays fresh noise every step and ranks with different seeds
+ * draw independent streams.  The launch bumps the draw counter.  One workgroup (n is B * d_latent). */
+int ark_normal_fill(float* out, int64_t n, uint64_t seed, float* hyper, void* stream);
+/* zero `nbytes` bytes (a memset node under graph capture) */
+int ark_zero(void* ptr, int64_t nbytes, void* stream);
 /* ---- optimiser and reductions (reference: optim.Adam, ablation_study.py:571,76) ---------------- */
 int ark_adam_tick(float* hyper, void* stream);
 int ark_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, void* stream);

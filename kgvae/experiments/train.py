@@ -225,7 +225,8 @@ def save_checkpoint(path, epoch, model, config, val_loss, vocabs, dataset_meta, 
             "optimizer_state_dict": optimizer_state(model, lr_next, base_lr if use_sched else None),
             "scheduler_state_dict": scheduler_state(base_lr, t_max, eta_min, epoch) if use_sched else None,
             "val_loss": val_loss, "config": {k: v for k, v in config.items()}, "vocabs": vocabs, "dataset_meta": dataset_meta,
-            "ark_amd": {"adam_steps": eng.adam_steps, "dropout_draws": eng.dropout_draws(), "best_val_loss": best_val_loss,
+            "ark_amd": {"adam_steps": eng.adam_steps, "dropout_draws": eng.dropout_draws(), "noise_draws": eng.noise_draws(),
+                        "best_val_loss": best_val_loss,
                         "cuda_rng_state": torch.cuda.get_rng_state(eng.device), "cpu_rng_state": torch.get_rng_state(),
                         "python_rng_state": random.getstate()}}
     torch.save(ckpt, path, _use_new_zipfile_serialization=False)
@@ -251,6 +252,7 @@ def load_checkpoint(path, model, device):
     extra = ckpt.get("ark_amd") or {}
     eng.set_optimizer_step(int(extra.get("adam_steps", step)))
     eng.set_dropout_draws(int(extra.get("dropout_draws", 0)))
+    eng.set_noise_draws(int(extra.get("noise_draws", 0)))
     if extra.get("cuda_rng_state") is not None:
         torch.cuda.set_rng_state(extra["cuda_rng_state"], device)
         torch.set_rng_state(extra["cpu_rng_state"])
@@ -376,11 +378,6 @@ def main(argv=None):
         if model_type == "SAIL":
             b = config["beta0"] + (config["beta1"] - config["beta0"]) * epoch / num_epochs
         lr = cosine_lr(base_lr, epoch, num_epochs, eta_min) if use_sched else base_lr
-        if nranks > 1:
-            # the latent noise is drawn on the device inside the step: every rank needs its OWN stream (the same seed on
-            # every rank would repeat one rank's noise nranks times across the global batch), re-derived from
-            # (seed, epoch, rank) so that a resumed run -- which loads rank 0's generator state -- splits again
-            torch.cuda.manual_seed((seed * 1000003 + epoch) * 8191 + rank)
         t0 = time.time()
         train_loss, train_recon, train_kl, _ = train_epoch(model, train_ds, config, device, b, lr, (rank, nranks),
                                                            config.get("max_steps_per_epoch"),

@@ -1,0 +1,73 @@
+"""The library's own latent-noise generator (ark_normal_fill; replaces torch.randn_like(mu), reference models.py:63):
+distribution, freshness per launch / graph replay, per-rank streams, and the checkpointable draw counter."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _fill(n, seed, hyper):
+    from ark_amd import _lib as L
+    out = torch.empty(n, device="cuda")
+    L.check(L.lib().ark_normal_fill(L.ptr(out), L.i64(n), L.u64(seed), L.ptr(hyper), L.cur_stream()), "ark_normal_fill")
+    return out
+
+
+def test_normal_fill_is_standard_normal_and_counter_based():
+    hyper = torch.zeros(16, device="cuda")
+    x = _fill(1 << 20, 1234, hyper).double().cpu().numpy()
+    assert abs(x.mean()) < 4e-3 and abs(x.std() - 1.0) < 4e-3
+    assert abs(((x - x.mean()) ** 3).mean()) < 1.5e-2                      # skewness 0
+    assert abs(((x - x.mean()) ** 4).mean() - 3.0) < 5e-2                  # kurtosis 3
+    for q, want in ((0.5, 0.0), (0.8413447, 1.0), (0.9772499, 2.0), (0.0013499, -3.0)):
+        assert abs(np.quantile(x, q) - want) < 2e-2, q
+    assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 4e-3 and abs(np.corrcoef(x[0::2], x[1::2])[0, 1]) < 4e-3
+    assert int(hyper.view(torch.int32)[13]) == 1                           # the launch bumped the draw counter
+    y = _fill(1 << 20, 1234, hyper).double().cpu().numpy()                 # next draw: fresh values
+    assert abs(np.corrcoef(x, y)[0, 1]) < 4e-3
+    hyper.view(torch.int32)[13] = 0                                        # same (seed, draw) -> the same values
+    assert np.array_equal(_fill(1 << 20, 1234, hyper).double().cpu().numpy(), x)
+    hyper.view(torch.int32)[13] = 0
+    z = _fill(1 << 20, 1235, hyper).double().cpu().numpy()                 # another seed: another stream
+    assert abs(np.corrcoef(x, z)[0, 1]) < 4e-3
+    odd = _fill(7, 5, hyper).cpu()
+    assert odd.shape == (7,) and torch.isfinite(odd).all()
+
+
+def test_engine_noise_is_fresh_per_step_per_rank_and_resumable():
+    from ark_amd.engine import Engine
+    from oracle import sail_oracle as O
+    from tests.parity_util import load_golden, synth_batch
+    _, cfg = load_golden("sail_synpaths_b32_s0")
+    cfg = dict(cfg, seed=7)
+    P = O.init_params(cfg, 0)
+    tri, seq = synth_batch(cfg, 64, seed=3)
+    tri, seq = tri.cuda(), seq.cuda()
+    engs = [Engine(cfg, "cuda:0", precision="mixed", world_size=2, rank=r) for r in (0, 1)]
+    eps = []
+    for e in engs:
+        e.load_params(P)
+        e.forward(tri, seq)
+        eps.append(e.ws["eps0"].clone())
+    assert not torch.equal(eps[0], eps[1]) and abs(float(eps[0].std()) - 1.0) < 0.2      # ranks draw different noise
+    e = engs[0]
+    assert e.noise_draws() == 1
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        step = e.capture_train_step(tri, seq)       # eps drawn INSIDE the captured step
+        a = e.ws["eps0"].clone()
+        step()
+        b = e.ws["eps0"].clone()
+        step()
+        c = e.ws["eps0"].clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(a, b) and not torch.equal(b, c)                                 # every replay draws afresh
+    n = e.noise_draws()
+    e.set_noise_draws(n - 1)                                                               # resume: rewind one draw
+    with torch.cuda.stream(st):
+        step()
+    torch.cuda.synchronize()
+    assert torch.equal(e.ws["eps0"], c)
