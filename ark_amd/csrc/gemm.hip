@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const int row = m0 + r, col = n0 + c;
     if (row >= M || col >= N) return;
     const long o = (long)row * p.ldc + col;
-    if (epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU) v += p.bias[col];
+    if (epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_BIAS_RELU) v += p.bias[col];
+    if (epi == ARK_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+    if (epi == ARK_EPI_MUL_RELU) v = p.aux[o] > 0.f ? v : 0.f;
     if (epi == ARK_EPI_BIAS_GELU) {
       p.C[o] = v;               // pre-activation, kept for the backward pass
       p.C2[o] = gelu_erf(v);    // activation
@@ -132,10 +134,10 @@ extern "C" int ark_gemm(int prec, int a_lay, int b_lay, int epi, const float* A,
                         int M, int N, int K, int accumulate, void* stream) {
   using namespace ark;
   if (M <= 0 || N <= 0 || K < 0 || !A || !B || !C) return ARK_ERR_ARG;
-  if ((epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU) && !bias) return ARK_ERR_ARG;
+  if ((epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_BIAS_RELU) && !bias) return ARK_ERR_ARG;
   if (epi == ARK_EPI_BIAS_GELU && !C2) return ARK_ERR_ARG;
-  if ((epi == ARK_EPI_MUL_DGELU || epi == ARK_EPI_MUL_AUX) && !aux) return ARK_ERR_ARG;
-  if (epi < 0 || epi > ARK_EPI_MUL_AUX) return ARK_ERR_ARG;
+  if ((epi == ARK_EPI_MUL_DGELU || epi == ARK_EPI_MUL_AUX || epi == ARK_EPI_MUL_RELU) && !aux) return ARK_ERR_ARG;
+  if (epi < 0 || epi > ARK_EPI_MUL_RELU) return ARK_ERR_ARG;
   GemmArgs p{A, B, C, C2, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, accumulate, 0, 1, K};
   hipStream_t st = (hipStream_t)stream;
   if (prec == PREC_F32) return dispatch_lay<PREC_F32>(a_lay, b_lay, p, st);

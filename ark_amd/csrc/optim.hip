@@ -304,10 +304,28 @@ extern "C" int ark_normal_fill(float* out, int64_t n, uint64_t seed, float* hype
   return 0;
 }
 
+namespace ark {
+// plain kernel (an ordinary node of a captured graph, ordered like every other launch): 16 B per lane, grid-stride
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, long n_words) {
+  const long n4 = n_words >> 2;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+    reinterpret_cast<u32x4*>(p)[i] = u32x4{0u, 0u, 0u, 0u};
+  if (blockIdx.x == 0 && threadIdx.x < (n_words & 3)) p[4 * n4 + threadIdx.x] = 0u;
+}
+}  // namespace ark
+
 extern "C" int ark_zero(void* ptr, int64_t nbytes, void* stream) {
-  if (!ptr || nbytes < 0) return ARK_ERR_ARG;
+  if (!ptr || nbytes < 0 || (nbytes & 3) != 0) return ARK_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(ptr) & 15) != 0) return ARK_ERR_ALIGN;
   if (nbytes == 0) return 0;
-  return (int)hipMemsetAsync(ptr, 0, (size_t)nbytes, (hipStream_t)stream);
+  const long words = nbytes >> 2;
+  long blocks = (words / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ark::zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint32_t*>(ptr), words);
+  ARK_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int ark_adam_tick(float* hyper, void* stream) {

@@ -223,7 +223,7 @@ class Engine:
         self.hyper.view(torch.int32)[HP["NOISE_STEP"]:HP["NOISE_STEP"] + 1].fill_(int(n) - (1 << 32) if int(n) >= (1 << 31) else int(n))
 
     def _zero(self, t):
-        """zero a contiguous device tensor on the current queue (library call; a memset node inside a captured graph)"""
+        """zero a contiguous device tensor on the current queue (library kernel)"""
         _call("ark_zero", L.ptr(t), L.i64(t.numel() * t.element_size()), L.cur_stream())
 
     def _layer_seed(self, l):

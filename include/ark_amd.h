@@ -32,6 +32,8 @@ extern "C" {
 #define ARK_EPI_BIAS_GELU 2 /* C = acc + bias (pre-act), C2 = gelu_erf(C) */
 #define ARK_EPI_MUL_DGELU 3 /* C = acc * gelu_erf'(aux[row,col])         */
 #define ARK_EPI_MUL_AUX 4   /* C = acc * aux[row,col]                    */
+#define ARK_EPI_BIAS_RELU 5 /* C = max(acc + bias[col], 0)   (Transformer feed-forward, nn.TransformerEncoderLayer default activation) */
+#define ARK_EPI_MUL_RELU 6  /* C = aux[row,col] > 0 ? acc : 0 (its backward: aux = the activation) */
 
 int ark_version(void);
 
@@ -313,7 +315,7 @@ int ark_argmax_rows(const float* x, int64_t ld, int64_t* out, int rows, int V, v
  * (two 32-bit hashes -> Box-Muller) -- so a captured graph replays fresh noise every step and ranks with different seeds
  * draw independent streams.  The launch bumps the draw counter.  One workgroup (n is B * d_latent). */
 int ark_normal_fill(float* out, int64_t n, uint64_t seed, float* hyper, void* stream);
-/* zero `nbytes` bytes (a memset node under graph capture) */
+/* zero `nbytes` bytes (multiple of 4, 16-byte aligned start): a plain kernel, ordered like every other launch of the stream */
 int ark_zero(void* ptr, int64_t nbytes, void* stream);
 /* ---- optimiser and reductions (reference: optim.Adam, ablation_study.py:571,76) ---------------- */
 int ark_adam_tick(float* hyper, void* stream);

@@ -17,6 +17,8 @@ Reference call sites restated (paths relative to the reference repo):
   kl_mean .................................. kgvae/model/models.py:199-200
   GRU decoder (tok_emb, z_proj, GRU, out) .. kgvae/model/models.py:116-142
   decoder-only ARK (tok+pos emb, GRU, out) . kgvae/model/models.py:323-345, 395-405
+  decoder-only t-ARK (Transformer) ......... kgvae/model/models.py:349-366 (stock nn.TransformerEncoderLayer: post-norm,
+                                             ReLU feed-forward 2048, causal mask; restated as explicit math)
   ELBO assembly (ce + b*kl) ................ kgvae/experiments/ablation_study.py:59-73
   Adam step ................................ kgvae/experiments/ablation_study.py:571,76
   greedy decode (beam=1) ................... kgvae/model/models.py:262-266, 282-300
@@ -76,6 +78,22 @@ def init_params(cfg, seed):
         tok = nn.Embedding(V, D)
         pos = nn.Embedding(cfg["seq_len"], D)
         P["dec.tok_emb.weight"], P["dec.pos_emb.weight"] = tok.weight, pos.weight
+    elif mt == "t-ARK":
+        # DecoderOnlyTransformer (models.py:349-359): tok_emb, pos_emb, ONE stock TransformerEncoderLayer that
+        # nn.TransformerEncoder deep-copies n times (every layer starts from the same tensors), out (tied)
+        tok = nn.Embedding(V, D)
+        pos = nn.Embedding(cfg["seq_len"], D)
+        P["dec.tok_emb.weight"], P["dec.pos_emb.weight"] = tok.weight, pos.weight
+        layer = nn.TransformerEncoderLayer(D, cfg["n_heads"], batch_first=True, dropout=0.0)
+        lsd = layer.state_dict()
+        for i in range(n):
+            for k, v in lsd.items():
+                P[f"dec.txf.layers.{i}.{k}"] = v.clone()
+        out = nn.Linear(D, V)
+        tied = cfg.get("tie_weights", True) and out.weight.shape == tok.weight.shape
+        P["dec.out.weight"] = tok.weight if tied else out.weight
+        P["dec.out.bias"] = out.bias
+        return _detach_tied(P, tied)
     else:
         raise NotImplementedError(f"Unknown model_type: {mt}")
     gru = nn.GRU(D, D, n, batch_first=True, dropout=0.0)
@@ -170,13 +188,68 @@ def decoder_forward(P, z, seq_in, cfg, drop_masks=None):
 
 
 def ark_forward(P, seq_in, cfg, drop_masks=None):
-    """decoder-only ARK: logits[B,L,V]   (models.py:340-345)"""
+    """decoder-only ARK: logits[B,L,V]   (models.py:340-345); model_type t-ARK: the Transformer of tark_forward"""
+    if cfg["model_type"] == "t-ARK":
+        return tark_forward(P, seq_in, cfg, drop_masks)
     n = cfg["n_layers"]
     B, L = seq_in.shape
     x = P["dec.tok_emb.weight"][seq_in] + P["dec.pos_emb.weight"][torch.arange(L)].unsqueeze(0)
     h0 = torch.zeros(n, B, cfg["d_model"], dtype=x.dtype)
     y = gru_stack(P, x, h0, n, drop_masks)
     return y @ P["dec.out.weight"].t() + P["dec.out.bias"]
+
+
+def layer_norm(x, g, b, eps=1e-5):
+    """nn.LayerNorm over the last dimension (biased variance)"""
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * g + b
+
+
+def self_attention(x, w_in, b_in, w_out, b_out, n_heads, causal, drop_p=None):
+    """nn.MultiheadAttention(batch_first=True) on q = k = v = x [B, L, D]: packed in-projection (rows q | k | v),
+    heads of D / n_heads, scores / sqrt(head dim), -inf above the diagonal (the reference's boolean triu mask,
+    models.py:364), softmax, optional dropout mask ON THE PROBABILITIES (already scaled by 1/(1-p)), out-projection"""
+    B, L, D = x.shape
+    dh = D // n_heads
+    qkv = x @ w_in.t() + b_in
+    q, k, v = (t.reshape(B, L, n_heads, dh).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    sc = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    if causal:
+        sc = sc.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), float("-inf"))
+    pr = torch.softmax(sc, dim=-1)
+    if drop_p is not None:
+        pr = pr * drop_p
+    o = (pr @ v).transpose(1, 2).reshape(B, L, D)
+    return o @ w_out.t() + b_out
+
+
+def txf_encoder_layer(P, pre, x, n_heads, causal, masks=None):
+    """nn.TransformerEncoderLayer, stock defaults (post-norm, ReLU feed-forward): x = LN1(x + drop1(SA(x)));
+    x = LN2(x + drop2(W2 drop(relu(W1 x)))).  masks (optional): dict of dropout keep-scales for the four dropout sites
+    ("attn" [B,h,L,L], "sa" / "ff2" [B,L,D], "ff1" [B,L,F]); None = no dropout (eval, or p = 0)."""
+    m = masks or {}
+    sa = self_attention(x, P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"],
+                        P[pre + "self_attn.out_proj.weight"], P[pre + "self_attn.out_proj.bias"], n_heads, causal, m.get("attn"))
+    if "sa" in m:
+        sa = sa * m["sa"]
+    x = layer_norm(x + sa, P[pre + "norm1.weight"], P[pre + "norm1.bias"])
+    h = torch.relu(x @ P[pre + "linear1.weight"].t() + P[pre + "linear1.bias"])
+    if "ff1" in m:
+        h = h * m["ff1"]
+    ff = h @ P[pre + "linear2.weight"].t() + P[pre + "linear2.bias"]
+    if "ff2" in m:
+        ff = ff * m["ff2"]
+    return layer_norm(x + ff, P[pre + "norm2.weight"], P[pre + "norm2.bias"])
+
+
+def tark_forward(P, seq_in, cfg, masks=None):
+    """decoder-only Transformer t-ARK: logits [B, L, V]   (DecoderOnlyTransformer.forward, models.py:361-366)"""
+    B, L = seq_in.shape
+    x = P["dec.tok_emb.weight"][seq_in] + P["dec.pos_emb.weight"][torch.arange(L)].unsqueeze(0)
+    for i in range(cfg["n_layers"]):
+        x = txf_encoder_layer(P, f"dec.txf.layers.{i}.", x, cfg["n_heads"], True, None if masks is None else masks[i])
+    return x @ P["dec.out.weight"].t() + P["dec.out.bias"]
 
 
 def kl_mean(mu, logv):

@@ -291,3 +291,59 @@ def test_ark_posterior_bits_match_the_reference_records():
     ar = O.ark_posterior_bits(P, torch.from_numpy(g["ark_tiny/seq"])[:n], cfg)
     np.testing.assert_allclose(ar, g["ark_tiny/ar_bits"], rtol=2e-5)
     assert np.all(g["ark_tiny/kl_bits"] == 0)
+
+
+# ---- Transformer variant t-ARK (reference models.py:349-366): the oracle's explicit-math restatement of the stock
+# nn.TransformerEncoderLayer stack against goldens of the REAL reference (tools/make_golden_txf.py)
+@pytest.mark.parametrize("name", ["tark_tiny", "tark_small", "tark_synpaths_b32_s0"])
+def test_tark_oracle_matches_reference(name):
+    z, cfg = load(name)
+    torch.set_num_threads(8)
+    P = O.init_params(cfg, int(z["seed"]))
+    for k in [f[len("w0sum/"):] for f in z.files if f.startswith("w0sum/")]:   # bit-identical initial weights
+        v = P[k].double()
+        # (float64 sums of the SAME float32 values: equal up to the summation order of the threaded reduction)
+        assert abs(float(v.sum()) - float(z["w0sum/" + k])) <= 1e-12 * v.numel() and \
+            abs(float((v * v).sum()) - float(z["w0sq/" + k])) <= 1e-12 * v.numel(), k
+    seq = torch.from_numpy(z["seq"])
+    st = O.adam_init(O.leaf_params(P))
+    for s in range(len(z["losses"])):
+        loss, ce, kl, grads = O.train_step(P, st, (None, seq), cfg, float(z["lr"]))
+        assert abs(loss - z["losses"][s][0]) <= 2e-5 * abs(z["losses"][s][0]), (s, loss, z["losses"][s])
+        if s == 0:
+            for (k, _), g in zip(O.leaf_params(P), grads):
+                want = float(z["g0norm/" + k])
+                assert abs(float(g.double().norm()) - want) <= 2e-4 * want + 1e-7, k
+                if "g0/" + k in z.files:
+                    np.testing.assert_allclose(g.numpy(), z["g0/" + k], rtol=2e-3, atol=2e-5 * (np.abs(z["g0/" + k]).max() + 1e-12))
+            if "w1/dec.tok_emb.weight" in z.files:
+                # Adam's first step is lr * sign(g): where the true gradient is zero (the key bias of a softmax attention:
+                # a shift of every score of a row) rounding noise decides the sign -- compare where |g| is not noise
+                for k, v in O.leaf_params(P):
+                    g0 = np.abs(z["g0/" + k])
+                    live = g0 > 1e-5 * (g0.max() + 1e-30)
+                    np.testing.assert_allclose(v.numpy()[live], z["w1/" + k][live], rtol=1e-4, atol=2e-6)
+        for k, v in O.leaf_params(P):
+            want = float(z[f"w{s + 1}sum/" + k])   # (sums: loose enough for the +-lr sign noise of zero-gradient elements)
+            assert abs(float(v.double().sum()) - want) <= 5e-4 * abs(want) + 2e-3 * (s + 1) * max(1.0, v.numel() / 64), (s, k)
+    if "logits0" in z.files:
+        P0 = O.init_params(cfg, int(z["seed"]))
+        with torch.no_grad():
+            lg = O.ark_forward(P0, seq[:, :-1], cfg)
+        np.testing.assert_allclose(lg.numpy(), z["logits0"], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name", ["tark_tiny", "tark_small"])
+def test_tark_generation_and_bits_match_reference(name):
+    """greedy AND sampled generations (the reference's draw order) and the teacher-forced AR bits of t-ARK from the seed's
+    initial weights, token for token / to 2e-5"""
+    z, cfg = load(name)
+    P = O.init_params(cfg, int(z["seed"]))
+    B = z["gen_greedy"].shape[0]
+    assert np.array_equal(O.ark_generate(P, cfg, B).numpy(), z["gen_greedy"])
+    for i, (temp, top_p, top_k) in enumerate(z["gen_combos"]):
+        torch.manual_seed(500 + i)
+        got = O.ark_generate(P, cfg, B, sample=True, temperature=float(temp), top_p=float(top_p), top_k=int(top_k))
+        assert np.array_equal(got.numpy(), z[f"gen_seq{i}"]), (name, i)
+    n = len(z["bits_ar"])
+    np.testing.assert_allclose(O.ark_posterior_bits(P, torch.from_numpy(z["seq"])[:n], cfg), z["bits_ar"], rtol=3e-5)
