@@ -315,6 +315,30 @@ __global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, lon
 }
 }  // namespace ark
 
+namespace ark {
+__global__ __launch_bounds__(256) void copy_kernel(uint32_t* __restrict__ d, const uint32_t* __restrict__ s, long n_words) {
+  const long n4 = n_words >> 2;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+    reinterpret_cast<u32x4*>(d)[i] = reinterpret_cast<const u32x4*>(s)[i];
+  if (blockIdx.x == 0 && threadIdx.x < (n_words & 3)) d[4 * n4 + threadIdx.x] = s[4 * n4 + threadIdx.x];
+}
+}  // namespace ark
+
+extern "C" int ark_copy(void* dst, const void* src, int64_t nbytes, void* stream) {
+  if (!dst || !src || nbytes < 0 || (nbytes & 3) != 0) return ARK_ERR_ARG;
+  if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) != 0) return ARK_ERR_ALIGN;
+  if (nbytes == 0) return 0;
+  const long words = nbytes >> 2;
+  long blocks = (words / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ark::copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint32_t*>(dst),
+                     reinterpret_cast<const uint32_t*>(src), words);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ark_zero(void* ptr, int64_t nbytes, void* stream) {
   if (!ptr || nbytes < 0 || (nbytes & 3) != 0) return ARK_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(ptr) & 15) != 0) return ARK_ERR_ALIGN;

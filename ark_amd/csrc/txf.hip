@@ -1,0 +1,373 @@
+// Transformer-variant kernels (t-ARK: reference kgvae/model/models.py:349-366, the stock nn.TransformerEncoderLayer with
+// its defaults -- post-norm, ReLU feed-forward, causal boolean mask): residual + LayerNorm, causal multi-head attention and
+// the counter-hash dropout of its four dropout sites, forward and backward.  The dense products of the layers run on the
+// generic tile engine (gemm.hip: exact-fp32 or 16-bit MFMA operands, bias / ReLU epilogues).
+//
+// Layout: rows are TIME-MAJOR like everything else in this library -- row (t, b) = t * B + b -- so the token gather, the
+// vocabulary projection and the cross-entropy kernels are shared with the GRU models.  Head h of token (t, b) is the
+// dh-wide slice [h * dh, (h + 1) * dh) of its row; qkv rows are [q | k | v] (nn.MultiheadAttention's packed in-projection).
+//
+// Attention is exact fp32 on the vector units: one wave per query row (scores: one key per lane; softmax by wave
+// reductions; context: one head column per lane), probabilities kept for the backward pass.  L is at most 640 here
+// (wd-articles: 637), head widths 8 ... 256.
+#include "common.h"
+#include "../../include/ark_amd.h"
+
+namespace ark {
+
+constexpr int kAttnMaxChunks = 10;   // keys per lane: L <= 640
+constexpr int kAttnMaxDh = 256;      // head width: 4 columns per lane
+
+// ---------------------------------------------------------------------------------------------------------------------
+// y = LayerNorm(x + res) * gamma + beta over the last dimension (biased variance, eps inside the root: nn.LayerNorm);
+// s_out (nullable) keeps x + res, stats keeps (mean, 1/sqrt(var + eps)) per row for the backward pass.  One wave per row.
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ s_out, float* __restrict__ y,
+                                                            float* __restrict__ stats, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * D;
+  const float* rr = res ? res + (long)row * D : nullptr;
+  float sum = 0.f;
+  for (int c = lane; c < D; c += 64) sum += xr[c] + (rr ? rr[c] : 0.f);
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float d = xr[c] + (rr ? rr[c] : 0.f) - mean;
+    sq += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+  for (int c = lane; c < D; c += 64) {
+    const float v = xr[c] + (rr ? rr[c] : 0.f);
+    if (s_out) s_out[(long)row * D + c] = v;
+    y[(long)row * D + c] = (v - mean) * rstd * gamma[c] + beta[c];
+  }
+  if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// ds = gradient w.r.t. the normalised sum s; dgamma / dbeta accumulate (+=).  With xhat = (s - mean) * rstd and
+// g = dy * gamma:  ds = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)).  A workgroup takes RPW rows per wave and keeps the
+// per-column sums of its rows in registers (column = lane + 64 k), combines its four waves in LDS: one atomic per column.
+template <int CPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            float* __restrict__ ds, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int rows, int D, int rows_per_wg) {
+  __shared__ float red[2][4][64 * CPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[CPL], ab[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) ag[k] = ab[k] = 0.f;
+  const int r0 = blockIdx.x * rows_per_wg;
+  for (int row = r0 + wave; row < min(rows, r0 + rows_per_wg); row += 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float g[CPL], xh[CPL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      const bool ok = c < D;
+      const float dyv = ok ? dy[(long)row * D + c] : 0.f;
+      xh[k] = ok ? (s[(long)row * D + c] - mean) * rstd : 0.f;
+      g[k] = ok ? dyv * gamma[c] : 0.f;
+      s1 += g[k];
+      s2 += g[k] * xh[k];
+      ag[k] += dyv * xh[k];
+      ab[k] += dyv;
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      if (c < D) ds[(long)row * D + c] = rstd * (g[k] - s1 - xh[k] * s2);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) { red[0][wave][lane + 64 * k] = ag[k]; red[1][wave][lane + 64 * k] = ab[k]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    atomicAdd(&dgamma[c], a);
+    atomicAdd(&dbeta[c], b);
+  }
+}
+
+// x[i] *= keep-scale(i) of the current dropout draw (common.h dropout_quad: hyper[ARK_HP_DROP_STEP], `seed`): forward on an
+// activation, backward on its gradient -- the same (seed, draw, index) gives the same mask.
+__global__ __launch_bounds__(256) void dropout_apply_kernel(float* __restrict__ x, long n4, uint64_t seed,
+                                                            const float* __restrict__ hyper, float p) {
+  const DropCtx dc = drop_ctx(seed, hyper, p);
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<f32x4*>(x)[q];
+    reinterpret_cast<f32x4*>(x)[q] = v * dropout_quad(dc, (uint64_t)q);
+  }
+}
+
+struct AttnArgs {
+  const float* qkv;     // [L*B, 3D] time-major rows: q | k | v
+  float* out;           // [L*B, D] context (forward output; read by the backward for delta = dO . O)
+  float* probs;         // [B, H, L, L] softmax probabilities BEFORE dropout (row i, column j; 0 beyond the causal limit)
+  const float* dout;    // backward: gradient of `out`
+  float* dscore;        // backward scratch [B, H, L, L]: dS * scale
+  float* dqkv;          // backward output [L*B, 3D]
+  const float* hyper;
+  uint64_t seed;
+  float drop_p, scale;
+  int B, L, D, H, dh, causal;
+};
+
+__device__ __forceinline__ float attn_keep(const DropCtx& dc, bool drop, long idx) { return drop ? dropout_one(dc, (uint64_t)idx) : 1.0f; }
+
+// one wave per query row i of one (batch b, head h): scores over the keys j <= i (causal) or all keys
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  __shared__ float qs[4][kAttnMaxDh];
+  __shared__ float ps[4][64 * kAttnMaxChunks];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int i = blockIdx.y * 4 + wave;
+  if (i >= p.L) return;   // (whole wave; no block-wide barrier below)
+  const int B = p.B, L = p.L, D = p.D, dh = p.dh;
+  const long rs = 3L * D;
+  const float* q = p.qkv + ((long)i * B + b) * rs + h * dh;
+  for (int d = lane; d < dh; d += 64) qs[wave][d] = q[d] * p.scale;
+  const int nk = p.causal ? i + 1 : L;
+  const bool drop = p.drop_p > 0.f;
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(p.seed, p.hyper, p.drop_p);
+  float sc[kAttnMaxChunks];
+  float m = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < kAttnMaxChunks; ++c) {
+    const int j = c * 64 + lane;
+    float s = -INFINITY;
+    if (c * 64 < nk && j < nk) {
+      const float* k = p.qkv + ((long)j * B + b) * rs + D + h * dh;
+      float a = 0.f;
+      for (int d = 0; d < dh; d += 4) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(k + d);
+        a += qs[wave][d] * kv[0] + qs[wave][d + 1] * kv[1] + qs[wave][d + 2] * kv[2] + qs[wave][d + 3] * kv[3];
+      }
+      s = a;
+    }
+    sc[c] = s;
+    m = fmaxf(m, s);
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < kAttnMaxChunks; ++c) {
+    sc[c] = (sc[c] == -INFINITY) ? 0.f : expf(sc[c] - m);
+    sum += sc[c];
+  }
+  const float inv = 1.0f / wave_sum(sum);
+  const long prow = (((long)b * p.H + h) * L + i) * L;
+#pragma unroll
+  for (int c = 0; c < kAttnMaxChunks; ++c) {
+    const int j = c * 64 + lane;
+    if (j < L) {
+      const float pr = sc[c] * inv;
+      p.probs[prow + j] = pr;
+      ps[wave][j] = pr * attn_keep(dc, drop, prow + j);
+    }
+  }
+  // context: column d = lane + 64 k of this head
+  float acc[kAttnMaxDh / 64] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < nk; ++j) {
+    const float pj = ps[wave][j];
+    const float* v = p.qkv + ((long)j * B + b) * rs + 2 * D + h * dh;
+#pragma unroll
+    for (int k = 0; k < kAttnMaxDh / 64; ++k) {
+      const int d = lane + 64 * k;
+      if (d < dh) acc[k] += pj * v[d];
+    }
+  }
+  float* o = p.out + ((long)i * B + b) * D + h * dh;
+#pragma unroll
+  for (int k = 0; k < kAttnMaxDh / 64; ++k) {
+    const int d = lane + 64 * k;
+    if (d < dh) o[d] = acc[k];
+  }
+}
+
+// backward, query side: dS[i, :] (kept for the key side) and dQ[i].  With M the dropout keep-scale and Pm = P o M:
+//   dPm[i, j] = dO[i] . V[j],  delta[i] = sum_j Pm[i, j] dPm[i, j] = dO[i] . O[i],  dS = P o (M o dPm - delta)
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
+  __shared__ float dos[4][kAttnMaxDh];
+  __shared__ float dss[4][64 * kAttnMaxChunks];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int i = blockIdx.y * 4 + wave;
+  if (i >= p.L) return;
+  const int B = p.B, L = p.L, D = p.D, dh = p.dh;
+  const long rs = 3L * D;
+  const float* dO = p.dout + ((long)i * B + b) * D + h * dh;
+  const float* O = p.out + ((long)i * B + b) * D + h * dh;
+  float dl = 0.f;
+  for (int d = lane; d < dh; d += 64) {
+    const float g = dO[d];
+    dos[wave][d] = g;
+    dl += g * O[d];
+  }
+  const float delta = wave_sum(dl);
+  const int nk = p.causal ? i + 1 : L;
+  const bool drop = p.drop_p > 0.f;
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(p.seed, p.hyper, p.drop_p);
+  const long prow = (((long)b * p.H + h) * L + i) * L;
+  for (int c = 0; c * 64 < L; ++c) {
+    const int j = c * 64 + lane;
+    if (j >= L) continue;
+    float ds = 0.f;
+    if (j < nk) {
+      const float* v = p.qkv + ((long)j * B + b) * rs + 2 * D + h * dh;
+      float a = 0.f;
+      for (int d = 0; d < dh; d += 4) {
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(v + d);
+        a += dos[wave][d] * vv[0] + dos[wave][d + 1] * vv[1] + dos[wave][d + 2] * vv[2] + dos[wave][d + 3] * vv[3];
+      }
+      ds = p.probs[prow + j] * (a * attn_keep(dc, drop, prow + j) - delta) * p.scale;
+    }
+    p.dscore[prow + j] = ds;
+    dss[wave][j] = ds;
+  }
+  float acc[kAttnMaxDh / 64] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < nk; ++j) {
+    const float dj = dss[wave][j];
+    const float* k = p.qkv + ((long)j * B + b) * rs + D + h * dh;
+#pragma unroll
+    for (int kk = 0; kk < kAttnMaxDh / 64; ++kk) {
+      const int d = lane + 64 * kk;
+      if (d < dh) acc[kk] += dj * k[d];
+    }
+  }
+  float* dq = p.dqkv + ((long)i * B + b) * rs + h * dh;
+#pragma unroll
+  for (int kk = 0; kk < kAttnMaxDh / 64; ++kk) {
+    const int d = lane + 64 * kk;
+    if (d < dh) dq[d] = acc[kk];
+  }
+}
+
+// backward, key side: dK[j] = sum_i dS[i, j] Q[i] (dS already carries the 1/sqrt(dh) scale), dV[j] = sum_i Pm[i, j] dO[i]
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
+  __shared__ float dsc[4][64 * kAttnMaxChunks];
+  __shared__ float pmc[4][64 * kAttnMaxChunks];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int j = blockIdx.y * 4 + wave;
+  if (j >= p.L) return;
+  const int B = p.B, L = p.L, D = p.D, dh = p.dh;
+  const long rs = 3L * D;
+  const int i0 = p.causal ? j : 0;
+  const bool drop = p.drop_p > 0.f;
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(p.seed, p.hyper, p.drop_p);
+  const long base = ((long)b * p.H + h) * L * L;
+  for (int i = i0 + lane; i < L; i += 64) {
+    const long idx = base + (long)i * L + j;
+    dsc[wave][i] = p.dscore[idx];
+    pmc[wave][i] = p.probs[idx] * attn_keep(dc, drop, idx);
+  }
+  float ak[kAttnMaxDh / 64] = {0.f, 0.f, 0.f, 0.f}, av[kAttnMaxDh / 64] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = i0; i < L; ++i) {
+    const float ds = dsc[wave][i], pm = pmc[wave][i];
+    const float* q = p.qkv + ((long)i * B + b) * rs + h * dh;
+    const float* dO = p.dout + ((long)i * B + b) * D + h * dh;
+#pragma unroll
+    for (int kk = 0; kk < kAttnMaxDh / 64; ++kk) {
+      const int d = lane + 64 * kk;
+      if (d < dh) { ak[kk] += ds * q[d]; av[kk] += pm * dO[d]; }
+    }
+  }
+  float* dk = p.dqkv + ((long)j * B + b) * rs + D + h * dh;
+  float* dv = p.dqkv + ((long)j * B + b) * rs + 2 * D + h * dh;
+#pragma unroll
+  for (int kk = 0; kk < kAttnMaxDh / 64; ++kk) {
+    const int d = lane + 64 * kk;
+    if (d < dh) { dk[d] = ak[kk]; dv[d] = av[kk]; }
+  }
+}
+
+static int attn_check(const AttnArgs& p) {
+  if (p.B <= 0 || p.L <= 0 || p.D <= 0 || p.H <= 0 || p.D % p.H != 0) return ARK_ERR_ARG;
+  if (p.L > 64 * kAttnMaxChunks || p.dh > kAttnMaxDh || p.dh % 4 != 0) return ARK_ERR_SHAPE;
+  if (p.drop_p < 0.f || p.drop_p >= 1.f || (p.drop_p > 0.f && !p.hyper)) return ARK_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(p.qkv) & 15) != 0) return ARK_ERR_ALIGN;
+  return 0;
+}
+
+}  // namespace ark
+
+extern "C" int ark_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* s_out, float* y,
+                                 float* stats, int rows, int D, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !stats || rows <= 0 || D <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(ark::layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
+                     beta, s_out, y, stats, rows, D, eps);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_layernorm_bwd(const float* dy, const float* s, const float* stats, const float* gamma, float* ds, float* dgamma,
+                                 float* dbeta, int rows, int D, void* stream) {
+  using namespace ark;
+  if (!dy || !s || !stats || !gamma || !ds || !dgamma || !dbeta || rows <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (D > 64 * 24) return ARK_ERR_SHAPE;   // (3 * d_model of the widest shipped config fits: 3 * 512)
+  int rpw = (rows + 511) / 512;            // ~512 workgroups, whole groups of 4 rows
+  rpw = (rpw + 3) / 4 * 4;
+  const unsigned grid = (unsigned)((rows + rpw - 1) / rpw);
+  hipStream_t st = (hipStream_t)stream;
+#define ARK_LN_BWD(C) hipLaunchKernelGGL((layernorm_bwd_kernel<C>), dim3(grid), dim3(256), 0, st, dy, s, stats, gamma, ds, dgamma, dbeta, rows, D, rpw)
+  if (D <= 64) ARK_LN_BWD(1);
+  else if (D <= 128) ARK_LN_BWD(2);
+  else if (D <= 256) ARK_LN_BWD(4);
+  else if (D <= 512) ARK_LN_BWD(8);
+  else if (D <= 1024) ARK_LN_BWD(16);
+  else ARK_LN_BWD(24);
+#undef ARK_LN_BWD
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_dropout_apply(float* x, int64_t n, float p, uint64_t seed, const float* hyper, void* stream) {
+  using namespace ark;
+  if (!x || !hyper || n <= 0 || p <= 0.f || p >= 1.f) return ARK_ERR_ARG;
+  if (n % 4 != 0) return ARK_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return ARK_ERR_ALIGN;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)(n / 4), seed, hyper, p);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_attn_fwd(const float* qkv, float* out, float* probs, int B, int L, int D, int n_heads, int causal, float drop_p,
+                            uint64_t seed, const float* hyper, void* stream) {
+  using namespace ark;
+  if (!qkv || !out || !probs) return ARK_ERR_ARG;
+  AttnArgs p{qkv, out, probs, nullptr, nullptr, nullptr, hyper, seed, drop_p, 0.f, B, L, D, n_heads, n_heads > 0 ? D / n_heads : 0, causal};
+  int rc = attn_check(p);
+  if (rc) return rc;
+  p.scale = 1.0f / sqrtf((float)p.dh);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * n_heads), (unsigned)((L + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_attn_bwd(const float* qkv, const float* out, const float* probs, const float* dout, float* dscore, float* dqkv, int B,
+                            int L, int D, int n_heads, int causal, float drop_p, uint64_t seed, const float* hyper, void* stream) {
+  using namespace ark;
+  if (!qkv || !out || !probs || !dout || !dscore || !dqkv) return ARK_ERR_ARG;
+  AttnArgs p{qkv, const_cast<float*>(out), const_cast<float*>(probs), dout, dscore, dqkv, hyper, seed, drop_p, 0.f, B, L, D, n_heads,
+             n_heads > 0 ? D / n_heads : 0, causal};
+  int rc = attn_check(p);
+  if (rc) return rc;
+  p.scale = 1.0f / sqrtf((float)p.dh);
+  const dim3 grid((unsigned)(B * n_heads), (unsigned)((L + 3) / 4));
+  hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}

@@ -36,6 +36,18 @@ def build_modules(cfg):
     elif mt == "ARK":
         dec["tok_emb"] = nn.Embedding(V, D)
         dec["pos_emb"] = nn.Embedding(cfg["seq_len"], D)
+    elif mt == "t-ARK":
+        # DecoderOnlyTransformer (reference models.py:349-359): ONE stock encoder layer is initialised and
+        # nn.TransformerEncoder deep-copies it n times -- every layer starts from the same tensors
+        drop = cfg.get("dec_dropout", 0.1)
+        dec["tok_emb"] = nn.Embedding(V, D)
+        dec["pos_emb"] = nn.Embedding(cfg["seq_len"], D)
+        layer = nn.TransformerEncoderLayer(D, cfg["n_heads"], batch_first=True, dropout=drop)
+        dec["txf"] = nn.TransformerEncoder(layer, n)
+        dec["out"] = nn.Linear(D, V)
+        if cfg.get("tie_weights", True) and dec["out"].weight.shape == dec["tok_emb"].weight.shape:
+            dec["out"].weight = dec["tok_emb"].weight
+        return enc, dec
     else:
         raise NotImplementedError(f"Unknown model_type: {mt}")
     drop = cfg.get("dec_dropout", 0.1)

@@ -310,6 +310,27 @@ int ark_loss_finalize_rows(const float* row_loss, int n_rows, const float* kl_ro
                            const float* hyper, float* out4, void* stream);
 int ark_argmax_rows(const float* x, int64_t ld, int64_t* out, int rows, int V, void* stream);
 
+/* ---- Transformer variant t-ARK (reference: DecoderOnlyTransformer, kgvae/model/models.py:349-366 = stock
+ *      nn.TransformerEncoderLayer stack: post-norm, ReLU feed-forward, causal mask).  Rows are time-major (t, b);
+ *      the dense products run on ark_gemm (ARK_EPI_BIAS / ARK_EPI_BIAS_RELU / ARK_EPI_MUL_RELU). ------------------------ */
+/* y = LayerNorm(x + res) * gamma + beta (res nullable); s_out (nullable) = x + res; stats[row] = (mean, rstd) */
+int ark_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* s_out, float* y,
+                      float* stats, int rows, int D, float eps, void* stream);
+/* ds = dL/d(x + res) from dy, the saved sum s and stats; dgamma / dbeta ACCUMULATE (+=) */
+int ark_layernorm_bwd(const float* dy, const float* s, const float* stats, const float* gamma, float* ds, float* dgamma,
+                      float* dbeta, int rows, int D, void* stream);
+/* x[i] *= keep-scale of element i for the current dropout draw (hyper[ARK_HP_DROP_STEP]) under `seed`: applied to an
+ * activation in the forward pass and to its gradient in the backward pass (n % 4 == 0) */
+int ark_dropout_apply(float* x, int64_t n, float p, uint64_t seed, const float* hyper, void* stream);
+/* multi-head scaled-dot-product attention of nn.MultiheadAttention on packed qkv rows [L*B, 3D] = [q | k | v]:
+ * out [L*B, D] = (softmax(q k^T / sqrt(dh) + causal mask) o dropout) v per (batch, head); probs [B, H, L, L] keeps the
+ * probabilities BEFORE dropout for the backward pass (the mask is a counter hash, regenerated there).  L <= 640, dh <= 256 */
+int ark_attn_fwd(const float* qkv, float* out, float* probs, int B, int L, int D, int n_heads, int causal, float drop_p,
+                 uint64_t seed, const float* hyper, void* stream);
+/* dqkv [L*B, 3D] from dout; dscore [B, H, L, L] is scratch */
+int ark_attn_bwd(const float* qkv, const float* out, const float* probs, const float* dout, float* dscore, float* dqkv, int B,
+                 int L, int D, int n_heads, int causal, float drop_p, uint64_t seed, const float* hyper, void* stream);
+
 /* out[0:n] = N(0,1) draws for the reparameterisation noise (reference: torch.randn_like(mu), kgvae/model/models.py:63):
  * counter-based -- element i of draw number hyper[ARK_HP_NOISE_STEP] under `seed` is a pure function of (seed, draw, i)
  * (two 32-bit hashes -> Box-Muller) -- so a captured graph replays fresh noise every step and ranks with different seeds
@@ -317,6 +338,8 @@ int ark_argmax_rows(const float* x, int64_t ld, int64_t* out, int rows, int V, v
 int ark_normal_fill(float* out, int64_t n, uint64_t seed, float* hyper, void* stream);
 /* zero `nbytes` bytes (multiple of 4, 16-byte aligned start): a plain kernel, ordered like every other launch of the stream */
 int ark_zero(void* ptr, int64_t nbytes, void* stream);
+/* device-to-device copy of `nbytes` bytes (multiple of 4, 16-byte aligned ends): a plain kernel */
+int ark_copy(void* dst, const void* src, int64_t nbytes, void* stream);
 /* ---- optimiser and reductions (reference: optim.Adam, ablation_study.py:571,76) ---------------- */
 int ark_adam_tick(float* hyper, void* stream);
 int ark_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, void* stream);

@@ -342,12 +342,12 @@ def main(argv=None):
     if verifier is None and main_rank:
         print(f"Warning: No verifier available for dataset {dataset_name}")
 
-    if model_type == "ARK":
+    if model_type in ("ARK", "t-ARK"):
         model = ARK(config).to(device)
     elif model_type == "SAIL":
         model = SAIL(config).to(device)
     else:
-        raise NotImplementedError(f"Model type '{model_type}' is not implemented. Use one of: 'ARK','SAIL'.")
+        raise NotImplementedError(f"Model type '{model_type}' is not implemented. Use one of: 'ARK','t-ARK','SAIL'.")
     if main_rank:
         print(f"Using model: {model_type}")
     eng = model.engine()

@@ -15,8 +15,8 @@ Two ways to train:
   * fused -- `model.train_step(triples, seq, beta=b, lr=lr)`: ELBO, backward and Adam stay on the
     device (what kgvae.experiments.train and bench.py use).
 
-Transformer variants (`t-SAIL`, `t-ARK`) are outside the hot path this repository covers and raise
-NotImplementedError, as unknown model types do in the reference (models.py:172,197,393).
+`t-ARK` (decoder-only Transformer) runs on ark_amd.txf_engine.TxfEngine; `t-SAIL` (Transformer VAE) is not built and
+raises NotImplementedError, as unknown model types do in the reference (models.py:172,197,393).
 """
 import math
 
@@ -66,10 +66,12 @@ class _EngineModel(nn.Module):
         named = dict(self.named_parameters())
         if self._eng is None or self._eng.device != dev:
             from ark_amd.engine import Engine
+            from ark_amd.txf_engine import TxfEngine
             import torch.distributed as dist
             live = dist.is_available() and dist.is_initialized()
-            self._eng = Engine(self.config, dev, precision=self.precision, world_size=dist.get_world_size() if live else 1,
-                               rank=dist.get_rank() if live else 0)
+            cls = TxfEngine if self.config["model_type"] == "t-ARK" else Engine
+            self._eng = cls(self.config, dev, precision=self.precision, world_size=dist.get_world_size() if live else 1,
+                            rank=dist.get_rank() if live else 0)
             self._adopt(named)
         else:
             for k, prm in named.items():  # .to() re-allocates storage
@@ -304,14 +306,15 @@ class SAIL(_EngineModel):
 
 
 class ARK(_EngineModel):
-    """decoder-only GRU: tok_emb + pos_emb -> GRU (h0 = 0) -> tied vocabulary projection."""
-    _kinds = ("ARK",)
+    """decoder-only models (reference models.py:368-405): `ARK` = tok_emb + pos_emb -> GRU (h0 = 0) -> tied vocabulary
+    projection; `t-ARK` = the same embeddings -> causal stack of stock Transformer encoder layers -> tied projection
+    (DecoderOnlyTransformer, models.py:349-366; engine: ark_amd.txf_engine.TxfEngine)."""
+    _kinds = ("ARK", "t-ARK")
 
     def __init__(self, config):
-        if config["model_type"] == "t-ARK":
-            raise NotImplementedError("t-ARK (decoder-only Transformer) is outside the MI355X hot path of this build")
         super().__init__(config)
-        print("Using GRU Decoder")
+        if config["model_type"] == "ARK":
+            print("Using GRU Decoder")
 
     def _tri(self, triples):
         return None
@@ -367,10 +370,11 @@ class ARK(_EngineModel):
         B = batch_size
         bos, eos = special_tokens["BOS"], special_tokens["EOS"]
         eng = self.engine()
-        d = eng.decode_begin(B)
+        txf = self.config["model_type"] == "t-ARK"   # (no recurrent state: the prefix is re-run, as the reference does)
+        d = None if txf else eng.decode_begin(B)
         seq = torch.full((B, 1), bos, dtype=torch.long, device=device)
         for t in range(seq_len - 1):
-            logits = eng.decode_step(d, seq[:, -1].contiguous(), t)
+            logits = eng.prefix_logits(seq) if txf else eng.decode_step(d, seq[:, -1].contiguous(), t)
             if not sample:
                 nxt = logits.argmax(dim=-1, keepdim=True)
             else:

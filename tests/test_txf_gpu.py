@@ -1,0 +1,200 @@
+"""t-ARK (decoder-only Transformer; reference models.py:349-366) on the MI355X engine: the new kernels against torch /
+the oracle, the train step against goldens of the REAL reference (tools/make_golden_txf.py), generation and bits."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.parity_util import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _call(name, *a):
+    from ark_amd import _lib as L
+    L.check(getattr(L.lib(), name)(*a), name)
+
+
+@pytest.mark.parametrize("rows,D,with_res", [(37, 32, True), (256, 512, True), (5, 1536, False), (130, 96, True)])
+def test_layernorm_fwd_bwd_match_torch(rows, D, with_res):
+    from ark_amd import _lib as L
+    torch.manual_seed(0)
+    x = torch.randn(rows, D, device="cuda") * 2 + 0.3
+    res = torch.randn(rows, D, device="cuda") if with_res else None
+    g, b = torch.randn(D, device="cuda"), torch.randn(D, device="cuda")
+    dy = torch.randn(rows, D, device="cuda")
+    s_out, y, stats = torch.empty_like(x), torch.empty_like(x), torch.empty(rows, 2, device="cuda")
+    _call("ark_layernorm_fwd", L.ptr(x), L.ptr(res), L.ptr(g), L.ptr(b), L.ptr(s_out), L.ptr(y), L.ptr(stats), L.i32(rows), L.i32(D),
+          L.f32(1e-5), L.cur_stream())
+    s = (x + res if with_res else x).double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    want = torch.nn.functional.layer_norm(s, (D,), gd, bd, 1e-5)
+    want.backward(dy.double())
+    assert torch.allclose(y.double(), want, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(s_out.double(), s.detach(), atol=1e-6)
+    ds, dg, db = torch.empty_like(x), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    _call("ark_layernorm_bwd", L.ptr(dy), L.ptr(s_out), L.ptr(stats), L.ptr(g), L.ptr(ds), L.ptr(dg), L.ptr(db), L.i32(rows), L.i32(D),
+          L.cur_stream())
+    assert torch.allclose(ds.double(), s.grad, atol=3e-5, rtol=1e-4)
+    assert torch.allclose(dg.double(), gd.grad, atol=1e-4 * rows ** 0.5, rtol=1e-4)
+    assert torch.allclose(db.double(), bd.grad, atol=1e-4 * rows ** 0.5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,Lq,D,H", [(3, 10, 32, 4), (2, 70, 128, 4), (1, 130, 512, 4), (2, 9, 1024, 4)])
+def test_attention_fwd_bwd_match_torch(B, Lq, D, H):
+    """causal multi-head attention on time-major packed qkv rows against torch (fp64), forward and backward"""
+    from ark_amd import _lib as L
+    torch.manual_seed(1)
+    dh = D // H
+    qkv = torch.randn(Lq * B, 3 * D, device="cuda")
+    dout = torch.randn(Lq * B, D, device="cuda")
+    out, probs = torch.empty(Lq * B, D, device="cuda"), torch.empty(B * H * Lq * Lq, device="cuda")
+    _call("ark_attn_fwd", L.ptr(qkv), L.ptr(out), L.ptr(probs), L.i32(B), L.i32(Lq), L.i32(D), L.i32(H), L.i32(1), L.f32(0.0),
+          L.u64(0), L.ptr(None), L.cur_stream())
+    x = qkv.double().view(Lq, B, 3, H, dh).requires_grad_(True)
+    q, k, v = (x[:, :, i].permute(1, 2, 0, 3) for i in range(3))          # [B, H, L, dh]
+    sc = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    sc = sc.masked_fill(torch.triu(torch.ones(Lq, Lq, dtype=torch.bool, device="cuda"), 1), float("-inf"))
+    pr = torch.softmax(sc, -1)
+    o = (pr @ v).permute(2, 0, 1, 3).reshape(Lq * B, D)
+    o.backward(dout.double())
+    assert torch.allclose(out.double(), o, atol=3e-5, rtol=1e-4)
+    assert torch.allclose(probs.view(B, H, Lq, Lq).double(), pr, atol=2e-6)
+    dsc, dqkv = torch.empty_like(probs), torch.empty_like(qkv)
+    _call("ark_attn_bwd", L.ptr(qkv), L.ptr(out), L.ptr(probs), L.ptr(dout), L.ptr(dsc), L.ptr(dqkv), L.i32(B), L.i32(Lq), L.i32(D),
+          L.i32(H), L.i32(1), L.f32(0.0), L.u64(0), L.ptr(None), L.cur_stream())
+    want = x.grad.reshape(Lq * B, 3 * D)
+    assert torch.allclose(dqkv.double(), want, atol=2e-4, rtol=2e-3), (dqkv.double() - want).abs().max()
+
+
+def _model(name, precision="f32", **over):
+    from kgvae.model.models import ARK
+    z, cfg = load_golden(name)
+    cfg = dict(cfg, precision=precision, **over)
+    torch.manual_seed(int(z["seed"]))
+    return ARK(cfg).to("cuda"), z, cfg
+
+
+@pytest.mark.parametrize("name", ["tark_tiny", "tark_small", "tark_synpaths_b32_s0"])
+def test_tark_train_steps_match_reference_goldens(name):
+    """exact-fp32 mode: logits, loss of 3 consecutive Adam steps, every gradient (norms; full tensors for the tiny case) and
+    the weights after step 1 against the REAL reference's numbers"""
+    model, z, cfg = _model(name)
+    eng = model.engine()
+    seq = torch.from_numpy(z["seq"]).cuda()
+    eng.set_hyper(lr=float(z["lr"]))
+    if "logits0" in z.files:
+        logits = model(seq[:, :-1].contiguous())
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), z["logits0"], rtol=3e-4, atol=3e-4)
+    for s in range(len(z["losses"])):
+        out4 = eng.train_step(None, seq).cpu().numpy()
+        assert rel_err(float(out4[0]), z["losses"][s][0]) < 2e-5 * (1 + 4 * s), (s, out4, z["losses"][s])
+        if s == 0:
+            for k in [f[7:] for f in z.files if f.startswith("g0norm/")]:
+                want = float(z["g0norm/" + k])
+                assert abs(float(eng.g[k].double().norm()) - want) <= 3e-4 * want + 1e-6, k
+                if "g0/" + k in z.files:
+                    g0 = z["g0/" + k]
+                    np.testing.assert_allclose(eng.g[k].cpu().numpy(), g0, rtol=3e-3, atol=3e-5 * (np.abs(g0).max() + 1e-12))
+            if "w1/dec.tok_emb.weight" in z.files:
+                for k in [f[3:] for f in z.files if f.startswith("w1/") and f[3:] in eng.p and "g0/" + f[3:] in z.files]:
+                    g0 = np.abs(z["g0/" + k])
+                    live = g0 > 1e-4 * (g0.max() + 1e-30)   # (Adam's first step is lr * sign(g): compare where g is not rounding noise)
+                    np.testing.assert_allclose(eng.p[k].cpu().numpy()[live], z["w1/" + k][live], rtol=1e-4, atol=3e-6)
+
+
+def test_tark_reference_style_loop_and_mixed_precision():
+    """the reference's own loop (model(seq), F.cross_entropy, loss.backward(), optim.Adam) on the engine-backed module; and
+    the 16-bit-operand mode's loss within 1e-4 of the oracle at a BASELINE-sized batch"""
+    import torch.nn.functional as F
+    from oracle import sail_oracle as O
+    from tests.parity_util import synth_batch
+    model, z, cfg = _model("tark_tiny")
+    seq = torch.from_numpy(z["seq"]).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=float(z["lr"]))
+    for s in range(2):
+        opt.zero_grad()
+        logits = model(seq[:, :-1].contiguous())
+        ce = F.cross_entropy(logits.reshape(-1, logits.size(-1)), seq[:, 1:].reshape(-1), ignore_index=0)
+        ce.backward()
+        opt.step()
+        assert rel_err(float(ce), z["losses"][s][0]) < 1e-4, (s, float(ce), z["losses"][s])
+    m2, z2, cfg2 = _model("tark_synpaths_b32_s0", precision="mixed")
+    P = O.init_params(cfg2, int(z2["seed"]))
+    _, seq2 = synth_batch(cfg2, 256, seed=4)
+    with torch.no_grad():
+        want, _ = O.ark_loss(P, seq2, cfg2)
+    got = m2.eval_loss(None, seq2.cuda()).cpu().numpy()
+    assert rel_err(float(got[0]), float(want)) < 1e-4, (got, float(want))
+
+
+@pytest.mark.parametrize("name", ["tark_tiny", "tark_small"])
+def test_tark_generation_and_bits_match_reference(name):
+    """ARK.generate for t-ARK (greedy; sampling with host draws = the reference's draw order) token for token, and
+    ARK.posterior_bits (one teacher-forced pass) against the reference's per-item records"""
+    from kgvae.model.utils import GraphSeqDataset
+    model, z, cfg = _model(name)
+    model.eval()
+    st = cfg["special_tokens"]
+    B = z["gen_greedy"].shape[0]
+    assert np.array_equal(model.generate(cfg["seq_len"], st, batch_size=B).cpu().numpy(), z["gen_greedy"])
+    for i, (temp, top_p, top_k) in enumerate(z["gen_combos"]):
+        torch.manual_seed(500 + i)
+        got = model.generate(cfg["seq_len"], st, batch_size=B, sample=True, temperature=float(temp), top_p=float(top_p),
+                             top_k=int(top_k), host_draws=True)
+        assert np.array_equal(got.cpu().numpy(), z[f"gen_seq{i}"]), (name, i)
+    graphs = [[tuple(int(x) for x in t) for t in g] for g in z["triples"]]
+    ds = GraphSeqDataset(graphs, None, None, special_tokens=st, ent_base=cfg["ENT_BASE"], rel_base=cfg["REL_BASE"], seq_len=cfg["seq_len"])
+    n = len(z["bits_ar"])
+    stats = model.posterior_bits(ds, "cuda", sample_frac=n / len(graphs))
+    np.testing.assert_allclose([r["ar_bits"] for r in stats["records"]], z["bits_ar"], rtol=5e-5)
+
+
+def test_tark_dropout_is_consistent_between_forward_and_backward():
+    """dropout 0.1 at the four sites (counter-hash masks regenerated in the backward pass): the analytic gradient of the
+    SAME masked network -- finite differences of the loss under a frozen draw counter -- matches the backward pass"""
+    model, z, cfg = _model("tark_tiny", dec_dropout=0.1)
+    eng = model.engine()
+    eng.training = True
+    seq = torch.from_numpy(z["seq"]).cuda()
+
+    def loss_at():
+        eng.set_dropout_draws(7)   # (the gather bumps it to 8 for this forward: every call sees the same masks)
+        return float(eng.forward(None, seq)["out4"][0])
+
+    eng.set_dropout_draws(7)
+    eng.forward(None, seq)
+    eng.backward()
+    torch.cuda.synchronize()
+    base = loss_at()
+    assert abs(base - float(z["losses"][0][0])) > 1e-3      # dropout is on: not the dropout-free golden loss
+    for k, idx in [("dec.txf.layers.1.linear2.weight", (3, 100)), ("dec.txf.layers.0.self_attn.in_proj_weight", (5, 7)),
+                   ("dec.txf.layers.0.norm1.weight", (4,)), ("dec.pos_emb.weight", (2, 3)), ("dec.txf.layers.1.linear1.bias", (17,))]:
+        g = float(eng.g[k][idx])
+        old = float(eng.p[k][idx])
+        h = 1e-2
+        eng.p[k][idx] = old + h
+        up = loss_at()
+        eng.p[k][idx] = old - h
+        dn = loss_at()
+        eng.p[k][idx] = old
+        fd = (up - dn) / (2 * h)
+        assert abs(fd - g) <= 2e-2 * max(abs(g), abs(fd)) + 2e-3, (k, idx, g, fd)
+
+
+def test_tark_through_the_train_entry_point(tmp_path):
+    """`model_type: t-ARK` trains end to end through kgvae.experiments.train.main() (reference dispatch: train.py:427-444)"""
+    import os
+    import yaml
+    from kgvae.experiments import train as T
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "configs", "sail_syn-paths.yaml")))
+    cfg.update(model_type="t-ARK", d_model=64, n_heads=4, n_layers=2, num_epochs=2, batch_size=64, save_every=2,
+               compression_log_every=2, verify_every=100, learning_rate=1e-3, precision="mixed",
+               synthetic_sizes={"n_train": 256, "n_val": 64, "n_test": 64}, dump_final_params=str(tmp_path / "P"))
+    cpath = tmp_path / "c.yaml"
+    yaml.safe_dump(cfg, open(cpath, "w"))
+    T.main(["--config", str(cpath), "--checkpoint-dir", str(tmp_path / "ck")])
+    P = torch.load(str(tmp_path / "P.rank0.pt"), weights_only=True)
+    assert torch.isfinite(P).all()
