@@ -27,7 +27,8 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
 // head[b, 0:Z] = mu, head[b, Z:2Z] = raw logv.  Single workgroup -> deterministic KL sum.
 __global__ __launch_bounds__(1024) void latent_fwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
                                                           float* __restrict__ mu, float* __restrict__ logv,
-                                                          float* __restrict__ z, float* __restrict__ kl_out, int B, int Z) {
+                                                          float* __restrict__ z, float* __restrict__ kl_out, int B, int Z,
+                                                          int clamp) {
   __shared__ float red[16];
   float acc = 0.f;
   const int n = B * Z;
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(1024) void latent_fwd_kernel(const float* __restric
     const int b = i / Z, j = i % Z;
     const float m = head[(long)b * 2 * Z + j];
     float lv = head[(long)b * 2 * Z + Z + j];
-    lv = fminf(fmaxf(lv, -10.0f), 10.0f);
+    if (clamp) lv = fminf(fmaxf(lv, -10.0f), 10.0f);   // (the MLP encoder clamps, models.py:62; the Transformer encoder does not, :93)
     mu[i] = m;
     logv[i] = lv;
     z[i] = m + (eps ? eps[i] : 0.f) * expf(0.5f * lv);
@@ -49,18 +50,18 @@ __global__ __launch_bounds__(1024) void latent_fwd_kernel(const float* __restric
 // only where the raw logv lies inside [-10, 10] (torch.clamp semantics, boundary inclusive).
 __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ head,
                                                          const float* __restrict__ eps, const float* __restrict__ hyper,
-                                                         float* __restrict__ dhead, int B, int Z) {
+                                                         float* __restrict__ dhead, int B, int Z, int clamp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * Z) return;
   const int b = i / Z, j = i % Z;
   const float ks = hyper[ARK_HP_BETA] * hyper[ARK_HP_KL_NORM];  // beta / (B_global * Z)
   const float m = head[(long)b * 2 * Z + j];
   const float raw = head[(long)b * 2 * Z + Z + j];
-  const float lv = fminf(fmaxf(raw, -10.0f), 10.0f);
+  const float lv = clamp ? fminf(fmaxf(raw, -10.0f), 10.0f) : raw;
   const float g = dz[i];
   const float dmu = g + ks * m;
   float dlv = g * (eps ? eps[i] : 0.f) * 0.5f * expf(0.5f * lv) + ks * 0.5f * (expf(lv) - 1.0f);
-  if (raw < -10.0f || raw > 10.0f) dlv = 0.f;
+  if (clamp && (raw < -10.0f || raw > 10.0f)) dlv = 0.f;
   dhead[(long)b * 2 * Z + j] = dmu;
   dhead[(long)b * 2 * Z + Z + j] = dlv;
 }
@@ -617,7 +618,27 @@ extern "C" int ark_latent_fwd(const float* head, const float* eps, float* mu, fl
                               int B, int Z, void* stream) {
   using namespace ark;
   if (!head || !mu || !logv || !z || !kl_out || B <= 0 || Z <= 0) return ARK_ERR_ARG;
-  hipLaunchKernelGGL(latent_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, head, eps, mu, logv, z, kl_out, B, Z);
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, head, eps, mu, logv, z, kl_out, B, Z, 1);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same without the [-10, 10] clamp of logv when clamp == 0 (AutoRegEncoder of t-SAIL, reference models.py:93)
+extern "C" int ark_latent_fwd_ex(const float* head, const float* eps, float* mu, float* logv, float* z, float* kl_out,
+                                 int B, int Z, int clamp, void* stream) {
+  using namespace ark;
+  if (!head || !mu || !logv || !z || !kl_out || B <= 0 || Z <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, head, eps, mu, logv, z, kl_out, B, Z, clamp);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_latent_bwd_ex(const float* dz, const float* head, const float* eps, const float* hyper, float* dhead,
+                                 int B, int Z, int clamp, void* stream) {
+  using namespace ark;
+  if (!dz || !head || !hyper || !dhead || B <= 0 || Z <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3((B * Z + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz, head, eps, hyper,
+                     dhead, B, Z, clamp);
   ARK_LAUNCH_CHECK();
   return 0;
 }
@@ -627,7 +648,7 @@ extern "C" int ark_latent_bwd(const float* dz, const float* head, const float* e
   using namespace ark;
   if (!dz || !head || !hyper || !dhead || B <= 0 || Z <= 0) return ARK_ERR_ARG;
   hipLaunchKernelGGL(latent_bwd_kernel, dim3((B * Z + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz, head, eps, hyper,
-                     dhead, B, Z);
+                     dhead, B, Z, 1);
   ARK_LAUNCH_CHECK();
   return 0;
 }

@@ -339,6 +339,21 @@ extern "C" int ark_copy(void* dst, const void* src, int64_t nbytes, void* stream
   return 0;
 }
 
+namespace ark {
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float a) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+}  // namespace ark
+
+extern "C" int ark_axpy(float* y, const float* x, int64_t n, float a, void* stream) {
+  if (!y || !x || n <= 0) return ARK_ERR_ARG;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ark::axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, x, (long)n, a);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ark_zero(void* ptr, int64_t nbytes, void* stream) {
   if (!ptr || nbytes < 0 || (nbytes & 3) != 0) return ARK_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(ptr) & 15) != 0) return ARK_ERR_ALIGN;

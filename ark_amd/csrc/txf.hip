@@ -16,7 +16,7 @@
 namespace ark {
 
 constexpr int kAttnMaxChunks = 10;   // keys per lane: L <= 640
-constexpr int kAttnMaxDh = 256;      // head width: 4 columns per lane
+constexpr int kAttnMaxDh = 384;      // head width: up to 6 columns per lane (t-SAIL encoder: 3 * 512 / 4 heads)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // y = LayerNorm(x + res) * gamma + beta over the last dimension (biased variance, eps inside the root: nn.LayerNorm);
@@ -114,6 +114,7 @@ struct AttnArgs {
   float* dscore;        // backward scratch [B, H, L, L]: dS * scale
   float* dqkv;          // backward output [L*B, 3D]
   const float* hyper;
+  const unsigned char* kmask;   // [B, L] 1 = key may be attended to (nullable: all keys; src_key_padding_mask of the reference)
   uint64_t seed;
   float drop_p, scale;
   int B, L, D, H, dh, causal;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   for (int c = 0; c < kAttnMaxChunks; ++c) {
     const int j = c * 64 + lane;
     float s = -INFINITY;
-    if (c * 64 < nk && j < nk) {
+    if (c * 64 < nk && j < nk && (!p.kmask || p.kmask[(long)b * L + j])) {
       const float* k = p.qkv + ((long)j * B + b) * rs + D + h * dh;
       float a = 0.f;
       for (int d = 0; d < dh; d += 4) {
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
   }
   // context: column d = lane + 64 k of this head
-  float acc[kAttnMaxDh / 64] = {0.f, 0.f, 0.f, 0.f};
+  float acc[kAttnMaxDh / 64] = {};
   for (int j = 0; j < nk; ++j) {
     const float pj = ps[wave][j];
     const float* v = p.qkv + ((long)j * B + b) * rs + 2 * D + h * dh;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
     const int j = c * 64 + lane;
     if (j >= L) continue;
     float ds = 0.f;
-    if (j < nk) {
+    if (j < nk && (!p.kmask || p.kmask[(long)b * L + j])) {
       const float* v = p.qkv + ((long)j * B + b) * rs + 2 * D + h * dh;
       float a = 0.f;
       for (int d = 0; d < dh; d += 4) {
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
     p.dscore[prow + j] = ds;
     dss[wave][j] = ds;
   }
-  float acc[kAttnMaxDh / 64] = {0.f, 0.f, 0.f, 0.f};
+  float acc[kAttnMaxDh / 64] = {};
   for (int j = 0; j < nk; ++j) {
     const float dj = dss[wave][j];
     const float* k = p.qkv + ((long)j * B + b) * rs + D + h * dh;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
     dsc[wave][i] = p.dscore[idx];
     pmc[wave][i] = p.probs[idx] * attn_keep(dc, drop, idx);
   }
-  float ak[kAttnMaxDh / 64] = {0.f, 0.f, 0.f, 0.f}, av[kAttnMaxDh / 64] = {0.f, 0.f, 0.f, 0.f};
+  float ak[kAttnMaxDh / 64] = {}, av[kAttnMaxDh / 64] = {};
   for (int i = i0; i < L; ++i) {
     const float ds = dsc[wave][i], pm = pmc[wave][i];
     const float* q = p.qkv + ((long)i * B + b) * rs + h * dh;
@@ -288,6 +289,109 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
   for (int kk = 0; kk < kAttnMaxDh / 64; ++kk) {
     const int d = lane + 64 * kk;
     if (d < dh) { dk[d] = ak[kk]; dv[d] = av[kk]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// t-SAIL encoder input (AutoRegEncoder.forward, reference models.py:80-86): x[(t, b)] = [E[h] | R[r] | E[t]] of triple t of
+// graph b (rows time-major over the TRIPLE index), kmask[b, t] = (r != pad_rid).  One wave per row.
+__global__ __launch_bounds__(256) void triple_gather_kernel(const int64_t* __restrict__ triples, const float* __restrict__ E,
+                                                            const float* __restrict__ R, float* __restrict__ x,
+                                                            unsigned char* __restrict__ kmask, int B, int T, int D, long pad_rid) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T * B) return;
+  const int t = row / B, b = row % B;
+  const int64_t* tr = triples + ((long)b * T + t) * 3;
+  const long h = tr[0], r = tr[1], tl = tr[2];
+  float* o = x + (long)row * 3 * D;
+  for (int c = lane; c < D; c += 64) {
+    o[c] = E[h * D + c];
+    o[D + c] = R[r * D + c];
+    o[2 * D + c] = E[tl * D + c];
+  }
+  if (lane == 0 && kmask) kmask[(long)b * T + t] = (pad_rid < 0 || r != pad_rid) ? 1 : 0;
+}
+
+// its backward: dE[h] += dx[:, 0:D], dR[r] += dx[:, D:2D], dE[t] += dx[:, 2D:3D]; padding rows (nn.Embedding padding_idx) get none
+__global__ __launch_bounds__(256) void triple_scatter_kernel(const int64_t* __restrict__ triples, const float* __restrict__ dx,
+                                                             float* __restrict__ dE, float* __restrict__ dR, int B, int T, int D,
+                                                             long pad_eid, long pad_rid) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T * B) return;
+  const int t = row / B, b = row % B;
+  const int64_t* tr = triples + ((long)b * T + t) * 3;
+  const long h = tr[0], r = tr[1], tl = tr[2];
+  const float* g = dx + (long)row * 3 * D;
+  for (int c = lane; c < D; c += 64) {
+    if (h != pad_eid) atomicAdd(&dE[h * D + c], g[c]);
+    if (r != pad_rid) atomicAdd(&dR[r * D + c], g[D + c]);
+    if (tl != pad_eid) atomicAdd(&dE[tl * D + c], g[2 * D + c]);
+  }
+}
+
+// masked mean over the sequence axis of time-major rows: g[b] = sum_t m[b,t] x[(t,b)] / max(1, sum_t m[b,t])  (models.py:86-91)
+__global__ __launch_bounds__(256) void seq_pool_fwd_kernel(const float* __restrict__ x, const unsigned char* __restrict__ kmask,
+                                                           float* __restrict__ g, float* __restrict__ inv_cnt, int B, int T, int W) {
+  const int b = blockIdx.x;
+  int cnt = 0;
+  for (int t = 0; t < T; ++t) cnt += (!kmask || kmask[(long)b * T + t]) ? 1 : 0;
+  const float ic = 1.0f / (float)max(cnt, 1);
+  for (int c = threadIdx.x; c < W; c += 256) {
+    float a = 0.f;
+    for (int t = 0; t < T; ++t)
+      if (!kmask || kmask[(long)b * T + t]) a += x[((long)t * B + b) * W + c];
+    g[(long)b * W + c] = a * ic;
+  }
+  if (threadIdx.x == 0) inv_cnt[b] = ic;
+}
+
+__global__ __launch_bounds__(256) void seq_pool_bwd_kernel(const float* __restrict__ dg, const unsigned char* __restrict__ kmask,
+                                                           const float* __restrict__ inv_cnt, float* __restrict__ dx, int B, int T, int W) {
+  const long n = (long)T * B * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / W;
+    const int c = (int)(i % W), t = (int)(row / B), b = (int)(row % B);
+    dx[i] = (!kmask || kmask[(long)b * T + t]) ? dg[(long)b * W + c] * inv_cnt[b] : 0.f;
+  }
+}
+
+// Cross-attention of t-SAIL's decoder (nn.TransformerDecoderLayer.multihead_attn over a memory that is L copies of ONE row,
+// reference models.py:112): all L scores of a query are equal, the softmax is uniform and the context is the value row
+// itself -- times c[t, b, h] = (#keys the attention dropout keeps) / (L (1 - p)) in training mode, exactly what dropping
+// uniform probabilities does.  ctx[(t, b), h*dh + d] = c[t, b, h] * v[b, h*dh + d]; the query / key projections do not reach
+// the output (their gradients are exactly zero).  One wave per (t, b) row.
+__global__ __launch_bounds__(256) void xattn_bcast_fwd_kernel(const float* __restrict__ v, float* __restrict__ ctx,
+                                                              float* __restrict__ cscale, int B, int L, int D, int H, float p,
+                                                              uint64_t seed, const float* __restrict__ hyper) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= L * B) return;
+  const int t = row / B, b = row % B, dh = D / H;
+  for (int h = 0; h < H; ++h) {
+    float c = 1.0f;
+    if (p > 0.f) {
+      const DropCtx dc = drop_ctx(seed, hyper, p);
+      const long base = (((long)b * H + h) * L + t) * L;
+      float kept = 0.f;
+      for (int j = lane; j < L; j += 64) kept += dropout_one(dc, (uint64_t)(base + j));   // keep-scale 1/(1-p) or 0
+      c = wave_sum(kept) / (float)L;
+    }
+    if (lane == 0) cscale[(long)row * H + h] = c;
+    for (int d = lane; d < dh; d += 64) ctx[(long)row * D + h * dh + d] = c * v[(long)b * D + h * dh + d];
+  }
+}
+
+// dv[b, h*dh + d] = sum_t c[t, b, h] * dctx[(t, b), h*dh + d]
+__global__ __launch_bounds__(256) void xattn_bcast_bwd_kernel(const float* __restrict__ dctx, const float* __restrict__ cscale,
+                                                              float* __restrict__ dv, int B, int L, int D, int H) {
+  const int b = blockIdx.x, dh = D / H;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const int h = c / dh;
+    float a = 0.f;
+    for (int t = 0; t < L; ++t) a += cscale[((long)t * B + b) * H + h] * dctx[((long)t * B + b) * D + c];
+    dv[(long)b * D + c] = a;
   }
 }
 
@@ -343,11 +447,11 @@ extern "C" int ark_dropout_apply(float* x, int64_t n, float p, uint64_t seed, co
   return 0;
 }
 
-extern "C" int ark_attn_fwd(const float* qkv, float* out, float* probs, int B, int L, int D, int n_heads, int causal, float drop_p,
-                            uint64_t seed, const float* hyper, void* stream) {
+extern "C" int ark_attn_fwd(const float* qkv, float* out, float* probs, const unsigned char* kmask, int B, int L, int D, int n_heads,
+                            int causal, float drop_p, uint64_t seed, const float* hyper, void* stream) {
   using namespace ark;
   if (!qkv || !out || !probs) return ARK_ERR_ARG;
-  AttnArgs p{qkv, out, probs, nullptr, nullptr, nullptr, hyper, seed, drop_p, 0.f, B, L, D, n_heads, n_heads > 0 ? D / n_heads : 0, causal};
+  AttnArgs p{qkv, out, probs, nullptr, nullptr, nullptr, hyper, kmask, seed, drop_p, 0.f, B, L, D, n_heads, n_heads > 0 ? D / n_heads : 0, causal};
   int rc = attn_check(p);
   if (rc) return rc;
   p.scale = 1.0f / sqrtf((float)p.dh);
@@ -356,11 +460,12 @@ extern "C" int ark_attn_fwd(const float* qkv, float* out, float* probs, int B, i
   return 0;
 }
 
-extern "C" int ark_attn_bwd(const float* qkv, const float* out, const float* probs, const float* dout, float* dscore, float* dqkv, int B,
-                            int L, int D, int n_heads, int causal, float drop_p, uint64_t seed, const float* hyper, void* stream) {
+extern "C" int ark_attn_bwd(const float* qkv, const float* out, const float* probs, const float* dout, float* dscore, float* dqkv,
+                            const unsigned char* kmask, int B, int L, int D, int n_heads, int causal, float drop_p, uint64_t seed,
+                            const float* hyper, void* stream) {
   using namespace ark;
   if (!qkv || !out || !probs || !dout || !dscore || !dqkv) return ARK_ERR_ARG;
-  AttnArgs p{qkv, const_cast<float*>(out), const_cast<float*>(probs), dout, dscore, dqkv, hyper, seed, drop_p, 0.f, B, L, D, n_heads,
+  AttnArgs p{qkv, const_cast<float*>(out), const_cast<float*>(probs), dout, dscore, dqkv, hyper, kmask, seed, drop_p, 0.f, B, L, D, n_heads,
              n_heads > 0 ? D / n_heads : 0, causal};
   int rc = attn_check(p);
   if (rc) return rc;
@@ -368,6 +473,58 @@ extern "C" int ark_attn_bwd(const float* qkv, const float* out, const float* pro
   const dim3 grid((unsigned)(B * n_heads), (unsigned)((L + 3) / 4));
   hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
   hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_triple_gather(const int64_t* triples, const float* E, const float* R, float* x, unsigned char* kmask, int B, int T,
+                                 int D, int64_t pad_rid, void* stream) {
+  if (!triples || !E || !R || !x || B <= 0 || T <= 0 || D <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(ark::triple_gather_kernel, dim3((unsigned)((T * B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, triples, E, R, x,
+                     kmask, B, T, D, (long)pad_rid);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_triple_scatter(const int64_t* triples, const float* dx, float* dE, float* dR, int B, int T, int D, int64_t pad_eid,
+                                  int64_t pad_rid, void* stream) {
+  if (!triples || !dx || !dE || !dR || B <= 0 || T <= 0 || D <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(ark::triple_scatter_kernel, dim3((unsigned)((T * B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, triples, dx, dE,
+                     dR, B, T, D, (long)pad_eid, (long)pad_rid);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_seq_pool_fwd(const float* x, const unsigned char* kmask, float* g, float* inv_cnt, int B, int T, int W, void* stream) {
+  if (!x || !g || !inv_cnt || B <= 0 || T <= 0 || W <= 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(ark::seq_pool_fwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, kmask, g, inv_cnt, B, T, W);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_seq_pool_bwd(const float* dg, const unsigned char* kmask, const float* inv_cnt, float* dx, int B, int T, int W,
+                                void* stream) {
+  if (!dg || !inv_cnt || !dx || B <= 0 || T <= 0 || W <= 0) return ARK_ERR_ARG;
+  long blocks = ((long)T * B * W + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ark::seq_pool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dg, kmask, inv_cnt, dx, B, T, W);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_xattn_bcast_fwd(const float* v, float* ctx, float* cscale, int B, int L, int D, int n_heads, float drop_p,
+                                   uint64_t seed, const float* hyper, void* stream) {
+  if (!v || !ctx || !cscale || B <= 0 || L <= 0 || D <= 0 || n_heads <= 0 || D % n_heads != 0) return ARK_ERR_ARG;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !hyper)) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(ark::xattn_bcast_fwd_kernel, dim3((unsigned)((L * B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, v, ctx, cscale, B,
+                     L, D, n_heads, drop_p, seed, hyper);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_xattn_bcast_bwd(const float* dctx, const float* cscale, float* dv, int B, int L, int D, int n_heads, void* stream) {
+  if (!dctx || !cscale || !dv || B <= 0 || L <= 0 || D <= 0 || n_heads <= 0 || D % n_heads != 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(ark::xattn_bcast_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dctx, cscale, dv, B, L, D, n_heads);
   ARK_LAUNCH_CHECK();
   return 0;
 }

@@ -36,6 +36,22 @@ def build_modules(cfg):
     elif mt == "ARK":
         dec["tok_emb"] = nn.Embedding(V, D)
         dec["pos_emb"] = nn.Embedding(cfg["seq_len"], D)
+    elif mt == "t-SAIL":
+        # AutoRegEncoder (reference models.py:66-76) and AutoRegDecoder (models.py:98-106), constructor order; the stock layers
+        # are built with their DEFAULT dropout (0.1: the reference passes none) and deep-copied n times; `out` is not tied
+        Z, W = cfg["d_latent"], 3 * D
+        enc = OrderedDict()
+        enc["e_emb"] = nn.Embedding(cfg["n_entities"], D, padding_idx=cfg.get("pad_eid"))
+        enc["r_emb"] = nn.Embedding(cfg["n_relations"], D, padding_idx=cfg.get("pad_rid"))
+        enc["txf"] = nn.TransformerEncoder(nn.TransformerEncoderLayer(W, cfg["n_heads"], batch_first=True), cfg.get("n_layers", 2))
+        enc["mu"] = nn.Linear(W, Z)
+        enc["logv"] = nn.Linear(W, Z)
+        dec["tok_emb"] = nn.Embedding(V, D)
+        dec["pos_emb"] = nn.Embedding(cfg["seq_len"], D)
+        dec["z_proj"] = nn.Linear(Z, D)
+        dec["txf"] = nn.TransformerDecoder(nn.TransformerDecoderLayer(D, cfg["n_heads"], batch_first=True), n)
+        dec["out"] = nn.Linear(D, V)
+        return enc, dec
     elif mt == "t-ARK":
         # DecoderOnlyTransformer (reference models.py:349-359): ONE stock encoder layer is initialised and
         # nn.TransformerEncoder deep-copies it n times -- every layer starts from the same tensors

@@ -1,15 +1,21 @@
-"""Host-side engine of the decoder-only Transformer variant t-ARK on MI355X.
+"""Host-side engine of the Transformer variants t-ARK and t-SAIL on MI355X.
 
-Reference: DecoderOnlyTransformer (kgvae/model/models.py:349-366) -- token + learned position embeddings, a stack of stock
-nn.TransformerEncoderLayer (post-norm, ReLU feed-forward of width 2048, dropout `dec_dropout` at its four sites, causal
-boolean mask), tied output projection -- trained by the reference's ARK loop (kgvae/experiments/train.py:42-58: token
-cross-entropy, Adam).
+Reference (kgvae/model/models.py):
+  t-ARK   DecoderOnlyTransformer :349-366 -- token + learned position embeddings, a causal stack of stock
+          nn.TransformerEncoderLayer (post-norm, ReLU feed-forward of width 2048, dropout `dec_dropout`), tied projection;
+          trained by the ARK loop (kgvae/experiments/train.py:42-58).
+  t-SAIL  AutoRegEncoder :66-95 -- [E[h] | R[r] | E[t]] per triple, Transformer encoder over the triples (padded triples
+          masked as keys), masked mean, mu / logv heads WITHOUT the logv clamp, reparameterisation -- and AutoRegDecoder
+          :98-114 -- token + position embeddings, causal stock nn.TransformerDecoderLayer stack whose memory is z_proj(z)
+          repeated L times, UNTIED projection; layer dropout hard-coded 0.1; trained by the VAE loop
+          (kgvae/experiments/ablation_study.py:59-73: ce + b * kl).
 
 Same division of labour as ark_amd.engine.Engine, whose optimiser / step-scalar / gradient-buffer plumbing this class
 inherits: flat fp32 parameter, gradient and Adam-moment buffers, time-major activations (row (t, b) = t*B + b, so the token
-gather, vocabulary projection and cross-entropy kernels are the GRU models'), every op a hand-written gfx950 kernel
-behind the C-ABI (csrc/txf.hip: residual + LayerNorm, causal attention, counter-hash dropout; csrc/gemm.hip: the dense
-products, exact fp32 or 16-bit MFMA operands).  No torch arithmetic, no CPU fallback.
+gather, vocabulary projection, cross-entropy and latent kernels are the GRU models'), every op a hand-written gfx950
+kernel behind the C-ABI (csrc/txf.hip: residual + LayerNorm, masked / causal attention, the uniform cross-attention of the
+repeated memory, counter-hash dropout; csrc/gemm.hip: the dense products, exact fp32 or 16-bit MFMA operands).  No torch
+arithmetic, no CPU fallback.
 """
 from collections import OrderedDict
 
@@ -18,31 +24,69 @@ import torch
 from . import _lib as L
 from .engine import Engine, HP, PREC, _call, _rup
 
-FF = 2048          # nn.TransformerEncoderLayer default dim_feedforward (the reference never passes another)
+FF = 2048          # nn.Transformer*Layer default dim_feedforward (the reference never passes another)
 LN_EPS = 1e-5      # nn.LayerNorm default
+TXF_DROPOUT = 0.1  # nn.Transformer*Layer default dropout: what t-SAIL's layers are built with (models.py:73,104)
+
+
+def _attn_entries(pre, W):
+    return [(pre + "in_proj_weight", (3 * W, W)), (pre + "in_proj_bias", (3 * W,)), (pre + "out_proj.weight", (W, W)),
+            (pre + "out_proj.bias", (W,))]
+
+
+def _ff_entries(pre, W):
+    return [(pre + "linear1.weight", (FF, W)), (pre + "linear1.bias", (FF,)), (pre + "linear2.weight", (W, FF)),
+            (pre + "linear2.bias", (W,))]
+
+
+def _norm_entries(pre, W, names):
+    out = []
+    for nm in names:
+        out += [(pre + nm + ".weight", (W,)), (pre + nm + ".bias", (W,))]
+    return out
 
 
 class TxfLayout:
-    """name -> (offset, shape, numel) in state-dict order; 16-byte aligned blocks"""
+    """name -> (offset, shape, numel) in the reference's state-dict order; 16-byte aligned blocks"""
 
     def __init__(self, cfg):
+        mt = cfg["model_type"]
         D, n, V = cfg["d_model"], cfg["n_layers"], cfg["vocab_size"]
-        ents = [("dec.tok_emb.weight", (V, D)), ("dec.pos_emb.weight", (cfg["seq_len"], D))]
-        for i in range(n):
-            pre = f"dec.txf.layers.{i}."
-            ents += [(pre + "self_attn.in_proj_weight", (3 * D, D)), (pre + "self_attn.in_proj_bias", (3 * D,)),
-                     (pre + "self_attn.out_proj.weight", (D, D)), (pre + "self_attn.out_proj.bias", (D,)),
-                     (pre + "linear1.weight", (FF, D)), (pre + "linear1.bias", (FF,)),
-                     (pre + "linear2.weight", (D, FF)), (pre + "linear2.bias", (D,)),
-                     (pre + "norm1.weight", (D,)), (pre + "norm1.bias", (D,)), (pre + "norm2.weight", (D,)), (pre + "norm2.bias", (D,))]
-        self.tied = bool(cfg.get("tie_weights", True))
-        if not self.tied:
-            ents.append(("dec.out.weight", (V, D)))
-        ents.append(("dec.out.bias", (V,)))
+        ents = []
+        if mt == "t-SAIL":
+            W, Z = 3 * D, cfg["d_latent"]
+            ents += [("enc.e_emb.weight", (cfg["n_entities"], D)), ("enc.r_emb.weight", (cfg["n_relations"], D))]
+            for i in range(cfg.get("n_layers", 2)):
+                pre = f"enc.txf.layers.{i}."
+                ents += _attn_entries(pre + "self_attn.", W) + _ff_entries(pre, W) + _norm_entries(pre, W, ("norm1", "norm2"))
+            # mu and logv are adjacent (weights, then biases): the two heads run as ONE [2Z, 3D] product
+            ents += [("enc.mu.weight", (Z, W)), ("enc.logv.weight", (Z, W)), ("enc.mu.bias", (Z,)), ("enc.logv.bias", (Z,))]
+            ents += [("dec.tok_emb.weight", (V, D)), ("dec.pos_emb.weight", (cfg["seq_len"], D)), ("dec.z_proj.weight", (D, Z)),
+                     ("dec.z_proj.bias", (D,))]
+            for i in range(n):
+                pre = f"dec.txf.layers.{i}."
+                ents += _attn_entries(pre + "self_attn.", D) + _attn_entries(pre + "multihead_attn.", D) + _ff_entries(pre, D) + \
+                    _norm_entries(pre, D, ("norm1", "norm2", "norm3"))
+            self.tied = False
+            ents += [("dec.out.weight", (V, D)), ("dec.out.bias", (V,))]
+        elif mt == "t-ARK":
+            ents += [("dec.tok_emb.weight", (V, D)), ("dec.pos_emb.weight", (cfg["seq_len"], D))]
+            for i in range(n):
+                pre = f"dec.txf.layers.{i}."
+                ents += _attn_entries(pre + "self_attn.", D) + _ff_entries(pre, D) + _norm_entries(pre, D, ("norm1", "norm2"))
+            self.tied = bool(cfg.get("tie_weights", True))
+            if not self.tied:
+                ents.append(("dec.out.weight", (V, D)))
+            ents.append(("dec.out.bias", (V,)))
+        else:
+            raise NotImplementedError(f"Unknown model_type: {mt}")
         self.entries = OrderedDict()
         off = 0
+        prev_packed = False
         for name, shape in ents:
-            off = _rup(off, 4)
+            packed = name in ("enc.logv.weight", "enc.logv.bias")   # directly behind enc.mu.*: no alignment gap
+            if not packed:
+                off = _rup(off, 4)
             numel = 1
             for s in shape:
                 numel *= s
@@ -59,22 +103,29 @@ class TxfEngine(Engine):
         if self.device.type != "cuda":
             raise L.ArkError("ark_amd.TxfEngine needs a GPU device (no CPU fallback exists)")
         L.lib()
-        if cfg["model_type"] != "t-ARK":
+        if cfg["model_type"] not in ("t-ARK", "t-SAIL"):
             raise NotImplementedError(f"Unknown model_type: {cfg['model_type']}")
         self.prec_fwd, self.prec_bwd = PREC[precision]
         self.prec = self.prec_fwd
         self.precision = precision
-        self.mt = "t-ARK"
+        self.mt = cfg["model_type"]
+        self.vae = self.mt == "t-SAIL"
         self.D, self.n, self.V = cfg["d_model"], cfg["n_layers"], cfg["vocab_size"]
+        self.n_enc = cfg.get("n_layers", 2) if self.vae else 0
         self.H = cfg["n_heads"]
-        if self.D % self.H != 0 or (self.D // self.H) % 4 != 0 or self.D // self.H > 256:
-            raise L.ArkError("t-ARK: d_model / n_heads must be a multiple of 4 and at most 256")
-        self.Z = 0
+        widths = [self.D] + ([3 * self.D] if self.vae else [])
+        for W in widths:
+            if W % self.H != 0 or (W // self.H) % 4 != 0 or W // self.H > 384 or W > 1536:
+                raise L.ArkError(f"{self.mt}: layer width {W} / n_heads {self.H}: head widths must be multiples of 4 up to 384, "
+                                 "layer widths at most 1536")
+        self.Z = cfg.get("d_latent", 0) if self.vae else 0
         self.seq_len = cfg["seq_len"]
         self.L = self.seq_len - 1
         if self.L > 640:
-            raise L.ArkError("t-ARK: sequences longer than 640 tokens are not supported by the attention kernels")
-        self.p_drop = float(cfg.get("dec_dropout", 0.1))
+            raise L.ArkError(f"{self.mt}: sequences longer than 640 tokens are not supported by the attention kernels")
+        self.pad_eid, self.pad_rid = cfg.get("pad_eid"), cfg.get("pad_rid")
+        # t-ARK's layers take `dec_dropout` (models.py:389); t-SAIL's are built with the stock default (models.py:73,104)
+        self.p_drop = float(cfg.get("ark_txf_dropout", TXF_DROPOUT)) if self.vae else float(cfg.get("dec_dropout", 0.1))
         self.world_size, self.rank = world_size, rank
         self.layout = TxfLayout(cfg)
         n = self.layout.total
@@ -113,13 +164,30 @@ class TxfEngine(Engine):
     def refresh_shadows(self):
         self._shadow_ok = True
 
-    def _site_seed(self, layer, site):
-        """dropout stream of one of a layer's four dropout sites (0 attention probabilities, 1 attention output,
-        2 feed-forward activation, 3 feed-forward output) on this rank"""
-        return (self.drop_seed + 7919 * (4 * layer + site) + 104729 * self.rank) & 0xFFFFFFFFFFFFFFFF
+    def _default_norms(self, B):
+        if self.vae:
+            self.set_hyper(kl_norm=1.0 / (B * self.world_size * self.Z))
 
-    def _workspace(self, B, Lq):
-        key = (B, Lq)
+    def _seed(self, stack, layer, site):
+        """dropout stream of one dropout site of a layer on this rank.  stack 0 = decoder, 1 = encoder; sites: 0 self-attention
+        probabilities, 1 self-attention output, 2 feed-forward activation, 3 feed-forward output, 4 cross-attention
+        probabilities, 5 cross-attention output"""
+        return (self.drop_seed + 7919 * (8 * (2 * layer + stack) + site) + 104729 * self.rank) & 0xFFFFFFFFFFFFFFFF
+
+    def _layer_bufs(self, R, W, B, Ls, cross):
+        dev = self.device
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        d = {k: f(R, c) for k, c in (("qkv", 3 * W), ("att", W), ("sa", W), ("s1", W), ("x1", W), ("f", FF), ("g2", W), ("s2", W),
+                                    ("x2", W))}
+        d["st1"], d["st2"] = f(R, 2), f(R, 2)
+        d["probs"] = f(B * self.H * Ls * Ls)
+        if cross:
+            d.update({"ctx": f(R, W), "cs": f(R, self.H), "ca": f(R, W), "s3": f(R, W), "x3": f(R, W), "st3": f(R, 2),
+                      "vmem": f(B, W)})
+        return d
+
+    def _workspace(self, B, Lq, T=0):
+        key = (B, Lq, T)
         if self.ws_key == key:
             return self.ws
         if key in self._ws_cache:
@@ -129,14 +197,25 @@ class TxfEngine(Engine):
         R = Lq * B
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         w = {"v2": False, "_R": R, "X0": f(R, D)}
-        for nm, cols in (("qkv", 3 * D), ("att", D), ("sa", D), ("s1", D), ("x1", D), ("f", FF), ("g2", D), ("s2", D), ("x2", D)):
-            w[nm] = [f(R, cols) for _ in range(n)]
-        w["st1"] = [f(R, 2) for _ in range(n)]
-        w["st2"] = [f(R, 2) for _ in range(n)]
-        w["probs"] = [f(B * H * Lq * Lq) for _ in range(n)]
+        w["dec"] = [self._layer_bufs(R, D, B, Lq, self.vae) for _ in range(n)]
         w["dscore"] = f(B * H * Lq * Lq)
         w["dA"], w["dB"], w["dC"] = f(R, D), f(R, D), f(R, D)
         w["dqkv"], w["df"] = f(R, 3 * D), f(R, FF)
+        if self.vae:
+            W3, Z, Re = 3 * D, self.Z, T * B
+            w["E0"] = f(Re, W3)
+            w["kmask"] = torch.ones(B, T, device=dev, dtype=torch.uint8)
+            w["enc"] = [self._layer_bufs(Re, W3, B, T, False) for _ in range(self.n_enc)]
+            w["e_dscore"] = f(B * H * T * T)
+            w["eA"], w["eB"], w["eC"] = f(Re, W3), f(Re, W3), f(Re, W3)
+            w["e_dqkv"], w["e_df"] = f(Re, 3 * W3), f(Re, FF)
+            w["g"], w["inv_cnt"], w["dg"] = f(B, W3), f(B), f(B, W3)
+            w["head"], w["dhead"] = f(B, 2 * Z), f(B, 2 * Z)
+            z0 = lambda *s: torch.zeros(*s, device=dev)
+            w["mu"], w["logv"], w["z"], w["dz"] = z0(B, Z), z0(B, Z), z0(B, Z), z0(B, Z)
+            w["kl"] = torch.zeros(1, device=dev)
+            w["eps0"] = torch.zeros(B, Z, device=dev)
+            w["mem"], w["dmem"], w["dv"] = f(B, D), f(B, D), f(B, D)
         w["logits"] = torch.zeros(R, self.ldl, device=dev)
         w["row_loss"] = f(R)
         w["out4"] = torch.zeros(4, device=dev)
@@ -152,55 +231,120 @@ class TxfEngine(Engine):
     def _copy(self, dst, src):
         _call("ark_copy", L.ptr(dst), L.ptr(src), L.i64(src.numel() * src.element_size()), L.cur_stream())
 
-    def _drop(self, x, layer, site):
-        _call("ark_dropout_apply", L.ptr(x), L.i64(x.numel()), L.f32(self.p_drop), L.u64(self._site_seed(layer, site)),
-              L.ptr(self.hyper), L.cur_stream())
+    def _drop(self, x, seed):
+        _call("ark_dropout_apply", L.ptr(x), L.i64(x.numel()), L.f32(self.p_drop), L.u64(seed), L.ptr(self.hyper), L.cur_stream())
+
+    def _ln_fwd(self, x, sub, pre, s, y, st, R, W):
+        _call("ark_layernorm_fwd", L.ptr(x), L.ptr(sub), L.ptr(self.p[pre + ".weight"]), L.ptr(self.p[pre + ".bias"]), L.ptr(s), L.ptr(y),
+              L.ptr(st), L.i32(R), L.i32(W), L.f32(LN_EPS), L.cur_stream())
+
+    def _ln_bwd(self, dy, s, st, pre, ds, R, W):
+        _call("ark_layernorm_bwd", L.ptr(dy), L.ptr(s), L.ptr(st), L.ptr(self.p[pre + ".weight"]), L.ptr(ds), L.ptr(self.g[pre + ".weight"]),
+              L.ptr(self.g[pre + ".bias"]), L.i32(R), L.i32(W), L.cur_stream())
+
+    # ------------------------------------------------------------------ sublayers, forward
+    def _self_attn_fwd(self, d, x, pre, R, W, B, Ls, causal, kmask, drop, stack, l):
+        """x -> LN1(x + drop(SA(x))): d['x1']"""
+        KM, p = L.LAY_KMAJ, self.p
+        a = pre + "self_attn."
+        self._gemm(KM, KM, L.EPI_BIAS, x, W, p[a + "in_proj_weight"], W, d["qkv"], 3 * W, R, 3 * W, W, bias=p[a + "in_proj_bias"])
+        _call("ark_attn_fwd", L.ptr(d["qkv"]), L.ptr(d["att"]), L.ptr(d["probs"]), L.ptr(kmask), L.i32(B), L.i32(Ls), L.i32(W), L.i32(self.H),
+              L.i32(1 if causal else 0), L.f32(self.p_drop if drop else 0.0), L.u64(self._seed(stack, l, 0)), L.ptr(self.hyper),
+              L.cur_stream())
+        self._gemm(KM, KM, L.EPI_BIAS, d["att"], W, p[a + "out_proj.weight"], W, d["sa"], W, R, W, W, bias=p[a + "out_proj.bias"])
+        if drop:
+            self._drop(d["sa"], self._seed(stack, l, 1))
+        self._ln_fwd(x, d["sa"], pre + "norm1", d["s1"], d["x1"], d["st1"], R, W)
+        return d["x1"]
+
+    def _ff_fwd(self, d, x, pre, norm, R, W, drop, stack, l, s_key, x_key, st_key):
+        """x -> LN(x + drop(W2 drop(relu(W1 x))))"""
+        KM, p = L.LAY_KMAJ, self.p
+        self._gemm(KM, KM, L.EPI_BIAS_RELU, x, W, p[pre + "linear1.weight"], W, d["f"], FF, R, FF, W, bias=p[pre + "linear1.bias"])
+        if drop:
+            self._drop(d["f"], self._seed(stack, l, 2))   # in place: positive exactly where ReLU fired AND the mask kept
+        self._gemm(KM, KM, L.EPI_BIAS, d["f"], FF, p[pre + "linear2.weight"], FF, d["g2"], W, R, W, FF, bias=p[pre + "linear2.bias"])
+        if drop:
+            self._drop(d["g2"], self._seed(stack, l, 3))
+        self._ln_fwd(x, d["g2"], pre + norm, d[s_key], d[x_key], d[st_key], R, W)
+        return d[x_key]
+
+    def _cross_attn_fwd(self, d, x, mem, pre, R, W, B, Ls, drop, l):
+        """x -> LN2(x + drop(MHA(x, mem repeated Ls times))): the softmax over Ls identical keys is uniform, so the context is
+        the value row of the memory (times the attention-dropout factor), whatever the queries are"""
+        KM, p = L.LAY_KMAJ, self.p
+        a = pre + "multihead_attn."
+        self._gemm(KM, KM, L.EPI_BIAS, mem, W, p[a + "in_proj_weight"][2 * W:], W, d["vmem"], W, B, W, W, bias=p[a + "in_proj_bias"][2 * W:])
+        _call("ark_xattn_bcast_fwd", L.ptr(d["vmem"]), L.ptr(d["ctx"]), L.ptr(d["cs"]), L.i32(B), L.i32(Ls), L.i32(W), L.i32(self.H),
+              L.f32(self.p_drop if drop else 0.0), L.u64(self._seed(0, l, 4)), L.ptr(self.hyper), L.cur_stream())
+        self._gemm(KM, KM, L.EPI_BIAS, d["ctx"], W, p[a + "out_proj.weight"], W, d["ca"], W, R, W, W, bias=p[a + "out_proj.bias"])
+        if drop:
+            self._drop(d["ca"], self._seed(0, l, 5))
+        self._ln_fwd(x, d["ca"], pre + "norm2", d["s2"], d["x2"], d["st2"], R, W)
+        return d["x2"]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, triples, seq, eps=None, with_loss=True, with_dlogits=True, L_run=None, ce_count=None):
-        """tok + pos embedding -> n x [self-attention, add & norm, feed-forward, add & norm] -> tied logits
-        (-> cross-entropy + its gradient w.r.t. the logits).  seq [B, >= L_run] int64 on the device."""
+    def forward(self, triples, seq, eps=None, with_loss=True, with_dlogits=True, L_run=None, ce_count=None, z_given=None):
+        """t-ARK: forward(None, seq).  t-SAIL: forward(triples, seq, eps) (eps None: drawn on the device), or
+        forward(None, seq, z_given=z) to run the decoder alone on given latents (generation).
+        seq [B, >= L_run] int64 on the device; results stay in the workspace (out4 = loss, ce, kl, token-loss sum)."""
         self.prec = self.prec_fwd
         self.fwd_gen += 1
         B = seq.shape[0]
         Lq = self.L if L_run is None else L_run
         assert seq.dtype == torch.int64 and seq.is_contiguous() and seq.device == self.device and seq.shape[1] >= Lq
-        w = self._workspace(B, Lq)
+        enc_on = self.vae and z_given is None
+        T = triples.shape[1] if enc_on else 0
+        w = self._workspace(B, Lq, T)
         D, n, V, H = self.D, self.n, self.V, self.H
         R = Lq * B
         st = L.cur_stream()
         KM = L.LAY_KMAJ
         p = self.p
         ld_seq = seq.shape[1]
-        self._seq, self._B, self._Lrun = seq, B, Lq
+        self._seq, self._triples, self._B, self._Lrun, self._T = seq, triples, B, Lq, T
         use_drop = self.training and self.p_drop > 0
         self._used_drop = use_drop
+        self._enc_on = enc_on
         _call("ark_tok_gather", L.ptr(seq), L.i64(ld_seq), L.ptr(p["dec.tok_emb.weight"]), L.ptr(p["dec.pos_emb.weight"]),
               L.ptr(w["X0"]), L.i32(B), L.i32(Lq), L.i32(D), L.ptr(self.hyper if use_drop else None), st)
+        if self.vae:
+            Z = self.Z
+            if enc_on:
+                assert triples.dtype == torch.int64 and triples.is_contiguous() and triples.device == self.device
+                W3, Re = 3 * D, T * B
+                masked = self.pad_rid is not None
+                _call("ark_triple_gather", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]), L.ptr(w["E0"]),
+                      L.ptr(w["kmask"] if masked else None), L.i32(B), L.i32(T), L.i32(D), L.i64(self.pad_rid if masked else -1), st)
+                km = w["kmask"] if masked else None
+                x = w["E0"]
+                for l in range(self.n_enc):
+                    pre = f"enc.txf.layers.{l}."
+                    x = self._self_attn_fwd(w["enc"][l], x, pre, Re, W3, B, T, False, km, use_drop, 1, l)
+                    x = self._ff_fwd(w["enc"][l], x, pre, "norm2", Re, W3, use_drop, 1, l, "s2", "x2", "st2")
+                _call("ark_seq_pool_fwd", L.ptr(x), L.ptr(km), L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.i32(B), L.i32(T), L.i32(W3), st)
+                self._gemm(KM, KM, L.EPI_BIAS, w["g"], W3, p["enc.mu.weight"], W3, w["head"], 2 * Z, B, 2 * Z, W3, bias=p["enc.mu.bias"])
+                if eps is None:
+                    eps = w["eps0"]
+                    _call("ark_normal_fill", L.ptr(eps), L.i64(eps.numel()), L.u64(self._noise_seed()), L.ptr(self.hyper), st)
+                self._eps = eps
+                _call("ark_latent_fwd_ex", L.ptr(w["head"]), L.ptr(eps), L.ptr(w["mu"]), L.ptr(w["logv"]), L.ptr(w["z"]), L.ptr(w["kl"]),
+                      L.i32(B), L.i32(Z), L.i32(0), st)
+                zt = w["z"]
+            else:
+                zt = z_given.to(self.device, dtype=torch.float32).contiguous()
+            self._gemm(KM, KM, L.EPI_BIAS, zt, Z, p["dec.z_proj.weight"], Z, w["mem"], D, B, D, Z, bias=p["dec.z_proj.bias"])
         x = w["X0"]
         for l in range(n):
             pre = f"dec.txf.layers.{l}."
-            self._gemm(KM, KM, L.EPI_BIAS, x, D, p[pre + "self_attn.in_proj_weight"], D, w["qkv"][l], 3 * D, R, 3 * D, D,
-                       bias=p[pre + "self_attn.in_proj_bias"])
-            _call("ark_attn_fwd", L.ptr(w["qkv"][l]), L.ptr(w["att"][l]), L.ptr(w["probs"][l]), L.i32(B), L.i32(Lq), L.i32(D), L.i32(H),
-                  L.i32(1), L.f32(self.p_drop if use_drop else 0.0), L.u64(self._site_seed(l, 0)), L.ptr(self.hyper), st)
-            self._gemm(KM, KM, L.EPI_BIAS, w["att"][l], D, p[pre + "self_attn.out_proj.weight"], D, w["sa"][l], D, R, D, D,
-                       bias=p[pre + "self_attn.out_proj.bias"])
-            if use_drop:
-                self._drop(w["sa"][l], l, 1)
-            _call("ark_layernorm_fwd", L.ptr(x), L.ptr(w["sa"][l]), L.ptr(p[pre + "norm1.weight"]), L.ptr(p[pre + "norm1.bias"]),
-                  L.ptr(w["s1"][l]), L.ptr(w["x1"][l]), L.ptr(w["st1"][l]), L.i32(R), L.i32(D), L.f32(LN_EPS), st)
-            self._gemm(KM, KM, L.EPI_BIAS_RELU, w["x1"][l], D, p[pre + "linear1.weight"], D, w["f"][l], FF, R, FF, D,
-                       bias=p[pre + "linear1.bias"])
-            if use_drop:
-                self._drop(w["f"][l], l, 2)   # in place: the dropped activation is positive exactly where ReLU fired AND the mask kept
-            self._gemm(KM, KM, L.EPI_BIAS, w["f"][l], FF, p[pre + "linear2.weight"], FF, w["g2"][l], D, R, D, FF,
-                       bias=p[pre + "linear2.bias"])
-            if use_drop:
-                self._drop(w["g2"][l], l, 3)
-            _call("ark_layernorm_fwd", L.ptr(w["x1"][l]), L.ptr(w["g2"][l]), L.ptr(p[pre + "norm2.weight"]), L.ptr(p[pre + "norm2.bias"]),
-                  L.ptr(w["s2"][l]), L.ptr(w["x2"][l]), L.ptr(w["st2"][l]), L.i32(R), L.i32(D), L.f32(LN_EPS), st)
-            x = w["x2"][l]
+            d = w["dec"][l]
+            x = self._self_attn_fwd(d, x, pre, R, D, B, Lq, True, None, use_drop, 0, l)
+            if self.vae:
+                x = self._cross_attn_fwd(d, x, w["mem"], pre, R, D, B, Lq, use_drop, l)
+                x = self._ff_fwd(d, x, pre, "norm3", R, D, use_drop, 0, l, "s3", "x3", "st3")
+            else:
+                x = self._ff_fwd(d, x, pre, "norm2", R, D, use_drop, 0, l, "s2", "x2", "st2")
+        self._top = x
         self._gemm(KM, KM, L.EPI_BIAS, x, D, p["dec.out.weight"], D, w["logits"], self.ldl, R, V, D, bias=p["dec.out.bias"])
         if with_loss:
             if ce_count is None:
@@ -209,12 +353,77 @@ class TxfEngine(Engine):
             _call("ark_ce_fwd_bwd", L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper),
                   L.ptr(w["row_loss"]), L.ptr(w["logits"] if with_dlogits else None), L.ptr(None), L.i32(0), L.i64(0), L.i32(B),
                   L.i32(Lq), L.i32(V), st)
-            _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R), L.ptr(None), L.ptr(self.hyper), L.ptr(w["out4"]), st)
+            _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R), L.ptr(w["kl"] if enc_on else None), L.ptr(self.hyper),
+                  L.ptr(w["out4"]), st)
         return w
+
+    # ------------------------------------------------------------------ sublayers, backward
+    def _ff_bwd(self, d, dy, x_in, pre, norm, s_key, st_key, R, W, drop, stack, l, ds, tmp, df):
+        """dy = gradient of LN(x_in + drop(FF(x_in))) -> gradient w.r.t. x_in, returned in `ds`"""
+        KM, MM, p, g = L.LAY_KMAJ, L.LAY_MMAJ, self.p, self.g
+        self._ln_bwd(dy, d[s_key], d[st_key], pre + norm, ds, R, W)
+        dg2 = ds
+        if drop:
+            dg2 = tmp
+            self._copy(dg2, ds)
+            self._drop(dg2, self._seed(stack, l, 3))
+        self._colsum(dg2, W, g[pre + "linear2.bias"], R, W)
+        self._gemm(MM, MM, L.EPI_NONE, dg2, W, d["f"], FF, g[pre + "linear2.weight"], FF, W, FF, R, acc=1)
+        # df = (dg2 W2) masked by ReLU (and by the feed-forward dropout: f is positive only where both let it through)
+        self._gemm(KM, MM, L.EPI_MUL_RELU, dg2, W, p[pre + "linear2.weight"], FF, df, FF, R, FF, W, aux=d["f"])
+        if drop:
+            self._drop(df, self._seed(stack, l, 2))
+        self._colsum(df, FF, g[pre + "linear1.bias"], R, FF)
+        self._gemm(MM, MM, L.EPI_NONE, df, FF, x_in, W, g[pre + "linear1.weight"], W, FF, W, R, acc=1)
+        self._gemm(KM, MM, L.EPI_NONE, df, FF, p[pre + "linear1.weight"], W, ds, W, R, W, FF, acc=1)   # + df W1 (residual already there)
+        return ds
+
+    def _self_attn_bwd(self, d, dy, x_in, pre, R, W, B, Ls, causal, kmask, drop, stack, l, ds, tmp, scratch, dqkv, dscore):
+        """dy = gradient of LN1(x_in + drop(SA(x_in))) -> gradient w.r.t. x_in, returned in `ds`"""
+        KM, MM, p, g = L.LAY_KMAJ, L.LAY_MMAJ, self.p, self.g
+        a = pre + "self_attn."
+        self._ln_bwd(dy, d["s1"], d["st1"], pre + "norm1", ds, R, W)
+        dsa = ds
+        if drop:
+            dsa = tmp
+            self._copy(dsa, ds)
+            self._drop(dsa, self._seed(stack, l, 1))
+        self._colsum(dsa, W, g[a + "out_proj.bias"], R, W)
+        self._gemm(MM, MM, L.EPI_NONE, dsa, W, d["att"], W, g[a + "out_proj.weight"], W, W, W, R, acc=1)
+        self._gemm(KM, MM, L.EPI_NONE, dsa, W, p[a + "out_proj.weight"], W, scratch, W, R, W, W)            # d(att)
+        _call("ark_attn_bwd", L.ptr(d["qkv"]), L.ptr(d["att"]), L.ptr(d["probs"]), L.ptr(scratch), L.ptr(dscore), L.ptr(dqkv), L.ptr(kmask),
+              L.i32(B), L.i32(Ls), L.i32(W), L.i32(self.H), L.i32(1 if causal else 0), L.f32(self.p_drop if drop else 0.0),
+              L.u64(self._seed(stack, l, 0)), L.ptr(self.hyper), L.cur_stream())
+        self._colsum(dqkv, 3 * W, g[a + "in_proj_bias"], R, 3 * W)
+        self._gemm(MM, MM, L.EPI_NONE, dqkv, 3 * W, x_in, W, g[a + "in_proj_weight"], W, 3 * W, W, R, acc=1)
+        self._gemm(KM, MM, L.EPI_NONE, dqkv, 3 * W, p[a + "in_proj_weight"], W, ds, W, R, W, 3 * W, acc=1)
+        return ds
+
+    def _cross_attn_bwd(self, d, dy, mem, pre, R, W, B, Ls, drop, l, ds, tmp, scratch, dmem, dv):
+        """dy = gradient of LN2(x + drop(CA)) -> gradient w.r.t. x in `ds` (the residual only: the queries do not reach the
+        output); the memory's gradient ACCUMULATES into dmem [B, W].  Query / key projection gradients are exactly zero."""
+        KM, MM, p, g = L.LAY_KMAJ, L.LAY_MMAJ, self.p, self.g
+        a = pre + "multihead_attn."
+        self._ln_bwd(dy, d["s2"], d["st2"], pre + "norm2", ds, R, W)
+        dca = ds
+        if drop:
+            dca = tmp
+            self._copy(dca, ds)
+            self._drop(dca, self._seed(0, l, 5))
+        self._colsum(dca, W, g[a + "out_proj.bias"], R, W)
+        self._gemm(MM, MM, L.EPI_NONE, dca, W, d["ctx"], W, g[a + "out_proj.weight"], W, W, W, R, acc=1)
+        self._gemm(KM, MM, L.EPI_NONE, dca, W, p[a + "out_proj.weight"], W, scratch, W, R, W, W)            # d(ctx)
+        _call("ark_xattn_bcast_bwd", L.ptr(scratch), L.ptr(d["cs"]), L.ptr(dv), L.i32(B), L.i32(Ls), L.i32(W), L.i32(self.H), L.cur_stream())
+        self._colsum(dv, W, g[a + "in_proj_bias"][2 * W:], B, W)
+        self._gemm(MM, MM, L.EPI_NONE, dv, W, mem, W, g[a + "in_proj_weight"][2 * W:], W, W, W, B, acc=1)
+        self._gemm(KM, MM, L.EPI_NONE, dv, W, p[a + "in_proj_weight"][2 * W:], W, dmem, W, B, W, W, acc=1)
+        return ds
 
     # ------------------------------------------------------------------ backward
     def backward(self, ext_dhead=None):
-        """backward of the last forward; the gradient w.r.t. the logits sits in ws['logits']"""
+        """backward of the last forward; the gradient w.r.t. the logits sits in ws['logits'].  t-SAIL: the KL gradient is
+        added inside the latent kernel (hyper BETA x KL_NORM); ext_dhead [B, 2Z] (optional) adds an external gradient
+        w.r.t. (mu | logv), as the reference-style autograd path needs."""
         self.prec = self.prec_bwd
         w, B, Lq = self.ws, self._B, self._Lrun
         D, n, V, H = self.D, self.n, self.V, self.H
@@ -224,64 +433,91 @@ class TxfEngine(Engine):
         p, g = self.p, self.g
         seq = self._seq
         ld_seq = seq.shape[1]
-        use_drop = self._used_drop
+        drop = self._used_drop
         self._zero(self.G)
         dlog = w["logits"]
-        top = w["x2"][n - 1]
         self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
-        self._gemm(MM, MM, L.EPI_NONE, dlog, self.ldl, top, D, g["dec.out.weight"], D, V, D, R, acc=1)
-        dx, other, third = w["dA"], w["dB"], w["dC"]
-        self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, dx, D, R, D, V)
+        self._gemm(MM, MM, L.EPI_NONE, dlog, self.ldl, self._top, D, g["dec.out.weight"], D, V, D, R, acc=1)
+        bufs = [w["dA"], w["dB"], w["dC"]]
+        dy = bufs[0]
+        self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, dy, D, R, D, V)
+        if self.vae:
+            self._zero(w["dmem"])
+
+        def others(cur):
+            """the two rotating [R, W] buffers that are not `cur`"""
+            o = [b for b in bufs if b is not cur]
+            return o[0], o[1]
+
         for l in range(n - 1, -1, -1):
             pre = f"dec.txf.layers.{l}."
-            xin = w["x2"][l - 1] if l > 0 else w["X0"]
-            # x2 = LN2(x1 + drop(ff)): ds2 feeds both the feed-forward branch and the residual
-            _call("ark_layernorm_bwd", L.ptr(dx), L.ptr(w["s2"][l]), L.ptr(w["st2"][l]), L.ptr(p[pre + "norm2.weight"]), L.ptr(other),
-                  L.ptr(g[pre + "norm2.weight"]), L.ptr(g[pre + "norm2.bias"]), L.i32(R), L.i32(D), st)
-            ds2 = other
-            dg2 = ds2
-            if use_drop:
-                dg2 = third
-                self._copy(dg2, ds2)
-                self._drop(dg2, l, 3)
-            self._colsum(dg2, D, g[pre + "linear2.bias"], R, D)
-            self._gemm(MM, MM, L.EPI_NONE, dg2, D, w["f"][l], FF, g[pre + "linear2.weight"], FF, D, FF, R, acc=1)
-            # df = (dg2 W2) masked by ReLU (and by the feed-forward dropout: f is positive only where both let it through)
-            self._gemm(KM, MM, L.EPI_MUL_RELU, dg2, D, p[pre + "linear2.weight"], FF, w["df"], FF, R, FF, D, aux=w["f"][l])
-            if use_drop:
-                self._drop(w["df"], l, 2)
-            self._colsum(w["df"], FF, g[pre + "linear1.bias"], R, FF)
-            self._gemm(MM, MM, L.EPI_NONE, w["df"], FF, w["x1"][l], D, g[pre + "linear1.weight"], D, FF, D, R, acc=1)
-            self._gemm(KM, MM, L.EPI_NONE, w["df"], FF, p[pre + "linear1.weight"], D, ds2, D, R, D, FF, acc=1)   # dx1 = ds2 + df W1
-            # x1 = LN1(x_in + drop(sa))
-            _call("ark_layernorm_bwd", L.ptr(ds2), L.ptr(w["s1"][l]), L.ptr(w["st1"][l]), L.ptr(p[pre + "norm1.weight"]), L.ptr(dx),
-                  L.ptr(g[pre + "norm1.weight"]), L.ptr(g[pre + "norm1.bias"]), L.i32(R), L.i32(D), st)
-            ds1 = dx
-            dsa = ds1
-            if use_drop:
-                dsa = third
-                self._copy(dsa, ds1)
-                self._drop(dsa, l, 1)
-            self._colsum(dsa, D, g[pre + "self_attn.out_proj.bias"], R, D)
-            self._gemm(MM, MM, L.EPI_NONE, dsa, D, w["att"][l], D, g[pre + "self_attn.out_proj.weight"], D, D, D, R, acc=1)
-            self._gemm(KM, MM, L.EPI_NONE, dsa, D, p[pre + "self_attn.out_proj.weight"], D, ds2, D, R, D, D)   # d(att) -> ds2 buffer
-            _call("ark_attn_bwd", L.ptr(w["qkv"][l]), L.ptr(w["att"][l]), L.ptr(w["probs"][l]), L.ptr(ds2), L.ptr(w["dscore"]),
-                  L.ptr(w["dqkv"]), L.i32(B), L.i32(Lq), L.i32(D), L.i32(H), L.i32(1), L.f32(self.p_drop if use_drop else 0.0),
-                  L.u64(self._site_seed(l, 0)), L.ptr(self.hyper), st)
-            self._colsum(w["dqkv"], 3 * D, g[pre + "self_attn.in_proj_bias"], R, 3 * D)
-            self._gemm(MM, MM, L.EPI_NONE, w["dqkv"], 3 * D, xin, D, g[pre + "self_attn.in_proj_weight"], D, 3 * D, D, R, acc=1)
-            self._gemm(KM, MM, L.EPI_NONE, w["dqkv"], 3 * D, p[pre + "self_attn.in_proj_weight"], D, ds1, D, R, D, 3 * D, acc=1)
-            dx, other = ds1, ds2
-        _call("ark_tok_scatter", L.ptr(seq), L.i64(ld_seq), L.ptr(dx), L.ptr(g["dec.tok_emb.weight"]), L.i32(B), L.i32(Lq), L.i32(D),
+            d = w["dec"][l]
+            x_in = w["dec"][l - 1]["x3" if self.vae else "x2"] if l > 0 else w["X0"]
+            if self.vae:
+                ds, tmp = others(dy)
+                dy = self._ff_bwd(d, dy, d["x2"], pre, "norm3", "s3", "st3", R, D, drop, 0, l, ds, tmp, w["df"])
+                ds, tmp = others(dy)
+                # (the scratch for d(ctx) is the feed-forward gradient buffer's first R*D floats: free at this point)
+                dy = self._cross_attn_bwd(d, dy, w["mem"], pre, R, D, B, Lq, drop, l, ds, tmp, w["df"].view(-1)[:R * D].view(R, D),
+                                          w["dmem"], w["dv"])
+            else:
+                ds, tmp = others(dy)
+                dy = self._ff_bwd(d, dy, d["x1"], pre, "norm2", "s2", "st2", R, D, drop, 0, l, ds, tmp, w["df"])
+            ds, tmp = others(dy)
+            dy = self._self_attn_bwd(d, dy, x_in, pre, R, D, B, Lq, True, None, drop, 0, l, ds, tmp, w["df"].view(-1)[:R * D].view(R, D),
+                                     w["dqkv"], w["dscore"])
+        _call("ark_tok_scatter", L.ptr(seq), L.i64(ld_seq), L.ptr(dy), L.ptr(g["dec.tok_emb.weight"]), L.i32(B), L.i32(Lq), L.i32(D),
               L.i32(V), st)
-        self._colsum(dx, D, g["dec.pos_emb.weight"], B, D, n_batch=Lq, bs_in=B * D, bs_out=D)
+        self._colsum(dy, D, g["dec.pos_emb.weight"], B, D, n_batch=Lq, bs_in=B * D, bs_out=D)
+        if not (self.vae and self._enc_on):
+            return
+        # ---- latent + encoder half (t-SAIL)
+        Z, T = self.Z, self._T
+        W3, Re = 3 * D, T * B
+        self._colsum(w["dmem"], D, g["dec.z_proj.bias"], B, D)
+        self._gemm(MM, MM, L.EPI_NONE, w["dmem"], D, w["z"], Z, g["dec.z_proj.weight"], Z, D, Z, B, acc=1)
+        self._gemm(KM, MM, L.EPI_NONE, w["dmem"], D, p["dec.z_proj.weight"], Z, w["dz"], Z, B, Z, D)
+        _call("ark_latent_bwd_ex", L.ptr(w["dz"]), L.ptr(w["head"]), L.ptr(self._eps), L.ptr(self.hyper), L.ptr(w["dhead"]), L.i32(B), L.i32(Z),
+              L.i32(0), st)
+        if ext_dhead is not None:
+            _call("ark_axpy", L.ptr(w["dhead"]), L.ptr(ext_dhead.contiguous()), L.i64(B * 2 * Z), L.f32(1.0), st)
+        self._colsum(w["dhead"], 2 * Z, g["enc.mu.bias"], B, 2 * Z)
+        self._gemm(MM, MM, L.EPI_NONE, w["dhead"], 2 * Z, w["g"], W3, g["enc.mu.weight"], W3, 2 * Z, W3, B, acc=1)
+        self._gemm(KM, MM, L.EPI_NONE, w["dhead"], 2 * Z, p["enc.mu.weight"], W3, w["dg"], W3, B, W3, 2 * Z)
+        km = w["kmask"] if self.pad_rid is not None else None
+        ebufs = [w["eA"], w["eB"], w["eC"]]
+        dy = ebufs[0]
+        _call("ark_seq_pool_bwd", L.ptr(w["dg"]), L.ptr(km), L.ptr(w["inv_cnt"]), L.ptr(dy), L.i32(B), L.i32(T), L.i32(W3), st)
+
+        def eothers(cur):
+            o = [b for b in ebufs if b is not cur]
+            return o[0], o[1]
+
+        for l in range(self.n_enc - 1, -1, -1):
+            pre = f"enc.txf.layers.{l}."
+            d = w["enc"][l]
+            x_in = w["enc"][l - 1]["x2"] if l > 0 else w["E0"]
+            ds, tmp = eothers(dy)
+            dy = self._ff_bwd(d, dy, d["x1"], pre, "norm2", "s2", "st2", Re, W3, drop, 1, l, ds, tmp, w["e_df"])
+            ds, tmp = eothers(dy)
+            dy = self._self_attn_bwd(d, dy, x_in, pre, Re, W3, B, T, False, km, drop, 1, l, ds, tmp, self._e_scratch(w, Re, W3),
+                                     w["e_dqkv"], w["e_dscore"])
+        _call("ark_triple_scatter", L.ptr(self._triples), L.ptr(dy), L.ptr(g["enc.e_emb.weight"]), L.ptr(g["enc.r_emb.weight"]), L.i32(B),
+              L.i32(T), L.i32(D), L.i64(-1 if self.pad_eid is None else self.pad_eid), L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
+
+    def _e_scratch(self, w, Re, W3):
+        """[Re, 3D] scratch of the encoder's attention backward (FF = 2048 columns may be narrower than 3D: own buffer)"""
+        if "e_scr" not in w:
+            w["e_scr"] = torch.empty(Re, W3, device=self.device, dtype=torch.float32)
+        return w["e_scr"]
 
     # ------------------------------------------------------------------ whole step
     def train_step(self, triples, seq, eps=None, grad_sync=None, ce_count=None, dp=False):
-        """forward + cross-entropy + backward (+ gradient all-reduce) + Adam; returns out4 on the device"""
+        """forward + loss + backward (+ gradient all-reduce) + Adam; returns out4 on the device"""
+        self._default_norms(seq.shape[0])
         if ce_count is not None:
             self.set_hyper(ce_count=ce_count)
-        self.forward(None, seq, None, ce_count=ce_count)
+        self.forward(triples if self.vae else None, seq, eps if self.vae else None, ce_count=ce_count)
         self.backward()
         if dp:   # one bucket: the whole flat gradient buffer, summed over the ranks
             import torch.distributed as dist
@@ -292,34 +528,75 @@ class TxfEngine(Engine):
         return self.ws["out4"]
 
     def graphed_train_step(self, triples, seq, ce_count=None, dp=False):
-        """(the Transformer variant's step is launched eagerly: no captured graph yet)"""
-        return self.train_step(None, seq, ce_count=ce_count, dp=dp)
+        """(the Transformer variants' step is launched eagerly: no captured graph yet)"""
+        return self.train_step(triples, seq, ce_count=ce_count, dp=dp)
 
     def capture_train_step(self, *a, **k):
-        raise L.ArkError("t-ARK: hipGraph capture of the train step is not implemented; use train_step()")
+        raise L.ArkError(f"{self.mt}: hipGraph capture of the train step is not implemented; use train_step()")
 
     def eval_loss(self, triples, seq, eps=None):
+        self._default_norms(seq.shape[0])
         was = self.training
         self.training = False
         try:
-            w = self.forward(None, seq, None, with_dlogits=False)
+            w = self.forward(triples if self.vae else None, seq, eps if self.vae else None, with_dlogits=False)
         finally:
             self.training = was
         return w["out4"]
 
     @torch.no_grad()
-    def prefix_logits(self, prefix):
+    def prefix_logits(self, prefix, z=None):
         """logits [B, V] of the position after `prefix` [B, t] (the reference re-runs the whole prefix per generated
-        token, models.py:430; so does this: the Transformer has no recurrent state to carry)"""
+        token, models.py:291,430; so does this: the Transformer has no recurrent state to carry).  t-SAIL: z [B, Z]."""
         was = self.training
         self.training = False
         try:
-            t = prefix.shape[1]
-            B = prefix.shape[0]
-            w = self.forward(None, prefix.contiguous(), None, with_loss=False, L_run=t)
+            t, B = prefix.shape[1], prefix.shape[0]
+            w = self.forward(None, prefix.contiguous(), None, with_loss=False, L_run=t, z_given=z)
         finally:
             self.training = was
         return w["logits"][(t - 1) * B:t * B, :self.V]
 
     def decode_begin(self, *a, **k):
-        raise L.ArkError("t-ARK has no incremental decoder state: use prefix_logits()")
+        raise L.ArkError(f"{self.mt} has no incremental decoder state: use prefix_logits()")
+
+    @torch.no_grad()
+    def greedy_decode(self, z, max_len=None, bos=1, eos=2):
+        """token sequences of SAIL.decode_latent(z, beam=1) for t-SAIL (reference models.py:282-300): prefix re-run,
+        argmax of the last position, stop once every row ends in EOS"""
+        assert self.vae
+        B = z.shape[0]
+        Lmax = (self.seq_len - 1) if max_len is None else max_len
+        z = z.to(self.device, dtype=torch.float32)
+        s = torch.full((B, 1), bos, dtype=torch.int64, device=self.device)
+        nxt = torch.empty(B, dtype=torch.int64, device=self.device)
+        for _ in range(Lmax):
+            logits = self.prefix_logits(s, z)
+            _call("ark_argmax_rows", L.ptr(logits), L.i64(self.ldl), L.ptr(nxt), L.i32(B), L.i32(self.V), L.cur_stream())
+            s = torch.cat([s, nxt[:, None]], 1)
+            if bool((s[:, -1] == eos).all()):
+                break
+        return s
+
+    @torch.no_grad()
+    def beam_decode(self, z, beam, max_len=None, bos=1, eos=2):
+        """the reference's batch-shared beam (models.py:282-300) on prefix re-runs: candidates ranked by the batch-MEAN
+        accumulated log-probability (stable descending sort), stop when every kept beam ends in EOS everywhere"""
+        assert self.vae and beam >= 1
+        B = z.shape[0]
+        Lmax = (self.seq_len - 1) if max_len is None else max_len
+        z = z.to(self.device, dtype=torch.float32)
+        beams = [(torch.full((B, 1), bos, dtype=torch.int64, device=self.device), torch.zeros(B, device=self.device))]
+        for _ in range(Lmax):
+            cand = []
+            for s, lp in beams:
+                logp = torch.log_softmax(self.prefix_logits(s, z).float(), dim=-1)
+                top_lp, ids = logp.topk(beam, dim=-1)
+                for k in range(beam):
+                    cand.append((torch.cat([s, ids[:, k:k + 1]], 1), lp + top_lp[:, k]))
+            means = torch.stack([c[1].mean() for c in cand])
+            order = torch.sort(means, descending=True, stable=True).indices[:beam].tolist()
+            beams = [cand[i] for i in order]
+            if all(bool((s[:, -1] == eos).all()) for s, _ in beams):
+                break
+        return beams[0][0]

@@ -325,11 +325,31 @@ int ark_dropout_apply(float* x, int64_t n, float p, uint64_t seed, const float* 
 /* multi-head scaled-dot-product attention of nn.MultiheadAttention on packed qkv rows [L*B, 3D] = [q | k | v]:
  * out [L*B, D] = (softmax(q k^T / sqrt(dh) + causal mask) o dropout) v per (batch, head); probs [B, H, L, L] keeps the
  * probabilities BEFORE dropout for the backward pass (the mask is a counter hash, regenerated there).  L <= 640, dh <= 256 */
-int ark_attn_fwd(const float* qkv, float* out, float* probs, int B, int L, int D, int n_heads, int causal, float drop_p,
-                 uint64_t seed, const float* hyper, void* stream);
+int ark_attn_fwd(const float* qkv, float* out, float* probs, const unsigned char* kmask /* [B, L] 1 = key visible, nullable */,
+                 int B, int L, int D, int n_heads, int causal, float drop_p, uint64_t seed, const float* hyper, void* stream);
 /* dqkv [L*B, 3D] from dout; dscore [B, H, L, L] is scratch */
-int ark_attn_bwd(const float* qkv, const float* out, const float* probs, const float* dout, float* dscore, float* dqkv, int B,
-                 int L, int D, int n_heads, int causal, float drop_p, uint64_t seed, const float* hyper, void* stream);
+int ark_attn_bwd(const float* qkv, const float* out, const float* probs, const float* dout, float* dscore, float* dqkv,
+                 const unsigned char* kmask, int B, int L, int D, int n_heads, int causal, float drop_p, uint64_t seed,
+                 const float* hyper, void* stream);
+/* ---- t-SAIL (reference: AutoRegEncoder / AutoRegDecoder, kgvae/model/models.py:66-114) ----------------------------------
+ * encoder input rows (t, b) over the TRIPLE index: x = [E[h] | R[r] | E[t]], kmask[b, t] = (r != pad_rid) (nullable) */
+int ark_triple_gather(const int64_t* triples, const float* E, const float* R, float* x, unsigned char* kmask, int B, int T, int D,
+                      int64_t pad_rid /* < 0: none */, void* stream);
+int ark_triple_scatter(const int64_t* triples, const float* dx, float* dE, float* dR, int B, int T, int D, int64_t pad_eid,
+                       int64_t pad_rid, void* stream);
+/* masked mean over the sequence axis of time-major rows [T*B, W] -> g [B, W]; inv_cnt[b] = 1 / max(1, #visible) */
+int ark_seq_pool_fwd(const float* x, const unsigned char* kmask, float* g, float* inv_cnt, int B, int T, int W, void* stream);
+int ark_seq_pool_bwd(const float* dg, const unsigned char* kmask, const float* inv_cnt, float* dx, int B, int T, int W, void* stream);
+/* cross-attention over a memory of L IDENTICAL rows (z_proj(z) repeated, models.py:112): uniform softmax, so
+ * ctx[(t, b), h] = c[t, b, h] * v[b, h] with c = 1 (no dropout) or (#kept keys) / (L (1 - p)); cscale [L*B, H] keeps c */
+int ark_xattn_bcast_fwd(const float* v, float* ctx, float* cscale, int B, int L, int D, int n_heads, float drop_p, uint64_t seed,
+                        const float* hyper, void* stream);
+int ark_xattn_bcast_bwd(const float* dctx, const float* cscale, float* dv, int B, int L, int D, int n_heads, void* stream);
+/* ark_latent_fwd / ark_latent_bwd with the [-10, 10] clamp of logv switchable (clamp = 0: t-SAIL, models.py:93) */
+int ark_latent_fwd_ex(const float* head, const float* eps, float* mu, float* logv, float* z, float* kl_out, int B, int Z,
+                      int clamp, void* stream);
+int ark_latent_bwd_ex(const float* dz, const float* head, const float* eps, const float* hyper, float* dhead, int B, int Z,
+                      int clamp, void* stream);
 
 /* out[0:n] = N(0,1) draws for the reparameterisation noise (reference: torch.randn_like(mu), kgvae/model/models.py:63):
  * counter-based -- element i of draw number hyper[ARK_HP_NOISE_STEP] under `seed` is a pure function of (seed, draw, i)
@@ -338,6 +358,8 @@ int ark_attn_bwd(const float* qkv, const float* out, const float* probs, const f
 int ark_normal_fill(float* out, int64_t n, uint64_t seed, float* hyper, void* stream);
 /* zero `nbytes` bytes (multiple of 4, 16-byte aligned start): a plain kernel, ordered like every other launch of the stream */
 int ark_zero(void* ptr, int64_t nbytes, void* stream);
+/* y[0:n] += a * x[0:n] */
+int ark_axpy(float* y, const float* x, int64_t n, float a, void* stream);
 /* device-to-device copy of `nbytes` bytes (multiple of 4, 16-byte aligned ends): a plain kernel */
 int ark_copy(void* dst, const void* src, int64_t nbytes, void* stream);
 /* ---- optimiser and reductions (reference: optim.Adam, ablation_study.py:571,76) ---------------- */

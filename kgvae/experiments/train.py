@@ -344,10 +344,10 @@ def main(argv=None):
 
     if model_type in ("ARK", "t-ARK"):
         model = ARK(config).to(device)
-    elif model_type == "SAIL":
+    elif model_type in ("SAIL", "t-SAIL"):
         model = SAIL(config).to(device)
     else:
-        raise NotImplementedError(f"Model type '{model_type}' is not implemented. Use one of: 'ARK','t-ARK','SAIL'.")
+        raise NotImplementedError(f"Model type '{model_type}' is not implemented. Use one of: 'ARK','t-ARK','SAIL','t-SAIL'.")
     if main_rank:
         print(f"Using model: {model_type}")
     eng = model.engine()
@@ -375,7 +375,7 @@ def main(argv=None):
         if main_rank:
             print(f"\nEpoch {epoch + 1}/{num_epochs}")
         b = 1
-        if model_type == "SAIL":
+        if model_type in ("SAIL", "t-SAIL"):
             b = config["beta0"] + (config["beta1"] - config["beta0"]) * epoch / num_epochs
         lr = cosine_lr(base_lr, epoch, num_epochs, eta_min) if use_sched else base_lr
         t0 = time.time()
@@ -398,12 +398,12 @@ def main(argv=None):
         log = {"epoch": epoch + 1, "train/loss": train_loss, "train/reconstruction_loss": train_recon,
                "val/loss": val_loss, "val/reconstruction_loss": val_recon, "learning_rate": lr,
                "train/graphs_per_sec": (len(train_ds) // config["batch_size"]) * config["batch_size"] / max(dt, 1e-9)}
-        if model_type == "SAIL":
+        if model_type in ("SAIL", "t-SAIL"):
             log["train/kl_loss"], log["val/kl_loss"] = train_kl, val_kl
 
         if verifier and (epoch + 1) % config.get("verify_every", 10) == 0:
             target_n = config.get("num_generated_latent_graphs", 1000)
-            if model_type == "SAIL":
+            if model_type in ("SAIL", "t-SAIL"):
                 zs = torch.randn(target_n, config["d_latent"], device=device)
                 graphs = model.decode_latent(zs, seq_len, special_tokens, seq_to_triples, ENT_BASE, REL_BASE, beam=1)
             else:
@@ -446,7 +446,7 @@ def main(argv=None):
         eng.dp_flush()
         torch.save(eng.P.detach().cpu(), f"{config['dump_final_params']}.rank{rank}.pt")
         wtrain = eng._ws_cache.get(config["batch_size"] // nranks)   # (workspace of this rank's training batches)
-        if model_type == "SAIL" and wtrain is not None:   # the last training step's device-drawn latent noise
+        if model_type in ("SAIL", "t-SAIL") and wtrain is not None:   # the last training step's device-drawn latent noise
             torch.save(wtrain["eps0"].detach().cpu(), f"{config['dump_final_params']}.eps.rank{rank}.pt")
     if nranks > 1:
         import torch.distributed as dist

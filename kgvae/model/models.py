@@ -15,8 +15,8 @@ Two ways to train:
   * fused -- `model.train_step(triples, seq, beta=b, lr=lr)`: ELBO, backward and Adam stay on the
     device (what kgvae.experiments.train and bench.py use).
 
-`t-ARK` (decoder-only Transformer) runs on ark_amd.txf_engine.TxfEngine; `t-SAIL` (Transformer VAE) is not built and
-raises NotImplementedError, as unknown model types do in the reference (models.py:172,197,393).
+The Transformer variants `t-ARK` (decoder-only) and `t-SAIL` (VAE) run on ark_amd.txf_engine.TxfEngine; unknown model
+types raise NotImplementedError as in the reference (models.py:172,197,393).
 """
 import math
 
@@ -69,7 +69,7 @@ class _EngineModel(nn.Module):
             from ark_amd.txf_engine import TxfEngine
             import torch.distributed as dist
             live = dist.is_available() and dist.is_initialized()
-            cls = TxfEngine if self.config["model_type"] == "t-ARK" else Engine
+            cls = TxfEngine if self.config["model_type"] in ("t-ARK", "t-SAIL") else Engine
             self._eng = cls(self.config, dev, precision=self.precision, world_size=dist.get_world_size() if live else 1,
                             rank=dist.get_rank() if live else 0)
             self._adopt(named)
@@ -160,7 +160,10 @@ class _SailFn(torch.autograd.Function):
             ext[:, :Z] = dmu
         if dlogv is not None:
             raw = w["head"][:, Z:]
-            ext[:, Z:] = dlogv * ((raw >= -10) & (raw <= 10))   # clamp(-10, 10) passes gradient inside only
+            if model.config["model_type"] == "t-SAIL":              # (no clamp in the Transformer encoder, reference models.py:93)
+                ext[:, Z:] = dlogv
+            else:
+                ext[:, Z:] = dlogv * ((raw >= -10) & (raw <= 10))   # clamp(-10, 10) passes gradient inside only
         eng.set_hyper(kl_norm=0.0)   # the KL gradient arrives through dmu / dlogv here
         eng.backward(ext_dhead=ext)
         grads = tuple(eng.g[k].clone() for k, _ in model._params_in_order())
@@ -191,15 +194,16 @@ class _ArkFn(torch.autograd.Function):
 
 
 class SAIL(_EngineModel):
-    """VAE: masked-mean-pooled triple embeddings -> (Linear+GELU)^n -> mu/logv -> z -> GRU decoder."""
-    _kinds = ("SAIL",)
+    """VAEs (reference models.py:144-320): `SAIL` = masked-mean-pooled triple embeddings -> (Linear+GELU)^n -> mu/logv -> z ->
+    GRU decoder; `t-SAIL` = Transformer encoder over the triples -> mu/logv (no clamp) -> z -> Transformer decoder over a
+    memory of z_proj(z) (AutoRegEncoder / AutoRegDecoder, models.py:66-114; engine: ark_amd.txf_engine.TxfEngine)."""
+    _kinds = ("SAIL", "t-SAIL")
 
     def __init__(self, config):
-        if config["model_type"] == "t-SAIL":
-            raise NotImplementedError("t-SAIL (Transformer encoder/decoder) is outside the MI355X hot path of this build")
         super().__init__(config)
-        print("Using MLP encoder")
-        print("Using GRU Decoder")
+        if config["model_type"] == "SAIL":
+            print("Using MLP encoder")
+            print("Using GRU Decoder")
 
     def forward(self, triples, seq_in, eps=None):
         """-> (logits [B,L,V], mu [B,Z], logv [B,Z]); eps defaults to N(0,1) drawn on the device"""

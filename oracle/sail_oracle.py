@@ -17,6 +17,8 @@ Reference call sites restated (paths relative to the reference repo):
   kl_mean .................................. kgvae/model/models.py:199-200
   GRU decoder (tok_emb, z_proj, GRU, out) .. kgvae/model/models.py:116-142
   decoder-only ARK (tok+pos emb, GRU, out) . kgvae/model/models.py:323-345, 395-405
+  t-SAIL (Transformer VAE) ................. kgvae/model/models.py:66-114 (AutoRegEncoder -- no logv clamp --, AutoRegDecoder
+                                             over a memory of z_proj(z) repeated L times, stock post-norm layers)
   decoder-only t-ARK (Transformer) ......... kgvae/model/models.py:349-366 (stock nn.TransformerEncoderLayer: post-norm,
                                              ReLU feed-forward 2048, causal mask; restated as explicit math)
   ELBO assembly (ce + b*kl) ................ kgvae/experiments/ablation_study.py:59-73
@@ -78,6 +80,30 @@ def init_params(cfg, seed):
         tok = nn.Embedding(V, D)
         pos = nn.Embedding(cfg["seq_len"], D)
         P["dec.tok_emb.weight"], P["dec.pos_emb.weight"] = tok.weight, pos.weight
+    elif mt == "t-SAIL":
+        # AutoRegEncoder (models.py:66-76) then AutoRegDecoder (models.py:98-106), constructor order; each stock layer is
+        # initialised ONCE and deep-copied n times by nn.TransformerEncoder / nn.TransformerDecoder; `out` is NOT tied
+        Z, H3 = cfg["d_latent"], 3 * D
+        e = nn.Embedding(cfg["n_entities"], D, padding_idx=cfg.get("pad_eid"))
+        r = nn.Embedding(cfg["n_relations"], D, padding_idx=cfg.get("pad_rid"))
+        P["enc.e_emb.weight"], P["enc.r_emb.weight"] = e.weight, r.weight
+        elayer = nn.TransformerEncoderLayer(H3, cfg["n_heads"], batch_first=True, dropout=0.0)
+        for i in range(cfg.get("n_layers", 2)):
+            for k, v in elayer.state_dict().items():
+                P[f"enc.txf.layers.{i}.{k}"] = v.clone()
+        mu, lv = nn.Linear(H3, Z), nn.Linear(H3, Z)
+        P["enc.mu.weight"], P["enc.mu.bias"] = mu.weight, mu.bias
+        P["enc.logv.weight"], P["enc.logv.bias"] = lv.weight, lv.bias
+        tok, pos, zp = nn.Embedding(V, D), nn.Embedding(cfg["seq_len"], D), nn.Linear(Z, D)
+        P["dec.tok_emb.weight"], P["dec.pos_emb.weight"] = tok.weight, pos.weight
+        P["dec.z_proj.weight"], P["dec.z_proj.bias"] = zp.weight, zp.bias
+        dlayer = nn.TransformerDecoderLayer(D, cfg["n_heads"], batch_first=True, dropout=0.0)
+        for i in range(n):
+            for k, v in dlayer.state_dict().items():
+                P[f"dec.txf.layers.{i}.{k}"] = v.clone()
+        out = nn.Linear(D, V)
+        P["dec.out.weight"], P["dec.out.bias"] = out.weight, out.bias
+        return _detach_tied(P, False)
     elif mt == "t-ARK":
         # DecoderOnlyTransformer (models.py:349-359): tok_emb, pos_emb, ONE stock TransformerEncoderLayer that
         # nn.TransformerEncoder deep-copies n times (every layer starts from the same tensors), out (tied)
@@ -141,7 +167,9 @@ def encoder_pool(P, triples, pad_rid=None):
 
 
 def encoder_forward(P, triples, eps, cfg):
-    """-> z, mu, logv   (models.py:46-64); eps replaces torch.randn_like(mu)"""
+    """-> z, mu, logv   (models.py:46-64); eps replaces torch.randn_like(mu).  model_type t-SAIL: tsail_encoder_forward"""
+    if cfg["model_type"] == "t-SAIL":
+        return tsail_encoder_forward(P, triples, eps, cfg)
     g = encoder_pool(P, triples, cfg.get("pad_rid"))
     for i in range(cfg["n_layers"]):
         g = F.gelu(g @ P[f"enc.mlp.{2 * i}.weight"].t() + P[f"enc.mlp.{2 * i}.bias"])
@@ -179,7 +207,9 @@ def gru_stack(P, x, h0, n_layers, drop_masks=None):
 
 
 def decoder_forward(P, z, seq_in, cfg, drop_masks=None):
-    """SAIL decoder: logits[B,L,V]   (models.py:136-142)"""
+    """SAIL decoder: logits[B,L,V]   (models.py:136-142).  model_type t-SAIL: tsail_decoder_forward"""
+    if cfg["model_type"] == "t-SAIL":
+        return tsail_decoder_forward(P, z, seq_in, cfg)
     n = cfg["n_layers"]
     x = P["dec.tok_emb.weight"][seq_in]
     h0 = torch.tanh(z @ P["dec.z_proj.weight"].t() + P["dec.z_proj.bias"])
@@ -206,17 +236,23 @@ def layer_norm(x, g, b, eps=1e-5):
     return (x - mu) / torch.sqrt(var + eps) * g + b
 
 
-def self_attention(x, w_in, b_in, w_out, b_out, n_heads, causal, drop_p=None):
-    """nn.MultiheadAttention(batch_first=True) on q = k = v = x [B, L, D]: packed in-projection (rows q | k | v),
-    heads of D / n_heads, scores / sqrt(head dim), -inf above the diagonal (the reference's boolean triu mask,
-    models.py:364), softmax, optional dropout mask ON THE PROBABILITIES (already scaled by 1/(1-p)), out-projection"""
+def self_attention(x, w_in, b_in, w_out, b_out, n_heads, causal, drop_p=None, mem=None, key_pad=None):
+    """nn.MultiheadAttention(batch_first=True): queries from x [B, L, D], keys / values from `mem` [B, S, D] (default x
+    itself); packed in-projection (rows q | k | v), heads of D / n_heads, scores / sqrt(head dim), -inf above the diagonal
+    (causal: the reference's boolean triu mask, models.py:113,364) and on padded keys (key_pad [B, S] True = ignore,
+    models.py:87), softmax, optional dropout keep-scales ON THE PROBABILITIES, out-projection"""
     B, L, D = x.shape
+    src = x if mem is None else mem
+    S = src.shape[1]
     dh = D // n_heads
-    qkv = x @ w_in.t() + b_in
-    q, k, v = (t.reshape(B, L, n_heads, dh).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    q = (x @ w_in[:D].t() + b_in[:D]).reshape(B, L, n_heads, dh).transpose(1, 2)
+    k = (src @ w_in[D:2 * D].t() + b_in[D:2 * D]).reshape(B, S, n_heads, dh).transpose(1, 2)
+    v = (src @ w_in[2 * D:].t() + b_in[2 * D:]).reshape(B, S, n_heads, dh).transpose(1, 2)
     sc = q @ k.transpose(-1, -2) / math.sqrt(dh)
     if causal:
-        sc = sc.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), float("-inf"))
+        sc = sc.masked_fill(torch.triu(torch.ones(L, S, dtype=torch.bool), 1), float("-inf"))
+    if key_pad is not None:
+        sc = sc.masked_fill(key_pad[:, None, None, :], float("-inf"))
     pr = torch.softmax(sc, dim=-1)
     if drop_p is not None:
         pr = pr * drop_p
@@ -224,13 +260,56 @@ def self_attention(x, w_in, b_in, w_out, b_out, n_heads, causal, drop_p=None):
     return o @ w_out.t() + b_out
 
 
-def txf_encoder_layer(P, pre, x, n_heads, causal, masks=None):
+def txf_decoder_layer(P, pre, x, mem, n_heads):
+    """nn.TransformerDecoderLayer, stock defaults (post-norm, ReLU): x = LN1(x + SA_causal(x)); x = LN2(x + MHA(x, mem));
+    x = LN3(x + FF(x))   (dropout-free: the parity / evaluation numerics)"""
+    g = lambda k: P[pre + k]
+    x = layer_norm(x + self_attention(x, g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias"), g("self_attn.out_proj.weight"),
+                                      g("self_attn.out_proj.bias"), n_heads, True), g("norm1.weight"), g("norm1.bias"))
+    x = layer_norm(x + self_attention(x, g("multihead_attn.in_proj_weight"), g("multihead_attn.in_proj_bias"),
+                                      g("multihead_attn.out_proj.weight"), g("multihead_attn.out_proj.bias"), n_heads, False, mem=mem),
+                   g("norm2.weight"), g("norm2.bias"))
+    ff = torch.relu(x @ g("linear1.weight").t() + g("linear1.bias")) @ g("linear2.weight").t() + g("linear2.bias")
+    return layer_norm(x + ff, g("norm3.weight"), g("norm3.bias"))
+
+
+def tsail_encoder_forward(P, triples, eps, cfg):
+    """AutoRegEncoder.forward (models.py:78-95): [E[h] | R[r] | E[t]] per triple -> Transformer encoder over the triples
+    (padded triples masked as keys) -> masked mean -> mu / logv heads -- NO clamp on logv (models.py:93) -> z"""
+    E, R = P["enc.e_emb.weight"], P["enc.r_emb.weight"]
+    x = torch.cat([E[triples[:, :, 0]], R[triples[:, :, 1]], E[triples[:, :, 2]]], dim=-1)
+    pad_rid = cfg.get("pad_rid")
+    valid = (triples[:, :, 1] != pad_rid) if pad_rid is not None else None
+    for i in range(cfg.get("n_layers", 2)):
+        x = txf_encoder_layer(P, f"enc.txf.layers.{i}.", x, cfg["n_heads"], False, key_pad=None if valid is None else ~valid)
+    if valid is not None:
+        g = (x * valid.unsqueeze(-1)).sum(1) / valid.sum(1, keepdim=True).clamp(min=1)
+    else:
+        g = x.mean(1)
+    mu = g @ P["enc.mu.weight"].t() + P["enc.mu.bias"]
+    logv = g @ P["enc.logv.weight"].t() + P["enc.logv.bias"]
+    return mu + eps * torch.exp(0.5 * logv), mu, logv
+
+
+def tsail_decoder_forward(P, z, seq_in, cfg):
+    """AutoRegDecoder.forward (models.py:108-114): tok + pos embeddings; the memory is z_proj(z) repeated L times; causal
+    Transformer decoder; untied output projection"""
+    B, L = seq_in.shape
+    x = P["dec.tok_emb.weight"][seq_in] + P["dec.pos_emb.weight"][torch.arange(L)].unsqueeze(0)
+    mem = (z @ P["dec.z_proj.weight"].t() + P["dec.z_proj.bias"]).unsqueeze(1).repeat(1, L, 1)
+    for i in range(cfg["n_layers"]):
+        x = txf_decoder_layer(P, f"dec.txf.layers.{i}.", x, mem, cfg["n_heads"])
+    return x @ P["dec.out.weight"].t() + P["dec.out.bias"]
+
+
+def txf_encoder_layer(P, pre, x, n_heads, causal, masks=None, key_pad=None):
     """nn.TransformerEncoderLayer, stock defaults (post-norm, ReLU feed-forward): x = LN1(x + drop1(SA(x)));
     x = LN2(x + drop2(W2 drop(relu(W1 x)))).  masks (optional): dict of dropout keep-scales for the four dropout sites
     ("attn" [B,h,L,L], "sa" / "ff2" [B,L,D], "ff1" [B,L,F]); None = no dropout (eval, or p = 0)."""
     m = masks or {}
     sa = self_attention(x, P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"],
-                        P[pre + "self_attn.out_proj.weight"], P[pre + "self_attn.out_proj.bias"], n_heads, causal, m.get("attn"))
+                        P[pre + "self_attn.out_proj.weight"], P[pre + "self_attn.out_proj.bias"], n_heads, causal, m.get("attn"),
+                        key_pad=key_pad)
     if "sa" in m:
         sa = sa * m["sa"]
     x = layer_norm(x + sa, P[pre + "norm1.weight"], P[pre + "norm1.bias"])
@@ -315,7 +394,7 @@ def train_step(P, state, batch, cfg, lr, beta=1.0, eps=None, drop_masks=None):
         p.requires_grad_(True)
         p.grad = None
     triples, seq = batch
-    if cfg["model_type"] == "SAIL":
+    if cfg["model_type"] in ("SAIL", "t-SAIL"):
         loss, ce, kl, *_ = sail_elbo(P, triples, seq, eps, beta, cfg, drop_masks)
     else:
         ce, _ = ark_loss(P, seq, cfg, drop_masks)
@@ -323,7 +402,7 @@ def train_step(P, state, batch, cfg, lr, beta=1.0, eps=None, drop_masks=None):
     loss.backward()
     grads = [p.grad.detach().clone() for _, p in leaves]
     # nn.Embedding(padding_idx=...) rows never receive gradient
-    if cfg["model_type"] == "SAIL":
+    if cfg["model_type"] in ("SAIL", "t-SAIL"):
         names = [k for k, _ in leaves]
         if cfg.get("pad_eid") is not None:
             grads[names.index("enc.e_emb.weight")][cfg["pad_eid"]] = 0

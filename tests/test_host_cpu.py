@@ -80,10 +80,14 @@ def test_model_refuses_to_run_on_cpu():
     m = SAIL(cfg)
     with pytest.raises(ArkError):
         m(torch.zeros(2, 3, 3, dtype=torch.long), torch.ones(2, 10, dtype=torch.long))
-    with pytest.raises(NotImplementedError):
-        SAIL(dict(cfg, model_type="t-SAIL"))
+    t = SAIL(dict(cfg, model_type="t-SAIL"))   # the Transformer VAE is built too (same keys as the reference's state dict)
+    assert "enc.txf.layers.0.self_attn.in_proj_weight" in t.state_dict() and "dec.txf.layers.0.multihead_attn.in_proj_bias" in t.state_dict()
+    with pytest.raises(ArkError):
+        t(torch.zeros(2, 3, 3, dtype=torch.long), torch.ones(2, 10, dtype=torch.long))
     with pytest.raises(NotImplementedError):
         SAIL(dict(cfg, model_type="nope"))
+    with pytest.raises(NotImplementedError):   # (model-type families as in the reference: ARK builds ARK / t-ARK, models.py:372-393)
+        SAIL(dict(cfg, model_type="ARK"))
     with pytest.raises(KeyError):
         SAIL({"model_type": "SAIL"})
 

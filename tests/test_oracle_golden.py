@@ -347,3 +347,50 @@ def test_tark_generation_and_bits_match_reference(name):
         assert np.array_equal(got.numpy(), z[f"gen_seq{i}"]), (name, i)
     n = len(z["bits_ar"])
     np.testing.assert_allclose(O.ark_posterior_bits(P, torch.from_numpy(z["seq"])[:n], cfg), z["bits_ar"], rtol=3e-5)
+
+
+# ---- Transformer VAE t-SAIL (reference models.py:66-114, 160-170, 187-195): oracle restatement vs reference goldens
+@pytest.mark.parametrize("name", ["tsail_tiny", "tsail_tiny_pad", "tsail_small"])
+def test_tsail_oracle_matches_reference(name):
+    z, cfg = load(name)
+    torch.set_num_threads(8)
+    P = O.init_params(cfg, int(z["seed"]))
+    for k in [f[len("w0sum/"):] for f in z.files if f.startswith("w0sum/")]:
+        v = P[k].double()
+        assert abs(float(v.sum()) - float(z["w0sum/" + k])) <= 1e-12 * v.numel() and \
+            abs(float((v * v).sum()) - float(z["w0sq/" + k])) <= 1e-12 * v.numel(), k
+    tri, seq = torch.from_numpy(z["triples"]), torch.from_numpy(z["seq"])
+    if "logits0" in z.files:
+        with torch.no_grad():
+            loss, ce, kl, logits, mu, logv = O.sail_elbo(P, tri, seq, torch.from_numpy(z["eps0"]), float(z["betas"][0]), cfg)
+        np.testing.assert_allclose(logits.numpy(), z["logits0"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(mu.numpy(), z["mu0"], rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(logv.numpy(), z["logv0"], rtol=2e-4, atol=2e-6)
+    st = O.adam_init(O.leaf_params(P))
+    for s in range(len(z["losses"])):
+        loss, ce, kl, grads = O.train_step(P, st, (tri, seq), cfg, float(z["lr"]), beta=float(z["betas"][s]),
+                                           eps=torch.from_numpy(z[f"eps{s}"]))
+        want = z["losses"][s]
+        assert abs(loss - want[0]) <= 3e-5 * abs(want[0]) * (1 + 3 * s), (s, loss, want)
+        assert abs(kl - want[2]) <= 1e-4 * abs(want[2]) * (1 + 3 * s) + 1e-7, (s, kl, want)
+        if s == 0:
+            for (k, _), g in zip(O.leaf_params(P), grads):
+                wn = float(z["g0norm/" + k])
+                assert abs(float(g.double().norm()) - wn) <= 3e-4 * wn + 2e-7, (k, float(g.double().norm()), wn)
+                if "g0/" + k in z.files:
+                    g0 = z["g0/" + k]
+                    np.testing.assert_allclose(g.numpy(), g0, rtol=3e-3, atol=3e-5 * (np.abs(g0).max() + 1e-12) + 1e-8)
+
+
+@pytest.mark.parametrize("name", ["tsail_tiny", "tsail_tiny_pad", "tsail_small"])
+def test_tsail_decode_matches_reference(name):
+    """greedy and beam-2 decode_latent of t-SAIL from the seed's initial weights, triple for triple"""
+    z, cfg = load(name)
+    P = O.init_params(cfg, int(z["seed"]))
+    zs = torch.from_numpy(z["dec_z"])
+    for b in (1, 2):
+        seqs = O.greedy_decode(P, zs, cfg) if b == 1 else O.beam_decode(P, zs, cfg, b)
+        want, n = z[f"beam{b}/triples"], z[f"beam{b}/n"]
+        for i in range(seqs.shape[0]):
+            got = O.seq_to_triples(seqs[i].tolist(), cfg["ENT_BASE"], cfg["REL_BASE"])
+            assert [list(t) for t in got] == want[i, :int(n[i])].tolist(), (b, i)

@@ -79,9 +79,69 @@ def dump_tark(M, U, name, D, heads, n, nE, nR, T, B, seed, lr=1e-3, steps=3, ful
     print(name, "losses", losses, "greedy", out["gen_greedy"][0].tolist())
 
 
+def dump_tsail(M, U, name, D, Z, heads, n, nE, nR, T, B, padded, seed, lr=1e-3, steps=3, full=True):
+    """t-SAIL (models.py:160-170, 187-195).  Its layers hard-code dropout 0.1 (models.py:73,104), so the deterministic
+    goldens are taken in eval() mode WITH autograd enabled: dropout off, the stock (non-fused) layer code path."""
+    cfg = make_cfg("t-SAIL", D, Z, n, nE, nR, T, padded)
+    cfg["n_heads"] = heads
+    torch.manual_seed(seed)
+    model = quiet_model(M.SAIL, cfg)
+    model.eval()
+    triples, seq, _ = make_batch(U, cfg, B, seed + 100, padded)
+    out = {"cfg_json": np.array(json.dumps(cfg)), "seed": np.array(seed), "lr": np.array(lr), "triples": triples.numpy(),
+           "seq": seq.numpy()}
+    for k, v in model.state_dict().items():
+        v64 = v.detach().double()
+        out["w0sum/" + k], out["w0sq/" + k] = np.array(float(v64.sum())), np.array(float((v64 * v64).sum()))
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    betas = [0.1, 0.55, 1.0]
+    losses = []
+    for s in range(steps):
+        opt.zero_grad()
+        torch.manual_seed(1000 + s)
+        eps = torch.randn(B, Z)
+        torch.manual_seed(1000 + s)
+        logits, mu, logv = model(triples, seq[:, :-1])
+        ce = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.size(-1)), seq[:, 1:].reshape(-1), ignore_index=0)
+        kl = model.kl_mean(mu, logv)
+        loss = ce + betas[s] * kl
+        out[f"eps{s}"] = eps.numpy()
+        loss.backward()
+        losses.append([loss.item(), ce.item(), kl.item()])
+        if s == 0:
+            if full:
+                out["logits0"], out["mu0"], out["logv0"] = logits.detach().numpy(), mu.detach().numpy(), logv.detach().numpy()
+            for k, p in model.named_parameters():
+                gnp = p.grad.detach().numpy()
+                if full:
+                    out["g0/" + k] = gnp
+                out["g0norm/" + k] = np.array(float(np.sqrt((gnp.astype(np.float64) ** 2).sum())))
+        opt.step()
+        for k, v in model.state_dict().items():
+            out[f"w{s + 1}sum/" + k] = np.array(float(v.detach().double().sum()))
+    out["losses"] = np.array(losses, dtype=np.float64)
+    out["betas"] = np.array(betas[:steps])
+    # decode from the INITIAL weights: greedy and beam 2 (decode_latent, models.py:262-300)
+    torch.manual_seed(seed)
+    gen = quiet_model(M.SAIL, cfg)
+    gen.eval()
+    zs = torch.randn(6, Z, generator=torch.Generator().manual_seed(seed + 7))
+    out["dec_z"] = zs.numpy()
+    from tools.make_golden_r3 import triples_array
+    for b in (1, 2):
+        with torch.no_grad():
+            trip = gen.decode_latent(zs, cfg["seq_len"], cfg["special_tokens"], U.seq_to_triples, cfg["ENT_BASE"], cfg["REL_BASE"], beam=b)
+        out[f"beam{b}/triples"], out[f"beam{b}/n"] = triples_array(trip)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "losses", losses)
+
+
 def main():
     torch.set_num_threads(4)
     M, U = import_reference()
+    dump_tsail(M, U, "tsail_tiny", D=16, Z=4, heads=4, n=2, nE=20, nR=3, T=3, B=4, padded=False, seed=7)
+    dump_tsail(M, U, "tsail_tiny_pad", D=16, Z=6, heads=2, n=2, nE=30, nR=4, T=5, B=6, padded=True, seed=8, full=False)
+    dump_tsail(M, U, "tsail_small", D=64, Z=10, heads=4, n=3, nE=49, nR=3, T=3, B=32, padded=False, seed=9, full=False)
     dump_tark(M, U, "tark_tiny", D=32, heads=4, n=2, nE=20, nR=3, T=3, B=4, seed=5)
     dump_tark(M, U, "tark_small", D=64, heads=4, n=3, nE=49, nR=3, T=5, B=24, seed=6, full=False)
     dump_tark(M, U, "tark_synpaths_b32_s0", D=512, heads=4, n=3, nE=49, nR=3, T=3, B=32, seed=0, lr=1e-4, full=False)
