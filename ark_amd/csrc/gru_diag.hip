@@ -272,8 +272,11 @@ static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t 
     else if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 64>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 64, 64>(p, st);
   } else if (units == 16) {   // 2 waves
-    if (ki2 && tn.fwd_nbuf >= 4) launch_diag<PREC, PRECB, 6, 2, 32, 16>(p, st);   // deep ring: 12 k-images in flight (120 KB)
-    else if (ki2) launch_diag<PREC, PRECB, 2, 2, 32, 16>(p, st);
+    // (measured on the wd-articles shape, B = 16, profiles/r03_deep_ring_sweep.txt / r03_helper_waves_sweep.txt: neither a
+    //  six-slot ring -- 12 k-images in flight -- nor two extra waves that only issue LDS-DMA move these launches: 7.8 us
+    //  per launch either way.  They are made of fixed costs -- launch boundary, first-stage latency, epilogue -- not of
+    //  their eight ring stages.)
+    if (ki2) launch_diag<PREC, PRECB, 2, 2, 32, 16>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 32, 16>(p, st);
   } else if (rows == 64) {
     if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 32>(p, st);
@@ -551,8 +554,7 @@ static int launch_diag_bwd_cfg(GruDiagBwdArgs& p, const ArkDiagTuning& tn, hipSt
     p.xcd_m = (xm > 1 && MT % xm == 0 && NT % (8 / xm) == 0) ? xm : 1;
   }
   if (narrow) {
-    if (ki2 && tn.bwd_nbuf >= 4) launch_diag_bwd<PREC, 8, 2, 32, 32>(p, st);   // deep ring: 16 k-images in flight (128 KB)
-    else if (ki2) launch_diag_bwd<PREC, 2, 2, 32, 32>(p, st);
+    if (ki2) launch_diag_bwd<PREC, 2, 2, 32, 32>(p, st);   // (eight slots / four helper waves: 12.1 -> 11.9 / 13.1 us, not kept)
     else launch_diag_bwd<PREC, 2, 1, 32, 32>(p, st);
     ARK_LAUNCH_CHECK();
     return 0;
