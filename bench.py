@@ -383,6 +383,11 @@ def main():
                             traffic[name] = v["hbm_bytes_corrected"]
             except Exception:
                 pass
+            # unit of the roofline object = ONE anti-diagonal of the full batch.  With row-block chains (Engine._chains) that is
+            # `chains` concurrent launches of B / chains rows each: the event-timed sweep gives the time per anti-diagonal, the
+            # committed PMC passes report bytes per LAUNCH -> x chains
+            chains = len(eng._chains(B))
+            traffic = {k: v * chains for k, v in traffic.items()}
             kern = {}
             for name, (kt, launches) in times.items():
                 m = models[name]
@@ -390,7 +395,7 @@ def main():
                               "bytes_per_launch": m["impl"] / launches, "bytes_per_launch_min_8d": m["min"] / launches,
                               "achieved": m["impl"] / launches / kt / 1e9, "frac": m["impl"] / launches / kt / 1e9 / 8000.0,
                               "frac_min_8d": m["min"] / launches / kt / 1e9 / 8000.0, "traffic": traffic.get(name),
-                              "flops_per_launch": m["flops"] / launches,
+                              "concurrent_launches_per_unit": chains, "flops_per_launch": m["flops"] / launches,
                               "mfma_frac": m["flops"] / launches / kt / 1e12 / mfma_peak,
                               # what actually bounds these kernels: the per-CU L2 -> LDS operand stream.
                               # ceiling = 110 GB/s per CU, measured with a consumer-less LDS-DMA ring (tools/l2_stream_bench.hip)
