@@ -321,7 +321,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--no-other", action="store_true", help="skip the other BASELINE workloads (development legs)")
-    ap.add_argument("--dp-overhead", action="store_true", help="also time the step through the data-parallel schedule with ONE rank")
     ap.add_argument("--cfg", default="", help="extra engine config ints, e.g. ark_overlap_wgrad=0,ark_fork_after=0")
     ap.add_argument("--diag", default="", help="diagonal-kernel tiles, e.g. fwd_rows=64,fwd_units=32,bwd_rows=32,bwd_ki=2")
     ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path even with one rank")
@@ -332,6 +331,13 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args, sys.argv[1:]))
+
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to fd 1 when its first communicator is
+    # created, so everything written to fd 1 from here on -- native libraries included -- goes to stderr, and the result line
+    # is written to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -439,31 +445,14 @@ def main():
             del eng
             torch.cuda.empty_cache()
             res["other_workloads"] = other_workloads(dev, args.precision, args.dropout, mfma_peak)
-        if args.dp_overhead and world == 1 and not args.force_dist and args.workload == "syn-paths":
-            # what the data-parallel SCHEDULE costs before a byte moves: the same step through the bucketed all-reduce path with a
-            # one-rank RCCL group (pack -> all-reduce -> unpack -> split Adam), same box, same process
-            try:
-                import torch.distributed as dist2
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
-                dist2.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-                r1 = time_workload(dev, args.workload, args.precision, args.dropout, args.batch, 200, 20, 100, extra, world=1, rank=0,
-                                   dist=dist2, use_dp=True)
-                ms1 = r1["dt"] / r1["steps"] * 1e3
-                res["dp_overhead_1rank"] = {"ms_per_step": ms1, "ratio": ms1 / res["ms_per_step"],
-                                            "bf16_buckets": bool(r1["eng"].dp_bf16), "steps": r1["steps"]}
-                del r1
-                torch.cuda.empty_cache()
-                dist2.destroy_process_group()
-            except Exception as e:
-                res["dp_overhead_1rank"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, B, steps=args.cpu_steps, warmup=5)
             if B == 1024:   # the plumbing batch and the YAML batch beside it
                 for b2 in (32, 256):
                     c2 = cpu_baseline(cfg, b2, steps=20, warmup=5)
                     res["cpu_baseline"][f"batch_{b2}"] = {"value": c2["value"], "sample": c2["sample"]}
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.barrier()   # leave together: rank 0 is still timing its kernels while the others are done
         dist.destroy_process_group()
