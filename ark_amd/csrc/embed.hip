@@ -262,7 +262,10 @@ __global__ __launch_bounds__(256) void enc_scatter_fused_kernel(const int64_t* _
   }
 }
 
-constexpr int g_scatter_chunk_items = 48;
+#ifndef ARK_SCATTER_CHUNK
+#define ARK_SCATTER_CHUNK 48
+#endif
+constexpr int g_scatter_chunk_items = ARK_SCATTER_CHUNK;
 
 static int launch_scatter(const ScatterArgs& p, hipStream_t st) {
   if (p.n_items <= 0) return 0;
