@@ -294,6 +294,8 @@ class TxfEngine(Engine):
         Lq = self.L if L_run is None else L_run
         assert seq.dtype == torch.int64 and seq.is_contiguous() and seq.device == self.device and seq.shape[1] >= Lq
         enc_on = self.vae and z_given is None
+        if enc_on and triples is None:
+            raise L.ArkError("t-SAIL forward needs `triples` (encoder input) or `z_given` (decoder alone)")
         T = triples.shape[1] if enc_on else 0
         w = self._workspace(B, Lq, T)
         D, n, V, H = self.D, self.n, self.V, self.H

@@ -394,3 +394,15 @@ def test_tsail_decode_matches_reference(name):
         for i in range(seqs.shape[0]):
             got = O.seq_to_triples(seqs[i].tolist(), cfg["ENT_BASE"], cfg["REL_BASE"])
             assert [list(t) for t in got] == want[i, :int(n[i])].tolist(), (b, i)
+
+
+@pytest.mark.parametrize("name", ["tsail_tiny", "tsail_tiny_pad", "tsail_small"])
+def test_tsail_posterior_bits_match_reference(name):
+    """the oracle's posterior_bits on t-SAIL against the reference's per-item records (AR bits by prefix re-runs of the
+    Transformer decoder, KL bits summed over the latent), fed the noise the reference drew"""
+    z, cfg = load(name)
+    P = O.init_params(cfg, int(z["seed"]))
+    n = len(z["bits_ar"])
+    ar, kl = O.posterior_bits(P, torch.from_numpy(z["triples"])[:n], torch.from_numpy(z["seq"])[:n], torch.from_numpy(z["bits_eps"]), cfg)
+    np.testing.assert_allclose(ar, z["bits_ar"], rtol=5e-5)
+    np.testing.assert_allclose(kl, z["bits_kl"], rtol=2e-4, atol=1e-7)

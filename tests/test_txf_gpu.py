@@ -354,3 +354,21 @@ def test_tsail_through_the_train_entry_point(tmp_path):
     yaml.safe_dump(cfg, open(cpath, "w"))
     T.main(["--config", str(cpath), "--checkpoint-dir", str(tmp_path / "ck")])
     assert torch.isfinite(torch.load(str(tmp_path / "P.rank0.pt"), weights_only=True)).all()
+
+
+@pytest.mark.parametrize("name,padded", [("tsail_tiny", False), ("tsail_tiny_pad", True)])
+def test_tsail_posterior_bits_match_reference_records(name, padded):
+    """SAIL.posterior_bits for t-SAIL (one teacher-forced pass) against the reference's per-item records, same noise"""
+    from kgvae.model.utils import GraphSeqDataset
+    model, z, cfg = _sail_model(name)
+    pr = cfg["pad_rid"]
+    graphs = [[tuple(int(x) for x in t) for t in g if not padded or int(t[1]) != pr] for g in z["triples"]]
+    ds = GraphSeqDataset(graphs, None, None, use_padding=padded, pad_eid=cfg["pad_eid"], pad_rid=pr, max_triples=z["triples"].shape[1],
+                         special_tokens=cfg["special_tokens"], ent_base=cfg["ENT_BASE"], rel_base=cfg["REL_BASE"], seq_len=cfg["seq_len"])
+    n = len(z["bits_ar"])
+    stats = model.posterior_bits(ds, "cuda", sample_frac=n / len(graphs), eps=torch.from_numpy(z["bits_eps"]))
+    assert len(stats["records"]) == n
+    np.testing.assert_allclose([r["ar_bits"] for r in stats["records"]], z["bits_ar"], rtol=1e-4)
+    np.testing.assert_allclose([r["kl_bits"] for r in stats["records"]], z["bits_kl"], rtol=3e-4, atol=1e-7)
+    with pytest.raises(Exception):
+        model.engine().forward(None, torch.from_numpy(z["seq"]).cuda())   # no triples, no z: refused loudly

@@ -132,6 +132,20 @@ def dump_tsail(M, U, name, D, Z, heads, n, nE, nR, T, B, padded, seed, lr=1e-3, 
         with torch.no_grad():
             trip = gen.decode_latent(zs, cfg["seq_len"], cfg["special_tokens"], U.seq_to_triples, cfg["ENT_BASE"], cfg["REL_BASE"], beam=b)
         out[f"beam{b}/triples"], out[f"beam{b}/n"] = triples_array(trip)
+    # posterior_bits of the first graphs (models.py:202-260) from the initial weights, with the noise those calls drew
+    # (DataLoader iterator: one int64 from the global generator first -- tools/make_golden_r3.py)
+    from tools.make_golden_r3 import dataset_of
+    import contextlib, io
+    ds, _, _ = dataset_of(U, cfg, B, seed + 100, padded)
+    torch.manual_seed(900 + seed)
+    with contextlib.redirect_stderr(io.StringIO()):
+        stats = gen.posterior_bits(ds, "cpu", pad_id=0, sample_frac=min(1.0, 6 / B))
+    nb = len(stats["records"])
+    out["bits_ar"] = np.array([r["ar_bits"] for r in stats["records"]])
+    out["bits_kl"] = np.array([r["kl_bits"] for r in stats["records"]])
+    torch.manual_seed(900 + seed)
+    torch.empty((), dtype=torch.int64).random_()
+    out["bits_eps"] = torch.cat([torch.randn(1, Z) for _ in range(nb)]).numpy()
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name, "losses", losses)
 
