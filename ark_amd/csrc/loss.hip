@@ -473,7 +473,6 @@ __global__ __launch_bounds__(256) void ce_kernel(float* logits, long ld, const i
   }
 }
 
-static int g_ce_lds = 1;
 
 // Large-vocabulary edition: ONE workgroup per row, the row cached in LDS -- the [B*L,V] fp32 logits are read from
 // HBM exactly once (the wave-per-row kernel above streams every row three times: max, sum-exp, gradient; at
@@ -792,7 +791,7 @@ extern "C" int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int
   __bf16* dbf = prec16 == 1 ? (__bf16*)dlogits16 : nullptr;
   _Float16* dh = prec16 == 2 ? (_Float16*)dlogits16 : nullptr;
   const size_t ld_bytes = (size_t)ld * sizeof(float);
-  if (V >= 4096 && ld_bytes <= 144 * 1024 && ld % 4 == 0 && g_ce_lds) {   // large vocabulary: row cached in LDS, read once
+  if (V >= 4096 && ld_bytes <= 144 * 1024 && ld % 4 == 0) {   // large vocabulary: row cached in LDS, read once
     const int nr = (int)((ld / 4 + 1023) / 1024);   // 16-byte loads per thread per row (<= 9 at 144 KB)
     int grid = 256 * 1;                              // one workgroup per CU (LDS), persistent over the rows
     if (grid > B * L) grid = B * L;

@@ -41,9 +41,8 @@ struct VocabCeArgs {
   float* dY_t;            // [R, D] tile-native fp32 (fwd kernel output, nullable)
   float* dW;              // [V, D] += (dw kernel)
   float* db;              // [V] +=
-  void* dlog16;           // [R, ld_dlog] 16-bit dlogits (small-vocabulary flavour of the fwd kernel: V <= 64), nullable
-  long ld_seq, ld_dlog;
-  int R, B, V, prec_dlog;
+  long ld_seq;
+  int R, B, V;
 };
 
 constexpr int kVcImg = 64 * 128;   // one k-image: 64 rows x 128 B (64 16-bit elements of the reduction index)
@@ -105,10 +104,7 @@ __device__ __forceinline__ void vc_wait_stages(int k) {
 // ---------------------------------------------------------------------------------------------------------
 // RG groups of 16 rows per workgroup (2*RG waves: RG row groups x 2 token halves), chosen on the host so that the row
 // tiles fill the 256 CUs evenly (64-row tiles gave 280 workgroups at wd-movies B=256: two rounds for 1.09 rounds of work)
-// WITH_DLOG (V <= 64, a single token tile): additionally writes dlogits = (softmax - onehot) / count as a row-major 16-bit
-// panel -- the small-vocabulary path takes dW_tok / db_out from it (ark_colsum16 + ark_wgrad16_rows) -- so that
-// logits -> cross-entropy -> dY, three dependent launches and a [R, V] fp32 round trip at V = 55, are one launch.
-template <int PREC, int DCH, int RG, bool WITH_DY, bool WITH_DLOG = false>
+template <int PREC, int DCH, int RG, bool WITH_DY>
 __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
@@ -148,7 +144,6 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   for (int s = 0; s < NSLOT && s < nsteps; ++s) issue(s);
 
   float m2 = -INFINITY, lsum = 0.f, picked = 0.f;   // running max (log2 domain), this LANE's partial sum, target logit
-  float svk[WITH_DLOG ? 8 : 1];                     // WITH_DLOG: this lane's 8 logits of the (only) tile, log2 domain
   f32x4 U[WITH_DY ? DT : 1];
   if constexpr (WITH_DY) {
 #pragma unroll
@@ -188,10 +183,6 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
       for (int j = 0; j < 8; ++j)
         if ((long)(s * 64 + vh * 32 + 16 * (j >> 2) + 4 * q + (j & 3)) == tgt) picked = sv[j];   // (log2 domain)
     }
-    if constexpr (WITH_DLOG) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) svk[j] = sv[j];
-    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) mt = fmaxf(mt, sv[j]);
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
@@ -230,38 +221,6 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   // combine the two token halves (waves w and w+4 share their rows) through the ring space
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if constexpr (WITH_DLOG) {
-    // both halves need the row's final log-sum-exp: swap (max, sum) first, through the start of the ring space
-    float* sx = reinterpret_cast<float*>(smem);                // [2 halves][RG][2][64]
-    sx[((vh * RG + rg) * 2 + 0) * 64 + lane] = m2;
-    sx[((vh * RG + rg) * 2 + 1) * 64 + lane] = lsum;
-    __syncthreads();
-    const float mo = sx[(((1 - vh) * RG + rg) * 2 + 0) * 64 + lane], lo = sx[(((1 - vh) * RG + rg) * 2 + 1) * 64 + lane];
-    __syncthreads();                                           // (the space is reused just below)
-    const float mm2 = fmaxf(m2, mo);
-    const float la = lsum * __builtin_amdgcn_exp2f(m2 - mm2) + ((mo == -INFINITY) ? 0.f : lo * __builtin_amdgcn_exp2f(mo - mm2));
-    const float lse2 = mm2 + __builtin_amdgcn_logf(la);        // log2 domain
-    if (r < R) {
-      const float sc = live ? p.hyper[ARK_HP_CE_INV_COUNT] : 0.f;
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int v0 = vh * 32 + 16 * hf + 4 * q;               // this lane's 4 consecutive tokens of the half-tile
-        float g[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          g[i] = sc * (__builtin_amdgcn_exp2f(svk[4 * hf + i] - lse2) - (((long)(v0 + i) == tgt) ? 1.0f : 0.f));
-        if (p.prec_dlog == PREC_F16) {
-          typedef _Float16 hh4 __attribute__((ext_vector_type(4)));
-          *reinterpret_cast<hh4*>(reinterpret_cast<_Float16*>(p.dlog16) + (long)r * p.ld_dlog + v0) =
-              hh4{(_Float16)g[0], (_Float16)g[1], (_Float16)g[2], (_Float16)g[3]};
-        } else {
-          typedef __bf16 bb4 __attribute__((ext_vector_type(4)));
-          *reinterpret_cast<bb4*>(reinterpret_cast<__bf16*>(p.dlog16) + (long)r * p.ld_dlog + v0) =
-              bb4{(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};
-        }
-      }
-    }
-  }
   float* xs = reinterpret_cast<float*>(smem);                  // [RG row groups][DT][64 lanes] f32x4 + stats
   constexpr int UW = (WITH_DY ? DT : 0) * 64 * 4;              // floats per row group
   float* st = xs + RG * UW;                                    // [RG][3][64]
@@ -443,12 +402,8 @@ template <int PREC, int DCH, int RG>
 static int vc_launch_fwd_rg(const VocabCeArgs& p, bool with_dy, hipStream_t st) {
   constexpr int LDS = vc_lds_bytes<DCH, RG>(kVcAux);
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static_assert(2 * RG * 2 * 64 * 4 <= LDS, "stats swap of the small-vocabulary flavour");
   const unsigned grid = (unsigned)((p.R + 16 * RG - 1) / (16 * RG));
-  if (p.dlog16) {   // (host checked: V <= 64, dY wanted)
-    static bool once = (vc_allow_lds(vocab_ce_fwd_kernel<PREC, DCH, RG, true, true>, LDS), true); (void)once;
-    hipLaunchKernelGGL((vocab_ce_fwd_kernel<PREC, DCH, RG, true, true>), dim3(grid), dim3(128 * RG), LDS, st, p);
-  } else if (with_dy) {
+  if (with_dy) {
     static bool once = (vc_allow_lds(vocab_ce_fwd_kernel<PREC, DCH, RG, true>, LDS), true); (void)once;
     hipLaunchKernelGGL((vocab_ce_fwd_kernel<PREC, DCH, RG, true>), dim3(grid), dim3(128 * RG), LDS, st, p);
   } else {
@@ -541,26 +496,9 @@ extern "C" int ark_vocab_ce_fwd(int prec, const void* Y16, const void* W16, cons
   if (rc) return rc;
   if (!row_loss || !lse) return ARK_ERR_ARG;
   if (dY_t && (B * L) % 16 != 0) return ARK_ERR_SHAPE;   // tile-native dY
-  VocabCeArgs p{Y16, W16, bias, seq, hyper, row_loss, lse, dY_t, nullptr, nullptr, nullptr, (long)ld_seq, 0L, B * L, B, V, 0};
+  VocabCeArgs p{Y16, W16, bias, seq, hyper, row_loss, lse, dY_t, nullptr, nullptr, (long)ld_seq, B * L, B, V};
   const bool with_dy = dY_t != nullptr;
   ARK_VC_DISPATCH(vc_launch_fwd, p, with_dy, (hipStream_t)stream);
-}
-
-// small vocabularies (V <= 64): the same sweep additionally writes dlogits as a row-major 16-bit panel [B*L, ld_dlog]
-// (type prec_dlog; columns V..63 are written as zeros, so ld_dlog >= 64) for the weight / bias gradient products
-extern "C" int ark_vocab_ce_fwd_small(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq,
-                                      int64_t ld_seq, const float* hyper, float* row_loss, float* lse, float* dY_t,
-                                      void* dlog16, int prec_dlog, int64_t ld_dlog, int B, int L, int V, int D, void* stream) {
-  using namespace ark;
-  int rc = vc_check(prec, Y16, W16, bias, seq, hyper, B, L, V, D);
-  if (rc) return rc;
-  if (!row_loss || !lse || !dY_t || !dlog16) return ARK_ERR_ARG;
-  if (prec_dlog != PREC_F16 && prec_dlog != PREC_BF16) return ARK_ERR_ARG;
-  if (V > 64 || ld_dlog < 64 || ld_dlog % 4 != 0 || (B * L) % 16 != 0) return ARK_ERR_SHAPE;
-  if ((uintptr_t)dlog16 & 7) return ARK_ERR_ALIGN;
-  VocabCeArgs p{Y16, W16, bias, seq, hyper, row_loss, lse, dY_t, nullptr, nullptr, dlog16, (long)ld_seq, (long)ld_dlog, B * L, B, V,
-                prec_dlog};
-  ARK_VC_DISPATCH(vc_launch_fwd, p, true, (hipStream_t)stream);
 }
 
 extern "C" int ark_vocab_ce_dw(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
@@ -571,6 +509,6 @@ extern "C" int ark_vocab_ce_dw(int prec, const void* Y16, const void* W16, const
   if (rc) return rc;
   if (!lse || !dW || !db) return ARK_ERR_ARG;
   if ((uintptr_t)dW & 15) return ARK_ERR_ALIGN;
-  VocabCeArgs p{Y16, W16, bias, seq, hyper, nullptr, const_cast<float*>(lse), nullptr, dW, db, nullptr, (long)ld_seq, 0L, B * L, B, V, 0};
+  VocabCeArgs p{Y16, W16, bias, seq, hyper, nullptr, const_cast<float*>(lse), nullptr, dW, db, (long)ld_seq, B * L, B, V};
   ARK_VC_DISPATCH(vc_launch_dw, p, (hipStream_t)stream);
 }

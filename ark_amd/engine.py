@@ -202,11 +202,6 @@ class Engine:
         self._adam_dec_early = False
         self._adam_dec_done = False
         self._adam_mlp_done = False
-        # small vocabularies (one 64-token tile): projection + cross-entropy + dY(top) + 16-bit dlogits in one launch
-        # (opt-in: at D = 512 the fused kernel measures 22 us against 7.8 + 6.4 + 13.3 us for the three launches it replaces,
-        #  and in steady state the step is 9 us SLOWER with it -- 1.168 vs 1.158 ms, 4 of 4 alternating rounds; it won only
-        #  while the device was still ramping up after the capture)
-        self.fused_ce_small = bool(cfg.get("ark_fused_ce_small", False)) and self.use_dma and self.V <= 64 and self.D in (64, 128, 256, 512)   # reparameterisation + z-projection as one launch
         self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))
         # large vocabularies: tied projection fused with the cross-entropy -- [B*L, V] logits / dlogits never exist
         # (csrc/vocab_ce.hip); small ones keep the three short launches (W_tok is a few KB there)
@@ -441,8 +436,6 @@ class Engine:
                 w["lse"] = f(R)
             else:
                 w["dlog16"] = torch.zeros(R, self.Vp, device=dev, dtype=torch.int16)   # K-padded 16-bit dlogits
-                if self.fused_ce_small:
-                    w["lse"] = f(R)
             # small vocabularies: token-embedding gradient and layer 0's input weight gradient from the per-token sums
             # of layer 0's gate-gradient panel instead of input-gradient GEMM + scatter + a [3D,D]x[B*L] weight-gradient
             # product (SAIL; ARK also needs dX0 for the position embedding)
@@ -609,11 +602,8 @@ class Engine:
         yield
         st = L.cur_stream()
         fused = bool(w["v2"] and self.fused_ce and with_loss)
-        small = bool(w["v2"] and self.fused_ce_small and not self.fused_ce and with_loss and R % 64 == 0 and self.dlog16_only
-                     and self.Vp >= 64)
         self._fused_ce_step = fused and with_dlogits
-        self._dy_ready = False
-        self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop, project=not (fused or small))
+        self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop, project=not fused)
         if with_loss:
             if ce_count is None:
                 _call("ark_count_targets", L.ptr(seq), L.i64(ld_seq), L.i32(B), L.i32(Lq), L.ptr(self.hyper), st)
@@ -623,21 +613,6 @@ class Engine:
             _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]),
                   L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
                   L.ptr(w["dYa"] if with_dlogits else None), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
-            self._finalize = self._make_finalize(w, R, B)
-            if not (self._defer_finalize and with_dlogits):
-                self._finalize()
-                self._finalize = None
-        elif with_loss and small:
-            if with_dlogits:
-                _call("ark_vocab_ce_fwd_small", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16),
-                      L.ptr(p["dec.out.bias"]), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
-                      L.ptr(w["dYa"]), L.ptr(w["dlog16"]), L.i32(self.prec_bwd), L.i64(self.Vp), L.i32(B), L.i32(Lq), L.i32(V),
-                      L.i32(D), st)
-                self._dlog16_valid, self._dlog16_only, self._dy_ready = True, True, True
-            else:
-                _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16),
-                      L.ptr(p["dec.out.bias"]), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
-                      L.ptr(None), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
             self._finalize = self._make_finalize(w, R, B)
             if not (self._defer_finalize and with_dlogits):
                 self._finalize()
@@ -1061,7 +1036,7 @@ class Engine:
                       L.ptr(g["dec.out.weight"]), L.i64(D), L.i32(V), L.i32(D), L.i32(R), L.i32(1), L.cur_stream())
         self._side_used = side is not main
         st = L.cur_stream()
-        if self._fused_ce_step or getattr(self, "_dy_ready", False):
+        if self._fused_ce_step:
             pass   # dY of the top layer was written by the fused forward kernel (w["dYa"], tile-native)
         elif getattr(self, "_dlog16_valid", False):
             _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(self.wtokT16),

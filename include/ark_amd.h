@@ -293,12 +293,6 @@ int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int64_t ld_seq
 int ark_vocab_ce_fwd(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
                      const float* hyper, float* row_loss, float* lse, float* dY_t /* nullable */, int B, int L, int V, int D,
                      void* stream);
-/* small vocabularies (V <= 64, one token tile): the same sweep also writes dlogits = (softmax - onehot) / count as a
- * row-major 16-bit panel [B*L, ld_dlog] (type prec_dlog, columns V..63 zero) for ark_colsum16 / ark_wgrad16_rows:
- * logits -> cross-entropy -> dY of the top layer as ONE launch instead of three dependent ones */
-int ark_vocab_ce_fwd_small(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
-                           const float* hyper, float* row_loss, float* lse, float* dY_t, void* dlog16, int prec_dlog,
-                           int64_t ld_dlog, int B, int L, int V, int D, void* stream);
 int ark_vocab_ce_dw(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
                     const float* hyper, const float* lse, float* dW, float* db, int B, int L, int V, int D, void* stream);
 /* out4 = {loss = ce + beta*kl, ce, kl, sum of token losses}; kl nullable (ARK) */
