@@ -97,6 +97,23 @@ class GruDiagBwdRole(ctypes.Structure):
         ("drop_seed", ctypes.c_uint64), ("drop_base", ctypes.c_int64), ("drop_p", ctypes.c_float), ("first", ctypes.c_int)]
 
 
+SWEEP_MAX_LAYERS = 4
+
+
+class GruSweepLayer(ctypes.Structure):
+    """ArkGruSweepLayer of include/ark_amd.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in (
+        "w_ih16", "w_hh16", "b_ih", "b_hh", "y_t", "y16a", "y16b", "yd16a", "yd16b", "save_r", "save_z", "save_n", "save_hn")] + [
+        ("drop_seed", ctypes.c_uint64), ("drop_p", ctypes.c_float), ("pad_", ctypes.c_int)]
+
+
+class GruSweep(ctypes.Structure):
+    """ArkGruSweep of include/ark_amd.h"""
+    _fields_ = [("layer", GruSweepLayer * SWEEP_MAX_LAYERS), ("x0_16", ctypes.c_void_p), ("exch", ctypes.c_void_p),
+                ("sync", ctypes.c_void_p), ("hyper", ctypes.c_void_p), ("n_layers", ctypes.c_int), ("B", ctypes.c_int),
+                ("D", ctypes.c_int), ("L", ctypes.c_int)]
+
+
 class DiagTuning(ctypes.Structure):
     """ArkDiagTuning of include/ark_amd.h (speed-only tile / ring choices, passed per call)"""
     _fields_ = [(k, ctypes.c_int) for k in ("fwd_rows", "fwd_ki", "fwd_nbuf", "fwd_xcd", "fwd_units", "bwd_rows", "bwd_ki",

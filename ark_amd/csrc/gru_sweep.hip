@@ -1,0 +1,314 @@
+// Persistent GRU sweep for SMALL batches of LONG sequences (wd-articles: 16 graphs x 637 tokens, wd-movies: 256 x 71).
+//
+// There the layer-diagonal launches of gru_diag.hip are all fixed cost: a [16 x 1024] x [1024 x 1536] cell is ~0.3 us of
+// MFMA work inside a 7.7-us launch, and a step is ~1 300 such launches in a row.  This file runs the whole recurrence of
+// a sequence as ONE launch: workgroup (layer l, row block rb, unit slice s) owns 16 hidden units of 16 batch rows for
+// every timestep, keeps ITS rows of W_ih and W_hh in registers for the whole sweep (96 VGPRs at D = 512), and the
+// hidden state moves between workgroups through an exchange buffer in global memory:
+//
+//   producer (wave 0 of the cell's workgroup): 16-B write-through (`sc1`) stores of the new state slice, every 128-B
+//     line whole, `s_waitcnt vmcnt(0)`, then ONE agent-scope atomic add on the counter of (l, t, rb);
+//   consumer: wave 0 polls that counter with `sc1` loads (relaxed, s_sleep between polls), a workgroup barrier, then
+//     EVERY load of handed-off bytes is a `buffer_load_dwordx4 ... sc1` straight into MFMA A fragments
+//     (MI355X_MICROARCH.md, visibility section, valid forms table row 1: no L1 acquire needed).
+//
+// Each (l, t) has its own exchange region and counter, zeroed by the call, so nothing is ever reused inside a launch.
+// Every spin is bounded: after ~0.25 s without progress (or when another workgroup has given up) a workgroup writes an
+// error word and leaves, so a scheduling accident ends in an error code, not in a hung GPU.  All workgroups must be
+// co-resident: the host checks grid <= CUs (96 KB of dynamic LDS pin one workgroup per CU) and uses a cooperative launch
+// outside stream capture.
+//
+// Outputs are exactly those of the diagonal kernels (tile-native fp32 state, tile-native fp16 gate saves, row-major
+// 16-bit copies, dropout-applied copies with the same counter-hash masks), so the projection, the cross-entropy and the
+// backward pass do not know which forward ran.  Reference op replaced: torch.nn.GRU (kgvae/model/models.py:121-127).
+#include "gemm_core.h"
+#include "../../include/ark_amd.h"
+
+namespace ark {
+
+typedef _Float16 shalf4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct GruSweepArgs {
+  ArkGruSweep a;
+};
+
+constexpr unsigned long long kSweepTimeoutTicks = 25000000ull;   // s_memrealtime runs at 100 MHz: 0.25 s
+constexpr int kSweepLds = 96 * 1024;                             // > half of a CU's LDS: one workgroup per CU
+constexpr int kSweepSyncHdr = 16;                                // words in front of the counters (error word + diagnostics)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sweep_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 ld_sc1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16);   // aux 16 = sc1
+}
+__device__ __forceinline__ void st_sc1(u32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 16);
+}
+
+// whole wave polls ONE word (one request); false = gave up (timeout here or elsewhere)
+__device__ __forceinline__ bool sweep_wait(unsigned* cnt, unsigned need, unsigned* sync, unsigned code) {
+  unsigned long long t0 = 0;
+  for (unsigned spins = 1;; ++spins) {
+    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+    if ((spins & 31u) == 0u) {
+      if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > kSweepTimeoutTicks) {
+        __hip_atomic_store(sync + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+__global__ void sweep_zero_kernel(unsigned* p, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
+// 4 waves: wave w forms the partial products of K-steps [w*KSW, (w+1)*KSW) of BOTH operands (x_t W_ih^T, h_{t-1} W_hh^T);
+// wave 0 adds the partials, does the gate math and owns the state.  D = 128 * KSW.
+template <int PREC, int PRECB, int KSW>
+__global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
+  using PT = PrecTraits<PREC>;
+  using PB = PrecTraits<PRECB>;
+  using h_t = typename PT::h_t;
+  using h8 = typename PT::h8;
+  using hb_t = typename PB::h_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ArkGruSweep& p = pa.a;
+  constexpr int TS = 24;                                   // row stride of the 16 x 16 transposition tiles (halves)
+  f32x4* part = reinterpret_cast<f32x4*>(smem);            // [3 waves][4 accumulators][64 lanes]
+  h_t* ta = reinterpret_cast<h_t*>(smem + 12288);          // h, forward type
+  hb_t* tb = reinterpret_cast<hb_t*>(smem + 12288 + 768);  // h, backward type
+  h_t* tda = reinterpret_cast<h_t*>(smem + 12288 + 1536);  // h * mask
+  hb_t* tdb = reinterpret_cast<hb_t*>(smem + 12288 + 2304);
+  int* lflag = reinterpret_cast<int*>(smem + 12288 + 3072);
+
+  const int D = p.D, B = p.B, L = p.L;
+  const int NS = D >> 4, RBK = B >> 4;
+  const int wg = blockIdx.x;
+  const int l = wg / (NS * RBK), rem = wg - l * (NS * RBK);
+  const int rb = rem / NS, s = rem - rb * NS;
+  const ArkGruSweepLayer& Ly = p.layer[l];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, kg = lane >> 4;
+  const int u = s * 16 + r;   // B-operand column / accumulator column of this lane
+
+  // this workgroup's weight rows, as MFMA B fragments, for the whole sweep
+  h8 wx[3][KSW], wh[3][KSW];
+  {
+    const h_t* wi = reinterpret_cast<const h_t*>(Ly.w_ih16);
+    const h_t* wr = reinterpret_cast<const h_t*>(Ly.w_hh16);
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int j = 0; j < KSW; ++j) {
+        const long o = (long)(g * D + u) * D + (wave * KSW + j) * 32 + kg * 8;
+        wx[g][j] = *reinterpret_cast<const h8*>(wi + o);
+        wh[g][j] = *reinterpret_cast<const h8*>(wr + o);
+      }
+  }
+  const float br = Ly.b_ih[u] + Ly.b_hh[u], bz = Ly.b_ih[D + u] + Ly.b_hh[D + u];
+  const float bin = Ly.b_ih[2 * D + u], bhn = Ly.b_hh[2 * D + u];
+  const long slot = (long)B * D;                              // elements per timestep
+  const long tile_off = (long)(rb * NS + s) * 256 + lane * 4;  // tile-native offset of this lane's quad inside a slot
+  f32x4 hprev = *reinterpret_cast<const f32x4*>(Ly.y_t + tile_off);   // slot 0 = initial state
+  const bool drop = Ly.drop_p > 0.f;
+  const bool below_drop = l > 0 && p.layer[l - 1].drop_p > 0.f;
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(Ly.drop_seed, p.hyper, Ly.drop_p);
+
+  const unsigned RG = (unsigned)(slot * 2);   // bytes of one exchange region == of one row-major 16-bit slot
+  const __amdgpu_buffer_rsrc_t rx = sweep_rsrc(p.x0_16, RG * (unsigned)L);
+  const __amdgpu_buffer_rsrc_t rh0 = sweep_rsrc(Ly.y16a, RG);
+  const __amdgpu_buffer_rsrc_t rex = sweep_rsrc(p.exch, RG * (unsigned)(2 * L * p.n_layers));
+  int voff_rm[KSW], voff_ex[KSW];
+#pragma unroll
+  for (int j = 0; j < KSW; ++j) {
+    const int ks = wave * KSW + j;
+    voff_rm[j] = ((rb * 16 + r) * D + ks * 32 + kg * 8) * 2;
+    voff_ex[j] = ((rb * NS + ks * 2 + (kg >> 1)) * 16 + r) * 32 + (kg & 1) * 16;
+  }
+  unsigned* sync = p.sync;
+  unsigned* cnt = p.sync + kSweepSyncHdr;
+  if (threadIdx.x == 0) *lflag = 0;
+  __syncthreads();
+
+  for (int t = 0; t < L; ++t) {
+    if (wave == 0) {
+      bool ok = true;
+      if (t > 0) ok = sweep_wait(cnt + ((long)l * L + (t - 1)) * RBK + rb, (unsigned)NS, sync, (unsigned)(wg << 12 | (t & 4095)));
+      if (ok && l > 0) ok = sweep_wait(cnt + ((long)(l - 1) * L + t) * RBK + rb, (unsigned)NS, sync, (unsigned)(wg << 12 | (t & 4095)) | 0x80000000u);
+      if (!ok && lane == 0) *lflag = 1;
+    }
+    __syncthreads();
+    if (*lflag) break;   // uniform: every wave reads the same word behind the barrier
+
+    u32x4 xa[KSW], ha[KSW];
+    if (l == 0) {
+#pragma unroll
+      for (int j = 0; j < KSW; ++j) xa[j] = ld_sc1(rx, voff_rm[j], (int)((unsigned)t * RG));
+    } else {
+      const int so = (int)((unsigned)(((l - 1) * L + t) * 2 + (below_drop ? 1 : 0)) * RG);
+#pragma unroll
+      for (int j = 0; j < KSW; ++j) xa[j] = ld_sc1(rex, voff_ex[j], so);
+    }
+    if (t == 0) {
+#pragma unroll
+      for (int j = 0; j < KSW; ++j) ha[j] = ld_sc1(rh0, voff_rm[j], 0);
+    } else {
+      const int so = (int)((unsigned)((l * L + (t - 1)) * 2) * RG);
+#pragma unroll
+      for (int j = 0; j < KSW; ++j) ha[j] = ld_sc1(rex, voff_ex[j], so);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+      const h8 a = __builtin_bit_cast(h8, xa[j]);
+      acc[0] = PT::mfma(a, wx[0][j], acc[0]);
+      acc[1] = PT::mfma(a, wx[1][j], acc[1]);
+      acc[2] = PT::mfma(a, wx[2][j], acc[2]);
+    }
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+      const h8 a = __builtin_bit_cast(h8, ha[j]);
+      acc[0] = PT::mfma(a, wh[0][j], acc[0]);
+      acc[1] = PT::mfma(a, wh[1][j], acc[1]);
+      acc[3] = PT::mfma(a, wh[2][j], acc[3]);
+    }
+    if (wave > 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) part[((wave - 1) * 4 + a) * 64 + lane] = acc[a];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc[a] += part[a * 64 + lane] + part[(4 + a) * 64 + lane] + part[(8 + a) * 64 + lane];
+      f32x4 rr, zz, nn, hn, h;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rr[i] = fast_sigmoid(acc[0][i] + br);
+        zz[i] = fast_sigmoid(acc[1][i] + bz);
+        hn[i] = acc[3][i] + bhn;
+        nn[i] = fast_tanh(acc[2][i] + bin + rr[i] * hn[i]);
+        h[i] = nn[i] + zz[i] * (hprev[i] - nn[i]);   // (1-z) n + z h_prev
+      }
+      hprev = h;
+      const long o = (long)t * slot + tile_off;   // element offset inside the [L*B, D] arrays
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ta[(4 * kg + i) * TS + r] = PT::cvt(h[i]);
+        tb[(4 * kg + i) * TS + r] = PB::cvt(h[i]);
+      }
+      if (drop) {
+        const f32x4 hd = h * dropout_quad(dc, (uint64_t)o >> 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          tda[(4 * kg + i) * TS + r] = PT::cvt(hd[i]);
+          tdb[(4 * kg + i) * TS + r] = PB::cvt(hd[i]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // hand the slice over: lanes 0-31 the state (own layer, next step), lanes 32-63 the masked copy (layer above)
+      const int hl = lane & 31, row = hl >> 1, half = hl & 1;
+      {
+        const bool hi = lane >= 32;
+        const h_t* src = hi ? tda : ta;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * TS + half * 8);
+        const int so = (int)((unsigned)((l * L + t) * 2 + (hi ? 1 : 0)) * RG);
+        if (!hi || drop) st_sc1(v, rex, (rb * NS + s) * 512 + hl * 16, so);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(cnt + ((long)l * L + t) * RBK + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // everything below is read only after the launch
+      *reinterpret_cast<f32x4*>(Ly.y_t + o + slot) = h;
+      if (Ly.save_r) {
+        *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_r) + o) = shalf4_t{(_Float16)rr[0], (_Float16)rr[1], (_Float16)rr[2], (_Float16)rr[3]};
+        *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_z) + o) = shalf4_t{(_Float16)zz[0], (_Float16)zz[1], (_Float16)zz[2], (_Float16)zz[3]};
+        *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_n) + o) = shalf4_t{(_Float16)nn[0], (_Float16)nn[1], (_Float16)nn[2], (_Float16)nn[3]};
+        *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_hn) + o) = shalf4_t{(_Float16)hn[0], (_Float16)hn[1], (_Float16)hn[2], (_Float16)hn[3]};
+      }
+      const long go = ((long)t * B + rb * 16 + row) * D + s * 16 + half * 8;   // row-major element offset, slot t
+      if (lane < 32) {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<h_t*>(Ly.y16a) + go + slot) = *reinterpret_cast<const u32x4*>(ta + row * TS + half * 8);
+        if (drop) *reinterpret_cast<u32x4*>(reinterpret_cast<h_t*>(Ly.yd16a) + go) = *reinterpret_cast<const u32x4*>(tda + row * TS + half * 8);
+      } else {
+        if (Ly.y16b) *reinterpret_cast<u32x4*>(reinterpret_cast<hb_t*>(Ly.y16b) + go + slot) = *reinterpret_cast<const u32x4*>(tb + row * TS + half * 8);
+        if (drop && Ly.yd16b) *reinterpret_cast<u32x4*>(reinterpret_cast<hb_t*>(Ly.yd16b) + go) = *reinterpret_cast<const u32x4*>(tdb + row * TS + half * 8);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+template <int PREC, int PRECB, int KSW>
+static int launch_sweep_fwd(const GruSweepArgs& p, unsigned grid, hipStream_t st) {
+  auto kern = gru_sweep_fwd_kernel<PREC, PRECB, KSW>;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
+  (void)once;
+  // every workgroup spins on others: all of them must be resident at once
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return ARK_ERR_ARG;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return ARK_ERR_ARG;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, kSweepLds) != hipSuccess || per_cu < 1) return ARK_ERR_SHAPE;
+  if ((long)grid > (long)cus * per_cu) return ARK_ERR_SHAPE;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cs);
+  if (cs == hipStreamCaptureStatusNone) {
+    GruSweepArgs arg = p;
+    void* params[] = {&arg};
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3(grid), dim3(256), params, kSweepLds, st);
+    if (e != hipSuccess) return (int)e;
+  } else {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kSweepLds, st, p);
+  }
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ark
+
+extern "C" long ark_gru_sweep_exch_bytes(int n_layers, int B, int D, int L) { return 2L * n_layers * L * B * D * 2; }
+extern "C" long ark_gru_sweep_sync_words(int n_layers, int B, int L) { return ark::kSweepSyncHdr + (long)n_layers * L * (B / 16); }
+
+extern "C" int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* a, void* stream) {
+  using namespace ark;
+  if (!a || a->n_layers <= 0 || a->n_layers > ARK_SWEEP_MAX_LAYERS || a->B <= 0 || a->D <= 0 || a->L <= 0) return ARK_ERR_ARG;
+  if (!a->x0_16 || !a->exch || !a->sync) return ARK_ERR_ARG;
+  const int D = a->D, B = a->B, L = a->L, n = a->n_layers;
+  if (B % 16 != 0 || (D != 128 && D != 256 && D != 512)) return ARK_ERR_SHAPE;
+  if (L > 4095 || 2.0 * n * L * B * D * 2 >= 2147483648.0) return ARK_ERR_SHAPE;   // 32-bit buffer offsets
+  for (int l = 0; l < n; ++l) {
+    const ArkGruSweepLayer& y = a->layer[l];
+    if (!y.w_ih16 || !y.w_hh16 || !y.b_ih || !y.b_hh || !y.y_t || !y.y16a) return ARK_ERR_ARG;
+    if (y.drop_p < 0.f || y.drop_p >= 1.f || (y.drop_p > 0.f && (!y.yd16a || !a->hyper))) return ARK_ERR_ARG;
+    if (y.save_r && (!y.save_z || !y.save_n || !y.save_hn)) return ARK_ERR_ARG;
+  }
+  GruSweepArgs p;
+  p.a = *a;
+  hipStream_t st = (hipStream_t)stream;
+  const long nw = ark_gru_sweep_sync_words(n, B, L);
+  hipLaunchKernelGGL(sweep_zero_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, a->sync, nw);
+  ARK_LAUNCH_CHECK();
+  const unsigned grid = (unsigned)(n * (D / 16) * (B / 16));
+#define ARK_SWEEP_GO(PF, PBK)                                            \
+  do {                                                                   \
+    if (D == 512) return launch_sweep_fwd<PF, PBK, 4>(p, grid, st);      \
+    if (D == 256) return launch_sweep_fwd<PF, PBK, 2>(p, grid, st);      \
+    return launch_sweep_fwd<PF, PBK, 1>(p, grid, st);                    \
+  } while (0)
+  if (prec == PREC_F16 && prec_b == PREC_BF16) ARK_SWEEP_GO(PREC_F16, PREC_BF16);
+  if (prec == PREC_F16 && prec_b == PREC_F16) ARK_SWEEP_GO(PREC_F16, PREC_F16);
+  if (prec == PREC_BF16 && prec_b == PREC_BF16) ARK_SWEEP_GO(PREC_BF16, PREC_BF16);
+#undef ARK_SWEEP_GO
+  return ARK_ERR_ARG;
+}

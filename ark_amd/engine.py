@@ -176,6 +176,9 @@ class Engine:
         self._chain_streams = []
         # (measured on MI355X, syn-paths B = 1024: see DESIGN.md; 1 = the single dependent chain of rounds 1-2)
         self.diag_chains = max(1, int(cfg.get("ark_diag_chains", 2)))
+        # small batches of long sequences: the whole forward recurrence as ONE persistent launch (csrc/gru_sweep.hip);
+        # "auto" = where the diagonal launches are all fixed cost (see _use_sweep)
+        self.sweep = cfg.get("ark_sweep", "auto")
         self._pad_bufs = {}
         self._n_valid = 0
         self._side_used = False
@@ -722,11 +725,67 @@ class Engine:
         for st in used:
             main.wait_stream(st)
 
+    def _use_sweep(self, B, Lq):
+        """the persistent sweep needs all n * (B/16) * (D/16) workgroups resident at once (one per CU) and pays where a
+        diagonal launch is all fixed cost: few rows, many steps"""
+        if self.sweep in (0, False, "0", "off") or not self.use_dma:
+            return False
+        if self.D not in (128, 256, 512) or self.n > L.SWEEP_MAX_LAYERS or B % 16 != 0:
+            return False
+        fits = self.n * (B // 16) * (self.D // 16) <= torch.cuda.get_device_properties(self.device).multi_processor_count
+        if self.sweep in (1, True, "1", "on"):
+            if not fits:
+                raise L.ArkError(f"ark_sweep=1: {self.n} x {B // 16} x {self.D // 16} workgroups cannot be co-resident")
+            return True
+        return fits and Lq >= 32
+
+    def _sweep_fwd(self, w, B, Lq, use_drop, save=True):
+        """the forward recurrence of all layers and steps as ONE launch (ark_gru_sweep_fwd); same inputs and outputs as
+        the diagonal launches"""
+        D, n, p = self.D, self.n, self.p
+        key = ("sweep", Lq)
+        if key not in w:
+            w[key] = (torch.empty(2 * n * Lq * B * D, device=self.device, dtype=torch.int16),
+                      torch.zeros(16 + n * Lq * (B // 16), device=self.device, dtype=torch.int32))
+        exch, sync = w[key]
+        a = L.GruSweep()
+        for l in range(n):
+            drop = use_drop and l < n - 1
+            y = a.layer[l]
+            y.w_ih16, y.w_hh16 = L.dptr(self.wih16[l]), L.dptr(self.whh16[l])
+            y.b_ih, y.b_hh = L.dptr(p[f"dec.gru.bias_ih_l{l}"]), L.dptr(p[f"dec.gru.bias_hh_l{l}"])
+            y.y_t, y.y16a = L.dptr(w["Y"][l]), L.dptr(w["Y16a"][l])
+            y.y16b = L.dptr(w["Y16b"][l])
+            y.yd16a = L.dptr(w["Yd16a"][l] if drop else None)
+            y.yd16b = L.dptr(w["Yd16b"][l] if drop else None)
+            if save:
+                y.save_r, y.save_z = L.dptr(w["SR"][l]), L.dptr(w["SZ"][l])
+                y.save_n, y.save_hn = L.dptr(w["SN"][l]), L.dptr(w["SHN"][l])
+            y.drop_seed = self._layer_seed(l)
+            y.drop_p = self.p_drop if drop else 0.0
+        a.x0_16, a.exch, a.sync, a.hyper = L.dptr(w["X0a"]), L.dptr(exch), L.dptr(sync), L.dptr(self.hyper)
+        a.n_layers, a.B, a.D, a.L = n, B, D, Lq
+        import ctypes
+        _call("ark_gru_sweep_fwd", L.i32(self.prec_fwd), L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
+        self._sweep_sync = sync
+
+    def sweep_error(self):
+        """(error word, detail) of the last persistent sweep: non-zero = a workgroup gave up waiting (outputs invalid).
+        Synchronises."""
+        sy = getattr(self, "_sweep_sync", None)
+        if sy is None:
+            return 0, 0
+        v = sy[:2].cpu()
+        return int(v[0]), int(v[1])
+
     def _diag_sweep(self, w, B, Lq, use_drop, save=True):
         """Layer-diagonal forward recurrence: cells (l, d-l) of one anti-diagonal are independent -> ONE
         launch per diagonal (one per ARK_DIAG_MAX_ROLES cells for deeper stacks), each role doing its own input
         projection (no gi buffers, no per-layer input GEMM): L+n-1 dependent launches instead of n*L + n.
         The batch is split into independent row-block chains on parallel queues (_chains)."""
+        if self._use_sweep(B, Lq):
+            self._sweep_fwd(w, B, Lq, use_drop, save)
+            return
         self._run_chains(B, lambda b0, Bc: self._diag_chain(w, B, b0, Bc, Lq, use_drop, save))
 
     def _diag_chain(self, w, B, b0, Bc, Lq, use_drop, save=True, diagonals=None):

@@ -168,6 +168,44 @@ typedef struct {
 } ArkGruDiagBwdRole;
 int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* roles, const float* hyper, int B, int D,
                      const ArkDiagTuning* tuning, void* stream);
+/* Persistent forward sweep for small batches of long sequences (csrc/gru_sweep.hip): the WHOLE stacked-GRU recurrence of
+ * L steps as ONE launch of n_layers * (B/16) * (D/16) co-resident workgroups, each keeping its 16 units' weight rows in
+ * registers and passing the hidden state on through `exch` with write-through stores, one counter per (layer, step,
+ * row block) and bounded spins.  Inputs and outputs are those of L + n - 1 ark_gru_diag_fwd launches: time-major arrays
+ * (row = t*B + b), slot 0 of y_t / y16a holding the initial state.  D in {128, 256, 512}, B % 16 == 0; returns
+ * ARK_ERR_SHAPE when the grid cannot be co-resident (then use the diagonal launches).  After the launch sync[0] != 0
+ * means a workgroup gave up waiting (sync[1] = its id << 12 | step): the outputs are then invalid.
+ * Reference: nn.GRU forward, kgvae/model/models.py:121-127. */
+#define ARK_SWEEP_MAX_LAYERS 4
+typedef struct {
+  const void* w_ih16;    /* [3D,D] shadows, forward type                                              */
+  const void* w_hh16;
+  const float* b_ih;     /* [3D]                                                                      */
+  const float* b_hh;
+  float* y_t;            /* tile-native fp32 [(L+1)*B, D]; slot 0 = initial state (read), 1..L written */
+  void* y16a;            /* row-major forward type [(L+1)*B, D]; slot 0 = initial state (read)        */
+  void* y16b;            /* row-major backward type [(L+1)*B, D] (nullable)                           */
+  void* yd16a;           /* [L*B, D] h * dropout mask (drop_p > 0 only)                               */
+  void* yd16b;           /* nullable                                                                  */
+  void* save_r;          /* tile-native fp16 [L*B, D] gate saves, nullable together                   */
+  void* save_z;
+  void* save_n;
+  void* save_hn;
+  uint64_t drop_seed;
+  float drop_p;
+  int pad_;
+} ArkGruSweepLayer;
+typedef struct {
+  ArkGruSweepLayer layer[ARK_SWEEP_MAX_LAYERS];
+  const void* x0_16;     /* [L*B, D] row-major forward type: layer 0's inputs                         */
+  void* exch;            /* workspace, ark_gru_sweep_exch_bytes() bytes                               */
+  unsigned* sync;        /* workspace, ark_gru_sweep_sync_words() words (zeroed by the call)          */
+  const float* hyper;
+  int n_layers, B, D, L;
+} ArkGruSweep;
+long ark_gru_sweep_exch_bytes(int n_layers, int B, int D, int L);
+long ark_gru_sweep_sync_words(int n_layers, int B, int L);
+int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* sweep, void* stream);
 /* up to 12 jobs in one launch: dst[i] = cast(src[i] [R,C]) in prec[i]; dstT[i] = cast(src[i]^T) in precT[i],
  * rows of dstT ldT[i] apart (ldT NULL or 0: dense, = R) */
 int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, void* const* dstT, const int* R,

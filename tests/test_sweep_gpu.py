@@ -1,0 +1,114 @@
+"""The persistent GRU sweep (csrc/gru_sweep.hip: the whole forward recurrence of a small batch of long sequences as ONE
+launch, hidden state handed between workgroups inside the launch) against the layer-diagonal launches it replaces: same
+states, saves, loss and gradients; no workgroup ever gives up waiting; eager and inside a captured graph.
+Reference op on both sides: torch.nn.GRU, kgvae/model/models.py:121-127 (the diagonal path is pinned to the oracle by
+tests/test_engine_gpu.py and tests/test_configs_gpu.py, whose wd-articles cases run THROUGH the sweep)."""
+import pytest
+import torch
+
+from tests.parity_util import make_engine, rel_err, synth_batch
+from tests.test_configs_gpu import _cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(cfg, B, P, drop):
+    a = make_engine(dict(cfg, dec_dropout=drop, ark_sweep=0), P, "mixed")
+    b = make_engine(dict(cfg, dec_dropout=drop, ark_sweep=1), P, "mixed")
+    Lq = cfg["seq_len"] - 1
+    assert not a._use_sweep(B, Lq) and b._use_sweep(B, Lq)
+    for eng in (a, b):
+        eng.set_hyper(beta=0.3)
+    a.drop_seed = b.drop_seed = 4321
+    return a, b
+
+
+@pytest.mark.parametrize("D,Z,B,T,padded", [(128, 16, 32, 12, True), (512, 32, 16, 10, True), (256, 8, 48, 6, False),
+                                            (512, 10, 32, 3, False)])
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_sweep_matches_diagonal_launches(D, Z, B, T, padded, drop):
+    from oracle import sail_oracle as O
+    cfg = _cfg(D, Z, 300, 5, T, padded)
+    P = O.init_params(cfg, 1)
+    triples, seq = synth_batch(cfg, B, seed=5, padded=padded)
+    torch.manual_seed(9)
+    eps = torch.randn(B, Z)
+    a, b = _pair(cfg, B, P, drop)
+    dev = a.device
+    args = (triples.to(dev), seq.to(dev), eps.to(dev))
+    oa = a.train_step(*args).cpu().numpy()
+    ob = b.train_step(*args).cpu().numpy()
+    torch.cuda.synchronize()
+    assert b.sweep_error() == (0, 0)
+    Lq = cfg["seq_len"] - 1
+    R = B * Lq
+    for l in range(cfg["n_layers"]):
+        ya, yb = a.ws["Y"][l], b.ws["Y"][l]
+        assert torch.isfinite(yb).all()
+        # the four waves of a sweep workgroup split K, the diagonal tiles do not: fp32 sums in another order, and a 16-bit
+        # state that rounds the other way now and then
+        assert (ya - yb).abs().max().item() < 2e-3, l
+        for nm in ("SR", "SZ", "SN", "SHN"):
+            sa, sb = a.ws[nm][l].view(torch.float16)[:R].float(), b.ws[nm][l].view(torch.float16)[:R].float()
+            assert (sa - sb).abs().max().item() < 4e-3, (nm, l)
+        fa = a.ws["Y16a"][l].view(torch.float16)[:R + B].float()
+        fb = b.ws["Y16a"][l].view(torch.float16)[:R + B].float()
+        assert (fa - fb).abs().max().item() < 3e-3, l
+        if drop > 0 and l < cfg["n_layers"] - 1:
+            da = a.ws["Yd16a"][l].view(torch.float16)[:R].float()
+            db = b.ws["Yd16a"][l].view(torch.float16)[:R].float()
+            assert ((da == 0) == (db == 0)).float().mean().item() > 0.9999, l   # the same counter-hash masks
+            assert (da - db).abs().max().item() < 4e-3, l
+            if a.ws["Yd16b"][l] is not None:
+                da = a.ws["Yd16b"][l].view(torch.bfloat16)[:R].float()
+                db = b.ws["Yd16b"][l].view(torch.bfloat16)[:R].float()
+                assert (da - db).abs().max().item() < 2e-2, l
+        if a.ws["Y16b"][l] is not None:
+            fa = a.ws["Y16b"][l].view(torch.bfloat16)[:R + B].float()
+            fb = b.ws["Y16b"][l].view(torch.bfloat16)[:R + B].float()
+            assert (fa - fb).abs().max().item() < 2e-2, l
+    assert rel_err(float(ob[0]), float(oa[0])) < 2e-5, (oa, ob)
+    for k in a.g:
+        da, db = a.g[k].float(), b.g[k].float()
+        assert (da - db).norm().item() <= 5e-3 * da.norm().item() + 1e-9, k
+
+
+def test_sweep_inside_a_captured_graph_and_oracle_elbo():
+    """replays of a captured step that contains the persistent launch reproduce the eager step; the ELBO is the oracle's"""
+    from oracle import sail_oracle as O
+    cfg = _cfg(512, 32, 500, 6, 14, True)
+    B = 16
+    P = O.init_params(cfg, 2)
+    triples, seq = synth_batch(cfg, B, seed=8, padded=True)
+    torch.manual_seed(4)
+    eps = torch.randn(B, cfg["d_latent"])
+    want = float(O.sail_elbo(P, triples, seq, eps, 0.3, cfg)[0])
+    eng = make_engine(dict(cfg, ark_sweep=1), P, "mixed")
+    eng.set_hyper(beta=0.3)
+    dev = eng.device
+    args = (triples.to(dev), seq.to(dev), eps.to(dev))
+    oe = eng.train_step(*args).cpu().numpy()
+    assert eng.sweep_error() == (0, 0)
+    assert rel_err(float(oe[0]), want) < 1e-4, (oe, want)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        step = eng.capture_train_step(*args)
+        for _ in range(3):
+            eng.load_params(P)
+            eng.reset_optimizer()
+            eng.refresh_shadows()
+            og = step().cpu().numpy()
+            assert eng.sweep_error() == (0, 0)
+            assert rel_err(float(og[0]), float(oe[0])) < 1e-6, (oe, og)
+
+
+def test_sweep_refuses_a_grid_that_cannot_be_resident():
+    from oracle import sail_oracle as O
+    from ark_amd import _lib as L
+    cfg = _cfg(512, 8, 50, 3, 3, False)
+    P = O.init_params(cfg, 0)
+    eng = make_engine(dict(cfg, ark_sweep=1), P, "mixed")
+    with pytest.raises(L.ArkError):
+        eng._use_sweep(256, 10)   # 3 x 16 x 32 workgroups
+    auto = make_engine(dict(cfg), P, "mixed")
+    assert not auto._use_sweep(256, 100) and not auto._use_sweep(16, 10) and auto._use_sweep(16, 100)
