@@ -114,6 +114,20 @@ class GruSweep(ctypes.Structure):
                 ("D", ctypes.c_int), ("L", ctypes.c_int)]
 
 
+class GruSweepBwdLayer(ctypes.Structure):
+    """ArkGruSweepBwdLayer of include/ark_amd.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in (
+        "w_hhT16", "w_ihT_up16", "save_r", "save_z", "save_n", "save_hn", "y_t", "dg16", "db_ih", "db_hh")] + [
+        ("drop_seed", ctypes.c_uint64), ("drop_p", ctypes.c_float), ("pad_", ctypes.c_int)]
+
+
+class GruSweepBwd(ctypes.Structure):
+    """ArkGruSweepBwd of include/ark_amd.h"""
+    _fields_ = [("layer", GruSweepBwdLayer * SWEEP_MAX_LAYERS), ("dy_t", ctypes.c_void_p), ("dh0", ctypes.c_void_p),
+                ("exch", ctypes.c_void_p), ("sync", ctypes.c_void_p), ("hyper", ctypes.c_void_p), ("n_layers", ctypes.c_int),
+                ("B", ctypes.c_int), ("D", ctypes.c_int), ("L", ctypes.c_int)]
+
+
 class DiagTuning(ctypes.Structure):
     """ArkDiagTuning of include/ark_amd.h (speed-only tile / ring choices, passed per call)"""
     _fields_ = [(k, ctypes.c_int) for k in ("fwd_rows", "fwd_ki", "fwd_nbuf", "fwd_xcd", "fwd_units", "bwd_rows", "bwd_ki",

@@ -250,11 +250,221 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
   }
 }
 
+template <class Kern, class Args>
+static int launch_persistent(Kern kern, const Args& p, unsigned grid, hipStream_t st);
+
 template <int PREC, int PRECB, int KSW>
 static int launch_sweep_fwd(const GruSweepArgs& p, unsigned grid, hipStream_t st) {
   auto kern = gru_sweep_fwd_kernel<PREC, PRECB, KSW>;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
   (void)once;
+  return launch_persistent(kern, p, grid, st);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward sweep (BPTT of the same recurrence, autograd of nn.GRU): workgroup (l, rb, s) walks t = L-1 .. 0 for its 16
+// units of 16 rows.  Per step it needs the gate-gradient panels [dr | dz | dn | dn*r] of its own layer at t+1 (recurrence,
+// K = 3D against W_hh^T) and of the layer above at t (input gradient, K = 3D against W_ih(l+1)^T, through this layer's
+// output-dropout mask); both arrive through the exchange buffer exactly as the hidden state does in the forward sweep.
+// The carry dh*z and the bias-gradient column sums stay in wave 0's registers for the whole sweep; after t = 0 the
+// workgroup adds its slice of the initial-state gradient (carry + dgh_0 W_hh) to dh0.  Math and outputs are those of
+// gru_diag_bwd_kernel (gru_diag.hip).
+struct GruSweepBwdArgs {
+  ArkGruSweepBwd a;
+};
+
+template <int PREC, int KSW>
+__global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) {
+  using PT = PrecTraits<PREC>;
+  using h_t = typename PT::h_t;
+  using h8 = typename PT::h8;
+  constexpr int KT = 3 * KSW;   // K-steps of 32 per wave and product (3D / 32 / 4 waves)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ArkGruSweepBwd& p = pa.a;
+  constexpr int TS = 24;
+  f32x4* part = reinterpret_cast<f32x4*>(smem);            // [3 waves][2 accumulators][64 lanes]
+  h_t* tg = reinterpret_cast<h_t*>(smem + 6144);           // [4 parts][16 rows][TS]
+  int* lflag = reinterpret_cast<int*>(smem + 6144 + 4 * 16 * TS * 2);
+
+  const int D = p.D, B = p.B, L = p.L, n = p.n_layers;
+  const int NS = D >> 4, RBK = B >> 4;
+  const int wg = blockIdx.x;
+  // the top layer starts the backward wavefront: give it the lowest workgroup ids
+  const int l = n - 1 - wg / (NS * RBK), rem = wg % (NS * RBK);
+  const int rb = rem / NS, s = rem - rb * NS;
+  const ArkGruSweepBwdLayer& Ly = p.layer[l];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, kg = lane >> 4;
+  const int u = s * 16 + r;
+  const bool top = l == n - 1;
+
+  h8 wo[KT], wu[KT];   // rows u of W_hh^T (own recurrence) and of W_ih(l+1)^T (gradient from above)
+  {
+    const h_t* wh = reinterpret_cast<const h_t*>(Ly.w_hhT16);
+    const h_t* wi = reinterpret_cast<const h_t*>(Ly.w_ihT_up16);
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      const long o = (long)u * 3 * D + (wave * KT + j) * 32 + kg * 8;
+      wo[j] = *reinterpret_cast<const h8*>(wh + o);
+      if (!top) wu[j] = *reinterpret_cast<const h8*>(wi + o);
+      else wu[j] = wo[j];
+    }
+  }
+  const long slot = (long)B * D;
+  const long tile_off = (long)(rb * NS + s) * 256 + lane * 4;
+  const bool drop = Ly.drop_p > 0.f && !top;
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(Ly.drop_seed, p.hyper, Ly.drop_p);
+  const unsigned RG = (unsigned)(slot * 8);   // bytes of one (layer, step) exchange region: [B, 4D] 16-bit
+  const __amdgpu_buffer_rsrc_t rex = sweep_rsrc(p.exch, RG * (unsigned)(L * n));
+  int voff_o[KT], voff_u[KT];
+#pragma unroll
+  for (int j = 0; j < KT; ++j) {
+    const int k = (wave * KT + j) * 32 + kg * 8;
+    {
+      const int c = k < 2 * D ? k : k + D;      // W_hh columns: [dr | dz] then dn*r
+      const int pt = c / D, un = c - pt * D;
+      voff_o[j] = ((((rb * 4 + pt) * NS + (un >> 4)) * 16 + r) * 16 + (un & 8)) * 2;
+    }
+    {
+      const int pt = k / D, un = k - pt * D;    // W_ih columns: [dr | dz | dn]
+      voff_u[j] = ((((rb * 4 + pt) * NS + (un >> 4)) * 16 + r) * 16 + (un & 8)) * 2;
+    }
+  }
+  unsigned* sync = p.sync;
+  unsigned* cnt = p.sync + kSweepSyncHdr;
+  if (threadIdx.x == 0) *lflag = 0;
+  __syncthreads();
+
+  f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of the ROUNDED dr, dz, dn, dn*r (this lane's 4 rows)
+  const _Float16* sr = reinterpret_cast<const _Float16*>(Ly.save_r);
+  const _Float16* sz = reinterpret_cast<const _Float16*>(Ly.save_z);
+  const _Float16* sn = reinterpret_cast<const _Float16*>(Ly.save_n);
+  const _Float16* shn = reinterpret_cast<const _Float16*>(Ly.save_hn);
+  const bool fin_step = p.dh0 != nullptr;
+
+  for (int t = L - 1; t >= (fin_step ? -1 : 0); --t) {
+    const bool fin = t < 0;          // initial-state step: dh0 += carry + dgh_0 W_hh
+    const bool rec = t < L - 1;      // a successor step exists
+    const bool up = !top && !fin;
+    const long o = (long)(fin ? 0 : t) * slot + tile_off;
+    // epilogue operands first (wave 0): none of them depends on the recurrence, they land during the wait
+    f32x4 hp = f32x4{0.f, 0.f, 0.f, 0.f}, dy = f32x4{0.f, 0.f, 0.f, 0.f};
+    shalf4_t qr{}, qz{}, qn{}, qhn{};
+    if (wave == 0 && !fin) {
+      hp = *reinterpret_cast<const f32x4*>(Ly.y_t + o);
+      if (top) dy = *reinterpret_cast<const f32x4*>(p.dy_t + o);
+      qr = *reinterpret_cast<const shalf4_t*>(sr + o);
+      qz = *reinterpret_cast<const shalf4_t*>(sz + o);
+      qn = *reinterpret_cast<const shalf4_t*>(sn + o);
+      qhn = *reinterpret_cast<const shalf4_t*>(shn + o);
+    }
+    if (wave == 0) {
+      bool ok = true;
+      const unsigned code = (unsigned)(wg << 12 | ((t + 1) & 4095));
+      if (rec) ok = sweep_wait(cnt + ((long)l * L + (t + 1)) * RBK + rb, (unsigned)NS, sync, code);
+      if (ok && up) ok = sweep_wait(cnt + ((long)(l + 1) * L + t) * RBK + rb, (unsigned)NS, sync, code | 0x80000000u);
+      if (!ok && lane == 0) *lflag = 1;
+    }
+    __syncthreads();
+    if (*lflag) break;
+
+    f32x4 ah = f32x4{0.f, 0.f, 0.f, 0.f}, ax = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 ao[KT], au[KT];
+    if (rec) {
+      const int so = (int)((unsigned)(l * L + (t + 1)) * RG);
+#pragma unroll
+      for (int j = 0; j < KT; ++j) ao[j] = ld_sc1(rex, voff_o[j], so);
+    }
+    if (up) {
+      const int so = (int)((unsigned)((l + 1) * L + t) * RG);
+#pragma unroll
+      for (int j = 0; j < KT; ++j) au[j] = ld_sc1(rex, voff_u[j], so);
+    }
+    if (rec) {
+#pragma unroll
+      for (int j = 0; j < KT; ++j) ah = PT::mfma(__builtin_bit_cast(h8, ao[j]), wo[j], ah);
+    }
+    if (up) {
+#pragma unroll
+      for (int j = 0; j < KT; ++j) ax = PT::mfma(__builtin_bit_cast(h8, au[j]), wu[j], ax);
+    }
+    if (wave > 0) {
+      part[((wave - 1) * 2 + 0) * 64 + lane] = ah;
+      part[((wave - 1) * 2 + 1) * 64 + lane] = ax;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      ah += part[0 * 64 + lane] + part[2 * 64 + lane] + part[4 * 64 + lane];
+      ax += part[1 * 64 + lane] + part[3 * 64 + lane] + part[5 * 64 + lane];
+      if (fin) {
+        const f32x4 dh = ah + carry;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&p.dh0[(long)(rb * 16 + 4 * kg + i) * D + u], dh[i]);
+      } else {
+        f32x4 dh = ah + carry + dy;
+        if (drop) dh += ax * dropout_quad(dc, (uint64_t)o >> 2);
+        else dh += ax;
+        f32x4 cz;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float rr = (float)qr[i], zz = (float)qz[i], nn = (float)qn[i], hn = (float)qhn[i];
+          const float dn_pre = dh[i] * (1.0f - zz) * (1.0f - nn * nn);
+          const float dz_pre = dh[i] * (hp[i] - nn) * zz * (1.0f - zz);
+          const float dr_pre = dn_pre * hn * rr * (1.0f - rr);
+          cz[i] = dh[i] * zz;
+          const int ro = (4 * kg + i) * TS + r;
+          const h_t v0 = PT::cvt(dr_pre), v1 = PT::cvt(dz_pre), v2 = PT::cvt(dn_pre), v3 = PT::cvt(dn_pre * rr);
+          tg[ro] = v0;
+          tg[16 * TS + ro] = v1;
+          tg[2 * 16 * TS + ro] = v2;
+          tg[3 * 16 * TS + ro] = v3;
+          bs[0] += (float)v0;
+          bs[1] += (float)v1;
+          bs[2] += (float)v2;
+          bs[3] += (float)v3;
+        }
+        carry = cz;
+        __builtin_amdgcn_wave_barrier();
+        // hand the four 512-byte slices over (two store instructions, every 128-B line whole), then the row-major copy
+        const int hl = lane & 31, row = hl >> 1, half = hl & 1, hi = lane >> 5;
+        const u32x4 v01 = *reinterpret_cast<const u32x4*>(tg + (hi * 16 + row) * TS + half * 8);
+        const u32x4 v23 = *reinterpret_cast<const u32x4*>(tg + ((2 + hi) * 16 + row) * TS + half * 8);
+        const int so = (int)((unsigned)(l * L + t) * RG);
+        st_sc1(v01, rex, ((rb * 4 + hi) * NS + s) * 512 + hl * 16, so);
+        st_sc1(v23, rex, ((rb * 4 + 2 + hi) * NS + s) * 512 + hl * 16, so);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt + ((long)l * L + t) * RBK + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h_t* g16 = reinterpret_cast<h_t*>(Ly.dg16) + ((long)t * B + rb * 16 + row) * 4 * D + s * 16 + half * 8;
+        *reinterpret_cast<u32x4*>(g16 + (long)hi * D) = v01;
+        *reinterpret_cast<u32x4*>(g16 + (long)(2 + hi) * D) = v23;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  // bias gradients: db_ih = colsum [dr | dz | dn], db_hh = colsum [dr | dz | dn*r], one atomic per (gate, unit)
+  if (wave == 0 && Ly.db_ih) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bs[g] += __shfl_xor(bs[g], 16, 64);
+      bs[g] += __shfl_xor(bs[g], 32, 64);
+    }
+    if (lane < 16) {
+      atomicAdd(&Ly.db_ih[u], bs[0]);
+      atomicAdd(&Ly.db_ih[D + u], bs[1]);
+      atomicAdd(&Ly.db_ih[2 * D + u], bs[2]);
+      atomicAdd(&Ly.db_hh[u], bs[0]);
+      atomicAdd(&Ly.db_hh[D + u], bs[1]);
+      atomicAdd(&Ly.db_hh[2 * D + u], bs[3]);
+    }
+  }
+}
+
+template <class Kern, class Args>
+static int launch_persistent(Kern kern, const Args& p, unsigned grid, hipStream_t st) {
   // every workgroup spins on others: all of them must be resident at once
   int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess) return ARK_ERR_ARG;
@@ -264,7 +474,7 @@ static int launch_sweep_fwd(const GruSweepArgs& p, unsigned grid, hipStream_t st
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cs);
   if (cs == hipStreamCaptureStatusNone) {
-    GruSweepArgs arg = p;
+    Args arg = p;
     void* params[] = {&arg};
     const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3(grid), dim3(256), params, kSweepLds, st);
     if (e != hipSuccess) return (int)e;
@@ -273,6 +483,14 @@ static int launch_sweep_fwd(const GruSweepArgs& p, unsigned grid, hipStream_t st
   }
   ARK_LAUNCH_CHECK();
   return 0;
+}
+
+template <int PREC, int KSW>
+static int launch_sweep_bwd(const GruSweepBwdArgs& p, unsigned grid, hipStream_t st) {
+  auto kern = gru_sweep_bwd_kernel<PREC, KSW>;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
+  (void)once;
+  return launch_persistent(kern, p, grid, st);
 }
 
 }  // namespace ark
@@ -309,6 +527,41 @@ extern "C" int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* a, voi
   if (prec == PREC_F16 && prec_b == PREC_BF16) ARK_SWEEP_GO(PREC_F16, PREC_BF16);
   if (prec == PREC_F16 && prec_b == PREC_F16) ARK_SWEEP_GO(PREC_F16, PREC_F16);
   if (prec == PREC_BF16 && prec_b == PREC_BF16) ARK_SWEEP_GO(PREC_BF16, PREC_BF16);
+#undef ARK_SWEEP_GO
+  return ARK_ERR_ARG;
+}
+
+extern "C" long ark_gru_sweep_bwd_exch_bytes(int n_layers, int B, int D, int L) { return (long)n_layers * L * B * 4 * D * 2; }
+
+extern "C" int ark_gru_sweep_bwd(int prec, const ArkGruSweepBwd* a, void* stream) {
+  using namespace ark;
+  if (!a || a->n_layers <= 0 || a->n_layers > ARK_SWEEP_MAX_LAYERS || a->B <= 0 || a->D <= 0 || a->L <= 0) return ARK_ERR_ARG;
+  if (!a->dy_t || !a->exch || !a->sync) return ARK_ERR_ARG;
+  const int D = a->D, B = a->B, L = a->L, n = a->n_layers;
+  if (B % 16 != 0 || (D != 128 && D != 256 && D != 512)) return ARK_ERR_SHAPE;
+  if (L > 4094 || 8.0 * n * L * B * D >= 2147483648.0) return ARK_ERR_SHAPE;   // 32-bit buffer offsets
+  for (int l = 0; l < n; ++l) {
+    const ArkGruSweepBwdLayer& y = a->layer[l];
+    if (!y.w_hhT16 || (l < n - 1 && !y.w_ihT_up16) || !y.save_r || !y.save_z || !y.save_n || !y.save_hn || !y.y_t || !y.dg16)
+      return ARK_ERR_ARG;
+    if ((y.db_ih == nullptr) != (y.db_hh == nullptr)) return ARK_ERR_ARG;
+    if (y.drop_p < 0.f || y.drop_p >= 1.f || (y.drop_p > 0.f && !a->hyper)) return ARK_ERR_ARG;
+  }
+  GruSweepBwdArgs p;
+  p.a = *a;
+  hipStream_t st = (hipStream_t)stream;
+  const long nw = ark_gru_sweep_sync_words(n, B, L);
+  hipLaunchKernelGGL(sweep_zero_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, a->sync, nw);
+  ARK_LAUNCH_CHECK();
+  const unsigned grid = (unsigned)(n * (D / 16) * (B / 16));
+#define ARK_SWEEP_GO(PB)                                          \
+  do {                                                            \
+    if (D == 512) return launch_sweep_bwd<PB, 4>(p, grid, st);    \
+    if (D == 256) return launch_sweep_bwd<PB, 2>(p, grid, st);    \
+    return launch_sweep_bwd<PB, 1>(p, grid, st);                  \
+  } while (0)
+  if (prec == PREC_BF16) ARK_SWEEP_GO(PREC_BF16);
+  if (prec == PREC_F16) ARK_SWEEP_GO(PREC_F16);
 #undef ARK_SWEEP_GO
   return ARK_ERR_ARG;
 }

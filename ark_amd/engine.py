@@ -179,6 +179,7 @@ class Engine:
         # small batches of long sequences: the whole forward recurrence as ONE persistent launch (csrc/gru_sweep.hip);
         # "auto" = where the diagonal launches are all fixed cost (see _use_sweep)
         self.sweep = cfg.get("ark_sweep", "auto")
+        self.sweep_bwd = bool(cfg.get("ark_sweep_bwd", True))   # (0: persistent forward, diagonal backward)
         self._pad_bufs = {}
         self._n_valid = 0
         self._side_used = False
@@ -769,14 +770,45 @@ class Engine:
         _call("ark_gru_sweep_fwd", L.i32(self.prec_fwd), L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
         self._sweep_sync = sync
 
+    def _sweep_bwd(self, w, B, Lq, use_drop):
+        """the backward recurrence of all layers and steps (+ the initial-state gradient, SAIL) as ONE launch
+        (ark_gru_sweep_bwd); same inputs and outputs as the backward diagonal launches"""
+        D, n, g = self.D, self.n, self.g
+        key = ("sweep_bwd", Lq)
+        if key not in w:
+            w[key] = (torch.empty(n * Lq * B * 4 * D, device=self.device, dtype=torch.int16),
+                      torch.zeros(16 + n * Lq * (B // 16), device=self.device, dtype=torch.int32))
+        exch, sync = w[key]
+        a = L.GruSweepBwd()
+        for l in range(n):
+            y = a.layer[l]
+            top = l == n - 1
+            y.w_hhT16 = L.dptr(self.whhT16[l])
+            y.w_ihT_up16 = 0 if top else L.dptr(self.wihT16[l + 1])
+            y.save_r, y.save_z = L.dptr(w["SR"][l]), L.dptr(w["SZ"][l])
+            y.save_n, y.save_hn = L.dptr(w["SN"][l]), L.dptr(w["SHN"][l])
+            y.y_t, y.dg16 = L.dptr(w["Y"][l]), L.dptr(w["dG16"][l])
+            y.db_ih, y.db_hh = L.dptr(g[f"dec.gru.bias_ih_l{l}"]), L.dptr(g[f"dec.gru.bias_hh_l{l}"])
+            y.drop_seed = self._layer_seed(l)
+            y.drop_p = self.p_drop if (use_drop and not top) else 0.0
+        a.dy_t = L.dptr(w["dYa"])
+        a.dh0 = L.dptr(w["dH0"]) if self.mt == "SAIL" else 0
+        a.exch, a.sync, a.hyper = L.dptr(exch), L.dptr(sync), L.dptr(self.hyper)
+        a.n_layers, a.B, a.D, a.L = n, B, D, Lq
+        import ctypes
+        _call("ark_gru_sweep_bwd", L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
+        self._sweep_bwd_sync = sync
+
     def sweep_error(self):
         """(error word, detail) of the last persistent sweep: non-zero = a workgroup gave up waiting (outputs invalid).
         Synchronises."""
-        sy = getattr(self, "_sweep_sync", None)
-        if sy is None:
-            return 0, 0
-        v = sy[:2].cpu()
-        return int(v[0]), int(v[1])
+        for nm in ("_sweep_sync", "_sweep_bwd_sync"):
+            sy = getattr(self, nm, None)
+            if sy is not None:
+                v = sy[:2].cpu()
+                if int(v[0]) != 0:
+                    return int(v[0]), int(v[1])
+        return 0, 0
 
     def _diag_sweep(self, w, B, Lq, use_drop, save=True):
         """Layer-diagonal forward recurrence: cells (l, d-l) of one anti-diagonal are independent -> ONE
@@ -1140,6 +1172,11 @@ class Engine:
         """the dependent chain of the decoder backward: one launch per backward anti-diagonal, then (SAIL) the
         initial-state roles.  Needs dY of the top layer in w["dYa"] and a zeroed w["dH0"].  Independent row-block
         chains run on parallel queues (_chains); `after_cells` runs once every chain's cells are queued and joined."""
+        if self._use_sweep(B, Lq) and self.sweep_bwd:
+            self._sweep_bwd(w, B, Lq, use_drop)   # every cell and the initial-state gradient in one persistent launch
+            if after_cells is not None:
+                after_cells()
+            return
         h0_done = {}
         self._run_chains(B, lambda b0, Bc: h0_done.setdefault(b0, self._diag_bwd_chain(w, B, b0, Bc, Lq, use_drop)))
         if after_cells is not None:

@@ -206,6 +206,36 @@ typedef struct {
 long ark_gru_sweep_exch_bytes(int n_layers, int B, int D, int L);
 long ark_gru_sweep_sync_words(int n_layers, int B, int L);
 int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* sweep, void* stream);
+/* The backward pass of the same recurrence (BPTT: autograd of nn.GRU) as ONE launch: what L + n - 1 ark_gru_diag_bwd
+ * launches and the initial-state roles compute.  Writes the gate-gradient panels dg16[l] = [dr | dz | dn | dn*r]
+ * (row-major [L*B, 4D], backward type), adds the bias gradients and (dh0 non-NULL) the initial-state gradient
+ * sum over layers of (carry + dgh_0 W_hh) into the pre-zeroed row-major dh0[B, D]. */
+typedef struct {
+  const void* w_hhT16;     /* [D,3D] W_hh^T shadow, backward type                                       */
+  const void* w_ihT_up16;  /* [D,3D] W_ih^T shadow of layer l+1 (NULL: top layer)                       */
+  const void* save_r;      /* tile-native fp16 saves of the forward pass [L*B, D]                       */
+  const void* save_z;
+  const void* save_n;
+  const void* save_hn;
+  const float* y_t;        /* tile-native fp32 [(L+1)*B, D]: slot t = h_{t-1}                           */
+  void* dg16;              /* row-major [L*B, 4D] output panels, backward type                          */
+  float* db_ih;            /* [3D] += (nullable together)                                               */
+  float* db_hh;
+  uint64_t drop_seed;      /* dropout of THIS layer's output                                            */
+  float drop_p;
+  int pad_;
+} ArkGruSweepBwdLayer;
+typedef struct {
+  ArkGruSweepBwdLayer layer[ARK_SWEEP_MAX_LAYERS];
+  const float* dy_t;       /* tile-native fp32 [L*B, D]: gradient of the loss wrt the top layer's outputs */
+  float* dh0;              /* row-major fp32 [B, D], += (nullable: no initial-state gradient wanted)    */
+  void* exch;              /* workspace, ark_gru_sweep_bwd_exch_bytes() bytes                           */
+  unsigned* sync;          /* workspace, ark_gru_sweep_sync_words() words (zeroed by the call)          */
+  const float* hyper;
+  int n_layers, B, D, L;
+} ArkGruSweepBwd;
+long ark_gru_sweep_bwd_exch_bytes(int n_layers, int B, int D, int L);
+int ark_gru_sweep_bwd(int prec, const ArkGruSweepBwd* sweep, void* stream);
 /* up to 12 jobs in one launch: dst[i] = cast(src[i] [R,C]) in prec[i]; dstT[i] = cast(src[i]^T) in precT[i],
  * rows of dstT ldT[i] apart (ldT NULL or 0: dense, = R) */
 int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, void* const* dstT, const int* R,

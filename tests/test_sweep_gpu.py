@@ -67,10 +67,45 @@ def test_sweep_matches_diagonal_launches(D, Z, B, T, padded, drop):
             fa = a.ws["Y16b"][l].view(torch.bfloat16)[:R + B].float()
             fb = b.ws["Y16b"][l].view(torch.bfloat16)[:R + B].float()
             assert (fa - fb).abs().max().item() < 2e-2, l
+        # backward: the gate-gradient panels [dr | dz | dn | dn*r] of the persistent BPTT launch
+        bt = torch.bfloat16 if b.prec_bwd == 1 else torch.float16
+        pa, pb = a.ws["dG16"][l].view(bt)[:R].float(), b.ws["dG16"][l].view(bt)[:R].float()
+        assert torch.isfinite(pb).all()
+        assert (pa - pb).norm().item() <= 1e-2 * pa.norm().item() + 1e-12, l
+        assert (pa - pb).abs().max().item() <= 4e-2 * pa.abs().max().item() + 1e-12, l
+    ha, hb = a.ws["dH0"], b.ws["dH0"]
+    assert (ha - hb).norm().item() <= 5e-3 * ha.norm().item() + 1e-12
     assert rel_err(float(ob[0]), float(oa[0])) < 2e-5, (oa, ob)
     for k in a.g:
         da, db = a.g[k].float(), b.g[k].float()
         assert (da - db).norm().item() <= 5e-3 * da.norm().item() + 1e-9, k
+
+
+def test_forward_sweep_with_diagonal_backward():
+    """ark_sweep_bwd=0: the persistent forward feeds the diagonal backward launches (same buffers either way)"""
+    from oracle import sail_oracle as O
+    cfg = _cfg(128, 16, 300, 5, 12, True)
+    B = 32
+    P = O.init_params(cfg, 1)
+    triples, seq = synth_batch(cfg, B, seed=5, padded=True)
+    torch.manual_seed(9)
+    eps = torch.randn(B, 16)
+    a, b = _pair(cfg, B, P, 0.1)
+    c = make_engine(dict(cfg, dec_dropout=0.1, ark_sweep=1, ark_sweep_bwd=0), P, "mixed")
+    c.set_hyper(beta=0.3)
+    c.drop_seed = 4321
+    dev = a.device
+    args = (triples.to(dev), seq.to(dev), eps.to(dev))
+    ob = b.train_step(*args).cpu().numpy()
+    oc = c.train_step(*args).cpu().numpy()
+    torch.cuda.synchronize()
+    assert c.sweep_error() == (0, 0) and b.sweep_error() == (0, 0)
+    assert rel_err(float(oc[0]), float(ob[0])) < 1e-6
+    for l in range(cfg["n_layers"]):
+        assert torch.equal(b.ws["Y"][l], c.ws["Y"][l])   # the same forward launch
+    for k in b.g:
+        db, dc = b.g[k].float(), c.g[k].float()
+        assert (db - dc).norm().item() <= 5e-3 * db.norm().item() + 1e-9, k
 
 
 def test_sweep_inside_a_captured_graph_and_oracle_elbo():

@@ -43,7 +43,17 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
+        tb = []
+        for _ in range(args.reps):
+            eng._zero(w["dH0"])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            eng._diag_bwd_sweep(w, B, Lq, True, None)
+            e1.record()
+            torch.cuda.synchronize()
+            tb.append(e0.elapsed_time(e1))
         steps = Lq + cfg["n_layers"] - 1
+        print(f"   backward: {min(tb):.3f} ms  ({min(tb) * 1e3 / steps:.2f} us per diagonal)  all: {' '.join(f'{t:.2f}' for t in tb)}", flush=True)
         best = min(ts)
         print(f"{args.workload} B={B} L={Lq} {'sweep' if mode else 'diagonals'}: {best:.3f} ms  ({best * 1e3 / steps:.2f} us per diagonal)"
               f"  all: {' '.join(f'{t:.2f}' for t in ts)}  err={eng.sweep_error()}", flush=True)
