@@ -139,6 +139,13 @@ class WgradTuning(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int) for k in ("tile", "nbuf", "target_wgs", "balance")]
 
 
+def sweep_sync_words(n_layers, B, Lq):
+    """words of the `sync` workspace of ark_gru_sweep_fwd / _bwd"""
+    f = lib().ark_gru_sweep_sync_words
+    f.restype = ctypes.c_long
+    return int(f(i32(n_layers), i32(B), i32(Lq)))
+
+
 def wgrad_tuning(**kw):
     """the library's measured defaults with the given fields replaced (a ctypes byref, ready to pass)"""
     t = WgradTuning()

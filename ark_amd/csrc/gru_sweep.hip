@@ -35,7 +35,9 @@ struct GruSweepArgs {
 
 constexpr unsigned long long kSweepTimeoutTicks = 25000000ull;   // s_memrealtime runs at 100 MHz: 0.25 s
 constexpr int kSweepLds = 96 * 1024;                             // > half of a CU's LDS: one workgroup per CU
-constexpr int kSweepSyncHdr = 16;                                // words in front of the counters (error word + diagnostics)
+constexpr int kSweepSyncHdr = 32;                                // words in front of the counters (error word + diagnostics)
+constexpr int kSweepCntStride = 32;                              // words per counter: each on a 128-byte line of its own (atomics and
+                                                                 // polls of different (layer, step, row block) never queue on one line)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sweep_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -72,8 +74,9 @@ __global__ void sweep_zero_kernel(unsigned* p, long n) {
 }
 
 // 4 waves: wave w forms the partial products of K-steps [w*KSW, (w+1)*KSW) of BOTH operands (x_t W_ih^T, h_{t-1} W_hh^T);
-// wave 0 adds the partials, does the gate math and owns the state.  D = 128 * KSW.
-template <int PREC, int PRECB, int KSW>
+// wave 0 adds the partials, does the gate math and owns the state.  D = 128 * KSW; MT 16-row tiles per workgroup (the
+// weights in registers serve all of them: wd-movies, B = 256 x D = 128, fits the chip with MT = 2).
+template <int PREC, int PRECB, int KSW, int MT>
 __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
   using PT = PrecTraits<PREC>;
   using PB = PrecTraits<PRECB>;
@@ -83,18 +86,17 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ArkGruSweep& p = pa.a;
   constexpr int TS = 24;                                   // row stride of the 16 x 16 transposition tiles (halves)
-  f32x4* part = reinterpret_cast<f32x4*>(smem);            // [3 waves][4 accumulators][64 lanes]
-  h_t* ta = reinterpret_cast<h_t*>(smem + 12288);          // h, forward type
-  hb_t* tb = reinterpret_cast<hb_t*>(smem + 12288 + 768);  // h, backward type
-  h_t* tda = reinterpret_cast<h_t*>(smem + 12288 + 1536);  // h * mask
-  hb_t* tdb = reinterpret_cast<hb_t*>(smem + 12288 + 2304);
-  int* lflag = reinterpret_cast<int*>(smem + 12288 + 3072);
+  constexpr int TILE = 16 * TS * 2;                        // bytes of one such tile
+  constexpr int PARTB = 3 * MT * 4 * 64 * 16;
+  f32x4* part = reinterpret_cast<f32x4*>(smem);            // [3 waves][MT][4 accumulators][64 lanes]
+  char* tiles = smem + PARTB;                              // [MT][h fwd type | h bwd type | h*mask fwd | h*mask bwd]
+  int* lflag = reinterpret_cast<int*>(smem + PARTB + MT * 4 * TILE);
 
   const int D = p.D, B = p.B, L = p.L;
-  const int NS = D >> 4, RBK = B >> 4;
+  const int NS = D >> 4, RBW = B / (16 * MT);
   const int wg = blockIdx.x;
-  const int l = wg / (NS * RBK), rem = wg - l * (NS * RBK);
-  const int rb = rem / NS, s = rem - rb * NS;
+  const int l = wg / (NS * RBW), rem = wg - l * (NS * RBW);
+  const int rbw = rem / NS, s = rem - rbw * NS;
   const ArkGruSweepLayer& Ly = p.layer[l];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -117,9 +119,14 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
   }
   const float br = Ly.b_ih[u] + Ly.b_hh[u], bz = Ly.b_ih[D + u] + Ly.b_hh[D + u];
   const float bin = Ly.b_ih[2 * D + u], bhn = Ly.b_hh[2 * D + u];
-  const long slot = (long)B * D;                              // elements per timestep
-  const long tile_off = (long)(rb * NS + s) * 256 + lane * 4;  // tile-native offset of this lane's quad inside a slot
-  f32x4 hprev = *reinterpret_cast<const f32x4*>(Ly.y_t + tile_off);   // slot 0 = initial state
+  const long slot = (long)B * D;   // elements per timestep
+  long tile_off[MT];               // tile-native offset of this lane's quad inside a slot
+  f32x4 hprev[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    tile_off[m] = (long)((rbw * MT + m) * NS + s) * 256 + lane * 4;
+    hprev[m] = *reinterpret_cast<const f32x4*>(Ly.y_t + tile_off[m]);   // slot 0 = initial state
+  }
   const bool drop = Ly.drop_p > 0.f;
   const bool below_drop = l > 0 && p.layer[l - 1].drop_p > 0.f;
   DropCtx dc{};
@@ -129,13 +136,15 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
   const __amdgpu_buffer_rsrc_t rx = sweep_rsrc(p.x0_16, RG * (unsigned)L);
   const __amdgpu_buffer_rsrc_t rh0 = sweep_rsrc(Ly.y16a, RG);
   const __amdgpu_buffer_rsrc_t rex = sweep_rsrc(p.exch, RG * (unsigned)(2 * L * p.n_layers));
-  int voff_rm[KSW], voff_ex[KSW];
+  int voff_rm[MT][KSW], voff_ex[MT][KSW];
 #pragma unroll
-  for (int j = 0; j < KSW; ++j) {
-    const int ks = wave * KSW + j;
-    voff_rm[j] = ((rb * 16 + r) * D + ks * 32 + kg * 8) * 2;
-    voff_ex[j] = ((rb * NS + ks * 2 + (kg >> 1)) * 16 + r) * 32 + (kg & 1) * 16;
-  }
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+      const int ks = wave * KSW + j, rb = rbw * MT + m;
+      voff_rm[m][j] = ((rb * 16 + r) * D + ks * 32 + kg * 8) * 2;
+      voff_ex[m][j] = ((rb * NS + ks * 2 + (kg >> 1)) * 16 + r) * 32 + (kg & 1) * 16;
+    }
   unsigned* sync = p.sync;
   unsigned* cnt = p.sync + kSweepSyncHdr;
   if (threadIdx.x == 0) *lflag = 0;
@@ -144,106 +153,129 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
   for (int t = 0; t < L; ++t) {
     if (wave == 0) {
       bool ok = true;
-      if (t > 0) ok = sweep_wait(cnt + ((long)l * L + (t - 1)) * RBK + rb, (unsigned)NS, sync, (unsigned)(wg << 12 | (t & 4095)));
-      if (ok && l > 0) ok = sweep_wait(cnt + ((long)(l - 1) * L + t) * RBK + rb, (unsigned)NS, sync, (unsigned)(wg << 12 | (t & 4095)) | 0x80000000u);
+      const unsigned code = (unsigned)(wg << 12 | (t & 4095));
+      if (t > 0) ok = sweep_wait(cnt + (((long)l * L + (t - 1)) * RBW + rbw) * kSweepCntStride, (unsigned)NS, sync, code);
+      if (ok && l > 0) ok = sweep_wait(cnt + (((long)(l - 1) * L + t) * RBW + rbw) * kSweepCntStride, (unsigned)NS, sync, code | 0x80000000u);
       if (!ok && lane == 0) *lflag = 1;
     }
     __syncthreads();
     if (*lflag) break;   // uniform: every wave reads the same word behind the barrier
 
-    u32x4 xa[KSW], ha[KSW];
-    if (l == 0) {
+    u32x4 xa[MT][KSW], ha[MT][KSW];
+    {
+      const bool ex = l > 0;
+      const int so = ex ? (int)((unsigned)(((l - 1) * L + t) * 2 + (below_drop ? 1 : 0)) * RG) : (int)((unsigned)t * RG);
 #pragma unroll
-      for (int j = 0; j < KSW; ++j) xa[j] = ld_sc1(rx, voff_rm[j], (int)((unsigned)t * RG));
-    } else {
-      const int so = (int)((unsigned)(((l - 1) * L + t) * 2 + (below_drop ? 1 : 0)) * RG);
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int j = 0; j < KSW; ++j) xa[j] = ld_sc1(rex, voff_ex[j], so);
+        for (int j = 0; j < KSW; ++j) xa[m][j] = ex ? ld_sc1(rex, voff_ex[m][j], so) : ld_sc1(rx, voff_rm[m][j], so);
     }
-    if (t == 0) {
+    {
+      const bool ex = t > 0;
+      const int so = ex ? (int)((unsigned)((l * L + (t - 1)) * 2) * RG) : 0;
 #pragma unroll
-      for (int j = 0; j < KSW; ++j) ha[j] = ld_sc1(rh0, voff_rm[j], 0);
-    } else {
-      const int so = (int)((unsigned)((l * L + (t - 1)) * 2) * RG);
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int j = 0; j < KSW; ++j) ha[j] = ld_sc1(rex, voff_ex[j], so);
+        for (int j = 0; j < KSW; ++j) ha[m][j] = ex ? ld_sc1(rex, voff_ex[m][j], so) : ld_sc1(rh0, voff_rm[m][j], so);
     }
-    f32x4 acc[4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-    for (int j = 0; j < KSW; ++j) {
-      const h8 a = __builtin_bit_cast(h8, xa[j]);
-      acc[0] = PT::mfma(a, wx[0][j], acc[0]);
-      acc[1] = PT::mfma(a, wx[1][j], acc[1]);
-      acc[2] = PT::mfma(a, wx[2][j], acc[2]);
-    }
+      for (int a = 0; a < 4; ++a) acc[m][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < KSW; ++j) {
-      const h8 a = __builtin_bit_cast(h8, ha[j]);
-      acc[0] = PT::mfma(a, wh[0][j], acc[0]);
-      acc[1] = PT::mfma(a, wh[1][j], acc[1]);
-      acc[3] = PT::mfma(a, wh[2][j], acc[3]);
+      for (int j = 0; j < KSW; ++j) {
+        const h8 a = __builtin_bit_cast(h8, xa[m][j]);
+        acc[m][0] = PT::mfma(a, wx[0][j], acc[m][0]);
+        acc[m][1] = PT::mfma(a, wx[1][j], acc[m][1]);
+        acc[m][2] = PT::mfma(a, wx[2][j], acc[m][2]);
+      }
+#pragma unroll
+      for (int j = 0; j < KSW; ++j) {
+        const h8 a = __builtin_bit_cast(h8, ha[m][j]);
+        acc[m][0] = PT::mfma(a, wh[0][j], acc[m][0]);
+        acc[m][1] = PT::mfma(a, wh[1][j], acc[m][1]);
+        acc[m][3] = PT::mfma(a, wh[2][j], acc[m][3]);
+      }
     }
     if (wave > 0) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) part[((wave - 1) * 4 + a) * 64 + lane] = acc[a];
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) part[(((wave - 1) * MT + m) * 4 + a) * 64 + lane] = acc[m][a];
     }
     __syncthreads();
     if (wave == 0) {
+      const int hl = lane & 31, row = hl >> 1, half = hl & 1;
+      const bool hi = lane >= 32;
+      f32x4 rr[MT], zz[MT], nn[MT], hn[MT];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) acc[a] += part[a * 64 + lane] + part[(4 + a) * 64 + lane] + part[(8 + a) * 64 + lane];
-      f32x4 rr, zz, nn, hn, h;
+      for (int m = 0; m < MT; ++m) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rr[i] = fast_sigmoid(acc[0][i] + br);
-        zz[i] = fast_sigmoid(acc[1][i] + bz);
-        hn[i] = acc[3][i] + bhn;
-        nn[i] = fast_tanh(acc[2][i] + bin + rr[i] * hn[i]);
-        h[i] = nn[i] + zz[i] * (hprev[i] - nn[i]);   // (1-z) n + z h_prev
-      }
-      hprev = h;
-      const long o = (long)t * slot + tile_off;   // element offset inside the [L*B, D] arrays
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ta[(4 * kg + i) * TS + r] = PT::cvt(h[i]);
-        tb[(4 * kg + i) * TS + r] = PB::cvt(h[i]);
-      }
-      if (drop) {
-        const f32x4 hd = h * dropout_quad(dc, (uint64_t)o >> 2);
+        for (int a = 0; a < 4; ++a)
+          acc[m][a] += part[((0 * MT + m) * 4 + a) * 64 + lane] + part[((1 * MT + m) * 4 + a) * 64 + lane] + part[((2 * MT + m) * 4 + a) * 64 + lane];
+        f32x4 h;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          tda[(4 * kg + i) * TS + r] = PT::cvt(hd[i]);
-          tdb[(4 * kg + i) * TS + r] = PB::cvt(hd[i]);
+          rr[m][i] = fast_sigmoid(acc[m][0][i] + br);
+          zz[m][i] = fast_sigmoid(acc[m][1][i] + bz);
+          hn[m][i] = acc[m][3][i] + bhn;
+          nn[m][i] = fast_tanh(acc[m][2][i] + bin + rr[m][i] * hn[m][i]);
+          h[i] = nn[m][i] + zz[m][i] * (hprev[m][i] - nn[m][i]);   // (1-z) n + z h_prev
+        }
+        hprev[m] = h;
+        h_t* ta = reinterpret_cast<h_t*>(tiles + (m * 4 + 0) * TILE);
+        hb_t* tb = reinterpret_cast<hb_t*>(tiles + (m * 4 + 1) * TILE);
+        h_t* tda = reinterpret_cast<h_t*>(tiles + (m * 4 + 2) * TILE);
+        hb_t* tdb = reinterpret_cast<hb_t*>(tiles + (m * 4 + 3) * TILE);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ta[(4 * kg + i) * TS + r] = PT::cvt(h[i]);
+          tb[(4 * kg + i) * TS + r] = PB::cvt(h[i]);
+        }
+        if (drop) {
+          const f32x4 hd = h * dropout_quad(dc, (uint64_t)((long)t * slot + tile_off[m]) >> 2);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            tda[(4 * kg + i) * TS + r] = PT::cvt(hd[i]);
+            tdb[(4 * kg + i) * TS + r] = PB::cvt(hd[i]);
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
-      // hand the slice over: lanes 0-31 the state (own layer, next step), lanes 32-63 the masked copy (layer above)
-      const int hl = lane & 31, row = hl >> 1, half = hl & 1;
-      {
-        const bool hi = lane >= 32;
-        const h_t* src = hi ? tda : ta;
+      // hand the slices over: lanes 0-31 the state (own layer, next step), lanes 32-63 the masked copy (layer above)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const h_t* src = reinterpret_cast<const h_t*>(tiles + (m * 4 + (hi ? 2 : 0)) * TILE);
         const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * TS + half * 8);
         const int so = (int)((unsigned)((l * L + t) * 2 + (hi ? 1 : 0)) * RG);
-        if (!hi || drop) st_sc1(v, rex, (rb * NS + s) * 512 + hl * 16, so);
+        if (!hi || drop) st_sc1(v, rex, ((rbw * MT + m) * NS + s) * 512 + hl * 16, so);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(cnt + ((long)l * L + t) * RBK + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_fetch_add(cnt + (((long)l * L + t) * RBW + rbw) * kSweepCntStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // everything below is read only after the launch
-      *reinterpret_cast<f32x4*>(Ly.y_t + o + slot) = h;
-      if (Ly.save_r) {
-        *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_r) + o) = shalf4_t{(_Float16)rr[0], (_Float16)rr[1], (_Float16)rr[2], (_Float16)rr[3]};
-        *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_z) + o) = shalf4_t{(_Float16)zz[0], (_Float16)zz[1], (_Float16)zz[2], (_Float16)zz[3]};
-        *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_n) + o) = shalf4_t{(_Float16)nn[0], (_Float16)nn[1], (_Float16)nn[2], (_Float16)nn[3]};
-        *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_hn) + o) = shalf4_t{(_Float16)hn[0], (_Float16)hn[1], (_Float16)hn[2], (_Float16)hn[3]};
-      }
-      const long go = ((long)t * B + rb * 16 + row) * D + s * 16 + half * 8;   // row-major element offset, slot t
-      if (lane < 32) {
-        *reinterpret_cast<u32x4*>(reinterpret_cast<h_t*>(Ly.y16a) + go + slot) = *reinterpret_cast<const u32x4*>(ta + row * TS + half * 8);
-        if (drop) *reinterpret_cast<u32x4*>(reinterpret_cast<h_t*>(Ly.yd16a) + go) = *reinterpret_cast<const u32x4*>(tda + row * TS + half * 8);
-      } else {
-        if (Ly.y16b) *reinterpret_cast<u32x4*>(reinterpret_cast<hb_t*>(Ly.y16b) + go + slot) = *reinterpret_cast<const u32x4*>(tb + row * TS + half * 8);
-        if (drop && Ly.yd16b) *reinterpret_cast<u32x4*>(reinterpret_cast<hb_t*>(Ly.yd16b) + go) = *reinterpret_cast<const u32x4*>(tdb + row * TS + half * 8);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const long o = (long)t * slot + tile_off[m];   // element offset inside the [L*B, D] arrays
+        *reinterpret_cast<f32x4*>(Ly.y_t + o + slot) = hprev[m];
+        if (Ly.save_r) {
+          *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_r) + o) = shalf4_t{(_Float16)rr[m][0], (_Float16)rr[m][1], (_Float16)rr[m][2], (_Float16)rr[m][3]};
+          *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_z) + o) = shalf4_t{(_Float16)zz[m][0], (_Float16)zz[m][1], (_Float16)zz[m][2], (_Float16)zz[m][3]};
+          *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_n) + o) = shalf4_t{(_Float16)nn[m][0], (_Float16)nn[m][1], (_Float16)nn[m][2], (_Float16)nn[m][3]};
+          *reinterpret_cast<shalf4_t*>(reinterpret_cast<_Float16*>(Ly.save_hn) + o) = shalf4_t{(_Float16)hn[m][0], (_Float16)hn[m][1], (_Float16)hn[m][2], (_Float16)hn[m][3]};
+        }
+        const h_t* ta = reinterpret_cast<const h_t*>(tiles + (m * 4 + 0) * TILE);
+        const hb_t* tb = reinterpret_cast<const hb_t*>(tiles + (m * 4 + 1) * TILE);
+        const h_t* tda = reinterpret_cast<const h_t*>(tiles + (m * 4 + 2) * TILE);
+        const hb_t* tdb = reinterpret_cast<const hb_t*>(tiles + (m * 4 + 3) * TILE);
+        const long go = ((long)t * B + (rbw * MT + m) * 16 + row) * D + s * 16 + half * 8;   // row-major element offset, slot t
+        if (!hi) {
+          *reinterpret_cast<u32x4*>(reinterpret_cast<h_t*>(Ly.y16a) + go + slot) = *reinterpret_cast<const u32x4*>(ta + row * TS + half * 8);
+          if (drop) *reinterpret_cast<u32x4*>(reinterpret_cast<h_t*>(Ly.yd16a) + go) = *reinterpret_cast<const u32x4*>(tda + row * TS + half * 8);
+        } else {
+          if (Ly.y16b) *reinterpret_cast<u32x4*>(reinterpret_cast<hb_t*>(Ly.y16b) + go + slot) = *reinterpret_cast<const u32x4*>(tb + row * TS + half * 8);
+          if (drop && Ly.yd16b) *reinterpret_cast<u32x4*>(reinterpret_cast<hb_t*>(Ly.yd16b) + go) = *reinterpret_cast<const u32x4*>(tdb + row * TS + half * 8);
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -253,9 +285,9 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
 template <class Kern, class Args>
 static int launch_persistent(Kern kern, const Args& p, unsigned grid, hipStream_t st);
 
-template <int PREC, int PRECB, int KSW>
+template <int PREC, int PRECB, int KSW, int MT>
 static int launch_sweep_fwd(const GruSweepArgs& p, unsigned grid, hipStream_t st) {
-  auto kern = gru_sweep_fwd_kernel<PREC, PRECB, KSW>;
+  auto kern = gru_sweep_fwd_kernel<PREC, PRECB, KSW, MT>;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
   (void)once;
   return launch_persistent(kern, p, grid, st);
@@ -274,7 +306,7 @@ struct GruSweepBwdArgs {
   ArkGruSweepBwd a;
 };
 
-template <int PREC, int KSW>
+template <int PREC, int KSW, int MT>
 __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) {
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
@@ -283,16 +315,18 @@ __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ArkGruSweepBwd& p = pa.a;
   constexpr int TS = 24;
-  f32x4* part = reinterpret_cast<f32x4*>(smem);            // [3 waves][2 accumulators][64 lanes]
-  h_t* tg = reinterpret_cast<h_t*>(smem + 6144);           // [4 parts][16 rows][TS]
-  int* lflag = reinterpret_cast<int*>(smem + 6144 + 4 * 16 * TS * 2);
+  constexpr int PARTB = 3 * MT * 2 * 64 * 16;
+  constexpr int TILE4 = 4 * 16 * TS * 2;                   // bytes of the four part tiles of one row tile
+  f32x4* part = reinterpret_cast<f32x4*>(smem);            // [3 waves][MT][2 accumulators][64 lanes]
+  char* tiles = smem + PARTB;                              // [MT][4 parts][16 rows][TS]
+  int* lflag = reinterpret_cast<int*>(smem + PARTB + MT * TILE4);
 
   const int D = p.D, B = p.B, L = p.L, n = p.n_layers;
-  const int NS = D >> 4, RBK = B >> 4;
+  const int NS = D >> 4, RBW = B / (16 * MT);
   const int wg = blockIdx.x;
   // the top layer starts the backward wavefront: give it the lowest workgroup ids
-  const int l = n - 1 - wg / (NS * RBK), rem = wg % (NS * RBK);
-  const int rb = rem / NS, s = rem - rb * NS;
+  const int l = n - 1 - wg / (NS * RBW), rem = wg % (NS * RBW);
+  const int rbw = rem / NS, s = rem - rbw * NS;
   const ArkGruSweepBwdLayer& Ly = p.layer[l];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -313,33 +347,38 @@ __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) 
     }
   }
   const long slot = (long)B * D;
-  const long tile_off = (long)(rb * NS + s) * 256 + lane * 4;
+  long tile_off[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) tile_off[m] = (long)((rbw * MT + m) * NS + s) * 256 + lane * 4;
   const bool drop = Ly.drop_p > 0.f && !top;
   DropCtx dc{};
   if (drop) dc = drop_ctx(Ly.drop_seed, p.hyper, Ly.drop_p);
   const unsigned RG = (unsigned)(slot * 8);   // bytes of one (layer, step) exchange region: [B, 4D] 16-bit
   const __amdgpu_buffer_rsrc_t rex = sweep_rsrc(p.exch, RG * (unsigned)(L * n));
-  int voff_o[KT], voff_u[KT];
+  int voff_o[KT], voff_u[KT];   // row tile 0; tile m adds m * 4 * NS * 512 bytes
 #pragma unroll
   for (int j = 0; j < KT; ++j) {
     const int k = (wave * KT + j) * 32 + kg * 8;
     {
       const int c = k < 2 * D ? k : k + D;      // W_hh columns: [dr | dz] then dn*r
       const int pt = c / D, un = c - pt * D;
-      voff_o[j] = ((((rb * 4 + pt) * NS + (un >> 4)) * 16 + r) * 16 + (un & 8)) * 2;
+      voff_o[j] = ((((rbw * MT * 4 + pt) * NS + (un >> 4)) * 16 + r) * 16 + (un & 8)) * 2;
     }
     {
       const int pt = k / D, un = k - pt * D;    // W_ih columns: [dr | dz | dn]
-      voff_u[j] = ((((rb * 4 + pt) * NS + (un >> 4)) * 16 + r) * 16 + (un & 8)) * 2;
+      voff_u[j] = ((((rbw * MT * 4 + pt) * NS + (un >> 4)) * 16 + r) * 16 + (un & 8)) * 2;
     }
   }
+  const int mstride = 4 * NS * 512;
   unsigned* sync = p.sync;
   unsigned* cnt = p.sync + kSweepSyncHdr;
   if (threadIdx.x == 0) *lflag = 0;
   __syncthreads();
 
-  f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bs[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of the ROUNDED dr, dz, dn, dn*r (this lane's 4 rows)
+  f32x4 carry[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) carry[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of the ROUNDED dr, dz, dn, dn*r (this lane's rows)
   const _Float16* sr = reinterpret_cast<const _Float16*>(Ly.save_r);
   const _Float16* sz = reinterpret_cast<const _Float16*>(Ly.save_z);
   const _Float16* sn = reinterpret_cast<const _Float16*>(Ly.save_n);
@@ -350,97 +389,128 @@ __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) 
     const bool fin = t < 0;          // initial-state step: dh0 += carry + dgh_0 W_hh
     const bool rec = t < L - 1;      // a successor step exists
     const bool up = !top && !fin;
-    const long o = (long)(fin ? 0 : t) * slot + tile_off;
     // epilogue operands first (wave 0): none of them depends on the recurrence, they land during the wait
-    f32x4 hp = f32x4{0.f, 0.f, 0.f, 0.f}, dy = f32x4{0.f, 0.f, 0.f, 0.f};
-    shalf4_t qr{}, qz{}, qn{}, qhn{};
-    if (wave == 0 && !fin) {
-      hp = *reinterpret_cast<const f32x4*>(Ly.y_t + o);
-      if (top) dy = *reinterpret_cast<const f32x4*>(p.dy_t + o);
-      qr = *reinterpret_cast<const shalf4_t*>(sr + o);
-      qz = *reinterpret_cast<const shalf4_t*>(sz + o);
-      qn = *reinterpret_cast<const shalf4_t*>(sn + o);
-      qhn = *reinterpret_cast<const shalf4_t*>(shn + o);
+    f32x4 hp[MT], dy[MT];
+    shalf4_t qr[MT], qz[MT], qn[MT], qhn[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      hp[m] = dy[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      qr[m] = qz[m] = qn[m] = qhn[m] = shalf4_t{};
+      if (wave == 0 && !fin) {
+        const long o = (long)t * slot + tile_off[m];
+        hp[m] = *reinterpret_cast<const f32x4*>(Ly.y_t + o);
+        if (top) dy[m] = *reinterpret_cast<const f32x4*>(p.dy_t + o);
+        qr[m] = *reinterpret_cast<const shalf4_t*>(sr + o);
+        qz[m] = *reinterpret_cast<const shalf4_t*>(sz + o);
+        qn[m] = *reinterpret_cast<const shalf4_t*>(sn + o);
+        qhn[m] = *reinterpret_cast<const shalf4_t*>(shn + o);
+      }
     }
     if (wave == 0) {
       bool ok = true;
       const unsigned code = (unsigned)(wg << 12 | ((t + 1) & 4095));
-      if (rec) ok = sweep_wait(cnt + ((long)l * L + (t + 1)) * RBK + rb, (unsigned)NS, sync, code);
-      if (ok && up) ok = sweep_wait(cnt + ((long)(l + 1) * L + t) * RBK + rb, (unsigned)NS, sync, code | 0x80000000u);
+      if (rec) ok = sweep_wait(cnt + (((long)l * L + (t + 1)) * RBW + rbw) * kSweepCntStride, (unsigned)NS, sync, code);
+      if (ok && up) ok = sweep_wait(cnt + (((long)(l + 1) * L + t) * RBW + rbw) * kSweepCntStride, (unsigned)NS, sync, code | 0x80000000u);
       if (!ok && lane == 0) *lflag = 1;
     }
     __syncthreads();
     if (*lflag) break;
 
-    f32x4 ah = f32x4{0.f, 0.f, 0.f, 0.f}, ax = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 ao[KT], au[KT];
-    if (rec) {
-      const int so = (int)((unsigned)(l * L + (t + 1)) * RG);
+    f32x4 ah[MT], ax[MT];
 #pragma unroll
-      for (int j = 0; j < KT; ++j) ao[j] = ld_sc1(rex, voff_o[j], so);
-    }
-    if (up) {
-      const int so = (int)((unsigned)((l + 1) * L + t) * RG);
+    for (int m = 0; m < MT; ++m) {
+      ah[m] = ax[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x4 ao[KT], au[KT];
+      if (rec) {
+        const int so = (int)((unsigned)(l * L + (t + 1)) * RG) + m * mstride;
 #pragma unroll
-      for (int j = 0; j < KT; ++j) au[j] = ld_sc1(rex, voff_u[j], so);
-    }
-    if (rec) {
+        for (int j = 0; j < KT; ++j) ao[j] = ld_sc1(rex, voff_o[j], so);
+      }
+      if (up) {
+        const int so = (int)((unsigned)((l + 1) * L + t) * RG) + m * mstride;
 #pragma unroll
-      for (int j = 0; j < KT; ++j) ah = PT::mfma(__builtin_bit_cast(h8, ao[j]), wo[j], ah);
-    }
-    if (up) {
+        for (int j = 0; j < KT; ++j) au[j] = ld_sc1(rex, voff_u[j], so);
+      }
+      if (rec) {
 #pragma unroll
-      for (int j = 0; j < KT; ++j) ax = PT::mfma(__builtin_bit_cast(h8, au[j]), wu[j], ax);
+        for (int j = 0; j < KT; ++j) ah[m] = PT::mfma(__builtin_bit_cast(h8, ao[j]), wo[j], ah[m]);
+      }
+      if (up) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j) ax[m] = PT::mfma(__builtin_bit_cast(h8, au[j]), wu[j], ax[m]);
+      }
     }
     if (wave > 0) {
-      part[((wave - 1) * 2 + 0) * 64 + lane] = ah;
-      part[((wave - 1) * 2 + 1) * 64 + lane] = ax;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        part[(((wave - 1) * MT + m) * 2 + 0) * 64 + lane] = ah[m];
+        part[(((wave - 1) * MT + m) * 2 + 1) * 64 + lane] = ax[m];
+      }
     }
     __syncthreads();
     if (wave == 0) {
-      ah += part[0 * 64 + lane] + part[2 * 64 + lane] + part[4 * 64 + lane];
-      ax += part[1 * 64 + lane] + part[3 * 64 + lane] + part[5 * 64 + lane];
+      const int hl = lane & 31, row = hl >> 1, half = hl & 1, hi = lane >> 5;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        ah[m] += part[((0 * MT + m) * 2 + 0) * 64 + lane] + part[((1 * MT + m) * 2 + 0) * 64 + lane] + part[((2 * MT + m) * 2 + 0) * 64 + lane];
+        ax[m] += part[((0 * MT + m) * 2 + 1) * 64 + lane] + part[((1 * MT + m) * 2 + 1) * 64 + lane] + part[((2 * MT + m) * 2 + 1) * 64 + lane];
+      }
       if (fin) {
-        const f32x4 dh = ah + carry;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(&p.dh0[(long)(rb * 16 + 4 * kg + i) * D + u], dh[i]);
-      } else {
-        f32x4 dh = ah + carry + dy;
-        if (drop) dh += ax * dropout_quad(dc, (uint64_t)o >> 2);
-        else dh += ax;
-        f32x4 cz;
+        for (int m = 0; m < MT; ++m) {
+          const f32x4 dh = ah[m] + carry[m];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float rr = (float)qr[i], zz = (float)qz[i], nn = (float)qn[i], hn = (float)qhn[i];
-          const float dn_pre = dh[i] * (1.0f - zz) * (1.0f - nn * nn);
-          const float dz_pre = dh[i] * (hp[i] - nn) * zz * (1.0f - zz);
-          const float dr_pre = dn_pre * hn * rr * (1.0f - rr);
-          cz[i] = dh[i] * zz;
-          const int ro = (4 * kg + i) * TS + r;
-          const h_t v0 = PT::cvt(dr_pre), v1 = PT::cvt(dz_pre), v2 = PT::cvt(dn_pre), v3 = PT::cvt(dn_pre * rr);
-          tg[ro] = v0;
-          tg[16 * TS + ro] = v1;
-          tg[2 * 16 * TS + ro] = v2;
-          tg[3 * 16 * TS + ro] = v3;
-          bs[0] += (float)v0;
-          bs[1] += (float)v1;
-          bs[2] += (float)v2;
-          bs[3] += (float)v3;
+          for (int i = 0; i < 4; ++i) atomicAdd(&p.dh0[(long)((rbw * MT + m) * 16 + 4 * kg + i) * D + u], dh[i]);
         }
-        carry = cz;
+      } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const long o = (long)t * slot + tile_off[m];
+          f32x4 dh = ah[m] + carry[m] + dy[m];
+          if (drop) dh += ax[m] * dropout_quad(dc, (uint64_t)o >> 2);
+          else dh += ax[m];
+          h_t* tg = reinterpret_cast<h_t*>(tiles + m * TILE4);
+          f32x4 cz;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float rr = (float)qr[m][i], zz = (float)qz[m][i], nn = (float)qn[m][i], hn = (float)qhn[m][i];
+            const float dn_pre = dh[i] * (1.0f - zz) * (1.0f - nn * nn);
+            const float dz_pre = dh[i] * (hp[m][i] - nn) * zz * (1.0f - zz);
+            const float dr_pre = dn_pre * hn * rr * (1.0f - rr);
+            cz[i] = dh[i] * zz;
+            const int ro = (4 * kg + i) * TS + r;
+            const h_t v0 = PT::cvt(dr_pre), v1 = PT::cvt(dz_pre), v2 = PT::cvt(dn_pre), v3 = PT::cvt(dn_pre * rr);
+            tg[ro] = v0;
+            tg[16 * TS + ro] = v1;
+            tg[2 * 16 * TS + ro] = v2;
+            tg[3 * 16 * TS + ro] = v3;
+            bs[0] += (float)v0;
+            bs[1] += (float)v1;
+            bs[2] += (float)v2;
+            bs[3] += (float)v3;
+          }
+          carry[m] = cz;
+        }
         __builtin_amdgcn_wave_barrier();
-        // hand the four 512-byte slices over (two store instructions, every 128-B line whole), then the row-major copy
-        const int hl = lane & 31, row = hl >> 1, half = hl & 1, hi = lane >> 5;
-        const u32x4 v01 = *reinterpret_cast<const u32x4*>(tg + (hi * 16 + row) * TS + half * 8);
-        const u32x4 v23 = *reinterpret_cast<const u32x4*>(tg + ((2 + hi) * 16 + row) * TS + half * 8);
+        // hand the 512-byte slices over (two store instructions per row tile, every 128-B line whole), then the row-major copy
+        u32x4 v01[MT], v23[MT];
         const int so = (int)((unsigned)(l * L + t) * RG);
-        st_sc1(v01, rex, ((rb * 4 + hi) * NS + s) * 512 + hl * 16, so);
-        st_sc1(v23, rex, ((rb * 4 + 2 + hi) * NS + s) * 512 + hl * 16, so);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const h_t* tg = reinterpret_cast<const h_t*>(tiles + m * TILE4);
+          v01[m] = *reinterpret_cast<const u32x4*>(tg + (hi * 16 + row) * TS + half * 8);
+          v23[m] = *reinterpret_cast<const u32x4*>(tg + ((2 + hi) * 16 + row) * TS + half * 8);
+          st_sc1(v01[m], rex, (((rbw * MT + m) * 4 + hi) * NS + s) * 512 + hl * 16, so);
+          st_sc1(v23[m], rex, (((rbw * MT + m) * 4 + 2 + hi) * NS + s) * 512 + hl * 16, so);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(cnt + ((long)l * L + t) * RBK + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        h_t* g16 = reinterpret_cast<h_t*>(Ly.dg16) + ((long)t * B + rb * 16 + row) * 4 * D + s * 16 + half * 8;
-        *reinterpret_cast<u32x4*>(g16 + (long)hi * D) = v01;
-        *reinterpret_cast<u32x4*>(g16 + (long)(2 + hi) * D) = v23;
+        if (lane == 0) __hip_atomic_fetch_add(cnt + (((long)l * L + t) * RBW + rbw) * kSweepCntStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          h_t* g16 = reinterpret_cast<h_t*>(Ly.dg16) + ((long)t * B + (rbw * MT + m) * 16 + row) * 4 * D + s * 16 + half * 8;
+          *reinterpret_cast<u32x4*>(g16 + (long)hi * D) = v01[m];
+          *reinterpret_cast<u32x4*>(g16 + (long)(2 + hi) * D) = v23[m];
+        }
         __builtin_amdgcn_wave_barrier();
       }
     }
@@ -485,9 +555,9 @@ static int launch_persistent(Kern kern, const Args& p, unsigned grid, hipStream_
   return 0;
 }
 
-template <int PREC, int KSW>
+template <int PREC, int KSW, int MT>
 static int launch_sweep_bwd(const GruSweepBwdArgs& p, unsigned grid, hipStream_t st) {
-  auto kern = gru_sweep_bwd_kernel<PREC, KSW>;
+  auto kern = gru_sweep_bwd_kernel<PREC, KSW, MT>;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
   (void)once;
   return launch_persistent(kern, p, grid, st);
@@ -495,8 +565,20 @@ static int launch_sweep_bwd(const GruSweepBwdArgs& p, unsigned grid, hipStream_t
 
 }  // namespace ark
 
+// 16-row tiles per workgroup: 1 where n * (B/16) * (D/16) workgroups fit the chip one per CU, else 2, else 0 (no fit)
+static int sweep_row_tiles(int n_layers, int B, int D) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (n_layers <= 0 || n_layers > ARK_SWEEP_MAX_LAYERS || B <= 0 || B % 16 != 0 || (D != 128 && D != 256 && D != 512)) return 0;
+  const long wgs = (long)n_layers * (B / 16) * (D / 16);
+  if (wgs <= cus) return 1;
+  if (B % 32 == 0 && wgs / 2 <= cus) return 2;
+  return 0;
+}
+extern "C" int ark_gru_sweep_row_tiles(int n_layers, int B, int D) { return sweep_row_tiles(n_layers, B, D); }
+
 extern "C" long ark_gru_sweep_exch_bytes(int n_layers, int B, int D, int L) { return 2L * n_layers * L * B * D * 2; }
-extern "C" long ark_gru_sweep_sync_words(int n_layers, int B, int L) { return ark::kSweepSyncHdr + (long)n_layers * L * (B / 16); }
+extern "C" long ark_gru_sweep_sync_words(int n_layers, int B, int L) { return ark::kSweepSyncHdr + (long)n_layers * L * (B / 16) * ark::kSweepCntStride; }
 
 extern "C" int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* a, void* stream) {
   using namespace ark;
@@ -505,6 +587,8 @@ extern "C" int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* a, voi
   const int D = a->D, B = a->B, L = a->L, n = a->n_layers;
   if (B % 16 != 0 || (D != 128 && D != 256 && D != 512)) return ARK_ERR_SHAPE;
   if (L > 4095 || 2.0 * n * L * B * D * 2 >= 2147483648.0) return ARK_ERR_SHAPE;   // 32-bit buffer offsets
+  const int mt = sweep_row_tiles(n, B, D);
+  if (mt == 0) return ARK_ERR_SHAPE;   // the workgroups could not all be resident: use the diagonal launches
   for (int l = 0; l < n; ++l) {
     const ArkGruSweepLayer& y = a->layer[l];
     if (!y.w_ih16 || !y.w_hh16 || !y.b_ih || !y.b_hh || !y.y_t || !y.y16a) return ARK_ERR_ARG;
@@ -517,12 +601,12 @@ extern "C" int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* a, voi
   const long nw = ark_gru_sweep_sync_words(n, B, L);
   hipLaunchKernelGGL(sweep_zero_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, a->sync, nw);
   ARK_LAUNCH_CHECK();
-  const unsigned grid = (unsigned)(n * (D / 16) * (B / 16));
-#define ARK_SWEEP_GO(PF, PBK)                                            \
-  do {                                                                   \
-    if (D == 512) return launch_sweep_fwd<PF, PBK, 4>(p, grid, st);      \
-    if (D == 256) return launch_sweep_fwd<PF, PBK, 2>(p, grid, st);      \
-    return launch_sweep_fwd<PF, PBK, 1>(p, grid, st);                    \
+  const unsigned grid = (unsigned)(n * (D / 16) * (B / 16) / mt);
+#define ARK_SWEEP_GO(PF, PBK)                                                                                   \
+  do {                                                                                                          \
+    if (D == 512) return mt == 1 ? launch_sweep_fwd<PF, PBK, 4, 1>(p, grid, st) : launch_sweep_fwd<PF, PBK, 4, 2>(p, grid, st); \
+    if (D == 256) return mt == 1 ? launch_sweep_fwd<PF, PBK, 2, 1>(p, grid, st) : launch_sweep_fwd<PF, PBK, 2, 2>(p, grid, st); \
+    return mt == 1 ? launch_sweep_fwd<PF, PBK, 1, 1>(p, grid, st) : launch_sweep_fwd<PF, PBK, 1, 2>(p, grid, st);               \
   } while (0)
   if (prec == PREC_F16 && prec_b == PREC_BF16) ARK_SWEEP_GO(PREC_F16, PREC_BF16);
   if (prec == PREC_F16 && prec_b == PREC_F16) ARK_SWEEP_GO(PREC_F16, PREC_F16);
@@ -540,6 +624,8 @@ extern "C" int ark_gru_sweep_bwd(int prec, const ArkGruSweepBwd* a, void* stream
   const int D = a->D, B = a->B, L = a->L, n = a->n_layers;
   if (B % 16 != 0 || (D != 128 && D != 256 && D != 512)) return ARK_ERR_SHAPE;
   if (L > 4094 || 8.0 * n * L * B * D >= 2147483648.0) return ARK_ERR_SHAPE;   // 32-bit buffer offsets
+  const int mt = sweep_row_tiles(n, B, D);
+  if (mt == 0) return ARK_ERR_SHAPE;
   for (int l = 0; l < n; ++l) {
     const ArkGruSweepBwdLayer& y = a->layer[l];
     if (!y.w_hhT16 || (l < n - 1 && !y.w_ihT_up16) || !y.save_r || !y.save_z || !y.save_n || !y.save_hn || !y.y_t || !y.dg16)
@@ -553,12 +639,12 @@ extern "C" int ark_gru_sweep_bwd(int prec, const ArkGruSweepBwd* a, void* stream
   const long nw = ark_gru_sweep_sync_words(n, B, L);
   hipLaunchKernelGGL(sweep_zero_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, a->sync, nw);
   ARK_LAUNCH_CHECK();
-  const unsigned grid = (unsigned)(n * (D / 16) * (B / 16));
-#define ARK_SWEEP_GO(PB)                                          \
-  do {                                                            \
-    if (D == 512) return launch_sweep_bwd<PB, 4>(p, grid, st);    \
-    if (D == 256) return launch_sweep_bwd<PB, 2>(p, grid, st);    \
-    return launch_sweep_bwd<PB, 1>(p, grid, st);                  \
+  const unsigned grid = (unsigned)(n * (D / 16) * (B / 16) / mt);
+#define ARK_SWEEP_GO(PB)                                                                                          \
+  do {                                                                                                            \
+    if (D == 512) return mt == 1 ? launch_sweep_bwd<PB, 4, 1>(p, grid, st) : launch_sweep_bwd<PB, 4, 2>(p, grid, st); \
+    if (D == 256) return mt == 1 ? launch_sweep_bwd<PB, 2, 1>(p, grid, st) : launch_sweep_bwd<PB, 2, 2>(p, grid, st); \
+    return mt == 1 ? launch_sweep_bwd<PB, 1, 1>(p, grid, st) : launch_sweep_bwd<PB, 1, 2>(p, grid, st);               \
   } while (0)
   if (prec == PREC_BF16) ARK_SWEEP_GO(PREC_BF16);
   if (prec == PREC_F16) ARK_SWEEP_GO(PREC_F16);

@@ -733,12 +733,17 @@ class Engine:
             return False
         if self.D not in (128, 256, 512) or self.n > L.SWEEP_MAX_LAYERS or B % 16 != 0:
             return False
-        fits = self.n * (B // 16) * (self.D // 16) <= torch.cuda.get_device_properties(self.device).multi_processor_count
+        fits = L.lib().ark_gru_sweep_row_tiles(L.i32(self.n), L.i32(B), L.i32(self.D)) > 0
         if self.sweep in (1, True, "1", "on"):
             if not fits:
                 raise L.ArkError(f"ark_sweep=1: {self.n} x {B // 16} x {self.D // 16} workgroups cannot be co-resident")
             return True
         return fits and Lq >= 32
+
+    def _sweep_wgs(self, B):
+        """workgroups (= CUs) a persistent sweep of this batch occupies"""
+        mt = L.lib().ark_gru_sweep_row_tiles(L.i32(self.n), L.i32(B), L.i32(self.D))
+        return self.n * (B // 16) * (self.D // 16) // max(1, mt)
 
     def _sweep_fwd(self, w, B, Lq, use_drop, save=True):
         """the forward recurrence of all layers and steps as ONE launch (ark_gru_sweep_fwd); same inputs and outputs as
@@ -747,7 +752,7 @@ class Engine:
         key = ("sweep", Lq)
         if key not in w:
             w[key] = (torch.empty(2 * n * Lq * B * D, device=self.device, dtype=torch.int16),
-                      torch.zeros(16 + n * Lq * (B // 16), device=self.device, dtype=torch.int32))
+                      torch.zeros(L.sweep_sync_words(n, B, Lq), device=self.device, dtype=torch.int32))
         exch, sync = w[key]
         a = L.GruSweep()
         for l in range(n):
@@ -777,7 +782,7 @@ class Engine:
         key = ("sweep_bwd", Lq)
         if key not in w:
             w[key] = (torch.empty(n * Lq * B * 4 * D, device=self.device, dtype=torch.int16),
-                      torch.zeros(16 + n * Lq * (B // 16), device=self.device, dtype=torch.int32))
+                      torch.zeros(L.sweep_sync_words(n, B, Lq), device=self.device, dtype=torch.int32))
         exch, sync = w[key]
         a = L.GruSweepBwd()
         for l in range(n):
@@ -1110,11 +1115,20 @@ class Engine:
             if self._finalize is not None:   # loss scalars of this step (deferred by forward)
                 self._finalize()
                 self._finalize = None
+            ce_dw_later = None
             if self._fused_ce_step:
                 # dW_tok and db_out from the recomputed softmax (no dlogits buffer): csrc/vocab_ce.hip
-                _call("ark_vocab_ce_dw", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]),
-                      L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["lse"]), L.ptr(g["dec.out.weight"]),
-                      L.ptr(g["dec.out.bias"]), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), L.cur_stream())
+                def ce_dw():
+                    _call("ark_vocab_ce_dw", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]),
+                          L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["lse"]), L.ptr(g["dec.out.weight"]),
+                          L.ptr(g["dec.out.bias"]), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), L.cur_stream())
+                # a persistent sweep that fills most of the chip cannot share it with this launch's one-workgroup-per-CU
+                # grid (measured, wd-movies: the sweep took 880 us beside it instead of 420): queue it behind the sweep,
+                # where it runs beside the short kernels of the latent / encoder backward instead
+                if side is not main and self._use_sweep(B, Lq) and self.sweep_bwd and self._sweep_wgs(B) > 128:
+                    ce_dw_later = ce_dw
+                else:
+                    ce_dw()
             elif getattr(self, "_dlog16_valid", False) and self._dlog16_only:
                 _call("ark_colsum16", L.i32(pb), L.ptr(w["dlog16"]), L.i64(self.Vp), L.ptr(g["dec.out.bias"]), L.i32(R), L.i32(V),
                       L.i32(1), L.cur_stream())
@@ -1158,6 +1172,10 @@ class Engine:
         def after_cells():
             self._side_used = side is not main
             self._fork_pending = None
+            if ce_dw_later is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    ce_dw_later()
             if not self._defer_wgrads:   # (data parallel schedules them itself, bucket by bucket)
                 if self.mt == "SAIL" and self.fork_after > 0 and side is not main:
                     self._fork_pending = fork_wgrads

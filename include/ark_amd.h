@@ -171,7 +171,7 @@ int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* roles, cons
 /* Persistent forward sweep for small batches of long sequences (csrc/gru_sweep.hip): the WHOLE stacked-GRU recurrence of
  * L steps as ONE launch of n_layers * (B/16) * (D/16) co-resident workgroups, each keeping its 16 units' weight rows in
  * registers and passing the hidden state on through `exch` with write-through stores, one counter per (layer, step,
- * row block) and bounded spins.  Inputs and outputs are those of L + n - 1 ark_gru_diag_fwd launches: time-major arrays
+ * row block) and bounded spins (two 16-row tiles per workgroup where that makes the grid fit the chip).  Inputs and outputs are those of L + n - 1 ark_gru_diag_fwd launches: time-major arrays
  * (row = t*B + b), slot 0 of y_t / y16a holding the initial state.  D in {128, 256, 512}, B % 16 == 0; returns
  * ARK_ERR_SHAPE when the grid cannot be co-resident (then use the diagonal launches).  After the launch sync[0] != 0
  * means a workgroup gave up waiting (sync[1] = its id << 12 | step): the outputs are then invalid.
@@ -203,6 +203,8 @@ typedef struct {
   const float* hyper;
   int n_layers, B, D, L;
 } ArkGruSweep;
+/* 16-row tiles per workgroup the sweeps would use on the current device: 1 or 2; 0 = the grid cannot be co-resident */
+int ark_gru_sweep_row_tiles(int n_layers, int B, int D);
 long ark_gru_sweep_exch_bytes(int n_layers, int B, int D, int L);
 long ark_gru_sweep_sync_words(int n_layers, int B, int L);
 int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* sweep, void* stream);

@@ -24,7 +24,9 @@ def _pair(cfg, B, P, drop):
 
 
 @pytest.mark.parametrize("D,Z,B,T,padded", [(128, 16, 32, 12, True), (512, 32, 16, 10, True), (256, 8, 48, 6, False),
-                                            (512, 10, 32, 3, False)])
+                                            (512, 10, 32, 3, False),
+                                            (128, 64, 256, 9, True),    # 384 cells' worth of workgroups: two row tiles each
+                                            (512, 16, 64, 4, True)])
 @pytest.mark.parametrize("drop", [0.0, 0.1])
 def test_sweep_matches_diagonal_launches(D, Z, B, T, padded, drop):
     from oracle import sail_oracle as O
