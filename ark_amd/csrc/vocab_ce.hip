@@ -43,6 +43,8 @@ struct VocabCeArgs {
   float* db;              // [V] +=
   long ld_seq;
   int R, B, V;
+  float* part_u;          // vocabulary-split forward: [NV][R*D] tile-native unnormalised U, relative to part_s's maximum
+  float* part_s;          // [NV][R][4] = {maximum (log2 domain), sum, target logit (log2 domain, 0 if not in this split), -}
 };
 
 constexpr int kVcImg = 64 * 128;   // one k-image: 64 rows x 128 B (64 16-bit elements of the reduction index)
@@ -51,9 +53,13 @@ constexpr int kVcAux = 256;        // per-wave side data of a stage: 64 dwords
 // issue one ring stage: DCH k-images of 64 rows = 8*DCH one-KB pieces, dealt round-robin over the NW waves (every wave
 // issues PPW = ceil(8*DCH / NW) instructions so that the counted vmcnt waits are the same for all; a wave whose last
 // piece does not exist repeats piece 0's bytes into piece 0 -- same data, harmless)
+// `lane` goes through an empty asm first: everything derived from it is then re-computed per call (a handful of VALU
+// instructions per piece).  Left to itself the compiler keeps up to sixteen loop-invariant per-piece offsets, spills them in
+// the register-bound wide kernels, and each reload waits -- vmcnt(0) -- for the LDS-DMA traffic of the stages in flight.
 template <int DCH, int NW, class T, class RM>
 __device__ __forceinline__ void vc_issue_stage(const T* src, int D, RM rowmap, char* slot, int wave, int lane) {
   constexpr int NP = 8 * DCH, PPW = (NP + NW - 1) / NW;
+  asm volatile("" : "+v"(lane));
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     int piece = wave + NW * i;
@@ -133,15 +139,21 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   const bool live = r < R && tgt != ARK_TOK_PAD;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on only LDS-DMA is outstanding (counted waits)
 
+  // the workgroups of blockIdx.y = vs sweep the tiles [s0, s1) of the vocabulary (gridDim.y > 1: few row blocks, e.g. 160 at
+  // wd-articles B = 16 -- the splits fill the other CUs; partial results meet in vocab_ce_combine_kernel)
   const int nsteps = (V + 63) / 64;
+  const int NV = gridDim.y, vs = blockIdx.y;
+  const int s0 = (int)((long)nsteps * vs / NV), s1 = (int)((long)nsteps * (vs + 1) / NV);
   auto issue = [&](int s) {
-    char* slot = smem + (s % NSLOT) * SLOT;
+    char* slot = smem + ((s - s0) % NSLOT) * SLOT;
     const int v0 = s * 64;
     vc_issue_stage<DCH, NW>(W, D, [=](int row) { return min(v0 + row, V - 1); }, slot, wave, lane);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + min(v0 + lane, V - 1)),
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + min(v0 + ln, V - 1)),
                                      (__attribute__((address_space(3))) void*)(slot + STAGE + wave * kVcAux), 4, 0, 0);
   };
-  for (int s = 0; s < NSLOT && s < nsteps; ++s) issue(s);
+  for (int s = s0; s < s0 + NSLOT && s < s1; ++s) issue(s);
 
   float m2 = -INFINITY, lsum = 0.f, picked = 0.f;   // running max (log2 domain), this LANE's partial sum, target logit
   f32x4 U[WITH_DY ? DT : 1];
@@ -149,11 +161,11 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) U[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int s = 0; s < nsteps; ++s) {
-    vc_wait_stages<LPS>(min(NSLOT - 1, nsteps - 1 - s));
+  for (int s = s0; s < s1; ++s) {
+    vc_wait_stages<LPS>(min(NSLOT - 1, s1 - 1 - s));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    const char* base = smem + (s % NSLOT) * SLOT;
+    const char* base = smem + ((s - s0) % NSLOT) * SLOT;
     f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
       for (int dt = 0; dt < DT; ++dt) U[dt] = PT::mfma(vc_tr_frag<h8>(base, vh * 32, dt, lane), pf, U[dt]);
     }
     m2 = mn;
-    if (s + NSLOT < nsteps) {
+    if (s + NSLOT < s1) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -241,6 +253,25 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   const float l = lsum * fa + lb * fb;
   const float lse = (mm + __builtin_amdgcn_logf(l)) * kLn2;   // v_log_f32 is log2
   const float tl = (picked + pb) * kLn2;   // the target logit was picked in the log2 domain
+  if constexpr (WITH_DY) {
+    if (NV > 1) {   // partial results of this vocabulary split, all relative to mm
+      if (r >= R) return;
+      if (q == 0) {
+        float* ps = p.part_s + ((long)vs * R + r) * 4;
+        ps[0] = mm;
+        ps[1] = l;
+        ps[2] = picked + pb;
+      }
+      float* pu = p.part_u + (long)vs * R * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const f32x4 ub = *reinterpret_cast<const f32x4*>(xs + rg * UW + (dt * 64 + lane) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pu[tile_native_off(r, 16 * dt + 4 * q + i, D)] = U[dt][i] * fa + ub[i] * fb;
+      }
+      return;
+    }
+  }
   if (q == 0 && r < R) {
     p.row_loss[r] = live ? (lse - tl) : 0.f;
     p.lse[r] = lse;
@@ -262,6 +293,51 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
       }
     }
   }
+}
+
+// vocabulary-split forward, second launch: one thread per quad (4 consecutive rows x one column) of the tile-native dY;
+// a row's splits are merged as in a split-K softmax: M = max M_i, l = sum l_i 2^(M_i - M), U = sum U_i 2^(M_i - M)
+template <int PREC>
+__global__ __launch_bounds__(256) void vocab_ce_combine_kernel(VocabCeArgs p, int D, int NV) {
+  using h_t = typename PrecTraits<PREC>::h_t;
+  const long quad = (long)blockIdx.x * 256 + threadIdx.x;
+  const long nquad = (long)p.R * D / 4;
+  if (quad >= nquad) return;
+  const long off = quad * 4;
+  const long tile = off >> 8;
+  const int within = (int)(off & 255);
+  const int row0 = (int)(tile / (D >> 4)) * 16 + ((within >> 6) & 3) * 4;
+  const int col = (int)(tile % (D >> 4)) * 16 + ((within >> 2) & 15);
+  const int R = p.R;
+  const h_t* W = reinterpret_cast<const h_t*>(p.W16);
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  float out[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = row0 + i;   // (R % 16 == 0: host check)
+    float M = -INFINITY;
+    for (int v = 0; v < NV; ++v) M = fmaxf(M, p.part_s[((long)v * R + r) * 4]);
+    float l = 0.f, pick = 0.f, u = 0.f;
+    for (int v = 0; v < NV; ++v) {
+      const float* ps = p.part_s + ((long)v * R + r) * 4;
+      const float f = __builtin_amdgcn_exp2f(ps[0] - M);
+      l += ps[1] * f;
+      pick += ps[2];
+      u += p.part_u[(long)v * R * D + off + i] * f;
+    }
+    const int t = r / p.B, b = r % p.B;
+    const long tgt = p.seq[(long)b * p.ld_seq + t + 1];
+    const bool live = tgt != ARK_TOK_PAD;
+    const float lse = (M + __builtin_amdgcn_logf(l)) * kLn2;
+    if (col == 0) {
+      p.row_loss[r] = live ? (lse - pick * kLn2) : 0.f;
+      p.lse[r] = lse;
+    }
+    const float sc = live ? p.hyper[ARK_HP_CE_INV_COUNT] : 0.f;
+    out[i] = sc * (u / l - (float)W[(live ? tgt : 0) * D + col]);
+  }
+  (void)acc;
+  *reinterpret_cast<f32x4*>(p.dY_t + off) = f32x4{out[0], out[1], out[2], out[3]};
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -299,7 +375,9 @@ __global__ __launch_bounds__(128 * VG) void vocab_ce_dw_kernel(VocabCeArgs p) {
     const int r0 = s * 64;
     vc_issue_stage<DCH, NW>(Y, D, [=](int row) { return min(r0 + row, R - 1); }, slot, wave, lane);
     // per-wave side data of the stage's 64 rows: lse and the target token (low dword of the int64)
-    const int rr = min(r0 + lane, R - 1);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int rr = min(r0 + ln, R - 1);
     const int t = rr / B, b = rr % B;
     char* aux = slot + STAGE + wave * 2 * kVcAux;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lse + rr),
@@ -428,8 +506,34 @@ static int vc_groups(int n16, int max_groups) {
   return best;
 }
 
+// vocabulary splits of the forward with dY: the count that minimises rounds-of-workgroups x work-per-workgroup on 256 CUs
+// (1 where the 64-row blocks alone fill the chip); each split keeps at least 32 tiles
+static int vc_splits(int R, int V) {
+  const int rb = (R + 63) / 64, nsteps = (V + 63) / 64;
+  if (rb > 192) return 1;   // (the row tiles fill the chip; vc_groups balances the last round)
+  int best = 1;
+  double best_t = (double)((rb + 255) / 256);
+  for (int nv = 2; nv <= 16 && nsteps / nv >= 32; ++nv) {
+    const double t = (double)((rb * nv + 255) / 256) / nv + 0.02 * nv;   // (+ ramp / combine cost per split)
+    if (t < best_t - 1e-9) { best_t = t; best = nv; }
+  }
+  return best;
+}
+extern "C" int ark_vocab_ce_fwd_splits(int R, int V, int D) { return (D == 64 || D == 128 || D == 256 || D == 512) && R % 16 == 0 ? vc_splits(R, V) : 1; }
+
 template <int PREC, int DCH>
 static int vc_launch_fwd(const VocabCeArgs& p, bool with_dy, hipStream_t st) {
+  if (with_dy && p.part_u) {   // few row blocks: the vocabulary is split over workgroups, 64-row tiles, one merging launch
+    constexpr int LDS = vc_lds_bytes<DCH, 4>(kVcAux);
+    static bool once = (vc_allow_lds(vocab_ce_fwd_kernel<PREC, DCH, 4, true>, LDS), true); (void)once;
+    const int nv = vc_splits(p.R, p.V);
+    hipLaunchKernelGGL((vocab_ce_fwd_kernel<PREC, DCH, 4, true>), dim3((unsigned)((p.R + 63) / 64), (unsigned)nv), dim3(512), LDS, st, p);
+    ARK_LAUNCH_CHECK();
+    const long nquad = (long)p.R * (64 * DCH) / 4;
+    hipLaunchKernelGGL((vocab_ce_combine_kernel<PREC>), dim3((unsigned)((nquad + 255) / 256)), dim3(256), 0, st, p, 64 * DCH, nv);
+    ARK_LAUNCH_CHECK();
+    return 0;
+  }
   // (measured: D = 512 is register-bound -- 256 VGPRs with spills -- and slower with anything but 4 groups: 3.9 -> 7.4 ms at
   //  wd-articles; D = 128 gains 10 % from 5 row groups at wd-movies, 280 -> 224 workgroups)
   switch (DCH >= 8 ? 4 : vc_groups((p.R + 15) / 16, DCH <= 2 ? 6 : 5)) {
@@ -499,6 +603,25 @@ extern "C" int ark_vocab_ce_fwd(int prec, const void* Y16, const void* W16, cons
   VocabCeArgs p{Y16, W16, bias, seq, hyper, row_loss, lse, dY_t, nullptr, nullptr, (long)ld_seq, B * L, B, V};
   const bool with_dy = dY_t != nullptr;
   ARK_VC_DISPATCH(vc_launch_fwd, p, with_dy, (hipStream_t)stream);
+}
+
+extern "C" int ark_vocab_ce_fwd_ws(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq,
+                                   int64_t ld_seq, const float* hyper, float* row_loss, float* lse, float* dY_t, float* ws,
+                                   int64_t ws_floats, int B, int L, int V, int D, void* stream) {
+  using namespace ark;
+  int rc = vc_check(prec, Y16, W16, bias, seq, hyper, B, L, V, D);
+  if (rc) return rc;
+  if (!row_loss || !lse || !dY_t) return ARK_ERR_ARG;
+  if ((B * L) % 16 != 0) return ARK_ERR_SHAPE;
+  const long R = (long)B * L;
+  const int nv = ark_vocab_ce_fwd_splits((int)R, V, D);
+  VocabCeArgs p{Y16, W16, bias, seq, hyper, row_loss, lse, dY_t, nullptr, nullptr, (long)ld_seq, B * L, B, V};
+  if (nv > 1) {
+    if (!ws || ws_floats < (long)nv * (R * D + R * 4)) return ARK_ERR_ARG;
+    p.part_u = ws;
+    p.part_s = ws + (long)nv * R * D;
+  }
+  ARK_VC_DISPATCH(vc_launch_fwd, p, true, (hipStream_t)stream);
 }
 
 extern "C" int ark_vocab_ce_dw(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,

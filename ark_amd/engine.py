@@ -614,9 +614,17 @@ class Engine:
                 self._hp.pop("CE_COUNT", None)   # the device slot no longer holds what set_hyper last wrote
         if with_loss and fused:
             # projection + cross-entropy (+ dY of the top layer, consumed by the backward diagonals) in one sweep over V
-            _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]),
-                  L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
-                  L.ptr(w["dYa"] if with_dlogits else None), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
+            nv = L.lib().ark_vocab_ce_fwd_splits(L.i32(R), L.i32(V), L.i32(D)) if with_dlogits else 1
+            if nv > 1:   # few rows, wide model: the vocabulary sweep is split over workgroups (+ one merging launch)
+                if "ce_ws" not in w or w["ce_ws"].numel() < nv * (R * D + 4 * R):
+                    w["ce_ws"] = torch.empty(nv * (R * D + 4 * R), device=self.device)
+                _call("ark_vocab_ce_fwd_ws", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16),
+                      L.ptr(p["dec.out.bias"]), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
+                      L.ptr(w["dYa"]), L.ptr(w["ce_ws"]), L.i64(w["ce_ws"].numel()), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
+            else:
+                _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]),
+                      L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
+                      L.ptr(w["dYa"] if with_dlogits else None), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
             self._finalize = self._make_finalize(w, R, B)
             if not (self._defer_finalize and with_dlogits):
                 self._finalize()

@@ -363,6 +363,14 @@ int ark_ce_fwd_bwd(float* logits, int64_t ld, const int64_t* seq, int64_t ld_seq
 int ark_vocab_ce_fwd(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
                      const float* hyper, float* row_loss, float* lse, float* dY_t /* nullable */, int B, int L, int V, int D,
                      void* stream);
+/* ark_vocab_ce_fwd with dY for FEW rows: the vocabulary is swept in ark_vocab_ce_fwd_splits() parts by different
+ * workgroups (the 64-row blocks alone would leave CUs idle: 160 at wd-articles B = 16, 20 on one of its 8 data-parallel
+ * ranks) and a second small launch merges the partial softmax statistics and products.  `ws` holds splits * (B*L*D + 4*B*L) floats (unused and
+ * may be NULL where ark_vocab_ce_fwd_splits() returns 1). */
+int ark_vocab_ce_fwd_splits(int R, int V, int D);
+int ark_vocab_ce_fwd_ws(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
+                        const float* hyper, float* row_loss, float* lse, float* dY_t, float* ws, int64_t ws_floats, int B,
+                        int L, int V, int D, void* stream);
 int ark_vocab_ce_dw(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
                     const float* hyper, const float* lse, float* dW, float* db, int B, int L, int V, int D, void* stream);
 /* out4 = {loss = ce + beta*kl, ce, kl, sum of token losses}; kl nullable (ARK) */

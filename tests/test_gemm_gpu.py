@@ -315,6 +315,20 @@ def test_fused_vocabulary_cross_entropy(prec, tol, B, Lq, V, D):
     assert close(dY, Yd.grad, tol), (dY - Yd.grad).abs().max().item() / Yd.grad.abs().max().item()
     assert close(dW.double().cpu() - 0.25, Wd.grad, tol), ((dW.double().cpu() - 0.25) - Wd.grad).abs().max().item() / Wd.grad.abs().max().item()
     assert close(db.double().cpu() - 0.5, bd.grad, tol)
+    # few rows x a wide model: the vocabulary-split forward (several workgroups per row block + a merging launch)
+    nv = L.lib().ark_vocab_ce_fwd_splits(L.i32(R), L.i32(V), L.i32(D))
+    assert (nv > 1) == (V > 4096)
+    if nv > 1:
+        ws = torch.full((nv * (R * D + 4 * R),), float("nan"), device=dev)
+        rl2, lse2, dY2 = torch.full((R,), 9.0, device=dev), torch.full((R,), 9.0, device=dev), torch.full((R * D,), 9.0, device=dev)
+        L.check(L.lib().ark_vocab_ce_fwd_ws(*common, L.ptr(rl2), L.ptr(lse2), L.ptr(dY2), L.ptr(ws), L.i64(ws.numel()), *tail),
+                "ark_vocab_ce_fwd_ws")
+        torch.cuda.synchronize()
+        assert (rl2.double().cpu() - per_row.detach()).abs().max().item() <= 2e-5 * per_row.max().item()
+        assert (lse2.double().cpu() - lse_ref).abs().max().item() <= 2e-5 * lse_ref.abs().max().item()
+        assert (rl2.cpu()[tgt == 0] == 0).all()
+        d2 = dY2.double().cpu()[idx].reshape(R, D)
+        assert close(d2, Yd.grad, tol), (d2 - Yd.grad).abs().max().item() / Yd.grad.abs().max().item()
 
 
 @pytest.mark.parametrize("B,nv,Z,D,n", [(32, 32, 10, 512, 3), (16, 7, 64, 384, 2), (48, 48, 128, 320, 1)])
