@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
                                                                float* __restrict__ dhead, float* __restrict__ dA, void* dA16,
                                                                int prec16, float* __restrict__ dA_colsum, int B, int Z, int D,
                                                                int H) {
-  static_assert(RW == 4, "one wave per row");
+  static_assert((ZT <= 64 && RW == 4) || (ZT > 64 && RW == 1), "one wave per row; the wide-latent form: one workgroup per row");
   extern __shared__ __attribute__((aligned(16))) char smem_lc[];
   float* zs = reinterpret_cast<float*>(smem_lc);   // Wz^T: [Z][D + 1]
   __shared__ float sh[RW][2 * ZT];
@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
   // squeeze in beside the weight-gradient launch: measured in situ, same box, alternating rounds -- wd-movies
   // (Z = 64, 64 workgroups) 2.50 -> 2.44 ms/step, syn-types (Z = 24) equal, syn-paths (Z = 10, 256 workgroups beside
   // 480 weight-gradient workgroups) 1.28 -> 1.30 ms/step.  So: batched for Z > 32 only.
-  if constexpr (!BATCHED) {
+  constexpr bool WIDE = ZT > 64;   // 64 < Z <= 128 (wd-articles): Wz^T does not fit LDS -- lanes own latent columns instead
+  if constexpr (WIDE) {
+  } else if constexpr (!BATCHED) {
     for (int i = threadIdx.x; i < D * Z; i += 256) zs[(i % Z) * DS + i / Z] = Wz[i];   // coalesced read, stride-(D+1) write
   } else {
     const int N4 = (D * Z) >> 2;   // D % 4 == 0 (host check) -> whole float4s; parameter blocks are 16-byte aligned
@@ -167,15 +169,40 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
       }
     }
   }
-  const int b = blockIdx.x * RW + wave;
+  const int b = WIDE ? (int)blockIdx.x : (int)blockIdx.x * RW + wave;
   const bool valid = b < B;
   const int bb = valid ? b : B - 1;
   __syncthreads();
-  float acc[ZT];
+  float mydz2[1] = {0.f};   // dz[b, lane]; WIDE: dz[b, thread] for threads 0..127
+  if constexpr (WIDE) {
+    // ONE row per workgroup.  dzp = dh0 (1 - h0^2) goes to LDS (and back to dh0); thread (j = t % 128, half = t / 128) sums
+    // dzp[d] Wz[d, j] over its half of d with coalesced reads of Wz rows (L2-resident: 256 KB) -- no transposed copy of Wz,
+    // sixteen loads in flight per thread; the two halves meet in LDS
+    float* gs = zs;            // [D]
+    float* ph = zs + D;        // [2][128] partial sums
+    for (int d = threadIdx.x; d < D; d += 256) {
+      const float h = h0[(long)bb * D + d];
+      const float g = dh0[(long)bb * D + d] * (1.0f - h * h);
+      if (valid) dh0[(long)bb * D + d] = g;
+      gs[d] = g;
+    }
+    __syncthreads();
+    const int zj = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const int dlo = half * (D / 2), dhi = dlo + D / 2;
+    float a0 = 0.f;
+    if (zj < Z) {
+#pragma unroll 16
+      for (int d = dlo; d < dhi; ++d) a0 += gs[d] * Wz[(long)d * Z + zj];
+    }
+    ph[half * 128 + zj] = a0;
+    __syncthreads();
+    if (threadIdx.x < 128) mydz2[0] = ph[threadIdx.x] + ph[128 + threadIdx.x];
+  }
+  float acc[WIDE ? 1 : ZT];
 #pragma unroll
-  for (int j = 0; j < ZT; ++j) acc[j] = 0.f;
+  for (int j = 0; j < (WIDE ? 1 : ZT); ++j) acc[j] = 0.f;
   constexpr int DU = BATCHED ? 8 : 1;
-  for (int d0 = lane; d0 < D; d0 += 64 * DU) {
+  for (int d0 = lane; d0 < (WIDE ? 0 : D); d0 += 64 * DU) {
     float hv[DU], gv[DU];
 #pragma unroll
     for (int u = 0; u < DU; ++u) {
@@ -190,35 +217,42 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
         const float g = gv[u] * (1.0f - hv[u] * hv[u]);
         if (valid) dh0[(long)bb * D + d] = g;
 #pragma unroll
-        for (int j = 0; j < ZT; ++j)
+        for (int j = 0; j < (WIDE ? 1 : ZT); ++j)
           if (j < Z) acc[j] += g * zs[j * DS + d];
       }
     }
   }
-  float mydz = 0.f;
+  if constexpr (!WIDE) {
 #pragma unroll
-  for (int j = 0; j < ZT; ++j)
-    if (j < Z) {
-      const float a = wave_sum(acc[j]);
-      if (lane == j) mydz = a;
-    }
-  if (lane < Z) {
+    for (int j = 0; j < ZT; ++j)
+      if (j < Z) {
+        const float a = wave_sum(acc[j]);
+        if (lane == j) mydz2[0] = a;
+      }
+  }
+  {
+    const int zj = WIDE ? (int)threadIdx.x : lane;           // WIDE: threads 0..127 own the row's latent columns
+    const int wv = WIDE ? 0 : wave;
+    const bool mine = WIDE ? threadIdx.x < 128 : true;
+    if (mine && zj < Z) {
+    const float mydz = mydz2[0];
     const float ks = hyper[ARK_HP_BETA] * hyper[ARK_HP_KL_NORM];  // beta / (B_global * Z)
-    const float m = head[(long)bb * 2 * Z + lane];
-    const float raw = head[(long)bb * 2 * Z + Z + lane];
+    const float m = head[(long)bb * 2 * Z + zj];
+    const float raw = head[(long)bb * 2 * Z + Z + zj];
     const float lv = fminf(fmaxf(raw, -10.0f), 10.0f);
     float dmu = mydz + ks * m;
-    float dlv = mydz * (eps ? eps[(long)bb * Z + lane] : 0.f) * 0.5f * expf(0.5f * lv) + ks * 0.5f * (expf(lv) - 1.0f);
+    float dlv = mydz * (eps ? eps[(long)bb * Z + zj] : 0.f) * 0.5f * expf(0.5f * lv) + ks * 0.5f * (expf(lv) - 1.0f);
     if (raw < -10.0f || raw > 10.0f) dlv = 0.f;
     if (ext_dhead) {
-      dmu += ext_dhead[(long)bb * 2 * Z + lane];
-      dlv += ext_dhead[(long)bb * 2 * Z + Z + lane];
+      dmu += ext_dhead[(long)bb * 2 * Z + zj];
+      dlv += ext_dhead[(long)bb * 2 * Z + Z + zj];
     }
-    sh[wave][lane] = dmu;
-    sh[wave][Z + lane] = dlv;
+    sh[wv][zj] = dmu;
+    sh[wv][Z + zj] = dlv;
     if (valid) {
-      dhead[(long)bb * 2 * Z + lane] = dmu;
-      dhead[(long)bb * 2 * Z + Z + lane] = dlv;
+      dhead[(long)bb * 2 * Z + zj] = dmu;
+      dhead[(long)bb * 2 * Z + Z + zj] = dlv;
+    }
     }
   }
   __syncthreads();
@@ -386,16 +420,18 @@ __global__ __launch_bounds__(256) void latent_reduce_bwd_kernel(LatentReduceArgs
   extern __shared__ __attribute__((aligned(16))) char smem_lr[];
   float* zs = reinterpret_cast<float*>(smem_lr);            // [b_chunk][ZT]
   float* red = zs + (size_t)p.b_chunk * ZT;                 // [4][64] reused per column
-  const int job = blockIdx.z;
-  const int NW = job == 0 ? p.D : p.H, NS = job == 0 ? p.Z : 2 * p.Z;
+  const int job = blockIdx.z;   // 0: z-projection; 1, 2, ..: blocks of ZT head columns
+  const int jbase = job == 0 ? 0 : (job - 1) * ZT;
+  const int NTOT = job == 0 ? p.Z : 2 * p.Z;
+  const int NW = job == 0 ? p.D : p.H, NS = min(NTOT - jbase, ZT);
   if ((int)blockIdx.x * 64 >= NW) return;   // block-uniform
-  const float* skinny = job == 0 ? p.z : p.dhead;
+  const float* skinny = (job == 0 ? p.z : p.dhead) + jbase;
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   const int b0 = blockIdx.y * p.b_chunk, nb = min(p.B, b0 + p.b_chunk) - b0;
   for (int i = threadIdx.x; i < p.b_chunk * ZT; i += 256) {
     const int bb = i / ZT, j = i % ZT;
-    zs[i] = (bb < nb && j < NS) ? skinny[(long)(b0 + bb) * NS + j] : 0.f;
+    zs[i] = (bb < nb && j < NS) ? skinny[(long)(b0 + bb) * NTOT + j] : 0.f;
   }
   __syncthreads();
   float acc[ZT];
@@ -424,15 +460,15 @@ __global__ __launch_bounds__(256) void latent_reduce_bwd_kernel(LatentReduceArgs
       const float t = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
       if (j == ZT) atomicAdd(&p.dbz[c], t);
       else if (job == 0) atomicAdd(&p.dWz[(long)c * p.Z + j], t);
-      else atomicAdd(&p.dWh[(long)j * p.H + c], t);
+      else atomicAdd(&p.dWh[(long)(jbase + j) * p.H + c], t);
     }
     __syncthreads();
   }
   // dbh[j] = column sums of the skinny operand itself: once per batch chunk, by the first column block
-  if (job == 1 && blockIdx.x == 0 && (int)threadIdx.x < NS) {
+  if (job >= 1 && blockIdx.x == 0 && (int)threadIdx.x < NS) {
     float t = 0.f;
     for (int bb = 0; bb < nb; ++bb) t += zs[bb * ZT + threadIdx.x];
-    atomicAdd(&p.dbh[threadIdx.x], t);
+    atomicAdd(&p.dbh[jbase + threadIdx.x], t);
   }
 }
 
@@ -729,10 +765,11 @@ extern "C" int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_
   using namespace ark;
   if (!dh0 || !h0 || !w_z || !head || !hyper || !w_head || !pre || !dhead || !dA || !dA16 || B <= 0 || Z <= 0 || D <= 0 || H <= 0)
     return ARK_ERR_ARG;
-  if (Z > 64) return ARK_ERR_SHAPE;
+  if (Z > 128) return ARK_ERR_SHAPE;
   if (prec16 != 1 && prec16 != 2) return ARK_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)Z * (D + 1) * sizeof(float);   // Wz^T
+  const size_t lds = Z > 64 ? (size_t)(D + 256) * sizeof(float)      // the row of dzp + partial sums
+                            : (size_t)Z * (D + 1) * sizeof(float);   // Wz^T
   if (lds > 150 * 1024) return ARK_ERR_SHAPE;
 #define ARK_LC(ZT)                                                                                                          \
   {                                                                                                                         \
@@ -744,7 +781,15 @@ extern "C" int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_
   }
   if (Z <= 16) ARK_LC(16)
   else if (Z <= 32) ARK_LC(32)
-  else ARK_LC(64)
+  else if (Z <= 64) ARK_LC(64)
+  else {   // wide latent (wd-articles Z = 128): one workgroup per row
+    if (D % 2 != 0) return ARK_ERR_SHAPE;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_bwd_kernel<128, 1, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL((latent_chain_bwd_kernel<128, 1, true>), dim3(B), dim3(256), lds, st, dh0, h0, w_z, head, eps, hyper,
+                       ext_dhead, w_head, pre, dhead, dA, dA16, prec16, dA_colsum, B, Z, D, H);
+  }
 #undef ARK_LC
   ARK_LAUNCH_CHECK();
   return 0;
@@ -760,10 +805,11 @@ extern "C" int ark_latent_reduce_bwd(const float* dzp, const float* z, float* d_
   if (!dzp || !z || !d_w_z || !d_b_z || !dhead || !act16 || !d_w_head || !d_b_head || B <= 0 || Z <= 0 || D <= 0 || H <= 0)
     return ARK_ERR_ARG;
   if (prec16 != PREC_F16 && prec16 != PREC_BF16) return ARK_ERR_ARG;
-  if (2 * Z > 128) return ARK_ERR_SHAPE;
+  if (Z > 128) return ARK_ERR_SHAPE;
   LatentReduceArgs p{dzp, z, d_w_z, d_b_z, dhead, act16, prec16, d_w_head, d_b_head, B, Z, D, H, 32};
   const int wide = D > H ? D : H;
-  dim3 grid((wide + 63) / 64, (B + p.b_chunk - 1) / p.b_chunk, 2);
+  const int zt = 2 * Z <= 32 ? 32 : 2 * Z <= 64 ? 64 : 128;
+  dim3 grid((wide + 63) / 64, (B + p.b_chunk - 1) / p.b_chunk, 1 + (2 * Z + zt - 1) / zt);
   hipStream_t st = (hipStream_t)stream;
 #define ARK_LR(ZT) hipLaunchKernelGGL(latent_reduce_bwd_kernel<ZT>, grid, dim3(256), (size_t)(p.b_chunk * ZT + 256) * sizeof(float), st, p)
   if (2 * Z <= 32) ARK_LR(32);

@@ -959,7 +959,7 @@ class Engine:
         # latent path
         H = 3 * D
         h0rm = w["h0"] if w["v2"] else w["Y"][0]   # row-major h0 (the v2 state buffers are tile-native)
-        fused = w["v2"] and Z <= 64
+        fused = w["v2"] and Z <= 128
         if fused:
             # ONE launch for the per-row chain dh0 -> dz -> dhead -> dA (it sits on the dependent chain);
             # the reductions over the batch it feeds go to the side queue

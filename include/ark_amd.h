@@ -332,7 +332,7 @@ int ark_zproj_bwd(float* dh0, const float* h0, const float* z, const float* w_z,
 /* the batch reductions of ark_zproj_bwd alone (dzp = dh0 * (1 - h0^2) already formed) */
 int ark_zproj_bwd_dw(const float* dzp, const float* z, float* d_w_z, float* d_b_z, int B, int Z, int D, int accumulate,
                      void* stream);
-/* Per-row latent backward in one launch (Z <= 64): dh0 -> dzp (in place) -> dz -> dhead[B,2Z] (KL + reparameterisation
+/* Per-row latent backward in one launch (Z <= 128): dh0 -> dzp (in place) -> dz -> dhead[B,2Z] (KL + reparameterisation
  * backward of models.py:61-63,199-200, plus optional external [dmu | dlogv]) -> dA[B,H] = (dhead W_head) * gelu'(pre)
  * and its 16-bit copy.  The reductions over the batch (ark_zproj_bwd_dw, db_head, dW_head) are separate. */
 int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_z, const float* head, const float* eps,

@@ -135,7 +135,8 @@ def test_token_sums16(prec, B, Lq, V, ncols, ld):
     assert (S.double().cpu() - want).abs().max().item() <= 2e-6 * (Lq * B / V + 1) ** 0.5 + 1e-6
 
 
-@pytest.mark.parametrize("B,Z,D,H,with_ext", [(8, 10, 64, 192, False), (37, 10, 512, 1536, True), (64, 32, 128, 384, False)])
+@pytest.mark.parametrize("B,Z,D,H,with_ext", [(8, 10, 64, 192, False), (37, 10, 512, 1536, True), (64, 32, 128, 384, False),
+                                              (16, 128, 512, 1536, False), (21, 100, 256, 768, True), (40, 64, 128, 384, False)])
 def test_latent_chain_bwd_matches_autograd(B, Z, D, H, with_ext):
     """ark_latent_chain_bwd (dh0 -> dz -> dhead -> dA in one launch, + bias gradient of the last MLP layer) and the
     batch reductions behind it (ark_zproj_bwd_dw; ark_latent_reduce_bwd, which fuses them) against torch autograd of
