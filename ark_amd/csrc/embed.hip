@@ -67,6 +67,52 @@ __device__ __forceinline__ void enc_pool_fwd_body(int b, const int64_t* __restri
   }
 }
 
+// Long graphs (wd-articles: T = 212 triples, 16 graphs): one workgroup per graph is 16 workgroups walking 212 random table
+// rows each, one after the other -- 210 us of load latency.  Here a workgroup owns 64 float4 columns of one graph and its
+// four waves each sum a quarter of the triples (eight row loads in flight per lane, the indices staged in LDS); the
+// quarters meet in LDS in a fixed order, so the result is deterministic (it differs from the t-ascending sum in rounding).
+__device__ __forceinline__ void enc_pool_fwd_split(int b, int cb, const int64_t* __restrict__ triples, const float* __restrict__ E,
+                                                   const float* __restrict__ R, float* __restrict__ g, float* __restrict__ inv_cnt,
+                                                   int T, int D, long pad_rid, void* g16a, int prec_a, void* g16b, int prec_b) {
+  extern __shared__ __attribute__((aligned(16))) char smem_pool[];
+  long* ids = reinterpret_cast<long*>(smem_pool);                       // [T][3], relation id = -1 for padding triples
+  f32x4* part = reinterpret_cast<f32x4*>(smem_pool + (size_t)((T * 3 * 8 + 15) / 16) * 16);   // [4 waves][64 columns]
+  const int64_t* tr = triples + (long)b * T * 3;
+  for (int i = threadIdx.x; i < 3 * T; i += 256) ids[i] = tr[i];
+  __syncthreads();
+  int cnt = 0;
+  for (int t = 0; t < T; ++t) cnt += (pad_rid < 0 || ids[t * 3 + 1] != pad_rid) ? 1 : 0;
+  const float w = 1.0f / (float)(pad_rid < 0 ? T : (cnt > 0 ? cnt : 1));
+  if (threadIdx.x == 0 && cb == 0 && inv_cnt) inv_cnt[b] = w;
+  const int D4 = D >> 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = cb * 64 + lane;
+  const bool live = c < 3 * D4;
+  const int part_i = live ? c / D4 : 0, d4 = live ? c % D4 : 0;
+  const float* tab = (part_i == 1) ? R : E;
+  const int tq = (T + 3) / 4, t_lo = wave * tq, t_hi = min(T, t_lo + tq);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int t0 = t_lo; t0 < t_hi; t0 += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + u;
+      const bool ok = live && t < t_hi && !(pad_rid >= 0 && ids[t * 3 + 1] == pad_rid);
+      v[u] = ok ? *reinterpret_cast<const f32x4*>(tab + ids[t * 3 + part_i] * D + 4 * d4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  part[wave * 64 + lane] = s;
+  __syncthreads();
+  if (wave == 0 && live) {
+    const f32x4 r = (((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane]) * w;
+    *reinterpret_cast<f32x4*>(g + (long)b * 3 * D + 4 * c) = r;
+    if (g16a) put16x4(g16a, (long)b * 3 * D4 + c, r, prec_a);
+    if (g16b) put16x4(g16b, (long)b * 3 * D4 + c, r, prec_b);
+  }
+}
+
 __global__ __launch_bounds__(256) void enc_pool_fwd_kernel(const int64_t* __restrict__ triples, const float* __restrict__ E,
                                                            const float* __restrict__ R, float* __restrict__ g,
                                                            float* __restrict__ inv_cnt, int T, int D, long pad_rid,
@@ -82,13 +128,19 @@ struct PoolGatherArgs {
   const int64_t* seq; const float* Wt; void* xa; void* xb; float* hyper_tick;
   long pad_rid, ld_seq;
   int B, T, D, Dd, L, prec_a, prec_b;
+  int col_blocks;   // 0: one pool workgroup per graph; > 0: this many 64-column workgroups per graph (long graphs)
 };
 __global__ __launch_bounds__(256) void pool_gather_fwd_kernel(PoolGatherArgs p) {
-  if ((int)blockIdx.x < p.B) {
-    enc_pool_fwd_body(blockIdx.x, p.triples, p.E, p.R, p.g, p.inv_cnt, p.T, p.D, p.pad_rid, p.g16a, p.prec_a, p.g16b, p.prec_b);
+  const int npool = p.col_blocks > 0 ? p.B * p.col_blocks : p.B;
+  if ((int)blockIdx.x < npool) {
+    if (p.col_blocks > 0)
+      enc_pool_fwd_split(blockIdx.x / p.col_blocks, blockIdx.x % p.col_blocks, p.triples, p.E, p.R, p.g, p.inv_cnt, p.T, p.D,
+                         p.pad_rid, p.g16a, p.prec_a, p.g16b, p.prec_b);
+    else
+      enc_pool_fwd_body(blockIdx.x, p.triples, p.E, p.R, p.g, p.inv_cnt, p.T, p.D, p.pad_rid, p.g16a, p.prec_a, p.g16b, p.prec_b);
     return;
   }
-  const int blk = blockIdx.x - p.B, nblk = gridDim.x - p.B;
+  const int blk = blockIdx.x - npool, nblk = gridDim.x - npool;
   if (p.hyper_tick && blk == 0 && threadIdx.x == 0) reinterpret_cast<uint32_t*>(p.hyper_tick)[kHpDropStep] += 1u;
   const int D4 = p.Dd >> 2;
   const long total = (long)p.B * p.L * D4;
@@ -325,10 +377,18 @@ extern "C" int ark_pool_gather_fwd16(const int64_t* triples, const float* E, con
   if ((prec_a != PREC_F16 && prec_a != PREC_BF16) || (g16b && prec_b != PREC_F16 && prec_b != PREC_BF16)) return ARK_ERR_ARG;
   if ((g16b == nullptr) != (x16b == nullptr)) return ARK_ERR_ARG;   // one backward type for both (or none)
   PoolGatherArgs p{triples, E, R, g, inv_cnt, g16a, g16b, seq, w_tok, x16a, x16b, hyper_tick, (long)pad_rid, (long)ld_seq,
-                   B, T, D, D_dec, L, prec_a, prec_b};
+                   B, T, D, D_dec, L, prec_a, prec_b, 0};
   const long total = (long)B * L * (D_dec / 4);
   long gb = (total + 255) / 256; if (gb > 4096) gb = 4096; if (gb < 1) gb = 1;
-  hipLaunchKernelGGL(pool_gather_fwd_kernel, dim3((unsigned)(B + gb)), dim3(256), 0, (hipStream_t)stream, p);
+  // long graphs in a small batch: the pool is all load latency -- spread each graph over column blocks and its triples over waves
+  size_t lds = 0;
+  if (T >= 32 && (long)B * ((3 * (D / 4) + 63) / 64) <= 2048) {
+    p.col_blocks = (3 * (D / 4) + 63) / 64;
+    lds = (size_t)((T * 3 * 8 + 15) / 16) * 16 + 4 * 64 * 16;
+    if (lds > 60 * 1024) { p.col_blocks = 0; lds = 0; }
+  }
+  const long npool = p.col_blocks > 0 ? (long)B * p.col_blocks : B;
+  hipLaunchKernelGGL(pool_gather_fwd_kernel, dim3((unsigned)(npool + gb)), dim3(256), lds, (hipStream_t)stream, p);
   ARK_LAUNCH_CHECK();
   return 0;
 }
