@@ -68,6 +68,15 @@ __device__ __forceinline__ bool sweep_wait(unsigned* cnt, unsigned need, unsigne
   }
 }
 
+// Diagnostic build only (-DARK_SWEEP_STAMPS, tools/sweep_stamps.py): 100-MHz real-time ticks wave 0 of every forward
+// workgroup spends in each phase of a step, summed over the sweep, into a buffer of their own (no such code is shipped).
+#ifdef ARK_SWEEP_STAMPS
+__device__ unsigned long long ark_sweep_stamp_buf[512 * 8];
+#define SW_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (wave == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); sacc_[i] += n_ - last_; last_ = n_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SW_STAMP(i) do {} while (0)
+#endif
+
 __global__ void sweep_zero_kernel(unsigned* p, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0u;
@@ -150,7 +159,18 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
   if (threadIdx.x == 0) *lflag = 0;
   __syncthreads();
 
+  u32x4 xn[MT][KSW];   // layer 0: the inputs of the coming step
+  if (l == 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < KSW; ++j) xn[m][j] = ld_sc1(rx, voff_rm[m][j], 0);
+  }
+#ifdef ARK_SWEEP_STAMPS
+  unsigned long long sacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int t = 0; t < L; ++t) {
+    SW_STAMP(7);   // bulk stores of the previous step + loop overhead
     if (wave == 0) {
       bool ok = true;
       const unsigned code = (unsigned)(wg << 12 | (t & 4095));
@@ -158,17 +178,21 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
       if (ok && l > 0) ok = sweep_wait(cnt + (((long)(l - 1) * L + t) * RBW + rbw) * kSweepCntStride, (unsigned)NS, sync, code | 0x80000000u);
       if (!ok && lane == 0) *lflag = 1;
     }
+    SW_STAMP(0);   // waiting for the two counters
     __syncthreads();
     if (*lflag) break;   // uniform: every wave reads the same word behind the barrier
+    SW_STAMP(1);   // barrier
 
+    // the handed-off fragments first: they are what the step waits for.  Layer 0's inputs do not depend on the recurrence:
+    // they were requested a step ago, and the next step's request goes out BEHIND the state loads (loads return in order:
+    // an input load in front of them would hold them back -- it cost 0.5 us per step of the layer that paces the sweep)
     u32x4 xa[MT][KSW], ha[MT][KSW];
-    {
-      const bool ex = l > 0;
-      const int so = ex ? (int)((unsigned)(((l - 1) * L + t) * 2 + (below_drop ? 1 : 0)) * RG) : (int)((unsigned)t * RG);
+    if (l > 0) {
+      const int so = (int)((unsigned)(((l - 1) * L + t) * 2 + (below_drop ? 1 : 0)) * RG);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int j = 0; j < KSW; ++j) xa[m][j] = ex ? ld_sc1(rex, voff_ex[m][j], so) : ld_sc1(rx, voff_rm[m][j], so);
+        for (int j = 0; j < KSW; ++j) xa[m][j] = ld_sc1(rex, voff_ex[m][j], so);
     }
     {
       const bool ex = t > 0;
@@ -178,6 +202,24 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
 #pragma unroll
         for (int j = 0; j < KSW; ++j) ha[m][j] = ex ? ld_sc1(rex, voff_ex[m][j], so) : ld_sc1(rh0, voff_rm[m][j], so);
     }
+    if (l == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < KSW; ++j) xa[m][j] = xn[m][j];
+      if (t + 1 < L) {
+        const int so = (int)((unsigned)(t + 1) * RG);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < KSW; ++j) xn[m][j] = ld_sc1(rx, voff_rm[m][j], so);
+      }
+    }
+#ifdef ARK_SWEEP_STAMPS
+    if (l == 0 && t + 1 < L) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * KSW) : "memory");   // (all but the prefetch)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SW_STAMP(2);   // handed-off fragments have landed
     f32x4 acc[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -205,6 +247,7 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
         for (int a = 0; a < 4; ++a) part[(((wave - 1) * MT + m) * 4 + a) * 64 + lane] = acc[m][a];
     }
     __syncthreads();
+    SW_STAMP(3);   // products + partial sums in LDS + barrier
     if (wave == 0) {
       const int hl = lane & 31, row = hl >> 1, half = hl & 1;
       const bool hi = lane >= 32;
@@ -243,6 +286,7 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
         }
       }
       __builtin_amdgcn_wave_barrier();
+      SW_STAMP(4);   // reduction + gate math + transposition tiles
       // hand the slices over: lanes 0-31 the state (own layer, next step), lanes 32-63 the masked copy (layer above)
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -252,8 +296,10 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
         if (!hi || drop) st_sc1(v, rex, ((rbw * MT + m) * NS + s) * 512 + hl * 16, so);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SW_STAMP(5);   // write-through stores drained
       if (lane == 0) __hip_atomic_fetch_add(cnt + (((long)l * L + t) * RBW + rbw) * kSweepCntStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // everything below is read only after the launch
+      // everything below is read only after the launch.  (Handing these stores to the idle waves through a second LDS
+      // buffer was measured: 1.96 -> 2.07 ms per wd-articles sweep -- the extra LDS writes cost wave 0 more than the stores.)
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const long o = (long)t * slot + tile_off[m];   // element offset inside the [L*B, D] arrays
@@ -280,6 +326,10 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
       __builtin_amdgcn_wave_barrier();
     }
   }
+#ifdef ARK_SWEEP_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 512)
+    for (int i_ = 0; i_ < 8; ++i_) ark_sweep_stamp_buf[blockIdx.x * 8 + i_] = sacc_[i_];
+#endif
 }
 
 template <class Kern, class Args>
@@ -651,3 +701,9 @@ extern "C" int ark_gru_sweep_bwd(int prec, const ArkGruSweepBwd* a, void* stream
 #undef ARK_SWEEP_GO
   return ARK_ERR_ARG;
 }
+
+#ifdef ARK_SWEEP_STAMPS
+extern "C" int ark_debug_sweep_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ark::ark_sweep_stamp_buf), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -118,8 +118,13 @@ def time_diag_kernels(eng, B, reps=8):
         # the dependent chain of the decoder backward only (bias gradients pile up in the gradient buffer: timing only)
         eng._diag_bwd_sweep(w, B, Lq, use_drop)
 
-    sweeps = {"gru_diag_fwd_kernel": (lambda: eng._diag_sweep(w, B, Lq, use_drop, True), Lq + n - 1),
-              "gru_diag_bwd_kernel": (bwd_sweep, Lq + n - 1 + (1 if eng.mt == "SAIL" else 0))}
+    if eng._use_sweep(B, Lq):
+        # small batch x long sequence: each direction of the recurrence is ONE persistent launch (csrc/gru_sweep.hip)
+        sweeps = {"gru_sweep_fwd_kernel": (lambda: eng._diag_sweep(w, B, Lq, use_drop, True), 1),
+                  "gru_sweep_bwd_kernel": (bwd_sweep, 1)}
+    else:
+        sweeps = {"gru_diag_fwd_kernel": (lambda: eng._diag_sweep(w, B, Lq, use_drop, True), Lq + n - 1),
+                  "gru_diag_bwd_kernel": (bwd_sweep, Lq + n - 1 + (1 if eng.mt == "SAIL" else 0))}
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
         for name, (fn, launches) in sweeps.items():
@@ -283,6 +288,9 @@ def other_workloads(dev, precision, dropout, mfma_peak):
                 times = time_diag_kernels(eng, B, reps=3)
                 ent["diag_kernels"] = {k: {"kernel_avg_us": kt * 1e6, "launches_per_step": n, "us_per_step": kt * 1e6 * n}
                                        for k, (kt, n) in times.items()}
+                if eng._use_sweep(B, eng.L):
+                    ent["persistent_sweep"] = {"workgroups": eng._sweep_wgs(B), "recurrence_steps": eng.L + eng.n - 1,
+                                               "us_per_recurrence_step": {k: kt * 1e6 / (eng.L + eng.n - 1) for k, (kt, n) in times.items()}}
                 ent["diag_share_of_step"] = sum(v["us_per_step"] for v in ent["diag_kernels"].values()) / (dt / steps * 1e6)
             ent["kernel_profile"] = f"profiles/r03_{name}_kernel_stats.csv"
             out[name] = ent
@@ -395,8 +403,9 @@ def main():
             chains = len(eng._chains(B))
             traffic = {k: v * chains for k, v in traffic.items()}
             kern = {}
+            alias = {"gru_sweep_fwd_kernel": "gru_diag_fwd_kernel", "gru_sweep_bwd_kernel": "gru_diag_bwd_kernel"}
             for name, (kt, launches) in times.items():
-                m = models[name]
+                m = models[alias.get(name, name)]   # (the sweeps move the same algorithmic bytes as the launches they replace)
                 kern[name] = {"kernel_avg_us": kt * 1e6, "launches_per_step": launches, "us_per_step": kt * 1e6 * launches,
                               "bytes_per_launch": m["impl"] / launches, "bytes_per_launch_min_8d": m["min"] / launches,
                               "achieved": m["impl"] / launches / kt / 1e9, "frac": m["impl"] / launches / kt / 1e9 / 8000.0,
@@ -409,6 +418,10 @@ def main():
                                             "achieved_gbs_per_cu": m["dma"] / launches / 256 / kt / 1e9,
                                             "measured_ceiling_gbs_per_cu": 110.0,
                                             "frac": m["dma"] / launches / 256 / kt / 1e9 / 110.0}}
+                if name in alias:   # persistent: one launch walks every (layer, step); no LDS-DMA operand stream
+                    del kern[name]["l2_to_lds"]
+                    kern[name]["recurrence_steps_per_launch"] = eng.L + eng.n - 1
+                    kern[name]["us_per_recurrence_step"] = kt * 1e6 / (eng.L + eng.n - 1)
                 log(f'{name}: {kt * 1e6:.2f} us/launch x {launches}')
             dom = max(kern, key=lambda k: kern[k]["us_per_step"])   # dominant = most time per step
             d = kern[dom]
