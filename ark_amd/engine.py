@@ -823,6 +823,15 @@ class Engine:
                     return int(v[0]), int(v[1])
         return 0, 0
 
+    def raise_on_sweep_error(self):
+        """fail loudly if a persistent sweep of any earlier step gave up waiting (its error word is sticky until the next
+        sweep of the same workspace zeroes it: call this where the step's scalars are read anyway)"""
+        e, d = self.sweep_error()
+        if e:
+            raise L.ArkError(f"persistent GRU sweep gave up waiting (workgroup {d >> 12 & 0x7FFFF}, step {d & 4095}): "
+                             "the workgroups were not all resident or the device is wedged; set ark_sweep: 0 to use the "
+                             "layer-diagonal launches")
+
     def _diag_sweep(self, w, B, Lq, use_drop, save=True):
         """Layer-diagonal forward recurrence: cells (l, d-l) of one anti-diagonal are independent -> ONE
         launch per diagonal (one per ARK_DIAG_MAX_ROLES cells for deeper stacks), each role doing its own input

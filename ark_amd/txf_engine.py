@@ -158,6 +158,8 @@ class TxfEngine(Engine):
         self._dp_pending, self._dp_flush_graph = None, None
         self.dp_bf16 = False
         self._graph_steps = {}
+        self._graphs = {}
+        self._pinned = set()   # workspace keys a captured graph points at: never evicted
         self.ldl = _rup(self.V, 4)
 
     # ------------------------------------------------------------------ plumbing the base class expects
@@ -220,7 +222,8 @@ class TxfEngine(Engine):
         w["row_loss"] = f(R)
         w["out4"] = torch.zeros(4, device=dev)
         if len(self._ws_cache) >= 8:
-            self._ws_cache.pop(next(iter(self._ws_cache)))
+            for k in [k for k in self._ws_cache if k not in self._pinned][:1]:
+                self._ws_cache.pop(k)
         self._ws_cache[key] = w
         self.ws, self.ws_key = w, key
         return w
@@ -529,12 +532,68 @@ class TxfEngine(Engine):
         self.adam()
         return self.ws["out4"]
 
-    def graphed_train_step(self, triples, seq, ce_count=None, dp=False):
-        """(the Transformer variants' step is launched eagerly: no captured graph yet)"""
-        return self.train_step(triples, seq, ce_count=ce_count, dp=dp)
+    def capture_train_step(self, triples, seq, eps=None, ce_count=None, grad_sync=None, dp=False):
+        """the single-process train step (forward + loss + backward + Adam, ~200 short launches) as ONE hipGraph on
+        fixed-address inputs; returns replay().  Everything that changes per step lives on the device: dropout and noise
+        draw counters, Adam's step scalars, the CE count.  (Data parallel: not captured -- use train_step(dp=True).)"""
+        if dp or grad_sync is not None:
+            raise L.ArkError(f"{self.mt}: the captured train step is single-process; use train_step(dp=True)")
+        self._default_norms(seq.shape[0])
+        if ce_count is not None:
+            self.set_hyper(ce_count=ce_count)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):   # warm-up outside capture (allocates the workspace); this IS a step
+            self.train_step(triples, seq, eps, ce_count=ce_count)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        steps0 = self.adam_steps
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.train_step(triples, seq, eps, ce_count=ce_count)
+        self.adam_steps = steps0   # capture does not execute
+        out4 = self.ws["out4"]
+        gstream = torch.cuda.Stream(device=self.device)
 
-    def capture_train_step(self, *a, **k):
-        raise L.ArkError(f"{self.mt}: hipGraph capture of the train step is not implemented; use train_step()")
+        def replay():
+            # (as Engine.capture_train_step: replays run on an explicit stream fenced against the caller's)
+            cur = torch.cuda.current_stream()
+            use = cur if cur.cuda_stream != 0 else gstream
+            if use is not cur:
+                use.wait_stream(cur)
+            with torch.cuda.stream(use):
+                g.replay()
+            if use is not cur:
+                cur.wait_stream(use)
+            self.adam_steps += 1
+            return out4
+
+        self._graphs[("train", self.ws_key)] = [g]
+        self._pinned.add(self.ws_key)
+        return replay
+
+    def graphed_train_step(self, triples, seq, ce_count=None, dp=False):
+        """train_step() through a cached hipGraph (single process; data parallel steps are launched eagerly)"""
+        if dp:
+            return self.train_step(triples, seq, ce_count=ce_count, dp=True)
+        assert self.training, "graphed_train_step is a training-mode step"
+        key = (None if triples is None else tuple(triples.shape), tuple(seq.shape), ce_count is None)
+        ent = self._graph_steps.get(key)
+        if ent is None:
+            tri_s = None if triples is None else triples.clone()
+            seq_s = seq.clone()
+            replay = self.capture_train_step(tri_s, seq_s, None, ce_count=ce_count)
+            self._graph_steps[key] = (tri_s, seq_s, replay)
+            return self.ws["out4"]
+        tri_s, seq_s, replay = ent
+        if tri_s is not None:
+            tri_s.copy_(triples, non_blocking=True)
+        seq_s.copy_(seq, non_blocking=True)
+        self._default_norms(seq.shape[0])
+        if ce_count is not None:
+            self.set_hyper(ce_count=ce_count)
+        self._workspace(seq.shape[0], seq.shape[1] - 1, 0 if tri_s is None else tri_s.shape[1])
+        return replay()
 
     def eval_loss(self, triples, seq, eps=None):
         self._default_norms(seq.shape[0])

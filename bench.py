@@ -262,6 +262,7 @@ def time_workload(dev, workload, precision, dropout, batch, steps, warmup, settl
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        eng.raise_on_sweep_error()   # a persistent sweep that gave up waiting voids the run
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -150,6 +150,7 @@ def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), ma
         import torch.distributed as dist
         dist.all_reduce(sums)    # token-loss sums add up; ce/loss are re-derived below
     s = sums.tolist()
+    model.engine().raise_on_sweep_error()   # (a persistent GRU sweep that gave up waiting: the epoch's numbers are void)
     if nb == 0:
         return 0.0, 0.0, 0.0, 0.0
     if nranks > 1:

@@ -372,3 +372,34 @@ def test_tsail_posterior_bits_match_reference_records(name, padded):
     np.testing.assert_allclose([r["kl_bits"] for r in stats["records"]], z["bits_kl"], rtol=3e-4, atol=1e-7)
     with pytest.raises(Exception):
         model.engine().forward(None, torch.from_numpy(z["seq"]).cuda())   # no triples, no z: refused loudly
+
+
+@pytest.mark.parametrize("kind,name", [("t-ARK", "tark_small"), ("t-SAIL", "tsail_small")])
+def test_captured_transformer_step_replays_the_eager_step(kind, name):
+    """TxfEngine.capture_train_step: replays of the one-graph step (dropout on: masks and latent noise come from device
+    counters that advance per replay) walk the same loss trajectory as eager steps from the same state"""
+    model, z, cfg = (_model if kind == "t-ARK" else _sail_model)(name, dec_dropout=0.1, ark_txf_dropout=0.1)
+    seq = torch.from_numpy(z["seq"]).cuda()
+    tri = torch.from_numpy(z["triples"]).cuda() if kind == "t-SAIL" else None
+    eng = model.engine()
+    eng.training = True
+    eng.set_hyper(lr=1e-3)
+    P0 = eng.P.clone()
+
+    def reset():
+        eng.P.copy_(P0)
+        eng.reset_optimizer()
+        eng.set_dropout_draws(0)
+        eng.set_noise_draws(0)
+
+    reset()
+    eager = [eng.train_step(tri, seq).cpu().numpy().copy() for _ in range(4)]
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        reset()
+        step = eng.capture_train_step(tri, seq)   # (its warm-up run is a step: start over)
+        reset()
+        got = [step().cpu().numpy().copy() for _ in range(4)]
+    for s in range(4):
+        assert rel_err(float(got[s][0]), float(eager[s][0])) < 1e-6, (s, got[s], eager[s])
+    assert eager[0][0] != eager[1][0]

@@ -1,4 +1,4 @@
-"""Development timing of the Transformer variants' train step (eager launches): python tools/txf_time.py [t-ARK|t-SAIL] [batch]"""
+"""Development timing of the Transformer variants' train step (eager launches, then the captured graph): python tools/txf_time.py [t-ARK|t-SAIL] [batch]"""
 import os
 import sys
 import time
@@ -30,5 +30,17 @@ for prec in ("mixed", "f32"):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print(f"{mt} B={B} {prec}: {dt * 1e3:.2f} ms/step = {B / dt:.0f} graphs/s, loss {float(out[0]):.4f}", flush=True)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        step = eng.capture_train_step(tri, seq)
+        for _ in range(5):
+            out = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = step()
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"{mt} B={B} {prec} captured: {dt * 1e3:.2f} ms/step = {B / dt:.0f} graphs/s, loss {float(out[0]):.4f}", flush=True)
     del eng
     torch.cuda.empty_cache()
