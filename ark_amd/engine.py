@@ -180,6 +180,8 @@ class Engine:
         # "auto" = where the diagonal launches are all fixed cost (see _use_sweep)
         self.sweep = cfg.get("ark_sweep", "auto")
         self.sweep_bwd = bool(cfg.get("ark_sweep_bwd", True))   # (0: persistent forward, diagonal backward)
+        self.ce_dw_after_latent = bool(cfg.get("ark_ce_dw_after_latent", True))
+        self._ce_dw_pending = None
         self._pad_bufs = {}
         self._n_valid = 0
         self._side_used = False
@@ -980,6 +982,9 @@ class Engine:
                   L.ptr(self._eps), L.ptr(self.hyper), L.ptr(ext), L.ptr(p["enc.mu.weight"]), L.ptr(w["pre"][n - 1]),
                   L.ptr(w["dhead"]), L.ptr(w["dA"]), L.ptr(w["dpre16"][n - 1]), L.i32(pb),
                   L.ptr(g[f"enc.mlp.{2 * (n - 1)}.bias"]), L.i32(nv), L.i32(Z), L.i32(D), L.i32(H), st)
+            if self._ce_dw_pending is not None:
+                self._ce_dw_pending()
+                self._ce_dw_pending = None
             if self._fork_pending is not None:
                 self._fork_pending()
             main = torch.cuda.current_stream()
@@ -992,6 +997,9 @@ class Engine:
                       L.ptr(g["enc.mu.bias"]), L.i32(nv), L.i32(Z), L.i32(D), L.i32(H), ss)
             self._side_used = self._side_used or (side is not main)
         else:
+            if self._ce_dw_pending is not None:
+                self._ce_dw_pending()
+                self._ce_dw_pending = None
             if self._fork_pending is not None:
                 self._fork_pending()
             _call("ark_zproj_bwd", L.ptr(w["dH0"]), L.ptr(h0rm), L.ptr(w["z"]), L.ptr(p["dec.z_proj.weight"]),
@@ -1190,9 +1198,15 @@ class Engine:
             self._side_used = side is not main
             self._fork_pending = None
             if ce_dw_later is not None:
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    ce_dw_later()
+                def go():
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        ce_dw_later()
+                # SAIL: behind the latent kernel, the head of the encoder chain (its one-per-CU grid leaves that kernel 4 CUs)
+                if self.mt == "SAIL" and self.ce_dw_after_latent and not self._defer_wgrads:
+                    self._ce_dw_pending = go
+                else:
+                    go()
             if not self._defer_wgrads:   # (data parallel schedules them itself, bucket by bucket)
                 if self.mt == "SAIL" and self.fork_after > 0 and side is not main:
                     self._fork_pending = fork_wgrads
