@@ -149,3 +149,49 @@ def test_sweep_refuses_a_grid_that_cannot_be_resident():
         eng._use_sweep(256, 10)   # 3 x 16 x 32 workgroups
     auto = make_engine(dict(cfg), P, "mixed")
     assert not auto._use_sweep(256, 100) and not auto._use_sweep(16, 10) and auto._use_sweep(16, 100)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_sweep_in_the_single_type_precisions(precision):
+    """the bf16 / bf16 and f16 / f16 instantiations of both sweeps against the diagonal launches of the same precision"""
+    from oracle import sail_oracle as O
+    cfg = _cfg(256, 16, 200, 4, 11, True)
+    B = 32
+    P = O.init_params(cfg, 3)
+    triples, seq = synth_batch(cfg, B, seed=6, padded=True)
+    torch.manual_seed(2)
+    eps = torch.randn(B, 16)
+    outs, grads = [], []
+    for sw in (0, 1):
+        eng = make_engine(dict(cfg, dec_dropout=0.1, ark_sweep=sw), P, precision)
+        eng.set_hyper(beta=0.2)
+        eng.drop_seed = 99
+        dev = eng.device
+        outs.append(eng.train_step(triples.to(dev), seq.to(dev), eps.to(dev)).cpu().numpy().copy())
+        torch.cuda.synchronize()
+        assert eng.sweep_error() == (0, 0)
+        grads.append({k: v.float().clone() for k, v in eng.g.items()})
+    tol = 3e-2 if precision == "bf16" else 5e-3   # (bf16 states: a rounding that flips is 2^-8 of the value)
+    assert rel_err(float(outs[1][0]), float(outs[0][0])) < (2e-3 if precision == "bf16" else 2e-5), outs
+    for k in grads[0]:
+        assert (grads[0][k] - grads[1][k]).norm().item() <= tol * grads[0][k].norm().item() + 1e-9, k
+
+
+def test_sweep_decoder_only_model():
+    """ARK (no encoder, zero initial state, position embeddings, no initial-state gradient): sweeps against diagonals"""
+    from oracle import sail_oracle as O
+    cfg = dict(_cfg(128, 4, 120, 4, 14, True), model_type="ARK")
+    B = 32
+    P = O.init_params(cfg, 4)
+    _, seq = synth_batch(cfg, B, seed=7, padded=True)
+    outs, grads = [], []
+    for sw in (0, 1):
+        eng = make_engine(dict(cfg, dec_dropout=0.1, ark_sweep=sw), P, "mixed")
+        eng.drop_seed = 5
+        outs.append(eng.train_step(None, seq.to(eng.device)).cpu().numpy().copy())
+        torch.cuda.synchronize()
+        assert eng.sweep_error() == (0, 0) and eng._use_sweep(B, cfg["seq_len"] - 1) == bool(sw)
+        grads.append({k: v.float().clone() for k, v in eng.g.items()})
+    assert rel_err(float(outs[1][0]), float(outs[0][0])) < 2e-5, outs
+    for k in grads[0]:
+        assert (grads[0][k] - grads[1][k]).norm().item() <= 5e-3 * grads[0][k].norm().item() + 1e-9, k
