@@ -136,7 +136,8 @@ def test_token_sums16(prec, B, Lq, V, ncols, ld):
 
 
 @pytest.mark.parametrize("B,Z,D,H,with_ext", [(8, 10, 64, 192, False), (37, 10, 512, 1536, True), (64, 32, 128, 384, False),
-                                              (16, 128, 512, 1536, False), (21, 100, 256, 768, True), (40, 64, 128, 384, False)])
+                                              (16, 128, 512, 1536, False), (21, 100, 256, 768, True), (40, 64, 128, 384, False),
+                                              (256, 24, 1024, 3072, False)])   # (syn-types: the dA phase as its own 2-D launch)
 def test_latent_chain_bwd_matches_autograd(B, Z, D, H, with_ext):
     """ark_latent_chain_bwd (dh0 -> dz -> dhead -> dA in one launch, + bias gradient of the last MLP layer) and the
     batch reductions behind it (ark_zproj_bwd_dw; ark_latent_reduce_bwd, which fuses them) against torch autograd of
