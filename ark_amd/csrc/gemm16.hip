@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
       const int col = n0 + wn * G::WTN + tn * 16 + (lane & 15);
       if (row0 >= M || col >= N) continue;   // (the column-sum shuffles below run outside this loop: all lanes take part)
       f32x4 v = acc[tm][tn];
-      if (p.epi == ARK_EPI_BIAS) v += p.bias[col];
+      if (p.epi == ARK_EPI_BIAS || p.epi == ARK_EPI_BIAS_RELU) v += p.bias[col];
       if (p.c_tiled) {  // M % 16 == 0 and ldc % 16 == 0 (checked on the host): the quad is whole
         const long o = tile_native_off(row0, col, (int)p.ldc);
         if (p.epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
@@ -57,6 +57,8 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
           float x = v[i];
           if (p.epi == ARK_EPI_MUL_AUX) x *= p.aux[o];
           if (p.epi == ARK_EPI_MUL_DGELU) x *= dgelu_erf(p.aux[o]);
+          if (p.epi == ARK_EPI_BIAS_RELU) x = fmaxf(x, 0.f);
+          if (p.epi == ARK_EPI_MUL_RELU) x = p.aux[o] > 0.f ? x : 0.f;
           if (p.epi == ARK_EPI_BIAS_GELU) {
             x += p.bias[col];
             p.C[o] = x;            // pre-activation (fp32, kept for the backward pass)
@@ -316,9 +318,10 @@ static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const vo
   if (!A16 || !B16 || !C || M <= 0 || N <= 0 || K <= 0) return ARK_ERR_ARG;
   if (K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0) return ARK_ERR_SHAPE;
   if (((uintptr_t)A16 | (uintptr_t)B16) & 15) return ARK_ERR_ALIGN;
-  if (epi < ARK_EPI_NONE || epi > ARK_EPI_MUL_AUX) return ARK_ERR_ARG;
-  if ((epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU) && !bias) return ARK_ERR_ARG;
-  if ((epi == ARK_EPI_MUL_AUX || epi == ARK_EPI_MUL_DGELU) && !aux) return ARK_ERR_ARG;
+  if (epi < ARK_EPI_NONE || epi > ARK_EPI_MUL_RELU) return ARK_ERR_ARG;
+  if ((epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_BIAS_RELU) && !bias) return ARK_ERR_ARG;
+  if ((epi == ARK_EPI_MUL_AUX || epi == ARK_EPI_MUL_DGELU || epi == ARK_EPI_MUL_RELU) && !aux) return ARK_ERR_ARG;
+  if (c_tiled && (epi == ARK_EPI_BIAS_RELU || epi == ARK_EPI_MUL_RELU)) return ARK_ERR_ARG;
   if (c_tiled && (M % 16 != 0 || ldc % 16 != 0 || N > ldc)) return ARK_ERR_SHAPE;
   if (c_tiled && (epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_MUL_DGELU || c16a || c16b || colsum)) return ARK_ERR_ARG;
   if (colsum && epi == ARK_EPI_BIAS_GELU) return ARK_ERR_ARG;

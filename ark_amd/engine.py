@@ -39,7 +39,11 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
+_calls = [0]   # library calls made so far (txf_engine: "nothing has run since the previous product")
+
+
 def _call(name, *args):
+    _calls[0] += 1
     L.check(getattr(L.lib(), name)(*args), name)
 
 

@@ -23,6 +23,7 @@ import torch
 
 from . import _lib as L
 from .engine import Engine, HP, PREC, _call, _rup
+from .engine import _calls as _launches   # library calls made so far (TxfEngine._cast: "nothing ran since the previous product")
 
 FF = 2048          # nn.Transformer*Layer default dim_feedforward (the reference never passes another)
 LN_EPS = 1e-5      # nn.LayerNorm default
@@ -158,6 +159,12 @@ class TxfEngine(Engine):
         self._dp_pending, self._dp_flush_graph = None, None
         self.dp_bf16 = False
         self._graph_steps = {}
+        # 16-bit precisions: the dense products run on the LDS-DMA engines (ark_gemm16 / ark_wgrad16) from 16-bit copies of
+        # their operands cast per call -- the register-staged ark_gemm converts the same fp32 operands on the fly, to the same
+        # 16-bit values, several times slower
+        self.fast_gemm = bool(cfg.get("ark_txf_fast_gemm", True)) and self.prec_fwd != L.PREC_F32
+        self._scratch = {}
+        self._last_cast = None   # (only consecutive _gemm calls may share an operand copy: anything else resets it)
         self._graphs = {}
         self._pinned = set()   # workspace keys a captured graph points at: never evicted
         self.ldl = _rup(self.V, 4)
@@ -230,6 +237,72 @@ class TxfEngine(Engine):
 
     def _logits(self, w):
         return w["logits"]
+
+    # ------------------------------------------------------------------ dense products, 16-bit fast path
+    def _buf(self, slot, nbytes):
+        """scratch of at least nbytes (uint8), one per slot; grown on demand by the eager warm-up step, never inside a capture"""
+        t = self._scratch.get(slot)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(int(nbytes * 1.25) + 256, device=self.device, dtype=torch.uint8)
+            self._scratch[slot] = t
+        return t
+
+    def _cast(self, slot, x, n, prec):
+        out = self._buf(slot, 2 * n)
+        # the backward pass multiplies the same gradient twice in a row (its weight gradient, then its input gradient):
+        # the second product finds the 16-bit copy of the first still in the slot
+        key = (x.data_ptr(), n, prec, out.data_ptr())
+        if slot == "a" and self._last_cast is not None and self._last_cast[0] == key and self._last_cast[1] == _launches[0]:
+            return out   # (valid only while NO other library call has run since that product)
+        _call("ark_cast16", L.i32(prec), L.ptr(x), L.ptr(out), L.i64(n), L.cur_stream())
+        if slot == "a":
+            self._last_cast = [key, None]
+        return out
+
+    def _cast_t(self, slot, x, R, C, prec):
+        """16-bit copy of x[R, C]^T: [C, R] dense"""
+        import ctypes
+        out = self._buf(slot, 2 * R * C)
+        one = lambda v, t: (t * 1)(v)
+        _call("ark_weight_shadows", L.i32(1), one(x.data_ptr(), ctypes.c_void_p), one(0, ctypes.c_void_p),
+              one(out.data_ptr(), ctypes.c_void_p), one(R, ctypes.c_int), one(C, ctypes.c_int), one(prec, ctypes.c_int),
+              one(prec, ctypes.c_int), one(R, ctypes.c_int), L.cur_stream())
+        return out
+
+    def _gemm(self, a_lay, b_lay, epi, A, lda, Bm, ldb, C, ldc, M, N, K, C2=None, bias=None, aux=None, acc=0):
+        KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
+        pr = self.prec
+        if not self.fast_gemm or pr == L.PREC_F32 or C2 is not None:
+            return super()._gemm(a_lay, b_lay, epi, A, lda, Bm, ldb, C, ldc, M, N, K, C2=C2, bias=bias, aux=aux, acc=acc)
+        st = L.cur_stream()
+        if a_lay == KM and K % 64 == 0 and lda == K and ((b_lay == KM and ldb == K) or (b_lay == MM and ldb == N)):
+            # C[M,N] (+)= A[M,K] op(B): B is [N,K] (KM) or [K,N] (MM: its transposed 16-bit copy is made)
+            A16 = self._cast("a", A, M * K, pr)
+            B16 = self._cast("b", Bm, N * K, pr) if b_lay == KM else self._cast_t("b", Bm, K, N, pr)
+            if acc:
+                tmp = self._buf("c", 4 * M * N)
+                _call("ark_gemm16", L.i32(pr), L.i32(epi), L.ptr(A16), L.i64(K), L.ptr(B16), L.i64(K), L.ptr(tmp), L.i64(N),
+                      L.ptr(bias), L.ptr(aux), L.i32(M), L.i32(N), L.i32(K), L.i32(0), st)
+                if ldc != N:
+                    raise L.ArkError("accumulating fast product needs a dense output")
+                _call("ark_axpy", L.ptr(C), L.ptr(tmp), L.i64(M * N), L.f32(1.0), st)
+            else:
+                _call("ark_gemm16", L.i32(pr), L.i32(epi), L.ptr(A16), L.i64(K), L.ptr(B16), L.i64(K), L.ptr(C), L.i64(ldc),
+                      L.ptr(bias), L.ptr(aux), L.i32(M), L.i32(N), L.i32(K), L.i32(0), st)
+            if self._last_cast is not None:
+                self._last_cast[1] = _launches[0]
+            return
+        if (a_lay == MM and b_lay == MM and acc and epi == L.EPI_NONE and M % 64 == 0 and N % 64 == 0 and K % 64 == 0
+                and lda == M and ldb == N):
+            # weight gradient C[M,N] += A[K,M]^T B[K,N] (K = rows of the batch)
+            A16 = self._cast("a", A, K * M, pr)
+            B16 = self._cast("b", Bm, K * N, pr)
+            _call("ark_wgrad16", L.i32(pr), L.ptr(A16), L.i64(M), L.ptr(B16), L.i64(N), L.ptr(C), L.i64(ldc), L.i32(M), L.i32(N),
+                  L.i32(K), None, st)
+            if self._last_cast is not None:
+                self._last_cast[1] = _launches[0]
+            return
+        return super()._gemm(a_lay, b_lay, epi, A, lda, Bm, ldb, C, ldc, M, N, K, C2=C2, bias=bias, aux=aux, acc=acc)
 
     def _copy(self, dst, src):
         _call("ark_copy", L.ptr(dst), L.ptr(src), L.i64(src.numel() * src.element_size()), L.cur_stream())
