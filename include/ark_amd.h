@@ -384,7 +384,8 @@ int ark_argmax_rows(const float* x, int64_t ld, int64_t* out, int rows, int V, v
 
 /* ---- Transformer variant t-ARK (reference: DecoderOnlyTransformer, kgvae/model/models.py:349-366 = stock
  *      nn.TransformerEncoderLayer stack: post-norm, ReLU feed-forward, causal mask).  Rows are time-major (t, b);
- *      the dense products run on ark_gemm (ARK_EPI_BIAS / ARK_EPI_BIAS_RELU / ARK_EPI_MUL_RELU). ------------------------ */
+ *      the dense products run on ark_gemm (exact fp32) or, in the 16-bit precisions, on ark_gemm16 / ark_wgrad16 from
+ *      16-bit operand copies (ARK_EPI_BIAS / ARK_EPI_BIAS_RELU / ARK_EPI_MUL_RELU on both). ----------------------------- */
 /* y = LayerNorm(x + res) * gamma + beta (res nullable); s_out (nullable) = x + res; stats[row] = (mean, rstd) */
 int ark_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* s_out, float* y,
                       float* stats, int rows, int D, float eps, void* stream);
