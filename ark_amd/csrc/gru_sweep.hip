@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
           tb[(4 * kg + i) * TS + r] = PB::cvt(h[i]);
         }
         if (drop) {
-          const f32x4 hd = h * dropout_quad(dc, (uint64_t)((long)t * slot + tile_off[m]) >> 2);
+          const f32x4 hd = h * dropout_quad(dc, (uint64_t)((long)(p.t0 + t) * slot + tile_off[m]) >> 2);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             tda[(4 * kg + i) * TS + r] = PT::cvt(hd[i]);
@@ -633,7 +633,7 @@ extern "C" long ark_gru_sweep_sync_words(int n_layers, int B, int L) { return ar
 extern "C" int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* a, void* stream) {
   using namespace ark;
   if (!a || a->n_layers <= 0 || a->n_layers > ARK_SWEEP_MAX_LAYERS || a->B <= 0 || a->D <= 0 || a->L <= 0) return ARK_ERR_ARG;
-  if (!a->x0_16 || !a->exch || !a->sync) return ARK_ERR_ARG;
+  if (!a->x0_16 || !a->exch || !a->sync || a->t0 < 0) return ARK_ERR_ARG;
   const int D = a->D, B = a->B, L = a->L, n = a->n_layers;
   if (B % 16 != 0 || (D != 128 && D != 256 && D != 512)) return ARK_ERR_SHAPE;
   if (L > 4095 || 2.0 * n * L * B * D * 2 >= 2147483648.0) return ARK_ERR_SHAPE;   // 32-bit buffer offsets

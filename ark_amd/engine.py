@@ -185,6 +185,7 @@ class Engine:
         self.sweep = cfg.get("ark_sweep", "auto")
         self.sweep_bwd = bool(cfg.get("ark_sweep_bwd", True))   # (0: persistent forward, diagonal backward)
         self.ce_dw_after_latent = bool(cfg.get("ark_ce_dw_after_latent", True))
+        self.ce_chunks = int(cfg.get("ark_ce_chunks", 4))   # time chunks of the sweep + CE pipeline (1: off)
         self._ce_dw_pending = None
         self._pad_bufs = {}
         self._n_valid = 0
@@ -613,24 +614,32 @@ class Engine:
         st = L.cur_stream()
         fused = bool(w["v2"] and self.fused_ce and with_loss)
         self._fused_ce_step = fused and with_dlogits
-        self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop, project=not fused)
-        if with_loss:
+        chunks = self._ce_chunks(B, Lq) if (fused and with_dlogits) else None
+        if chunks:
+            # long sequences: the forward sweep in a few time chunks, the fused CE of a chunk on the side queue beside the
+            # sweep of the next one (the sweep leaves 160 of the 256 CUs idle; the CE of all rows only started after it)
+            self._decoder_prologue(w, seq, ld_seq, B, Lq, use_drop)
             if ce_count is None:
                 _call("ark_count_targets", L.ptr(seq), L.i64(ld_seq), L.i32(B), L.i32(Lq), L.ptr(self.hyper), st)
-                self._hp.pop("CE_COUNT", None)   # the device slot no longer holds what set_hyper last wrote
+                self._hp.pop("CE_COUNT", None)
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            for (t0, t1) in chunks:
+                self._sweep_fwd(w, B, Lq, use_drop, True, t0, t1)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._fused_ce_fwd(w, seq, ld_seq, B, t0, t1, True)
+            main.wait_stream(side)
+        else:
+            self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop, project=not fused)
+            if with_loss:
+                if ce_count is None:
+                    _call("ark_count_targets", L.ptr(seq), L.i64(ld_seq), L.i32(B), L.i32(Lq), L.ptr(self.hyper), st)
+                    self._hp.pop("CE_COUNT", None)   # the device slot no longer holds what set_hyper last wrote
         if with_loss and fused:
             # projection + cross-entropy (+ dY of the top layer, consumed by the backward diagonals) in one sweep over V
-            nv = L.lib().ark_vocab_ce_fwd_splits(L.i32(R), L.i32(V), L.i32(D)) if with_dlogits else 1
-            if nv > 1:   # few rows, wide model: the vocabulary sweep is split over workgroups (+ one merging launch)
-                if "ce_ws" not in w or w["ce_ws"].numel() < nv * (R * D + 4 * R):
-                    w["ce_ws"] = torch.empty(nv * (R * D + 4 * R), device=self.device)
-                _call("ark_vocab_ce_fwd_ws", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16),
-                      L.ptr(p["dec.out.bias"]), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
-                      L.ptr(w["dYa"]), L.ptr(w["ce_ws"]), L.i64(w["ce_ws"].numel()), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
-            else:
-                _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(w["Y16a"][n - 1][B:]), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]),
-                      L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(w["lse"]),
-                      L.ptr(w["dYa"] if with_dlogits else None), L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
+            if not chunks:
+                self._fused_ce_fwd(w, seq, ld_seq, B, 0, Lq, with_dlogits)
             self._finalize = self._make_finalize(w, R, B)
             if not (self._defer_finalize and with_dlogits):
                 self._finalize()
@@ -653,6 +662,37 @@ class Engine:
                 self._finalize = None
             # (else: the two-queue backward launches it on its side queue -- the loss scalars are not on the
             #  dependent chain)
+
+    def _ce_chunks(self, B, Lq):
+        """[(t0, t1), ...] time chunks of a chunked forward sweep + CE pipeline, or None (one launch each)"""
+        nc = self.ce_chunks
+        if nc <= 1 or not self.overlap_wgrad or not self._use_sweep(B, Lq) or Lq < 64 * nc:
+            return None
+        if self._sweep_wgs(B) > 128:   # the sweep has to leave CUs for the CE that runs beside it
+            return None
+        step = -(-Lq // nc)
+        return [(t, min(Lq, t + step)) for t in range(0, Lq, step)]
+
+    def _fused_ce_fwd(self, w, seq, ld_seq, B, t0, t1, with_dlogits):
+        """tied projection + cross-entropy (+ dY of the top layer) of the rows of steps [t0, t1) in one sweep over V"""
+        D, n, V, p = self.D, self.n, self.V, self.p
+        st = L.cur_stream()
+        Lc, o = t1 - t0, t0 * B
+        Rc = Lc * B
+        y = w["Y16a"][n - 1][B + o:]
+        sq = seq[:, t0:]   # (the kernels index seq[b * ld + t + 1] with t counted from the chunk's first step)
+        dY = w["dYa"][o:] if with_dlogits else None
+        nv = L.lib().ark_vocab_ce_fwd_splits(L.i32(Rc), L.i32(V), L.i32(D)) if with_dlogits else 1
+        if nv > 1:   # few rows, wide model: the vocabulary sweep is split over workgroups (+ one merging launch)
+            if "ce_ws" not in w or w["ce_ws"].numel() < nv * (Rc * D + 4 * Rc):
+                w["ce_ws"] = torch.empty(nv * (Rc * D + 4 * Rc), device=self.device)
+            _call("ark_vocab_ce_fwd_ws", L.i32(self.prec_fwd), L.ptr(y), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]), L.ptr(sq),
+                  L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"][o:]), L.ptr(w["lse"][o:]), L.ptr(dY), L.ptr(w["ce_ws"]),
+                  L.i64(w["ce_ws"].numel()), L.i32(B), L.i32(Lc), L.i32(V), L.i32(D), st)
+        else:
+            _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(y), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]), L.ptr(sq),
+                  L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"][o:]), L.ptr(w["lse"][o:]), L.ptr(dY), L.i32(B), L.i32(Lc),
+                  L.i32(V), L.i32(D), st)
 
     def _make_finalize(self, w, R, B):
         """the launch that turns per-row losses (and the KL terms) into out4 = [loss, ce, kl, token-loss sum]"""
@@ -681,6 +721,16 @@ class Engine:
         for l in range(self.n):
             _call("ark_zproj_fwd", *zp, L.ptr(w["Y"][l]), L.i64(0), L.i32(1), L.i32(B), L.i32(self.Z), L.i32(self.D), st)
 
+    def _decoder_prologue(self, w, seq, ld_seq, B, Lq, use_drop):
+        """layer 0's inputs: 16-bit token (+ position) embeddings of every step, unless the step's first launch made them"""
+        p = self.p
+        if self._x0_ready:   # (gathered by the step's first launch, beside the encoder pool)
+            self._x0_ready = False
+        else:
+            _call("ark_tok_gather16", L.i32(self.prec_fwd), L.i32(self.prec_bwd), L.ptr(seq), L.i64(ld_seq),
+                  L.ptr(p["dec.tok_emb.weight"]), L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0a"]),
+                  L.ptr(w["X0b"]), L.i32(B), L.i32(Lq), L.i32(self.D), L.ptr(self.hyper if use_drop else None), L.cur_stream())
+
     def _decoder_forward_v2(self, w, seq, ld_seq, B, Lq, use_drop, save=True, project=True):
         """fast decoder forward: token gather -> layer-diagonal GRU sweep -> tied vocabulary projection
         (project=False: the caller fuses the projection into the cross-entropy)"""
@@ -689,12 +739,7 @@ class Engine:
         st = L.cur_stream()
         p = self.p
         pf, pb = self.prec_fwd, self.prec_bwd
-        if self._x0_ready:   # (gathered by the step's first launch, beside the encoder pool)
-            self._x0_ready = False
-        else:
-            _call("ark_tok_gather16", L.i32(pf), L.i32(pb), L.ptr(seq), L.i64(ld_seq), L.ptr(p["dec.tok_emb.weight"]),
-                  L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0a"]), L.ptr(w["X0b"]), L.i32(B),
-                  L.i32(Lq), L.i32(D), L.ptr(self.hyper if use_drop else None), st)
+        self._decoder_prologue(w, seq, ld_seq, B, Lq, use_drop)
         self._diag_sweep(w, B, Lq, use_drop, save)
         if project:
             _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(w["Y16a"][n - 1][B:]), L.i64(D), L.ptr(self.wtok16), L.i64(D),
@@ -759,35 +804,42 @@ class Engine:
         mt = L.lib().ark_gru_sweep_row_tiles(L.i32(self.n), L.i32(B), L.i32(self.D))
         return self.n * (B // 16) * (self.D // 16) // max(1, mt)
 
-    def _sweep_fwd(self, w, B, Lq, use_drop, save=True):
-        """the forward recurrence of all layers and steps as ONE launch (ark_gru_sweep_fwd); same inputs and outputs as
-        the diagonal launches"""
+    def _sweep_fwd(self, w, B, Lq, use_drop, save=True, t0=0, t1=None):
+        """the forward recurrence of all layers over the steps [t0, t1) (default: all) as ONE launch (ark_gru_sweep_fwd);
+        same inputs and outputs as the diagonal launches.  A later chunk starts from the state the previous one left in
+        slot t0 of the state arrays."""
         D, n, p = self.D, self.n, self.p
-        key = ("sweep", Lq)
-        if key not in w:
-            w[key] = (torch.empty(2 * n * Lq * B * D, device=self.device, dtype=torch.int16),
-                      torch.zeros(L.sweep_sync_words(n, B, Lq), device=self.device, dtype=torch.int32))
+        t1 = Lq if t1 is None else t1
+        Lc = t1 - t0
+        key = ("sweep", Lq, t0, t1)
+        if key not in w:   # (every chunk has its own counters: an error word survives the chunks after it)
+            w[key] = (torch.empty(2 * n * Lc * B * D, device=self.device, dtype=torch.int16),
+                      torch.zeros(L.sweep_sync_words(n, B, Lc), device=self.device, dtype=torch.int32))
         exch, sync = w[key]
+        o = t0 * B   # rows of the time-major arrays in front of this chunk
+        at = lambda t: None if t is None else t[o:]
         a = L.GruSweep()
         for l in range(n):
             drop = use_drop and l < n - 1
             y = a.layer[l]
             y.w_ih16, y.w_hh16 = L.dptr(self.wih16[l]), L.dptr(self.whh16[l])
             y.b_ih, y.b_hh = L.dptr(p[f"dec.gru.bias_ih_l{l}"]), L.dptr(p[f"dec.gru.bias_hh_l{l}"])
-            y.y_t, y.y16a = L.dptr(w["Y"][l]), L.dptr(w["Y16a"][l])
-            y.y16b = L.dptr(w["Y16b"][l])
-            y.yd16a = L.dptr(w["Yd16a"][l] if drop else None)
-            y.yd16b = L.dptr(w["Yd16b"][l] if drop else None)
+            y.y_t, y.y16a = L.dptr(at(w["Y"][l])), L.dptr(at(w["Y16a"][l]))
+            y.y16b = L.dptr(at(w["Y16b"][l]))
+            y.yd16a = L.dptr(at(w["Yd16a"][l]) if drop else None)
+            y.yd16b = L.dptr(at(w["Yd16b"][l]) if drop else None)
             if save:
-                y.save_r, y.save_z = L.dptr(w["SR"][l]), L.dptr(w["SZ"][l])
-                y.save_n, y.save_hn = L.dptr(w["SN"][l]), L.dptr(w["SHN"][l])
+                y.save_r, y.save_z = L.dptr(at(w["SR"][l])), L.dptr(at(w["SZ"][l]))
+                y.save_n, y.save_hn = L.dptr(at(w["SN"][l])), L.dptr(at(w["SHN"][l]))
             y.drop_seed = self._layer_seed(l)
             y.drop_p = self.p_drop if drop else 0.0
-        a.x0_16, a.exch, a.sync, a.hyper = L.dptr(w["X0a"]), L.dptr(exch), L.dptr(sync), L.dptr(self.hyper)
-        a.n_layers, a.B, a.D, a.L = n, B, D, Lq
+        a.x0_16, a.exch, a.sync, a.hyper = L.dptr(at(w["X0a"])), L.dptr(exch), L.dptr(sync), L.dptr(self.hyper)
+        a.n_layers, a.B, a.D, a.L, a.t0 = n, B, D, Lc, t0
         import ctypes
         _call("ark_gru_sweep_fwd", L.i32(self.prec_fwd), L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
-        self._sweep_sync = sync
+        if t0 == 0:
+            self._sweep_syncs = []
+        self._sweep_syncs.append(sync)
 
     def _sweep_bwd(self, w, B, Lq, use_drop):
         """the backward recurrence of all layers and steps (+ the initial-state gradient, SAIL) as ONE launch
@@ -821,8 +873,7 @@ class Engine:
     def sweep_error(self):
         """(error word, detail) of the last persistent sweep: non-zero = a workgroup gave up waiting (outputs invalid).
         Synchronises."""
-        for nm in ("_sweep_sync", "_sweep_bwd_sync"):
-            sy = getattr(self, nm, None)
+        for sy in list(getattr(self, "_sweep_syncs", [])) + [getattr(self, "_sweep_bwd_sync", None)]:
             if sy is not None:
                 v = sy[:2].cpu()
                 if int(v[0]) != 0:

@@ -202,6 +202,9 @@ typedef struct {
   unsigned* sync;        /* workspace, ark_gru_sweep_sync_words() words (zeroed by the call)          */
   const float* hyper;
   int n_layers, B, D, L;
+  int t0;                /* index of this launch's first step inside the whole sequence (a sequence swept in several launches
+                          * passes arrays advanced by t0 steps): only the dropout hash offsets use it                    */
+  int pad_;
 } ArkGruSweep;
 /* 16-row tiles per workgroup the sweeps would use on the current device: 1 or 2; 0 = the grid cannot be co-resident */
 int ark_gru_sweep_row_tiles(int n_layers, int B, int D);

@@ -195,3 +195,42 @@ def test_sweep_decoder_only_model():
     assert rel_err(float(outs[1][0]), float(outs[0][0])) < 2e-5, outs
     for k in grads[0]:
         assert (grads[0][k] - grads[1][k]).norm().item() <= 5e-3 * grads[0][k].norm().item() + 1e-9, k
+
+
+@pytest.mark.parametrize("nc", [2, 3])
+def test_chunked_sweep_with_the_fused_ce_beside_it(nc):
+    """long sequences: the forward sweep in time chunks (each starting from the state its predecessor left, dropout masks
+    indexed by the absolute step) with the fused vocabulary CE of a chunk running beside the next chunk's sweep -- same
+    states, per-row losses, dY and gradients as one sweep followed by one CE"""
+    from oracle import sail_oracle as O
+    cfg = _cfg(128, 16, 3000, 5, 64, True)   # L = 193 steps, V = 3 010: fused CE
+    B = 32
+    P = O.init_params(cfg, 5)
+    triples, seq = synth_batch(cfg, B, seed=9, padded=True)
+    torch.manual_seed(1)
+    eps = torch.randn(B, 16)
+    outs, engs = [], []
+    for chunks in (1, nc):
+        eng = make_engine(dict(cfg, dec_dropout=0.1, ark_sweep=1, ark_ce_chunks=chunks), P, "mixed")
+        eng.set_hyper(beta=0.3)
+        eng.drop_seed = 77
+        dev = eng.device
+        Lq = cfg["seq_len"] - 1
+        assert eng.fused_ce and (eng._ce_chunks(B, Lq) is not None) == (chunks > 1)
+        outs.append(eng.train_step(triples.to(dev), seq.to(dev), eps.to(dev)).cpu().numpy().copy())
+        torch.cuda.synchronize()
+        assert eng.sweep_error() == (0, 0)
+        engs.append(eng)
+    a, b = engs
+    assert len(b._sweep_syncs) == nc
+    for l in range(cfg["n_layers"]):
+        assert torch.equal(a.ws["Y"][l], b.ws["Y"][l]), l            # the same arithmetic, launch boundaries apart
+        assert torch.equal(a.ws["SR"][l], b.ws["SR"][l]), l
+        if l < cfg["n_layers"] - 1:
+            assert torch.equal(a.ws["Yd16a"][l], b.ws["Yd16a"][l]), l  # masks indexed by the absolute step
+    assert torch.equal(a.ws["row_loss"], b.ws["row_loss"])
+    assert (a.ws["dYa"] - b.ws["dYa"]).abs().max().item() <= 1e-6 * a.ws["dYa"].abs().max().item()
+    assert rel_err(float(outs[1][0]), float(outs[0][0])) < 1e-6, outs
+    for k in a.g:
+        da, db = a.g[k].float(), b.g[k].float()
+        assert (da - db).norm().item() <= 2e-3 * da.norm().item() + 1e-9, k
