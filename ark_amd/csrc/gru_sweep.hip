@@ -77,6 +77,28 @@ __device__ unsigned long long ark_sweep_stamp_buf[512 * 8];
 #define SW_STAMP(i) do {} while (0)
 #endif
 
+// two counters at once: both polls are in flight together (one round trip through the memory system instead of two in a row
+// -- the second dependency of a step is normally satisfied long before the first)
+__device__ __forceinline__ bool sweep_wait2(unsigned* c0, unsigned* c1, unsigned need, unsigned* sync, unsigned code) {
+  unsigned long long t0 = 0;
+  for (unsigned spins = 1;; ++spins) {
+    const unsigned a = __hip_atomic_load(c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned b = __hip_atomic_load(c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a >= need && b >= need) return true;
+    if ((spins & 31u) == 0u) {
+      if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > kSweepTimeoutTicks) {
+        __hip_atomic_store(sync + 1, code | (a >= need ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 __global__ void sweep_zero_kernel(unsigned* p, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0u;
@@ -174,8 +196,11 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
     if (wave == 0) {
       bool ok = true;
       const unsigned code = (unsigned)(wg << 12 | (t & 4095));
-      if (t > 0) ok = sweep_wait(cnt + (((long)l * L + (t - 1)) * RBW + rbw) * kSweepCntStride, (unsigned)NS, sync, code);
-      if (ok && l > 0) ok = sweep_wait(cnt + (((long)(l - 1) * L + t) * RBW + rbw) * kSweepCntStride, (unsigned)NS, sync, code | 0x80000000u);
+      unsigned* cown = cnt + (((long)l * L + (t - 1)) * RBW + rbw) * kSweepCntStride;
+      unsigned* cbel = cnt + (((long)(l - 1) * L + t) * RBW + rbw) * kSweepCntStride;
+      if (t > 0 && l > 0) ok = sweep_wait2(cown, cbel, (unsigned)NS, sync, code);
+      else if (t > 0) ok = sweep_wait(cown, (unsigned)NS, sync, code);
+      else if (l > 0) ok = sweep_wait(cbel, (unsigned)NS, sync, code | 0x80000000u);
       if (!ok && lane == 0) *lflag = 1;
     }
     SW_STAMP(0);   // waiting for the two counters
@@ -459,8 +484,11 @@ __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) 
     if (wave == 0) {
       bool ok = true;
       const unsigned code = (unsigned)(wg << 12 | ((t + 1) & 4095));
-      if (rec) ok = sweep_wait(cnt + (((long)l * L + (t + 1)) * RBW + rbw) * kSweepCntStride, (unsigned)NS, sync, code);
-      if (ok && up) ok = sweep_wait(cnt + (((long)(l + 1) * L + t) * RBW + rbw) * kSweepCntStride, (unsigned)NS, sync, code | 0x80000000u);
+      unsigned* cown = cnt + (((long)l * L + (t + 1)) * RBW + rbw) * kSweepCntStride;
+      unsigned* cabv = cnt + (((long)(l + 1) * L + t) * RBW + rbw) * kSweepCntStride;
+      if (rec && up) ok = sweep_wait2(cown, cabv, (unsigned)NS, sync, code);
+      else if (rec) ok = sweep_wait(cown, (unsigned)NS, sync, code);
+      else if (up) ok = sweep_wait(cabv, (unsigned)NS, sync, code | 0x80000000u);
       if (!ok && lane == 0) *lflag = 1;
     }
     __syncthreads();
