@@ -12,11 +12,17 @@
 //     EVERY load of handed-off bytes is a `buffer_load_dwordx4 ... sc1` straight into MFMA A fragments
 //     (MI355X_MICROARCH.md, visibility section, valid forms table row 1: no L1 acquire needed).
 //
-// Each (l, t) has its own exchange region and counter, zeroed by the call, so nothing is ever reused inside a launch.
-// Every spin is bounded: after ~0.25 s without progress (or when another workgroup has given up) a workgroup writes an
-// error word and leaves, so a scheduling accident ends in an error code, not in a hung GPU.  All workgroups must be
-// co-resident: the host checks grid <= CUs (96 KB of dynamic LDS pin one workgroup per CU) and uses a cooperative launch
-// outside stream capture.
+// Each (l, t) has its own exchange region and counter, so nothing is ever reused inside a launch.  The counters are
+// MONOTONE over the launches that share a `sync` workspace: launch number e (the epoch word of the header, read by every
+// workgroup when it starts and bumped by the last workgroup to leave) waits for counter >= (e + 1) * NS, so no launch has
+// to zero anything in front of a sweep (round 3 did: inside a captured step that 60-KB fill queued behind whatever held
+// the CUs).  Every spin is bounded: after ~0.25 s without progress (or when another workgroup has given up) a workgroup
+// sets the error word and leaves, so a scheduling accident ends in an error code, not in a hung GPU.  The error word is
+// STICKY: no kernel ever clears it, every later sweep on the workspace leaves at once, and only ark_gru_sweep_sync_reset
+// (host, after the error has been read) makes the workspace usable again.  All workgroups must be co-resident: the host
+// proves that with the occupancy API (96 KB of dynamic LDS pin one workgroup per CU); the launch itself is a plain one
+// inside and outside stream capture (round 3 used hipLaunchCooperativeKernel outside capture: it added nothing to the
+// residency proof and rocprofv3 crashed in its exit handlers after such a launch).
 //
 // Outputs are exactly those of the diagonal kernels (tile-native fp32 state, tile-native fp16 gate saves, row-major
 // 16-bit copies, dropout-applied copies with the same counter-hash masks), so the projection, the cross-entropy and the
@@ -35,7 +41,9 @@ struct GruSweepArgs {
 
 constexpr unsigned long long kSweepTimeoutTicks = 25000000ull;   // s_memrealtime runs at 100 MHz: 0.25 s
 constexpr int kSweepLds = 96 * 1024;                             // > half of a CU's LDS: one workgroup per CU
-constexpr int kSweepSyncHdr = 32;                                // words in front of the counters (error word + diagnostics)
+constexpr int kSweepSyncHdr = 32;                                // words in front of the counters: [0] sticky error, [1] who / where,
+                                                                 // [2] epoch = launches completed on this workspace, [3] workgroups
+                                                                 // of the running launch that have left
 constexpr int kSweepCntStride = 32;                              // words per counter: each on a 128-byte line of its own (atomics and
                                                                  // polls of different (layer, step, row block) never queue on one line)
 
@@ -53,7 +61,7 @@ __device__ __forceinline__ void st_sc1(u32x4 v, __amdgpu_buffer_rsrc_t r, int vo
 __device__ __forceinline__ bool sweep_wait(unsigned* cnt, unsigned need, unsigned* sync, unsigned code) {
   unsigned long long t0 = 0;
   for (unsigned spins = 1;; ++spins) {
-    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+    if ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) >= 0) return true;   // (wrap-safe: monotone counters)
     if ((spins & 31u) == 0u) {
       if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -84,13 +92,13 @@ __device__ __forceinline__ bool sweep_wait2(unsigned* c0, unsigned* c1, unsigned
   for (unsigned spins = 1;; ++spins) {
     const unsigned a = __hip_atomic_load(c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned b = __hip_atomic_load(c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a >= need && b >= need) return true;
+    if ((int)(a - need) >= 0 && (int)(b - need) >= 0) return true;
     if ((spins & 31u) == 0u) {
       if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (t0 == 0) t0 = now;
       else if (now - t0 > kSweepTimeoutTicks) {
-        __hip_atomic_store(sync + 1, code | (a >= need ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + 1, code | ((int)(a - need) >= 0 ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
       }
@@ -99,9 +107,29 @@ __device__ __forceinline__ bool sweep_wait2(unsigned* c0, unsigned* c1, unsigned
   }
 }
 
-__global__ void sweep_zero_kernel(unsigned* p, long n) {
+__global__ void sweep_reset_kernel(unsigned* p, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0u;
+}
+
+// first thing a workgroup does: the launch's epoch (-> the counter value that means "this launch's producer is done") and
+// whether the workspace is poisoned by an earlier failure
+__device__ __forceinline__ unsigned sweep_enter(unsigned* sync, int* lflag, unsigned NS) {
+  const unsigned e = __hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) *lflag = __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 1 : 0;
+  return (e + 1u) * NS;
+}
+// last thing: the workgroup that leaves last closes the epoch (every workgroup read it when it entered, and none can have
+// left before all had entered their first step: they wait for each other)
+__device__ __forceinline__ void sweep_leave(unsigned* sync) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned gone = __hip_atomic_fetch_add(sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == gridDim.x - 1u) {
+      __hip_atomic_store(sync + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // 4 waves: wave w forms the partial products of K-steps [w*KSW, (w+1)*KSW) of BOTH operands (x_t W_ih^T, h_{t-1} W_hh^T);
@@ -178,8 +206,9 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
     }
   unsigned* sync = p.sync;
   unsigned* cnt = p.sync + kSweepSyncHdr;
-  if (threadIdx.x == 0) *lflag = 0;
+  const unsigned need = sweep_enter(sync, lflag, (unsigned)NS);
   __syncthreads();
+  const bool poisoned = *lflag != 0;   // (uniform) an earlier sweep on this workspace failed: touch nothing
 
   u32x4 xn[MT][KSW];   // layer 0: the inputs of the coming step
   if (l == 0) {
@@ -191,16 +220,16 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
 #ifdef ARK_SWEEP_STAMPS
   unsigned long long sacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (int t = 0; t < L; ++t) {
+  for (int t = 0; t < L && !poisoned; ++t) {
     SW_STAMP(7);   // bulk stores of the previous step + loop overhead
     if (wave == 0) {
       bool ok = true;
       const unsigned code = (unsigned)(wg << 12 | (t & 4095));
       unsigned* cown = cnt + (((long)l * L + (t - 1)) * RBW + rbw) * kSweepCntStride;
       unsigned* cbel = cnt + (((long)(l - 1) * L + t) * RBW + rbw) * kSweepCntStride;
-      if (t > 0 && l > 0) ok = sweep_wait2(cown, cbel, (unsigned)NS, sync, code);
-      else if (t > 0) ok = sweep_wait(cown, (unsigned)NS, sync, code);
-      else if (l > 0) ok = sweep_wait(cbel, (unsigned)NS, sync, code | 0x80000000u);
+      if (t > 0 && l > 0) ok = sweep_wait2(cown, cbel, need, sync, code);
+      else if (t > 0) ok = sweep_wait(cown, need, sync, code);
+      else if (l > 0) ok = sweep_wait(cbel, need, sync, code | 0x80000000u);
       if (!ok && lane == 0) *lflag = 1;
     }
     SW_STAMP(0);   // waiting for the two counters
@@ -355,6 +384,7 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
   if (threadIdx.x == 0 && blockIdx.x < 512)
     for (int i_ = 0; i_ < 8; ++i_) ark_sweep_stamp_buf[blockIdx.x * 8 + i_] = sacc_[i_];
 #endif
+  sweep_leave(sync);
 }
 
 template <class Kern, class Args>
@@ -447,8 +477,9 @@ __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) 
   const int mstride = 4 * NS * 512;
   unsigned* sync = p.sync;
   unsigned* cnt = p.sync + kSweepSyncHdr;
-  if (threadIdx.x == 0) *lflag = 0;
+  const unsigned need = sweep_enter(sync, lflag, (unsigned)NS);
   __syncthreads();
+  const bool poisoned = *lflag != 0;
 
   f32x4 carry[MT];
 #pragma unroll
@@ -460,7 +491,7 @@ __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) 
   const _Float16* shn = reinterpret_cast<const _Float16*>(Ly.save_hn);
   const bool fin_step = p.dh0 != nullptr;
 
-  for (int t = L - 1; t >= (fin_step ? -1 : 0); --t) {
+  for (int t = L - 1; t >= (fin_step ? -1 : 0) && !poisoned; --t) {
     const bool fin = t < 0;          // initial-state step: dh0 += carry + dgh_0 W_hh
     const bool rec = t < L - 1;      // a successor step exists
     const bool up = !top && !fin;
@@ -486,9 +517,9 @@ __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) 
       const unsigned code = (unsigned)(wg << 12 | ((t + 1) & 4095));
       unsigned* cown = cnt + (((long)l * L + (t + 1)) * RBW + rbw) * kSweepCntStride;
       unsigned* cabv = cnt + (((long)(l + 1) * L + t) * RBW + rbw) * kSweepCntStride;
-      if (rec && up) ok = sweep_wait2(cown, cabv, (unsigned)NS, sync, code);
-      else if (rec) ok = sweep_wait(cown, (unsigned)NS, sync, code);
-      else if (up) ok = sweep_wait(cabv, (unsigned)NS, sync, code | 0x80000000u);
+      if (rec && up) ok = sweep_wait2(cown, cabv, need, sync, code);
+      else if (rec) ok = sweep_wait(cown, need, sync, code);
+      else if (up) ok = sweep_wait(cabv, need, sync, code | 0x80000000u);
       if (!ok && lane == 0) *lflag = 1;
     }
     __syncthreads();
@@ -594,7 +625,7 @@ __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) 
     }
   }
   // bias gradients: db_ih = colsum [dr | dz | dn], db_hh = colsum [dr | dz | dn*r], one atomic per (gate, unit)
-  if (wave == 0 && Ly.db_ih) {
+  if (wave == 0 && Ly.db_ih && !poisoned) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       bs[g] += __shfl_xor(bs[g], 16, 64);
@@ -609,6 +640,7 @@ __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) 
       atomicAdd(&Ly.db_hh[2 * D + u], bs[3]);
     }
   }
+  sweep_leave(sync);
 }
 
 template <class Kern, class Args>
@@ -619,16 +651,9 @@ static int launch_persistent(Kern kern, const Args& p, unsigned grid, hipStream_
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return ARK_ERR_ARG;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, kSweepLds) != hipSuccess || per_cu < 1) return ARK_ERR_SHAPE;
   if ((long)grid > (long)cus * per_cu) return ARK_ERR_SHAPE;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(st, &cs);
-  if (cs == hipStreamCaptureStatusNone) {
-    Args arg = p;
-    void* params[] = {&arg};
-    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3(grid), dim3(256), params, kSweepLds, st);
-    if (e != hipSuccess) return (int)e;
-  } else {
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kSweepLds, st, p);
-  }
+  // a plain launch, captured or not: residency is what the occupancy query above proves (nothing else may hold more
+  // than 64 KB of LDS on the CUs this grid needs: the caller's business, see ark_amd.h); a failure is bounded and sticky
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kSweepLds, st, p);
   ARK_LAUNCH_CHECK();
   return 0;
 }
@@ -676,9 +701,6 @@ extern "C" int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* a, voi
   GruSweepArgs p;
   p.a = *a;
   hipStream_t st = (hipStream_t)stream;
-  const long nw = ark_gru_sweep_sync_words(n, B, L);
-  hipLaunchKernelGGL(sweep_zero_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, a->sync, nw);
-  ARK_LAUNCH_CHECK();
   const unsigned grid = (unsigned)(n * (D / 16) * (B / 16) / mt);
 #define ARK_SWEEP_GO(PF, PBK)                                                                                   \
   do {                                                                                                          \
@@ -694,6 +716,13 @@ extern "C" int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* a, voi
 }
 
 extern "C" long ark_gru_sweep_bwd_exch_bytes(int n_layers, int B, int D, int L) { return (long)n_layers * L * B * 4 * D * 2; }
+
+extern "C" int ark_gru_sweep_sync_reset(unsigned* sync, long words, void* stream) {
+  if (!sync || words < ark::kSweepSyncHdr) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(ark::sweep_reset_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sync, words);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int ark_gru_sweep_bwd(int prec, const ArkGruSweepBwd* a, void* stream) {
   using namespace ark;
@@ -714,9 +743,6 @@ extern "C" int ark_gru_sweep_bwd(int prec, const ArkGruSweepBwd* a, void* stream
   GruSweepBwdArgs p;
   p.a = *a;
   hipStream_t st = (hipStream_t)stream;
-  const long nw = ark_gru_sweep_sync_words(n, B, L);
-  hipLaunchKernelGGL(sweep_zero_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, a->sync, nw);
-  ARK_LAUNCH_CHECK();
   const unsigned grid = (unsigned)(n * (D / 16) * (B / 16) / mt);
 #define ARK_SWEEP_GO(PB)                                                                                          \
   do {                                                                                                            \

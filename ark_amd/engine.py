@@ -812,9 +812,8 @@ class Engine:
         t1 = Lq if t1 is None else t1
         Lc = t1 - t0
         key = ("sweep", Lq, t0, t1)
-        if key not in w:   # (every chunk has its own counters: an error word survives the chunks after it)
-            w[key] = (torch.empty(2 * n * Lc * B * D, device=self.device, dtype=torch.int16),
-                      torch.zeros(L.sweep_sync_words(n, B, Lc), device=self.device, dtype=torch.int32))
+        if key not in w:   # (zeroed once: the launches keep monotone counters; the error word is sticky)
+            w[key] = (torch.empty(2 * n * Lc * B * D, device=self.device, dtype=torch.int16), self._new_sweep_sync(B, Lc))
         exch, sync = w[key]
         o = t0 * B   # rows of the time-major arrays in front of this chunk
         at = lambda t: None if t is None else t[o:]
@@ -837,9 +836,6 @@ class Engine:
         a.n_layers, a.B, a.D, a.L, a.t0 = n, B, D, Lc, t0
         import ctypes
         _call("ark_gru_sweep_fwd", L.i32(self.prec_fwd), L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
-        if t0 == 0:
-            self._sweep_syncs = []
-        self._sweep_syncs.append(sync)
 
     def _sweep_bwd(self, w, B, Lq, use_drop):
         """the backward recurrence of all layers and steps (+ the initial-state gradient, SAIL) as ONE launch
@@ -847,8 +843,7 @@ class Engine:
         D, n, g = self.D, self.n, self.g
         key = ("sweep_bwd", Lq)
         if key not in w:
-            w[key] = (torch.empty(n * Lq * B * 4 * D, device=self.device, dtype=torch.int16),
-                      torch.zeros(L.sweep_sync_words(n, B, Lq), device=self.device, dtype=torch.int32))
+            w[key] = (torch.empty(n * Lq * B * 4 * D, device=self.device, dtype=torch.int16), self._new_sweep_sync(B, Lq))
         exch, sync = w[key]
         a = L.GruSweepBwd()
         for l in range(n):
@@ -868,26 +863,42 @@ class Engine:
         a.n_layers, a.B, a.D, a.L = n, B, D, Lq
         import ctypes
         _call("ark_gru_sweep_bwd", L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
-        self._sweep_bwd_sync = sync
+
+    def _new_sweep_sync(self, B, Lc):
+        """a zeroed sync workspace of a persistent sweep (header: sticky error word, detail, epoch, leave count; then one
+        padded monotone counter per (layer, step, row block)); registered so that sweep_error() sees every one of them"""
+        sy = torch.zeros(L.sweep_sync_words(self.n, B, Lc), device=self.device, dtype=torch.int32)
+        self.__dict__.setdefault("_sweep_sync_all", []).append(sy)
+        return sy
 
     def sweep_error(self):
-        """(error word, detail) of the last persistent sweep: non-zero = a workgroup gave up waiting (outputs invalid).
-        Synchronises."""
-        for sy in list(getattr(self, "_sweep_syncs", [])) + [getattr(self, "_sweep_bwd_sync", None)]:
-            if sy is not None:
-                v = sy[:2].cpu()
-                if int(v[0]) != 0:
-                    return int(v[0]), int(v[1])
+        """(error word, detail) of the persistent sweeps: non-zero = a workgroup of SOME sweep since the last
+        clear_sweep_error() gave up waiting -- that launch's outputs and everything computed from them are invalid.  The
+        word is sticky: no launch clears it, later sweeps on the same workspace leave at once.  Synchronises."""
+        syncs = getattr(self, "_sweep_sync_all", [])
+        if not syncs:
+            return 0, 0
+        v = torch.stack([sy[:2] for sy in syncs]).cpu()
+        for e, d in v.tolist():
+            if e != 0:
+                return int(e), int(d)
         return 0, 0
 
+    def clear_sweep_error(self):
+        """make the sweep workspaces usable again after a reported failure (zeroes error words, epochs and counters)"""
+        for sy in getattr(self, "_sweep_sync_all", []):
+            _call("ark_gru_sweep_sync_reset", L.ptr(sy), L.i64(sy.numel()), L.cur_stream())
+
     def raise_on_sweep_error(self):
-        """fail loudly if a persistent sweep of any earlier step gave up waiting (its error word is sticky until the next
-        sweep of the same workspace zeroes it: call this where the step's scalars are read anyway)"""
+        """fail loudly if a persistent sweep of ANY step since the last check gave up waiting (sticky error word: a
+        failure in step k of an epoch is still there after step n).  Call it where the step's scalars are read anyway.
+        The error is cleared before raising, so a caller that catches it can fall back (`ark_sweep: 0`) and go on."""
         e, d = self.sweep_error()
         if e:
+            self.clear_sweep_error()
             raise L.ArkError(f"persistent GRU sweep gave up waiting (workgroup {d >> 12 & 0x7FFFF}, step {d & 4095}): "
-                             "the workgroups were not all resident or the device is wedged; set ark_sweep: 0 to use the "
-                             "layer-diagonal launches")
+                             "the workgroups were not all resident or the device is wedged; every result since the last "
+                             "check is invalid.  Set ark_sweep: 0 to use the layer-diagonal launches")
 
     def _diag_sweep(self, w, B, Lq, use_drop, save=True):
         """Layer-diagonal forward recurrence: cells (l, d-l) of one anti-diagonal are independent -> ONE

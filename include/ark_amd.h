@@ -173,8 +173,14 @@ int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* roles, cons
  * registers and passing the hidden state on through `exch` with write-through stores, one counter per (layer, step,
  * row block) and bounded spins (two 16-row tiles per workgroup where that makes the grid fit the chip).  Inputs and outputs are those of L + n - 1 ark_gru_diag_fwd launches: time-major arrays
  * (row = t*B + b), slot 0 of y_t / y16a holding the initial state.  D in {128, 256, 512}, B % 16 == 0; returns
- * ARK_ERR_SHAPE when the grid cannot be co-resident (then use the diagonal launches).  After the launch sync[0] != 0
- * means a workgroup gave up waiting (sync[1] = its id << 12 | step): the outputs are then invalid.
+ * ARK_ERR_SHAPE when the grid cannot be co-resident (then use the diagonal launches).
+ * `sync` protocol: zero the workspace ONCE (allocation, or ark_gru_sweep_sync_reset); the launches that share it keep
+ * monotone counters and an epoch word, so no call clears anything.  After a launch sync[0] != 0 means a workgroup gave up
+ * waiting (sync[1] = its id << 12 | step): the outputs of that launch AND of every later launch on the workspace are
+ * invalid -- the word is sticky, later sweeps leave at once -- until the caller has read it and called
+ * ark_gru_sweep_sync_reset.  The launch is a plain one: the caller must not run anything beside it that keeps a CU from
+ * offering 96 KB of LDS to one of its workgroups for longer than the 0.25-s spin bound (the grid needs n_layers *
+ * (B/16) * (D/16) / row_tiles CUs).
  * Reference: nn.GRU forward, kgvae/model/models.py:121-127. */
 #define ARK_SWEEP_MAX_LAYERS 4
 typedef struct {
@@ -199,7 +205,7 @@ typedef struct {
   ArkGruSweepLayer layer[ARK_SWEEP_MAX_LAYERS];
   const void* x0_16;     /* [L*B, D] row-major forward type: layer 0's inputs                         */
   void* exch;            /* workspace, ark_gru_sweep_exch_bytes() bytes                               */
-  unsigned* sync;        /* workspace, ark_gru_sweep_sync_words() words (zeroed by the call)          */
+  unsigned* sync;        /* workspace, ark_gru_sweep_sync_words() words (zeroed ONCE by the caller)   */
   const float* hyper;
   int n_layers, B, D, L;
   int t0;                /* index of this launch's first step inside the whole sequence (a sequence swept in several launches
@@ -211,6 +217,8 @@ int ark_gru_sweep_row_tiles(int n_layers, int B, int D);
 long ark_gru_sweep_exch_bytes(int n_layers, int B, int D, int L);
 long ark_gru_sweep_sync_words(int n_layers, int B, int L);
 int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* sweep, void* stream);
+/* zero a sync workspace (error word, epoch, counters) on the stream: after allocation and after a reported failure */
+int ark_gru_sweep_sync_reset(unsigned* sync, long words, void* stream);
 /* The backward pass of the same recurrence (BPTT: autograd of nn.GRU) as ONE launch: what L + n - 1 ark_gru_diag_bwd
  * launches and the initial-state roles compute.  Writes the gate-gradient panels dg16[l] = [dr | dz | dn | dn*r]
  * (row-major [L*B, 4D], backward type), adds the bias gradients and (dh0 non-NULL) the initial-state gradient
@@ -235,7 +243,7 @@ typedef struct {
   const float* dy_t;       /* tile-native fp32 [L*B, D]: gradient of the loss wrt the top layer's outputs */
   float* dh0;              /* row-major fp32 [B, D], += (nullable: no initial-state gradient wanted)    */
   void* exch;              /* workspace, ark_gru_sweep_bwd_exch_bytes() bytes                           */
-  unsigned* sync;          /* workspace, ark_gru_sweep_sync_words() words (zeroed by the call)          */
+  unsigned* sync;          /* workspace, ark_gru_sweep_sync_words() words (zeroed ONCE by the caller)   */
   const float* hyper;
   int n_layers, B, D, L;
 } ArkGruSweepBwd;

@@ -180,6 +180,7 @@ def validate(model, dataset, config, device, compute_compression=False, b=1.0, s
         import torch.distributed as dist
         dist.all_reduce(tot)
     t = (tot[:4] / tot[4].clamp(min=1)).tolist()
+    model.engine().raise_on_sweep_error()   # (evaluation forwards of long sequences run the persistent sweep too)
     res = [t[0], t[1], t[2], 0.0]
     if compute_compression and rank == 0:
         bits = model.posterior_bits(dataset, device, pad_id=config["special_tokens"]["PAD"],

@@ -222,7 +222,7 @@ def test_chunked_sweep_with_the_fused_ce_beside_it(nc):
         assert eng.sweep_error() == (0, 0)
         engs.append(eng)
     a, b = engs
-    assert len(b._sweep_syncs) == nc
+    assert len(b._sweep_sync_all) == nc + 1   # one counter workspace per forward chunk + the backward sweep's
     for l in range(cfg["n_layers"]):
         assert torch.equal(a.ws["Y"][l], b.ws["Y"][l]), l            # the same arithmetic, launch boundaries apart
         assert torch.equal(a.ws["SR"][l], b.ws["SR"][l]), l
@@ -234,3 +234,125 @@ def test_chunked_sweep_with_the_fused_ce_beside_it(nc):
     for k in a.g:
         da, db = a.g[k].float(), b.g[k].float()
         assert (da - db).norm().item() <= 2e-3 * da.norm().item() + 1e-9, k
+
+
+@pytest.mark.parametrize("shape", ["wd-movies-like", "wd-articles-like"])
+def test_sweep_with_dropout_matches_oracle_with_the_same_masks(shape):
+    """DIRECT pin of the persistent sweeps with dropout on (round 3 had it only through the diagonal path): a padded
+    wd-shaped batch (long sequences, V >= 2 048 so the fused / vocabulary-split CE runs, mixed precision, dec_dropout
+    0.1) through the forward AND backward sweep; the counter-hash masks of that draw are materialised with
+    ark_dropout_mask and handed to the CPU oracle: ELBO within north_star's 1e-4, every gradient.
+    Reference semantics: nn.GRU(dropout=p) kgvae/model/models.py:121-127,184; loss ablation_study.py:59-73."""
+    from oracle import sail_oracle as O
+    from tests.test_engine_gpu import _row_major_masks
+    # (D, Z, nE, nR, T, padded), batch: wd-movies is D = 128 / Z = 64 / L = 70, wd-articles D = 512 / Z = 128 / B = 16
+    cfg, B = {"wd-movies-like": (_cfg(128, 64, 3000, 3, 23, True), 64),
+              "wd-articles-like": (_cfg(512, 128, 2500, 6, 24, True), 16)}[shape]
+    cfg = dict(cfg, dec_dropout=0.1)
+    P = O.init_params(cfg, 3)
+    triples, seq = synth_batch(cfg, B, seed=21, padded=True)
+    torch.manual_seed(17)
+    eps = torch.randn(B, cfg["d_latent"])
+    eng = make_engine(cfg, P, "mixed")
+    Lq = cfg["seq_len"] - 1
+    assert eng._use_sweep(B, Lq) and eng.sweep_bwd and eng.fused_ce      # the default configuration takes these paths
+    dev = eng.device
+    eng.training = True
+    eng.set_hyper(beta=0.4)
+    eng._default_norms(B)
+    eng.forward(triples.to(dev), seq.to(dev), eps.to(dev))
+    eng.backward()
+    torch.cuda.synchronize()
+    assert eng.sweep_error() == (0, 0)
+    out4 = eng.ws["out4"].cpu().numpy()
+    got = {k: v.detach().double().cpu().clone() for k, v in eng.g.items()}
+    masks = _row_major_masks(eng, B, Lq)
+    Pc = O._detach_tied(P, True)
+    leaves = O.leaf_params(Pc)
+    for _, t in leaves:
+        t.requires_grad_(True)
+    loss, ce, kl, *_ = O.sail_elbo(Pc, triples, seq, eps, 0.4, cfg, drop_masks=masks)
+    with torch.no_grad():
+        plain, *_ = O.sail_elbo(Pc, triples, seq, eps, 0.4, cfg)
+    assert abs(float(plain) - float(loss)) > 1e-4 * float(loss)          # the masks matter
+    assert rel_err(float(out4[0]), float(loss)) < 1e-4, (out4, float(loss), float(ce), float(kl))
+    loss.backward()
+    checked = 0
+    for k, t in leaves:
+        want = t.grad.double()
+        if cfg["pad_eid"] is not None and k in ("enc.e_emb.weight", "enc.r_emb.weight"):
+            want = want.clone()
+            want[cfg["pad_eid"] if k == "enc.e_emb.weight" else cfg["pad_rid"]] = 0   # padding_idx rows get no gradient
+        g = got[k]
+        nw = want.norm().item()
+        if nw < 1e-12:
+            assert g.norm().item() < 1e-9, k
+            continue
+        assert (g - want).norm().item() <= 2e-2 * nw, (k, (g - want).norm().item() / nw)
+        assert torch.dot(g.flatten(), want.flatten()).item() / (g.norm().item() * nw) >= 0.9997, k
+        checked += 1
+    assert checked >= 20
+
+
+def test_many_consecutive_sweep_steps_track_the_diagonal_path():
+    """monotone epoch counters: no launch zeroes the sweep's counters, step k waits for counter >= (k + 1) * NS.  Twelve
+    consecutive optimiser steps (eager, then replays of one captured graph) stay on the diagonal path's trajectory."""
+    from oracle import sail_oracle as O
+    cfg = _cfg(128, 16, 2500, 5, 12, True)
+    B = 32
+    P = O.init_params(cfg, 1)
+    triples, seq = synth_batch(cfg, B, seed=5, padded=True)
+    torch.manual_seed(9)
+    eps = torch.randn(B, 16)
+    a, b = _pair(cfg, B, P, 0.1)
+    dev = a.device
+    args = (triples.to(dev), seq.to(dev), eps.to(dev))
+    la = [float(a.train_step(*args)[0]) for _ in range(12)]
+    lb = [float(b.train_step(*args)[0]) for _ in range(6)]
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        step = b.capture_train_step(*args)   # (its eager warm-up is step 7)
+        lb.append(float(b.ws["out4"][0]))
+        lb += [float(step()[0]) for _ in range(5)]
+    torch.cuda.synchronize()
+    assert b.sweep_error() == (0, 0)
+    epochs = [int(sy[2]) for sy in b._sweep_sync_all]
+    assert min(epochs) >= 12 and all(int(sy[3]) == 0 for sy in b._sweep_sync_all), epochs
+    assert la[-1] < la[0]
+    for x, y in zip(la, lb):
+        assert rel_err(y, x) < 2e-3, (la, lb)
+
+
+def test_a_failed_sweep_is_remembered_until_the_host_reads_it():
+    """sticky error word (round 3: the next step's zero launch erased it).  One counter of the forward sweep is poisoned
+    so that step 2 of 4 times out; steps 3 and 4 leave at once; the failure is still there after step 4, raise_on_sweep_error
+    raises and clears, and the engine then works again."""
+    from oracle import sail_oracle as O
+    from ark_amd import _lib as L
+    cfg = _cfg(128, 16, 300, 5, 12, True)
+    B = 32
+    P = O.init_params(cfg, 1)
+    triples, seq = synth_batch(cfg, B, seed=5, padded=True)
+    eng = make_engine(dict(cfg, ark_sweep=1), P, "mixed")
+    dev = eng.device
+    torch.manual_seed(3)
+    args = (triples.to(dev), seq.to(dev), torch.randn(B, 16).to(dev))
+    good = float(eng.train_step(*args)[0])
+    torch.cuda.synchronize()
+    assert eng.sweep_error() == (0, 0)
+    fwd_sync = eng._sweep_sync_all[0]
+    fwd_sync[32 + 32 * 3].fill_(-1000)       # counter of (layer 0, step 0, row block 3): never reaches its target again
+    for _ in range(3):
+        eng.train_step(*args)
+    torch.cuda.synchronize()
+    e, d = eng.sweep_error()
+    assert e != 0
+    with pytest.raises(L.ArkError):
+        eng.raise_on_sweep_error()
+    assert eng.sweep_error() == (0, 0)        # cleared by the raise: the workspaces are usable again
+    eng.load_params(P)
+    eng.reset_optimizer()
+    again = float(eng.train_step(*args)[0])
+    torch.cuda.synchronize()
+    assert eng.sweep_error() == (0, 0)
+    assert rel_err(again, good) < 1e-5, (good, again)
