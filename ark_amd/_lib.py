@@ -81,7 +81,8 @@ class GruDiagRole(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in (
         "x16", "h_prev16", "w_ih16", "w_hh16", "b_ih", "b_hh", "y_prev_t", "y_out_t", "y16a", "y16b", "yd16a", "yd16b",
         "save_r", "save_z", "save_n", "save_hn")] + [
-        ("drop_seed", ctypes.c_uint64), ("drop_base", ctypes.c_int64), ("drop_p", ctypes.c_float), ("pad_", ctypes.c_int)]
+        ("drop_seed", ctypes.c_uint64), ("drop_base", ctypes.c_int64), ("drop_p", ctypes.c_float), ("pad_", ctypes.c_int),
+        ("x_tab", ctypes.c_void_p), ("x_tok", ctypes.c_void_p)]
 
 
 def dptr(t):

@@ -60,18 +60,24 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
   x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
   return x;
 }
-struct DropCtx { uint32_t s0, s1, step, p16; float ks; };
+// The draw counter is hashed on its own (hs) before it meets the element index: a LINEAR mix i*A + step*B would give two
+// (index, step) pairs with di*A + ds*B = 0 (mod 2^32) the same stream, i.e. step s + 433 983 would replay step s's values
+// shifted by 1 511 elements (found on the noise generator, which shared the construction).
+struct DropCtx { uint32_t s0, s1, hs, p16; float ks; };
+__device__ __forceinline__ uint32_t step_hash(uint32_t step, uint32_t s0, uint32_t s1) {
+  return fmix32(fmix32(step ^ s1) + 0x85EBCA77u) + s0;
+}
 __device__ __forceinline__ DropCtx drop_ctx(uint64_t seed, const float* hyper, float p) {
   DropCtx c;
   c.s0 = (uint32_t)seed; c.s1 = (uint32_t)(seed >> 32);
-  c.step = reinterpret_cast<const uint32_t*>(hyper)[kHpDropStep];
+  c.hs = step_hash(reinterpret_cast<const uint32_t*>(hyper)[kHpDropStep], c.s0, c.s1);
   c.p16 = (uint32_t)(p * 65536.0f + 0.5f);
   c.ks = 1.0f / (1.0f - p);
   return c;
 }
 __device__ __forceinline__ f32x4 dropout_quad(const DropCtx& c, uint64_t quad) {
   const uint32_t q0 = (uint32_t)quad, q1 = (uint32_t)(quad >> 32);
-  uint32_t a = fmix32(q0 * 0x9E3779B1u + c.step * 0x85EBCA77u + c.s0);
+  uint32_t a = fmix32(q0 * 0x9E3779B1u + c.hs);
   a = fmix32(a ^ (q1 * 0xC2B2AE3Du + c.s1));
   const uint32_t b = fmix32(a + 0x6C8E9CF5u);
   f32x4 m;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void enc_pool_fwd_kernel(const int64_t* __rest
 // instead of two dependent ones.  The gather role also bumps the dropout draw counter (see tok_gather16_kernel).
 struct PoolGatherArgs {
   const int64_t* triples; const float* E; const float* R; float* g; float* inv_cnt; void* g16a; void* g16b;
-  const int64_t* seq; const float* Wt; void* xa; void* xb; float* hyper_tick;
+  const int64_t* seq; const float* Wt; void* xa; void* xb; float* hyper_tick; int* tok_tm;
   long pad_rid, ld_seq;
   int B, T, D, Dd, L, prec_a, prec_b;
   int col_blocks;   // 0: one pool workgroup per graph; > 0: this many 64-column workgroups per graph (long graphs)
@@ -142,6 +142,14 @@ __global__ __launch_bounds__(256) void pool_gather_fwd_kernel(PoolGatherArgs p) 
   }
   const int blk = blockIdx.x - npool, nblk = gridDim.x - npool;
   if (p.hyper_tick && blk == 0 && threadIdx.x == 0) reinterpret_cast<uint32_t*>(p.hyper_tick)[kHpDropStep] += 1u;
+  if (!p.xa) {   // small vocabulary: the forward cells read rows of W_tok W_ih^T by token id, no embedding rows needed
+    const long rows = (long)p.B * p.L;
+    for (long row = (long)blk * 256 + threadIdx.x; row < rows; row += (long)nblk * 256) {
+      const int t = (int)(row / p.B), b = (int)(row % p.B);
+      p.tok_tm[row] = (int)p.seq[(long)b * p.ld_seq + t];
+    }
+    return;
+  }
   const int D4 = p.Dd >> 2;
   const long total = (long)p.B * p.L * D4;
   for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblk * 256) {
@@ -149,9 +157,20 @@ __global__ __launch_bounds__(256) void pool_gather_fwd_kernel(PoolGatherArgs p) 
     const long row = i / D4;
     const int t = (int)(row / p.B), b = (int)(row % p.B);
     const long tok = p.seq[(long)b * p.ld_seq + t];
+    if (p.tok_tm && d4 == 0) p.tok_tm[row] = (int)tok;
     const f32x4 v = *reinterpret_cast<const f32x4*>(p.Wt + tok * p.Dd + 4 * d4);
     put16x4(p.xa, row * D4 + d4, v, p.prec_a);
     if (p.xb) put16x4(p.xb, row * D4 + d4, v, p.prec_b);
+  }
+}
+
+__global__ __launch_bounds__(256) void tok_time_major_kernel(const int64_t* __restrict__ seq, long ld_seq, int* __restrict__ tok_tm,
+                                                             int B, int L, float* hyper_tick) {
+  if (hyper_tick && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<uint32_t*>(hyper_tick)[kHpDropStep] += 1u;
+  const long rows = (long)B * L;
+  for (long row = (long)blockIdx.x * 256 + threadIdx.x; row < rows; row += (long)gridDim.x * 256) {
+    const int t = (int)(row / B), b = (int)(row % B);
+    tok_tm[row] = (int)seq[(long)b * ld_seq + t];
   }
 }
 
@@ -369,16 +388,17 @@ extern "C" int ark_enc_pool_fwd16(const int64_t* triples, const float* E, const 
 extern "C" int ark_pool_gather_fwd16(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt,
                                      void* g16a, int prec_a, void* g16b, int prec_b, int B, int T, int D, int64_t pad_rid,
                                      const int64_t* seq, int64_t ld_seq, const float* w_tok, void* x16a, void* x16b, int L,
-                                     int D_dec, float* hyper_tick, void* stream) {
+                                     int D_dec, int* tok_tm, float* hyper_tick, void* stream) {
   using namespace ark;
-  if (!triples || !E || !R || !g || !g16a || !seq || !w_tok || !x16a || B <= 0 || T <= 0 || D <= 0 || L <= 0 || D_dec <= 0)
+  if (!triples || !E || !R || !g || !g16a || !seq || !w_tok || (!x16a && !tok_tm) || B <= 0 || T <= 0 || D <= 0 || L <= 0 || D_dec <= 0)
     return ARK_ERR_ARG;
+  if (!x16a && x16b) return ARK_ERR_ARG;
   if (D % 4 != 0 || D_dec % 4 != 0) return ARK_ERR_SHAPE;
   if ((prec_a != PREC_F16 && prec_a != PREC_BF16) || (g16b && prec_b != PREC_F16 && prec_b != PREC_BF16)) return ARK_ERR_ARG;
-  if ((g16b == nullptr) != (x16b == nullptr)) return ARK_ERR_ARG;   // one backward type for both (or none)
-  PoolGatherArgs p{triples, E, R, g, inv_cnt, g16a, g16b, seq, w_tok, x16a, x16b, hyper_tick, (long)pad_rid, (long)ld_seq,
+  if (x16a && (g16b == nullptr) != (x16b == nullptr)) return ARK_ERR_ARG;   // one backward type for both (or none)
+  PoolGatherArgs p{triples, E, R, g, inv_cnt, g16a, g16b, seq, w_tok, x16a, x16b, hyper_tick, tok_tm, (long)pad_rid, (long)ld_seq,
                    B, T, D, D_dec, L, prec_a, prec_b, 0};
-  const long total = (long)B * L * (D_dec / 4);
+  const long total = x16a ? (long)B * L * (D_dec / 4) : (long)B * L;
   long gb = (total + 255) / 256; if (gb > 4096) gb = 4096; if (gb < 1) gb = 1;
   // long graphs in a small batch: the pool is all load latency -- spread each graph over column blocks and its triples over waves
   size_t lds = 0;
@@ -389,6 +409,16 @@ extern "C" int ark_pool_gather_fwd16(const int64_t* triples, const float* E, con
   }
   const long npool = p.col_blocks > 0 ? (long)B * p.col_blocks : B;
   hipLaunchKernelGGL(pool_gather_fwd_kernel, dim3((unsigned)(npool + gb)), dim3(256), lds, (hipStream_t)stream, p);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_tok_time_major(const int64_t* seq, int64_t ld_seq, int* tok_tm, int B, int L, float* hyper_tick, void* stream) {
+  if (!seq || !tok_tm || B <= 0 || L <= 0) return ARK_ERR_ARG;
+  const long rows = (long)B * L;
+  long gb = (rows + 255) / 256; if (gb > 1024) gb = 1024;
+  hipLaunchKernelGGL(ark::tok_time_major_kernel, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, seq, (long)ld_seq, tok_tm, B, L,
+                     hyper_tick);
   ARK_LAUNCH_CHECK();
   return 0;
 }

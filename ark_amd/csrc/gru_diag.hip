@@ -119,12 +119,18 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
   const bool drop = R.drop_p > 0.f;
   DropCtx dc{};
   if (drop) dc = drop_ctx(R.drop_seed, p.hyper, R.drop_p);
+  // layer 0 of a small vocabulary: x_t W_ih^T is a ROW of x_tab = W_tok W_ih^T per token -- no K-segment for it (half of
+  // this role's stream); the token ids ride with the other early loads, the table rows are read in the epilogue
+  const float* xt = R.x_tab;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 tk[TM];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     rl[tm] = wm * G::WTM + tm * 16 + 4 * (lane >> 4);
     const int rowc = min(m0 + rl[tm], B - 4);   // B % 16 == 0: clamped quads stay in bounds
     o[tm] = tile_native_off(rowc, u, D);
     if constexpr (PRE) hp[tm] = ld_stream(reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]));
+    tk[tm] = xt ? *reinterpret_cast<const i32x4*>(R.x_tok + rowc) : i32x4{0, 0, 0, 0};
   }
   const float br = R.b_ih[u] + R.b_hh[u], bz = R.b_ih[D + u] + R.b_hh[D + u];
   const float bin = R.b_ih[2 * D + u], bhn = R.b_hh[2 * D + u];
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
     for (int tn = 0; tn <= TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
   typename G::template Segs<2> sg{{reinterpret_cast<const h_t*>(R.x16), reinterpret_cast<const h_t*>(R.h_prev16)},
                                   {reinterpret_cast<const h_t*>(R.w_ih16), reinterpret_cast<const h_t*>(R.w_hh16)},
-                                  {D, D}};
+                                  {xt ? 0 : D, D}};
   auto rma = [=](int r) -> long { return (long)min(m0 + r, B - 1); };
   auto rmb = [=](int j) -> long { return (long)((j >> 4) % 3) * D + u0 + (j / 48) * 16 + (j & 15); };
   auto mm = [&](auto seg, const h8 (&a)[TM], const h8 (&b)[TN]) {
@@ -171,6 +177,19 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
     f32x4 hpv;
     if constexpr (PRE) hpv = hp[tm];
     else hpv = ld_stream(reinterpret_cast<const f32x4*>(R.y_prev_t + o[tm]));
+    if (xt) {   // (block-uniform) the input projection of these four rows' tokens
+      f32x4 gx[3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* row = xt + (long)tk[tm][i] * 3 * D + u;
+        gx[0][i] = row[0];
+        gx[1][i] = row[D];
+        gx[2][i] = row[2 * D];
+      }
+      acc[tm][0] += gx[0];
+      acc[tm][1] += gx[1];
+      acc[tm][2] += gx[2];
+    }
     f32x4 r, z, n, hn, h;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -322,14 +341,19 @@ extern "C" int ark_gru_diag_fwd(int prec, int prec_b, int n_roles, const ArkGruD
   GruDiagArgs p;
   for (int i = 0; i < n_roles; ++i) {
     const ArkGruDiagRole& r = roles[i];
-    if (!r.x16 || !r.h_prev16 || !r.w_ih16 || !r.w_hh16 || !r.b_ih || !r.b_hh || !r.y_prev_t || !r.y_out_t || !r.y16a)
-      return ARK_ERR_ARG;
+    if (!r.h_prev16 || !r.w_hh16 || !r.b_ih || !r.b_hh || !r.y_prev_t || !r.y_out_t || !r.y16a) return ARK_ERR_ARG;
+    if (r.x_tab ? !r.x_tok : (!r.x16 || !r.w_ih16)) return ARK_ERR_ARG;
+    if (r.x_tab && ((uintptr_t)r.x_tok & 15)) return ARK_ERR_ALIGN;   // four token ids per lane in one load
     if (r.drop_p < 0.f || r.drop_p >= 1.f || (r.drop_p > 0.f && (!r.yd16a || !hyper))) return ARK_ERR_ARG;
     if ((r.drop_base & 3) != 0) return ARK_ERR_ALIGN;   // one hash serves a quad of elements
     if (r.save_r && (!r.save_z || !r.save_n || !r.save_hn)) return ARK_ERR_ARG;
     p.role[i] = r;
+    if (r.x_tab) {   // (the ring computes lane offsets from these bases even for a K = 0 segment: keep them valid)
+      p.role[i].x16 = r.h_prev16;
+      p.role[i].w_ih16 = r.w_hh16;
+    }
   }
-  for (int i = n_roles; i < ARK_DIAG_MAX_ROLES; ++i) p.role[i] = roles[0];
+  for (int i = n_roles; i < ARK_DIAG_MAX_ROLES; ++i) p.role[i] = p.role[0];
   p.hyper = hyper;
   p.n_roles = n_roles;
   p.B = B;

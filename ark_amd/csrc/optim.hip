@@ -280,8 +280,9 @@ __global__ __launch_bounds__(1024) void normal_fill_kernel(float* __restrict__ o
   const uint32_t step = *ctr;
   __syncthreads();
   const long pairs = (n + 1) >> 1;
+  const uint32_t hs = step_hash(step, s0, s1);   // (the draw counter hashed on its own: no linear (index, draw) aliasing)
   for (long i = threadIdx.x; i < pairs; i += blockDim.x) {
-    uint32_t a = fmix32((uint32_t)i * 0x9E3779B1u + step * 0x85EBCA77u + s0);
+    uint32_t a = fmix32((uint32_t)i * 0x9E3779B1u + hs);
     a = fmix32(a ^ ((uint32_t)(i >> 32) * 0xC2B2AE3Du + s1));
     const uint32_t b = fmix32(a + 0x6C8E9CF5u);
     const float u1 = (float)((a >> 8) + 1u) * 5.9604644775390625e-8f;   // (0, 1]: 24 bits

@@ -506,27 +506,31 @@ static int vc_groups(int n16, int max_groups) {
   return best;
 }
 
-// vocabulary splits of the forward with dY: the count that minimises rounds-of-workgroups x work-per-workgroup on 256 CUs
-// (1 where the 64-row blocks alone fill the chip); each split keeps at least 32 tiles
-static int vc_splits(int R, int V) {
+// vocabulary splits of the forward with dY: the count that minimises rounds-of-workgroups x work-per-workgroup on `cus` CUs
+// (1 where the 64-row blocks alone fill them); each split keeps at least 32 tiles.  cus = 256, or the CUs a persistent
+// sweep running beside this launch leaves free (cu_budget: one 512-thread workgroup owns a CU's whole register file, so
+// a grid capped there can never keep a sweep workgroup off the chip).
+static int vc_splits(int R, int V, int cus) {
+  if (cus <= 0 || cus > 256) cus = 256;
   const int rb = (R + 63) / 64, nsteps = (V + 63) / 64;
-  if (rb > 192) return 1;   // (the row tiles fill the chip; vc_groups balances the last round)
+  if (rb > cus * 3 / 4) return 1;   // (the row tiles fill the chip; vc_groups balances the last round)
   int best = 1;
-  double best_t = (double)((rb + 255) / 256);
+  double best_t = (double)((rb + cus - 1) / cus);
   for (int nv = 2; nv <= 16 && nsteps / nv >= 32; ++nv) {
-    const double t = (double)((rb * nv + 255) / 256) / nv + 0.02 * nv;   // (+ ramp / combine cost per split)
+    const double t = (double)((rb * nv + cus - 1) / cus) / nv + 0.02 * nv;   // (+ ramp / combine cost per split)
     if (t < best_t - 1e-9) { best_t = t; best = nv; }
   }
   return best;
 }
-extern "C" int ark_vocab_ce_fwd_splits(int R, int V, int D) { return (D == 64 || D == 128 || D == 256 || D == 512) && R % 16 == 0 ? vc_splits(R, V) : 1; }
+extern "C" int ark_vocab_ce_fwd_splits(int R, int V, int D, int cu_budget) {
+  return (D == 64 || D == 128 || D == 256 || D == 512) && R % 16 == 0 ? vc_splits(R, V, cu_budget) : 1;
+}
 
 template <int PREC, int DCH>
-static int vc_launch_fwd(const VocabCeArgs& p, bool with_dy, hipStream_t st) {
+static int vc_launch_fwd(const VocabCeArgs& p, bool with_dy, hipStream_t st, int nv = 1) {
   if (with_dy && p.part_u) {   // few row blocks: the vocabulary is split over workgroups, 64-row tiles, one merging launch
     constexpr int LDS = vc_lds_bytes<DCH, 4>(kVcAux);
     static bool once = (vc_allow_lds(vocab_ce_fwd_kernel<PREC, DCH, 4, true>, LDS), true); (void)once;
-    const int nv = vc_splits(p.R, p.V);
     hipLaunchKernelGGL((vocab_ce_fwd_kernel<PREC, DCH, 4, true>), dim3((unsigned)((p.R + 63) / 64), (unsigned)nv), dim3(512), LDS, st, p);
     ARK_LAUNCH_CHECK();
     const long nquad = (long)p.R * (64 * DCH) / 4;
@@ -607,21 +611,21 @@ extern "C" int ark_vocab_ce_fwd(int prec, const void* Y16, const void* W16, cons
 
 extern "C" int ark_vocab_ce_fwd_ws(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq,
                                    int64_t ld_seq, const float* hyper, float* row_loss, float* lse, float* dY_t, float* ws,
-                                   int64_t ws_floats, int B, int L, int V, int D, void* stream) {
+                                   int64_t ws_floats, int B, int L, int V, int D, int cu_budget, void* stream) {
   using namespace ark;
   int rc = vc_check(prec, Y16, W16, bias, seq, hyper, B, L, V, D);
   if (rc) return rc;
   if (!row_loss || !lse || !dY_t) return ARK_ERR_ARG;
   if ((B * L) % 16 != 0) return ARK_ERR_SHAPE;
   const long R = (long)B * L;
-  const int nv = ark_vocab_ce_fwd_splits((int)R, V, D);
+  const int nv = ark_vocab_ce_fwd_splits((int)R, V, D, cu_budget);
   VocabCeArgs p{Y16, W16, bias, seq, hyper, row_loss, lse, dY_t, nullptr, nullptr, (long)ld_seq, B * L, B, V};
   if (nv > 1) {
     if (!ws || ws_floats < (long)nv * (R * D + R * 4)) return ARK_ERR_ARG;
     p.part_u = ws;
     p.part_s = ws + (long)nv * R * D;
   }
-  ARK_VC_DISPATCH(vc_launch_fwd, p, true, (hipStream_t)stream);
+  ARK_VC_DISPATCH(vc_launch_fwd, p, true, (hipStream_t)stream, nv);
 }
 
 extern "C" int ark_vocab_ce_dw(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,

@@ -167,6 +167,11 @@ class Engine:
                 self.wm16 = [i16(H, H) for _ in range(self.n)]      # encoder MLP weights, forward type
                 self.wmT16 = [i16(H, H) for _ in range(self.n)]     # their transposes, backward type
                 self.wh16 = i16(2 * self.Z, H)                      # [mu; logv] head, forward type
+            # small vocabularies: layer 0's input projection per TOKEN, x_tab[V, 3D] = W_tok16 W_ih0_16^T (fp32 sums of the
+            # same 16-bit products the cells would form), refreshed with the shadows; the forward diagonals' layer-0 roles
+            # add its rows instead of streaming x_t W_ih0^T (the backward has used the same identity since round 1: token sums)
+            self.xtab = (torch.zeros(V, 3 * D, device=dev) if (self.mt == "SAIL" and self.Vp <= 256 and cfg.get("ark_fwd_tab", True))
+                         else None)
             self._shadow_jobs = self._build_shadow_jobs()
             off, tot = self.layout.dec_grad_offset, self.layout.total
             self._adam_jobs = {"all": self._build_adam_jobs(0, tot), "enc": self._build_adam_jobs(0, off),
@@ -287,7 +292,16 @@ class Engine:
         if self.use_dma:
             for (n, src, dst, dstT, R, C, pf, pb, ldT) in self._shadow_jobs:
                 _call("ark_weight_shadows", L.i32(n), src, dst, dstT, R, C, pf, pb, ldT, L.cur_stream())
+            self._refresh_xtab()
         self._shadow_ok = True
+
+    def _refresh_xtab(self):
+        """x_tab = W_tok16 W_ih0_16^T from the current shadows (one small product; queued right behind whatever wrote them)"""
+        if self.use_dma and self.xtab is not None:
+            D = self.D
+            _call("ark_gemm16", L.i32(self.prec_fwd), L.i32(L.EPI_NONE), L.ptr(self.wtok16), L.i64(D), L.ptr(self.wih16[0]), L.i64(D),
+                  L.ptr(self.xtab), L.i64(3 * D), L.ptr(None), L.ptr(None), L.i32(self.V), L.i32(3 * D), L.i32(D), L.i32(0),
+                  L.cur_stream())
 
     def _build_adam_jobs(self, *ranges):
         """job tables of ark_adam_step_shadows for the flat ranges [lo, hi), ... : one MATRIX job per shadowed weight (its
@@ -349,6 +363,8 @@ class Engine:
             for (n, off, R, C, dst, dstT, pf, pb, ldT) in self._adam_jobs[which]:
                 _call("ark_adam_step_shadows", L.ptr(self.P), L.ptr(self.G), L.ptr(self.M), L.ptr(self.Vv), L.i32(n), off, R, C,
                       dst, dstT, pf, pb, ldT, L.ptr(self.hyper), st)
+            if which in ("all", "dec"):   # (the bucket that holds W_tok and W_ih0)
+                self._refresh_xtab()
         else:
             lo, hi = {"all": (0, self.layout.total), "enc": (0, self.layout.dec_grad_offset),
                       "dec": (self.layout.dec_grad_offset, self.layout.total)}[which]
@@ -454,6 +470,9 @@ class Engine:
             if w["emb_gemm"]:
                 w["S_tok"] = f(self.Vp, 3 * D)
                 w["tok_scratch"] = torch.empty(4 * R + 32 + 4 * (R // 64 + 1), device=dev, dtype=torch.uint8)
+            w["xtab"] = bool(self.xtab is not None)
+            if w["xtab"]:
+                w["tok_tm"] = torch.zeros(Rp, device=dev, dtype=torch.int32)  # time-major token ids (rows of x_tab)
             w["h0"] = f(B, D)                                                # row-major h0 (z-projection)
             w["dX0"] = f(R, D)
             if self.p_drop > 0:   # the dropout mask itself is regenerated in-kernel from a counter hash
@@ -553,11 +572,12 @@ class Engine:
                 if self._dp_pending is None and self.fused_prologue:
                     # the decoder's token gather shares the encoder pool's launch (both only need the batch indices); not
                     # while a pipelined data-parallel update of the token table is still owed (it lands at the seam)
+                    skip = self._skip_x0(w, B, Lq)   # (small vocabulary, diagonal path: nobody reads the embedding rows)
                     _call("ark_pool_gather_fwd16", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
                           L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.ptr(w["g16a"]), L.i32(pf), L.ptr(w["g16b"]), L.i32(pb), L.i32(B),
                           L.i32(T), L.i32(D), L.i64(-1 if self.pad_rid is None else self.pad_rid), L.ptr(seq), L.i64(ld_seq),
-                          L.ptr(p["dec.tok_emb.weight"]), L.ptr(w["X0a"]), L.ptr(w["X0b"]), L.i32(Lq), L.i32(D),
-                          L.ptr(self.hyper if use_drop else None), st)
+                          L.ptr(p["dec.tok_emb.weight"]), L.ptr(None if skip else w["X0a"]), L.ptr(None if skip else w["X0b"]),
+                          L.i32(Lq), L.i32(D), L.ptr(w["tok_tm"] if w["xtab"] else None), L.ptr(self.hyper if use_drop else None), st)
                     self._x0_ready = True
                 else:
                     _call("ark_enc_pool_fwd16", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
@@ -624,11 +644,24 @@ class Engine:
                 self._hp.pop("CE_COUNT", None)
             main = torch.cuda.current_stream()
             side = self._side_stream()
-            for (t0, t1) in chunks:
+            # Queue order matters (round-3 trace: CE(k) was queued first, its one-per-CU workgroups took the whole chip and the
+            # next chunk's sweep sat behind it -- 3 % overlap): sweep(k + 1) goes out BEFORE CE(k), so its co-resident
+            # workgroups are on their CUs when the CE grid arrives, and the CE grid is capped at the CUs the sweep leaves
+            # (`cu_budget`: a 512-thread CE workgroup owns a CU's whole register file), so neither order can starve the sweep.
+            free_cus = max(32, 256 - self._sweep_wgs(B))
+            done = []
+            for k, (t0, t1) in enumerate(chunks):
                 self._sweep_fwd(w, B, Lq, use_drop, True, t0, t1)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self._fused_ce_fwd(w, seq, ld_seq, B, t0, t1, True)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                done.append(ev)
+                if k > 0:
+                    side.wait_event(done[k - 1])
+                    with torch.cuda.stream(side):
+                        self._fused_ce_fwd(w, seq, ld_seq, B, chunks[k - 1][0], chunks[k - 1][1], True, cu_budget=free_cus)
+            side.wait_event(done[-1])
+            with torch.cuda.stream(side):   # (the last chunk's CE has the chip to itself)
+                self._fused_ce_fwd(w, seq, ld_seq, B, chunks[-1][0], chunks[-1][1], True)
             main.wait_stream(side)
         else:
             self._decoder_forward(w, seq, ld_seq, B, Lq, use_drop, project=not fused)
@@ -673,8 +706,9 @@ class Engine:
         step = -(-Lq // nc)
         return [(t, min(Lq, t + step)) for t in range(0, Lq, step)]
 
-    def _fused_ce_fwd(self, w, seq, ld_seq, B, t0, t1, with_dlogits):
-        """tied projection + cross-entropy (+ dY of the top layer) of the rows of steps [t0, t1) in one sweep over V"""
+    def _fused_ce_fwd(self, w, seq, ld_seq, B, t0, t1, with_dlogits, cu_budget=0):
+        """tied projection + cross-entropy (+ dY of the top layer) of the rows of steps [t0, t1) in one sweep over V;
+        cu_budget: the CUs the launch may fill (beside a persistent sweep: the ones it leaves free; 0 = all)"""
         D, n, V, p = self.D, self.n, self.V, self.p
         st = L.cur_stream()
         Lc, o = t1 - t0, t0 * B
@@ -682,13 +716,15 @@ class Engine:
         y = w["Y16a"][n - 1][B + o:]
         sq = seq[:, t0:]   # (the kernels index seq[b * ld + t + 1] with t counted from the chunk's first step)
         dY = w["dYa"][o:] if with_dlogits else None
-        nv = L.lib().ark_vocab_ce_fwd_splits(L.i32(Rc), L.i32(V), L.i32(D)) if with_dlogits else 1
+        nv = L.lib().ark_vocab_ce_fwd_splits(L.i32(Rc), L.i32(V), L.i32(D), L.i32(cu_budget)) if with_dlogits else 1
         if nv > 1:   # few rows, wide model: the vocabulary sweep is split over workgroups (+ one merging launch)
-            if "ce_ws" not in w or w["ce_ws"].numel() < nv * (Rc * D + 4 * Rc):
-                w["ce_ws"] = torch.empty(nv * (Rc * D + 4 * Rc), device=self.device)
+            # (one scratch per chunk position: the CE launches of consecutive chunks may overlap on the side queue's tail)
+            key = ("ce_ws", t0)
+            if key not in w or w[key].numel() < nv * (Rc * D + 4 * Rc):
+                w[key] = torch.empty(nv * (Rc * D + 4 * Rc), device=self.device)
             _call("ark_vocab_ce_fwd_ws", L.i32(self.prec_fwd), L.ptr(y), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]), L.ptr(sq),
-                  L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"][o:]), L.ptr(w["lse"][o:]), L.ptr(dY), L.ptr(w["ce_ws"]),
-                  L.i64(w["ce_ws"].numel()), L.i32(B), L.i32(Lc), L.i32(V), L.i32(D), st)
+                  L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"][o:]), L.ptr(w["lse"][o:]), L.ptr(dY), L.ptr(w[key]),
+                  L.i64(w[key].numel()), L.i32(B), L.i32(Lc), L.i32(V), L.i32(D), L.i32(cu_budget), st)
         else:
             _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(y), L.ptr(self.wtok16), L.ptr(p["dec.out.bias"]), L.ptr(sq),
                   L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"][o:]), L.ptr(w["lse"][o:]), L.ptr(dY), L.i32(B), L.i32(Lc),
@@ -726,10 +762,20 @@ class Engine:
         p = self.p
         if self._x0_ready:   # (gathered by the step's first launch, beside the encoder pool)
             self._x0_ready = False
-        else:
+            return
+        tick = self.hyper if use_drop else None
+        if w["xtab"]:
+            _call("ark_tok_time_major", L.ptr(seq), L.i64(ld_seq), L.ptr(w["tok_tm"]), L.i32(B), L.i32(Lq), L.ptr(tick), L.cur_stream())
+            tick = None   # (one dropout draw per training forward)
+        if not self._skip_x0(w, B, Lq):
             _call("ark_tok_gather16", L.i32(self.prec_fwd), L.i32(self.prec_bwd), L.ptr(seq), L.i64(ld_seq),
                   L.ptr(p["dec.tok_emb.weight"]), L.ptr(p["dec.pos_emb.weight"] if self.mt == "ARK" else None), L.ptr(w["X0a"]),
-                  L.ptr(w["X0b"]), L.i32(B), L.i32(Lq), L.i32(self.D), L.ptr(self.hyper if use_drop else None), L.cur_stream())
+                  L.ptr(w["X0b"]), L.i32(B), L.i32(Lq), L.i32(self.D), L.ptr(tick), L.cur_stream())
+
+    def _skip_x0(self, w, B, Lq):
+        """True where no kernel reads the 16-bit embedding rows X0: the forward diagonals take layer 0's input projection from
+        x_tab, the backward takes dW_ih0 / dW_tok from the token sums; the persistent sweep still streams X0"""
+        return bool(w.get("xtab") and w.get("emb_gemm") and not self._use_sweep(B, Lq))
 
     def _decoder_forward_v2(self, w, seq, ld_seq, B, Lq, use_drop, save=True, project=True):
         """fast decoder forward: token gather -> layer-diagonal GRU sweep -> tied vocabulary projection
@@ -927,13 +973,16 @@ class Engine:
                     Y, Ya, Yb = w["Y"][l], w["Y16a"][l], w["Y16b"][l]
                     sl = slice(t * B + b0, t * B + b0 + Bc)
                     nx = slice((t + 1) * B + b0, (t + 1) * B + b0 + Bc)
-                    if l == 0:
+                    r = roles[k]
+                    if l == 0 and w["xtab"]:   # layer 0, small vocabulary: rows of x_tab by token id, no input K-segment
+                        x = None
+                        r.x_tab, r.x_tok = L.dptr(self.xtab), L.dptr(w["tok_tm"][t * B + b0:])
+                    elif l == 0:
                         x = w["X0a"][sl]
                     else:
                         x = w["Yd16a"][l - 1][sl] if use_drop else w["Y16a"][l - 1][nx]
-                    r = roles[k]
                     r.x16, r.h_prev16 = L.dptr(x), L.dptr(Ya[sl])
-                    r.w_ih16, r.w_hh16 = L.dptr(self.wih16[l]), L.dptr(self.whh16[l])
+                    r.w_ih16, r.w_hh16 = L.dptr(None if x is None else self.wih16[l]), L.dptr(self.whh16[l])
                     r.b_ih, r.b_hh = L.dptr(p[f"dec.gru.bias_ih_l{l}"]), L.dptr(p[f"dec.gru.bias_hh_l{l}"])
                     r.y_prev_t, r.y_out_t = L.dptr(Y[sl]), L.dptr(Y[nx])
                     r.y16a, r.y16b = L.dptr(Ya[nx]), L.dptr(Yb[nx] if Yb is not None else None)
@@ -1206,7 +1255,7 @@ class Engine:
             if self._finalize is not None:   # loss scalars of this step (deferred by forward)
                 self._finalize()
                 self._finalize = None
-            ce_dw_later = None
+            ce_dw_later = ce_dw_beside = None
             if self._fused_ce_step:
                 # dW_tok and db_out from the recomputed softmax (no dlogits buffer): csrc/vocab_ce.hip
                 def ce_dw():
@@ -1218,6 +1267,11 @@ class Engine:
                 # where it runs beside the short kernels of the latent / encoder backward instead
                 if side is not main and self._use_sweep(B, Lq) and self.sweep_bwd and self._sweep_wgs(B) > 128:
                     ce_dw_later = ce_dw
+                elif side is not main and self._use_sweep(B, Lq) and self.sweep_bwd:
+                    # a sweep that leaves most of the chip free (wd-articles: 96 CUs): the two run side by side, but the
+                    # sweep's co-resident workgroups must be dispatched FIRST -- this launch's ~1 000 one-per-CU workgroups
+                    # would otherwise take every CU and the sweep's would trickle in as they drain, spinning on each other
+                    ce_dw_beside = ce_dw
                 else:
                     ce_dw()
             elif getattr(self, "_dlog16_valid", False) and self._dlog16_only:
@@ -1263,6 +1317,9 @@ class Engine:
         def after_cells():
             self._side_used = side is not main
             self._fork_pending = None
+            if ce_dw_beside is not None:   # (queued behind the sweep's launch, not behind its completion)
+                with torch.cuda.stream(side):
+                    ce_dw_beside()
             if ce_dw_later is not None:
                 def go():
                     side.wait_stream(torch.cuda.current_stream())

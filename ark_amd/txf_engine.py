@@ -195,7 +195,34 @@ class TxfEngine(Engine):
                       "vmem": f(B, W)})
         return d
 
-    def _workspace(self, B, Lq, T=0):
+    def _workspace(self, B, Lq, T=0, decode=False):
+        """buffers of a (batch, decoder length, triples) shape.  decode=True: the ONE workspace generation uses for every
+        prefix length (allocated at the full length; buffers are time-major, so a prefix of t steps is a leading slice and
+        the kernels take the run length as an argument) -- kept apart from the training workspaces, which a stream of
+        per-token shapes used to evict"""
+        if decode:
+            cache = self.__dict__.setdefault("_dec_ws_cache", {})
+            cap, w = cache.get((B, T), (0, None))
+            if cap < Lq:
+                cap = max(self.L, Lq)
+                keep = (self.ws, self.ws_key)
+                had = (B, cap, T) in self._ws_cache
+                self.ws_key = None
+                w = self._workspace(B, cap, T)
+                if had:   # a training workspace of that very shape exists: decode gets buffers of its own
+                    self._ws_cache.pop((B, cap, T))
+                    self.ws_key = None
+                    w2 = self._workspace(B, cap, T)
+                    self._ws_cache[(B, cap, T)] = w
+                    w = w2
+                else:
+                    self._ws_cache.pop((B, cap, T), None)   # (built by the ordinary path below, owned by the decode cache)
+                self.ws, self.ws_key = keep
+                cache.pop((B, T), None)
+                if len(cache) >= 2:
+                    cache.pop(next(iter(cache)))
+                cache[(B, T)] = (cap, w)
+            return w
         key = (B, Lq, T)
         if self.ws_key == key:
             return self.ws
@@ -360,7 +387,8 @@ class TxfEngine(Engine):
         return d["x2"]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, triples, seq, eps=None, with_loss=True, with_dlogits=True, L_run=None, ce_count=None, z_given=None):
+    def forward(self, triples, seq, eps=None, with_loss=True, with_dlogits=True, L_run=None, ce_count=None, z_given=None,
+                decode_ws=False):
         """t-ARK: forward(None, seq).  t-SAIL: forward(triples, seq, eps) (eps None: drawn on the device), or
         forward(None, seq, z_given=z) to run the decoder alone on given latents (generation).
         seq [B, >= L_run] int64 on the device; results stay in the workspace (out4 = loss, ce, kl, token-loss sum)."""
@@ -373,7 +401,7 @@ class TxfEngine(Engine):
         if enc_on and triples is None:
             raise L.ArkError("t-SAIL forward needs `triples` (encoder input) or `z_given` (decoder alone)")
         T = triples.shape[1] if enc_on else 0
-        w = self._workspace(B, Lq, T)
+        w = self._workspace(B, Lq, T, decode=decode_ws)
         D, n, V, H = self.D, self.n, self.V, self.H
         R = Lq * B
         st = L.cur_stream()
@@ -686,7 +714,7 @@ class TxfEngine(Engine):
         self.training = False
         try:
             t, B = prefix.shape[1], prefix.shape[0]
-            w = self.forward(None, prefix.contiguous(), None, with_loss=False, L_run=t, z_given=z)
+            w = self.forward(None, prefix.contiguous(), None, with_loss=False, L_run=t, z_given=z, decode_ws=True)
         finally:
             self.training = was
         return w["logits"][(t - 1) * B:t * B, :self.V]

@@ -117,6 +117,12 @@ typedef struct {
   int64_t drop_base;
   float drop_p;
   int pad_;
+  /* Small vocabularies (layer 0 only): the input projection of a token is a ROW of the table x_tab[V, 3D] =
+   * W_tok16 W_ih16^T (fp32 sums of the same 16-bit products, formed once per optimiser step), so the role adds
+   * x_tab[x_tok[row]] to its gate pre-activations instead of streaming x16 W_ih^T through the ring: x16 / w_ih16 are then
+   * unused (may be NULL) and half of the role's operand stream is gone.  x_tok: int32 token id of each of the B rows. */
+  const float* x_tab;    /* nullable */
+  const int* x_tok;      /* [B], required with x_tab */
 } ArkGruDiagRole;
 /* speed-only tile / ring choices of the two diagonal kernels; passed per call (NULL = the measured defaults of
  * ark_diag_tuning_default), so the library keeps no mutable state */
@@ -324,10 +330,14 @@ int ark_tok_gather(const int64_t* seq, int64_t ld_seq, const float* w_tok, const
                    float* x, int B, int L, int D, float* hyper_tick /* nullable, as ark_tok_gather16 */, void* stream);
 /* encoder pool (ark_enc_pool_fwd16) + decoder token gather (ark_tok_gather16, no position table) in ONE launch: the two
  * first kernels of a SAIL step only need the batch indices.  x16a/x16b[(t, b), :] = cast(W_tok[seq[b, t]]), t < L. */
+/* tok_tm (nullable): int32 [L*B] time-major token ids, tok_tm[t*B + b] = seq[b, t] (the x_tok rows of ArkGruDiagRole);
+ * with tok_tm given x16a / x16b may be NULL: the embedding rows are then not gathered at all. */
 int ark_pool_gather_fwd16(const int64_t* triples, const float* E, const float* R, float* g, float* inv_cnt, void* g16a,
                           int prec_a, void* g16b, int prec_b, int B, int T, int D, int64_t pad_rid, const int64_t* seq,
-                          int64_t ld_seq, const float* w_tok, void* x16a, void* x16b, int L, int D_dec, float* hyper_tick,
-                          void* stream);
+                          int64_t ld_seq, const float* w_tok, void* x16a, void* x16b, int L, int D_dec, int* tok_tm,
+                          float* hyper_tick, void* stream);
+/* the token half of that launch on its own: tok_tm[t*B + b] = seq[b, t] (+ the dropout tick) */
+int ark_tok_time_major(const int64_t* seq, int64_t ld_seq, int* tok_tm, int B, int L, float* hyper_tick, void* stream);
 int ark_tok_scatter(const int64_t* seq, int64_t ld_seq, const float* dx, float* d_w_tok, int B, int L, int D,
                     int vocab, void* stream);
 
@@ -378,10 +388,13 @@ int ark_vocab_ce_fwd(int prec, const void* Y16, const void* W16, const float* bi
  * workgroups (the 64-row blocks alone would leave CUs idle: 160 at wd-articles B = 16, 20 on one of its 8 data-parallel
  * ranks) and a second small launch merges the partial softmax statistics and products.  `ws` holds splits * (B*L*D + 4*B*L) floats (unused and
  * may be NULL where ark_vocab_ce_fwd_splits() returns 1). */
-int ark_vocab_ce_fwd_splits(int R, int V, int D);
+/* cu_budget: the CUs this launch may fill (0 or 256 = the whole chip).  A 512-thread workgroup of this kernel owns a CU's
+ * whole register file; the engine passes the CUs a persistent GRU sweep running BESIDE the launch leaves free, so the grid
+ * can never keep one of the sweep's co-resident workgroups off the chip. */
+int ark_vocab_ce_fwd_splits(int R, int V, int D, int cu_budget);
 int ark_vocab_ce_fwd_ws(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
                         const float* hyper, float* row_loss, float* lse, float* dY_t, float* ws, int64_t ws_floats, int B,
-                        int L, int V, int D, void* stream);
+                        int L, int V, int D, int cu_budget, void* stream);
 int ark_vocab_ce_dw(int prec, const void* Y16, const void* W16, const float* bias, const int64_t* seq, int64_t ld_seq,
                     const float* hyper, const float* lse, float* dW, float* db, int B, int L, int V, int D, void* stream);
 /* out4 = {loss = ce + beta*kl, ce, kl, sum of token losses}; kl nullable (ARK) */

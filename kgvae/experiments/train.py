@@ -447,7 +447,10 @@ def main(argv=None):
     if config.get("dump_final_params"):   # test hook: every rank's flat parameter buffer
         eng.dp_flush()
         torch.save(eng.P.detach().cpu(), f"{config['dump_final_params']}.rank{rank}.pt")
-        wtrain = eng._ws_cache.get(config["batch_size"] // nranks)   # (workspace of this rank's training batches)
+        Bl = config["batch_size"] // nranks   # (workspace of this rank's training batches: the GRU engine keys by batch
+        wtrain = eng._ws_cache.get(Bl)        #  size, the Transformer engine by (batch, decoder length, triples))
+        if wtrain is None:
+            wtrain = next((w for k, w in eng._ws_cache.items() if isinstance(k, tuple) and k[0] == Bl and "eps0" in w), None)
         if model_type in ("SAIL", "t-SAIL") and wtrain is not None:   # the last training step's device-drawn latent noise
             torch.save(wtrain["eps0"].detach().cpu(), f"{config['dump_final_params']}.eps.rank{rank}.pt")
     if nranks > 1:

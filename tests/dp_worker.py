@@ -12,21 +12,39 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def case(variant):
+    """(model config, global batch, padded graphs?) of a data-parallel test variant.
+      sail / nopipe / ark: the syn-paths golden shape (L = 10, V = 55), B = 128
+      wd-movies[-drop]:   BASELINE config 4's kind of shape (reference configs/autoreg_wd-movies.yaml:7-12): D = 128,
+                          Z = 64, padded graphs of 1..12 triples (per-rank target counts differ), L = 37 -> the persistent
+                          sweeps, V = 3 010 -> the fused / vocabulary-split CE; 32 graphs per rank
+      wd-articles:        config 5's (configs/autoreg_wd-articles.yaml:5-11): D = 512, Z = 128, GLOBAL batch 16 -> 8 graphs
+                          per rank, padded to the 16-row tiles; L = 259 -> sweep + CE in time chunks"""
+    from tests.parity_util import load_golden
+    from tests.test_configs_gpu import _cfg
+    if variant.startswith("wd-movies"):
+        return dict(_cfg(128, 64, 3000, 3, 12, True), dec_dropout=0.1 if variant.endswith("-drop") else 0.0), 64, True
+    if variant == "wd-articles":
+        return _cfg(512, 128, 2500, 6, 86, True), 16, True
+    _, cfg = load_golden("ark_synpaths_b32_s0" if variant == "ark" else "sail_synpaths_b32_s0")
+    return dict(cfg, dec_dropout=0.0), 128, False
+
+
 def main(rank, world, port, out_path, graph, steps, bf16=False, variant="sail"):
     from oracle import sail_oracle as O
-    from tests.parity_util import load_golden, synth_batch
+    from tests.parity_util import synth_batch
     from ark_amd.engine import Engine
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    # variants: "sail" (pipelined two-bucket schedule), "nopipe" (ark_dp_pipeline: false), "ark" (decoder-only: one bucket)
-    _, cfg = load_golden("ark_synpaths_b32_s0" if variant == "ark" else "sail_synpaths_b32_s0")
-    cfg = dict(cfg, dec_dropout=0.0, learning_rate=1e-3, ark_dp_bf16=bf16, ark_dp_pipeline=(variant != "nopipe"))
+    # variants: "sail" (pipelined two-bucket schedule), "nopipe" (ark_dp_pipeline: false), "ark" (decoder-only: one bucket),
+    # and the wd-shaped ones of case()
+    cfg, B, padded = case(variant)
+    cfg = dict(cfg, learning_rate=1e-3, ark_dp_bf16=bf16, ark_dp_pipeline=(variant != "nopipe"))
     sail = cfg["model_type"] == "SAIL"
     P = O.init_params(cfg, 0)
-    B = 128
     eng = Engine(cfg, dev, precision="mixed", world_size=world, rank=rank)
     eng.load_params(P)
     eng.set_hyper(lr=1e-3, beta=0.5)
@@ -34,7 +52,7 @@ def main(rank, world, port, out_path, graph, steps, bf16=False, variant="sail"):
     sl = slice(rank * Bl, (rank + 1) * Bl)
     batches = []
     for s in range(steps):
-        tri, seq = synth_batch(cfg, B, seed=20 + s)
+        tri, seq = synth_batch(cfg, B, seed=20 + s, padded=padded)
         torch.manual_seed(40 + s)
         eps = torch.randn(B, cfg["d_latent"])
         batches.append((tri, seq, eps, int((seq[:, 1:] != 0).sum())))
@@ -53,19 +71,29 @@ def main(rank, world, port, out_path, graph, steps, bf16=False, variant="sail"):
         else:
             def step():
                 return eng.train_step(tri_in, seq_in, eps_in, ce_count=eng._hp["CE_COUNT"], dp=True)
+        losses = []
         for (tri, seq, eps, cnt) in batches:
             seq_in.copy_(seq[sl].to(dev))
             if sail:
                 tri_in.copy_(tri[sl].to(dev)); eps_in.copy_(eps[sl].to(dev))
             eng.set_hyper(ce_count=cnt)
-            step()
+            losses.append(step()[:3].clone())
         eng.dp_flush()
         torch.cuda.synchronize()
     mine = eng.P.detach().cpu()
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
+    Lq = cfg["seq_len"] - 1
+    Bp = (Bl + 15) // 16 * 16
+    # which paths this rank took, its sweep error words, its own non-PAD target count of the first batch, its
+    # (token-loss / global count, kl) per step
+    info = torch.tensor([float(eng._use_sweep(Bp, Lq)), float(eng.fused_ce), float(eng._ce_chunks(Bp, Lq) is not None),
+                         float(eng.sweep_error()[0]), float((batches[0][1][sl][:, 1:] != 0).sum()), float(Bp)] +
+                        [float(x) for l3 in losses for x in l3.cpu()])
+    infos = [torch.empty_like(info) for _ in range(world)]
+    dist.all_gather(infos, info)
     if rank == 0:
-        torch.save({"P": gathered, "adam_steps": eng.adam_steps}, out_path)
+        torch.save({"P": gathered, "adam_steps": eng.adam_steps, "info": infos}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 

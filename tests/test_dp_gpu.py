@@ -29,9 +29,45 @@ def _free_port():
 def test_two_process_data_parallel_matches_single_process(tmp_path, graph, bf16, variant):
     """variants: the pipelined two-bucket SAIL schedule; the same with `ark_dp_pipeline: false` and decoder-only ARK (one
     bucket) -- both take the UNPIPELINED tail of Engine.train_step (wait, unpack, Adam), eager and captured"""
+    steps = 3
+    res = _run_two_ranks(tmp_path, graph, bf16, variant, steps)
+    P0, P1 = res["P"]
+    assert res["adam_steps"] == steps
+    assert torch.equal(P0, P1)          # identical Adam on identical reduced gradients
+    _single_process_reference(variant, steps, P0, bf16)
+
+
+def _single_process_reference(variant, steps, P0, bf16):
+    """ONE process training on the full global batch must land on the weights the ranks share"""
     from oracle import sail_oracle as O
     from ark_amd.engine import Engine
-    steps, B = 3, 128
+    from tests.dp_worker import case
+    cfg, B, padded = case(variant)
+    cfg = dict(cfg, learning_rate=1e-3)
+    sail = cfg["model_type"] == "SAIL"
+    eng = Engine(cfg, "cuda:0", precision="mixed")
+    eng.load_params(O.init_params(cfg, 0))
+    eng.set_hyper(lr=1e-3, beta=0.5)
+    dev = eng.device
+    for s in range(steps):
+        tri, seq = synth_batch(cfg, B, seed=20 + s, padded=padded)
+        torch.manual_seed(40 + s)
+        eps = torch.randn(B, cfg["d_latent"])
+        eng.train_step(tri.to(dev) if sail else None, seq.to(dev), eps.to(dev) if sail else None,
+                       ce_count=int((seq[:, 1:] != 0).sum()))
+    torch.cuda.synchronize()
+    assert eng.sweep_error() == (0, 0)
+    ref = eng.P.detach().cpu()
+    moved = (ref - O_flat(eng, O.init_params(cfg, 0))).abs().max().item()
+    assert moved > 1e-3                  # the weights did train
+    # Adam normalises the update: where a gradient is ~0 its rounded sign decides a full +-lr step, so the worst single
+    # weight may differ by up to ~lr per step (3 steps x 1e-3); the mean below is the meaningful bar
+    assert (P0 - ref).abs().max().item() <= steps * 1e-3 * 1.05
+    # (bf16 transport of the gradient buckets, `ark_dp_bf16`: the reduced gradients carry 8 significant bits)
+    assert (P0 - ref).abs().mean().item() <= (1e-4 if bf16 else 2e-5)
+
+
+def _run_two_ranks(tmp_path, graph, bf16, variant, steps):
     out = str(tmp_path / "dp.pt")
     port = _free_port()
     env = dict(os.environ, PYTHONPATH=ROOT)
@@ -45,33 +81,47 @@ def test_two_process_data_parallel_matches_single_process(tmp_path, graph, bf16,
             if p.poll() is None:
                 p.kill()
     assert rcs == [0, 0], rcs
-    res = torch.load(out, weights_only=True)
+    return torch.load(out, weights_only=True)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("variant", ["wd-movies", "wd-articles"])
+def test_two_process_data_parallel_at_wd_shapes(tmp_path, graph, variant):
+    """BASELINE.json configs 4 and 5 are DATA-PARALLEL configurations of the wd datasets; round 3's two-process tests ran
+    the syn-paths shape only.  Here both ranks take the paths those shapes take -- persistent forward and backward
+    sweeps, the fused / vocabulary-split CE (in time chunks beside the sweep for the long sequences), padded graphs whose
+    non-PAD target counts differ per rank, and (wd-articles: 16 graphs globally) an 8-graph shard padded to the 16-row
+    tiles -- eager and captured, and must land on the weights of ONE process training on the full batch.
+    Reference: configs/autoreg_wd-movies.yaml:7-12, autoreg_wd-articles.yaml:5-11; partition: SURVEY.md section 8e."""
+    steps = 3
+    res = _run_two_ranks(tmp_path, graph, False, variant, steps)
     P0, P1 = res["P"]
-    assert res["adam_steps"] == steps
-    assert torch.equal(P0, P1)          # identical Adam on identical reduced gradients
-    # single process, full batch
-    _, cfg = load_golden("ark_synpaths_b32_s0" if variant == "ark" else "sail_synpaths_b32_s0")
-    cfg = dict(cfg, dec_dropout=0.0, learning_rate=1e-3)
-    sail = cfg["model_type"] == "SAIL"
-    eng = Engine(cfg, "cuda:0", precision="mixed")
-    eng.load_params(O.init_params(cfg, 0))
-    eng.set_hyper(lr=1e-3, beta=0.5)
-    dev = eng.device
-    for s in range(steps):
-        tri, seq = synth_batch(cfg, B, seed=20 + s)
-        torch.manual_seed(40 + s)
-        eps = torch.randn(B, cfg["d_latent"])
-        eng.train_step(tri.to(dev) if sail else None, seq.to(dev), eps.to(dev) if sail else None,
-                       ce_count=int((seq[:, 1:] != 0).sum()))
-    torch.cuda.synchronize()
-    ref = eng.P.detach().cpu()
-    moved = (ref - O_flat(eng, O.init_params(cfg, 0))).abs().max().item()
-    assert moved > 1e-3                  # the weights did train
-    # Adam normalises the update: where a gradient is ~0 its rounded sign decides a full +-lr step, so the worst single
-    # weight may differ by up to ~lr per step (3 steps x 1e-3); the mean below is the meaningful bar
-    assert (P0 - ref).abs().max().item() <= steps * 1e-3 * 1.05
-    # (bf16 transport of the gradient buckets, `ark_dp_bf16`: the reduced gradients carry 8 significant bits)
-    assert (P0 - ref).abs().mean().item() <= (1e-4 if bf16 else 2e-5)
+    assert res["adam_steps"] == steps and torch.equal(P0, P1)
+    i0, i1 = [t.tolist() for t in res["info"]]
+    for info in (i0, i1):
+        assert info[0] == 1.0 and info[1] == 1.0 and info[3] == 0.0, info      # sweeps ran, fused CE ran, nobody gave up
+        assert info[2] == (1.0 if variant == "wd-articles" else 0.0), info     # time-chunked sweep + CE pipeline
+    assert i0[4] != i1[4]                                                        # unequal non-PAD target counts
+    if variant == "wd-articles":
+        assert i0[5] == 16.0                                                     # the 8-graph shard ran padded to 16 rows
+    _single_process_reference(variant, steps, P0, False)
+
+
+def test_two_process_data_parallel_with_dropout_on_the_sweep_path(tmp_path):
+    """dropout on (the masks mix the rank: no single-process twin exists): both ranks' persistent sweeps run to the end
+    (error words zero), the ranks stay bit-identical, the loss is finite and falls"""
+    steps = 4
+    res = _run_two_ranks(tmp_path, True, True, "wd-movies-drop", steps)
+    P0, P1 = res["P"]
+    assert res["adam_steps"] == steps and torch.equal(P0, P1) and torch.isfinite(P0).all()
+    for info in res["info"]:
+        info = info.tolist()
+        assert info[0] == 1.0 and info[3] == 0.0, info
+        ce = info[6 + 1::3]
+        assert all(c == c and c > 0 for c in ce)
+    # (a rank's CE term is ITS token losses over the GLOBAL count: the ranks' terms add up to the batch's CE)
+    ce_tot = [a + b for a, b in zip(res["info"][0].tolist()[7::3], res["info"][1].tolist()[7::3])]
+    assert ce_tot[-1] < ce_tot[0] + 0.02, ce_tot   # (a fresh batch per step, four steps: no worse, usually lower)
 
 
 def O_flat(eng, P):

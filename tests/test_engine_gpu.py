@@ -662,6 +662,109 @@ def test_gru_diag_fwd_matches_torch_gru_cell(B, D, n_roles):
             assert (sv.float().cpu()[idx].reshape(B, D) - want).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("B,D,V", [(64, 128, 55), (48, 256, 36)])
+def test_gru_diag_fwd_token_table_role(B, D, V):
+    """layer 0 of a small vocabulary through the C-ABI: a role with x_tab / x_tok (rows of W_tok16 W_ih16^T by token id,
+    formed by ark_gemm16 as the engine does) beside an ordinary role in ONE launch, both against fp32 GRU-cell math on the
+    same fp16-rounded operands.  Reference: the input half of nn.GRU, kgvae/model/models.py:121-127, on nn.Embedding rows
+    (:119, :137)."""
+    from ark_amd import _lib as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + D + V)
+    idx = _tile_native_index(B, D).reshape(-1)
+    wtok = (torch.randn(V, D, generator=g) * 0.5).half()
+    tok = torch.randint(0, V, (B,), generator=g)
+    roles = (L.GruDiagRole * L.DIAG_MAX_ROLES)()
+    keep, refs = [], []
+    for k in range(2):
+        x = wtok[tok] if k == 0 else (torch.randn(B, D, generator=g) * 0.5).half()
+        h = torch.tanh(torch.randn(B, D, generator=g))
+        wih = (torch.randn(3 * D, D, generator=g) * 0.1).half()
+        whh = (torch.randn(3 * D, D, generator=g) * 0.1).half()
+        bih, bhh = torch.randn(3 * D, generator=g) * 0.1, torch.randn(3 * D, generator=g) * 0.1
+        h16 = h.half()
+        gi = x.float() @ wih.float().t() + bih
+        gh = h16.float() @ whh.float().t() + bhh
+        r = torch.sigmoid(gi[:, :D] + gh[:, :D])
+        z = torch.sigmoid(gi[:, D:2 * D] + gh[:, D:2 * D])
+        n = torch.tanh(gi[:, 2 * D:] + r * gh[:, 2 * D:])
+        refs.append(((1 - z) * n + z * h, r, z, n, gh[:, 2 * D:]))
+        y_prev_t = torch.zeros(B * D)
+        y_prev_t[idx] = h.reshape(-1)
+        bufs = dict(x=x.to(dev), h16=h16.to(dev), wih=wih.to(dev), whh=whh.to(dev), bih=bih.to(dev), bhh=bhh.to(dev),
+                    yp=y_prev_t.to(dev), yo=torch.zeros(B * D, device=dev), ya=torch.zeros(B, D, dtype=torch.float16, device=dev),
+                    sv=[torch.zeros(B * D, dtype=torch.float16, device=dev) for _ in range(4)])
+        ro = roles[k]
+        if k == 0:
+            bufs["wtok"], bufs["tok"] = wtok.to(dev), tok.to(dev, dtype=torch.int32)
+            bufs["tab"] = torch.full((V, 3 * D), float("nan"), device=dev)
+            L.check(L.lib().ark_gemm16(L.i32(L.PREC_F16), L.i32(L.EPI_NONE), L.ptr(bufs["wtok"]), L.i64(D), L.ptr(bufs["wih"]), L.i64(D),
+                                       L.ptr(bufs["tab"]), L.i64(3 * D), L.ptr(None), L.ptr(None), L.i32(V), L.i32(3 * D), L.i32(D),
+                                       L.i32(0), L.cur_stream()), "ark_gemm16")
+            ro.x_tab, ro.x_tok = L.dptr(bufs["tab"]), L.dptr(bufs["tok"])      # (x16 / w_ih16 stay NULL)
+        else:
+            ro.x16, ro.w_ih16 = L.dptr(bufs["x"]), L.dptr(bufs["wih"])
+        keep.append(bufs)
+        ro.h_prev16, ro.w_hh16 = L.dptr(bufs["h16"]), L.dptr(bufs["whh"])
+        ro.b_ih, ro.b_hh, ro.y_prev_t, ro.y_out_t = (L.dptr(bufs[n_]) for n_ in ("bih", "bhh", "yp", "yo"))
+        ro.y16a = L.dptr(bufs["ya"])
+        ro.save_r, ro.save_z, ro.save_n, ro.save_hn = (L.dptr(t) for t in bufs["sv"])
+        ro.drop_p = 0.0
+    L.check(L.lib().ark_gru_diag_fwd(L.i32(L.PREC_F16), L.i32(L.PREC_F16), L.i32(2), roles, L.ptr(None), L.i32(B), L.i32(D),
+                                     L.ptr(None), L.cur_stream()), "ark_gru_diag_fwd")
+    torch.cuda.synchronize()
+    tab = keep[0]["tab"].cpu()
+    assert (tab - wtok.float() @ keep[0]["wih"].float().cpu().t()).abs().max().item() < 1e-4
+    for bufs, (hn, r, z, n, ghn) in zip(keep, refs):
+        got = bufs["yo"].cpu()[idx].reshape(B, D)
+        assert (got - hn).abs().max().item() < 2e-5
+        assert (bufs["ya"].float().cpu() - hn).abs().max().item() < 1e-3
+        for sv, want in zip(bufs["sv"], (r, z, n, ghn)):
+            assert (sv.float().cpu()[idx].reshape(B, D) - want).abs().max().item() < 2e-3
+    # a role must name its input one way or the other
+    roles[1].x16 = 0
+    rc = L.lib().ark_gru_diag_fwd(L.i32(L.PREC_F16), L.i32(L.PREC_F16), L.i32(2), roles, L.ptr(None), L.i32(B), L.i32(D),
+                                  L.ptr(None), L.cur_stream())
+    assert rc < 0
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_token_table_forward_agrees_with_the_streamed_input_projection(drop):
+    """`ark_fwd_tab` (default on for V <= 256): layer 0's roles add rows of x_tab = W_tok W_ih0^T instead of streaming
+    x_t W_ih0^T, and the 16-bit embedding rows X0 are not gathered at all.  Same states, loss, gradients as the streamed
+    path (fp32 sums in another order), over three optimiser steps (the table is refreshed with the weights)."""
+    from oracle import sail_oracle as O
+    cfg = dict(_big_cfg(), dec_dropout=drop)
+    P = O.init_params(cfg, 0)
+    B = 256
+    triples, seq = synth_batch(cfg, B, seed=3)
+    torch.manual_seed(5)
+    eps = torch.randn(B, cfg["d_latent"])
+    a = make_engine(dict(cfg, ark_fwd_tab=0), P, "mixed", lr=1e-3)
+    b = make_engine(cfg, P, "mixed", lr=1e-3)
+    assert a.xtab is None and b.xtab is not None
+    dev = a.device
+    args = (triples.to(dev), seq.to(dev), eps.to(dev))
+    for eng in (a, b):
+        eng.set_hyper(beta=0.1)
+    a.drop_seed = b.drop_seed = 1234
+    for step in range(3):
+        oa = a.train_step(*args).cpu().numpy()
+        ob = b.train_step(*args).cpu().numpy()
+        torch.cuda.synchronize()
+        assert b._skip_x0(b.ws, B, b.L) and not a._skip_x0(a.ws, B, a.L)
+        assert rel_err(float(ob[0]), float(oa[0])) < 2e-5, (step, oa, ob)
+        for l in range(cfg["n_layers"]):
+            assert (a.ws["Y"][l] - b.ws["Y"][l]).abs().max().item() < 2e-3, (step, l)
+        if step == 0:
+            for k in a.g:
+                da, db = a.g[k].float(), b.g[k].float()
+                assert (da - db).norm().item() <= 5e-3 * da.norm().item() + 1e-9, k
+    want = b.wtok16.view(torch.float16).float() @ b.wih16[0].view(torch.float16).float().t()
+    assert (b.xtab - want).abs().max().item() < 1e-4      # the table follows the updated shadows
+    assert (a.P - b.P).abs().max().item() <= 3 * 1e-3 * 1.05 and (a.P - b.P).abs().mean().item() < 2e-5
+
+
 @pytest.mark.parametrize("top", [False, True])
 def test_gru_diag_bwd_matches_autograd(top):
     """ark_gru_diag_bwd through the C-ABI against torch autograd of one GRU cell: dh = carry + dgh_next W_hh + dy with

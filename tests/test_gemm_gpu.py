@@ -318,13 +318,16 @@ def test_fused_vocabulary_cross_entropy(prec, tol, B, Lq, V, D):
     assert close(dW.double().cpu() - 0.25, Wd.grad, tol), ((dW.double().cpu() - 0.25) - Wd.grad).abs().max().item() / Wd.grad.abs().max().item()
     assert close(db.double().cpu() - 0.5, bd.grad, tol)
     # few rows x a wide model: the vocabulary-split forward (several workgroups per row block + a merging launch)
-    nv = L.lib().ark_vocab_ce_fwd_splits(L.i32(R), L.i32(V), L.i32(D))
-    assert (nv > 1) == (V > 4096)
-    if nv > 1:
-        ws = torch.full((nv * (R * D + 4 * R),), float("nan"), device=dev)
+    nv0 = L.lib().ark_vocab_ce_fwd_splits(L.i32(R), L.i32(V), L.i32(D), L.i32(0))
+    assert (nv0 > 1) == (V > 4096)
+    # (cu_budget: the CUs a persistent sweep beside the launch leaves free -- fewer, larger splits, the same result)
+    for budget in ((0, 160) if nv0 > 1 else ()):
+        nv = L.lib().ark_vocab_ce_fwd_splits(L.i32(R), L.i32(V), L.i32(D), L.i32(budget))
+        assert 1 <= nv <= nv0 and ((R + 63) // 64) * nv <= max(budget or 256, (R + 63) // 64)
+        ws = torch.full((max(nv, 2) * (R * D + 4 * R),), float("nan"), device=dev)
         rl2, lse2, dY2 = torch.full((R,), 9.0, device=dev), torch.full((R,), 9.0, device=dev), torch.full((R * D,), 9.0, device=dev)
-        L.check(L.lib().ark_vocab_ce_fwd_ws(*common, L.ptr(rl2), L.ptr(lse2), L.ptr(dY2), L.ptr(ws), L.i64(ws.numel()), *tail),
-                "ark_vocab_ce_fwd_ws")
+        L.check(L.lib().ark_vocab_ce_fwd_ws(*common, L.ptr(rl2), L.ptr(lse2), L.ptr(dY2), L.ptr(ws), L.i64(ws.numel()), *tail[:-1],
+                                            L.i32(budget), tail[-1]), "ark_vocab_ce_fwd_ws")
         torch.cuda.synchronize()
         assert (rl2.double().cpu() - per_row.detach()).abs().max().item() <= 2e-5 * per_row.max().item()
         assert (lse2.double().cpu() - lse_ref).abs().max().item() <= 2e-5 * lse_ref.abs().max().item()

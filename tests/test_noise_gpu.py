@@ -37,6 +37,38 @@ def test_normal_fill_is_standard_normal_and_counter_based():
     assert odd.shape == (7,) and torch.isfinite(odd).all()
 
 
+def test_no_draw_replays_a_shifted_copy_of_another_draw():
+    """the first generator mixed (index, draw) LINEARLY -- i * 0x9E3779B1 + draw * 0x85EBCA77 -- so draw
+    s + 433 983 was draw s shifted by 1 511 pairs (433 983 * 0x85EBCA77 + 1 511 * 0x9E3779B1 = 0 mod 2^32), 151 183 draws
+    apart for 16 k pairs.  The draw counter is now hashed on its own first: the two draws (and a few neighbours of that
+    lattice) share no shifted run, and the dropout masks -- same construction -- do not either."""
+    from ark_amd import _lib as L
+    hyper = torch.zeros(16, device="cuda")
+    n = 1 << 15
+
+    def draw(k):
+        hyper.view(torch.int32)[13] = k
+        return _fill(n, 99, hyper).cpu().numpy()
+    assert (433983 * 0x85EBCA77 + 1511 * 0x9E3779B1) % (1 << 32) == 0       # the relation the old hash fell to
+    for s, ds, dp in ((5, 433983, 1511), (0, 151183, 12417 - 1511), (17, 2 * 433983, 2 * 1511)):
+        a, b = draw(s), draw(s + ds)
+        best = 0.0
+        for shift in {2 * dp, 2 * dp + 1, 2 * dp - 1, 0} | set(range(0, 64)):
+            if 0 <= shift < n - 4096:
+                best = max(best, float(np.mean(a[shift:shift + 4096] == b[:4096])), float(np.mean(b[shift:shift + 4096] == a[:4096])))
+        assert best < 0.01, (s, ds, best)
+    # dropout masks: ark_dropout_mask of two draws on that lattice
+    m = []
+    for k in (3, 3 + 433983):
+        hyper.view(torch.int32)[12] = k
+        out = torch.empty(n, device="cuda")
+        L.check(L.lib().ark_dropout_mask(L.ptr(out), L.i64(n), L.f32(0.5), L.u64(4242), L.ptr(hyper), L.cur_stream()), "mask")
+        m.append((out.cpu().numpy() != 0))
+    for shift in (0, 4 * 1511, 4 * 1511 - 4, 4 * 1511 + 4):
+        agree = float(np.mean(m[0][shift:shift + 8192] == m[1][:8192]))
+        assert 0.45 < agree < 0.55, (shift, agree)
+
+
 def test_engine_noise_is_fresh_per_step_per_rank_and_resumable():
     from ark_amd.engine import Engine
     from oracle import sail_oracle as O

@@ -16,11 +16,11 @@ rl, lse, dY = torch.zeros(R, device=dev), torch.zeros(R, device=dev), torch.zero
 dW, db = torch.zeros(V, D, device=dev), torch.zeros(V, device=dev)
 common = (L.i32(L.PREC_F16), L.ptr(Y), L.ptr(W), L.ptr(bias), L.ptr(seq), L.i64(Lq + 1), L.ptr(hyper))
 tail = (L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), L.cur_stream())
-nv = L.lib().ark_vocab_ce_fwd_splits(L.i32(R), L.i32(V), L.i32(D))
+nv = L.lib().ark_vocab_ce_fwd_splits(L.i32(R), L.i32(V), L.i32(D), L.i32(0))
 ws = torch.empty(nv * (R * D + 4 * R), device=dev) if nv > 1 else None
 print("vocabulary splits:", nv)
 def fwd():
-    if nv > 1: L.check(L.lib().ark_vocab_ce_fwd_ws(*common, L.ptr(rl), L.ptr(lse), L.ptr(dY), L.ptr(ws), L.i64(ws.numel()), *tail), "f")
+    if nv > 1: L.check(L.lib().ark_vocab_ce_fwd_ws(*common, L.ptr(rl), L.ptr(lse), L.ptr(dY), L.ptr(ws), L.i64(ws.numel()), *tail[:-1], L.i32(0), tail[-1]), "f")
     else: L.check(L.lib().ark_vocab_ce_fwd(*common, L.ptr(rl), L.ptr(lse), L.ptr(dY), *tail), "f")
 def dw(): L.check(L.lib().ark_vocab_ce_dw(*common, L.ptr(lse), L.ptr(dW), L.ptr(db), *tail), "d")
 def fwd1(): L.check(L.lib().ark_vocab_ce_fwd(*common, L.ptr(rl), L.ptr(lse), L.ptr(dY), *tail), "f")
