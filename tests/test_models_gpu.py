@@ -388,7 +388,8 @@ def test_checkpoint_format_and_resume(tmp_path):
     assert moved > 1e-3      # the second epoch did train: the resumed run is not trivially equal
     for i, s2 in ck2["optimizer_state_dict"]["state"].items():
         sr = ckr["optimizer_state_dict"]["state"][i]
-        torch.testing.assert_close(s2["exp_avg"], sr["exp_avg"], rtol=1e-4, atol=1e-9)
+        # (fp32 atomics of the split-K weight gradients land in another order on the resumed run: ~1e-7 of the gradient)
+        torch.testing.assert_close(s2["exp_avg"], sr["exp_avg"], rtol=1e-4, atol=1e-8)
         torch.testing.assert_close(s2["exp_avg_sq"], sr["exp_avg_sq"], rtol=1e-4, atol=1e-12)
         assert float(s2["step"]) == float(sr["step"]) == 8.0
     assert ck2["ark_amd"]["dropout_draws"] == ckr["ark_amd"]["dropout_draws"] == 8
