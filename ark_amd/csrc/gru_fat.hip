@@ -1,0 +1,411 @@
+// Weights-stationary forward recurrence of a FULL batch (syn-paths: 1024 graphs x 10 steps x 3 layers, D = 512).
+//
+// The layer-diagonal launches (gru_diag.hip) re-stream every weight panel through LDS for every cell: with three 64 x 32
+// tiles per CU a forward diagonal moves 819-983 KB per CU through the ~100 GB/s L2 -> LDS path and takes 18.5 us for 3.9 us
+// of MFMA work; three rounds of tile / ring / residency tuning never got past 0.84 of that path's ceiling, because the limit
+// is BYTES PER CU, and two thirds of those bytes are weights that never change during the step.  The 9.4 MB of 16-bit GRU
+// weights fit the chip's register files (128 MB).  So here, as in gru_sweep.hip but for many rows:
+//
+//   workgroup (layer l, unit slice s, row group g): US = 32 hidden units (16 at D = 1024) x 3 gates x K = 2D of W_ih / W_hh
+//   = 196 KB live in the registers of its 4 waves (K split four ways, 192 VGPRs each, one wave per SIMD) for the WHOLE
+//   recurrence; per step it walks the 16-row tiles of its row group: the tile's x / h fragments come straight from global
+//   memory into MFMA A operands (each wave loads only ITS K-quarter: no redundant operand traffic, no LDS staging), the four
+//   K-partials meet in LDS, all 256 threads do the gate math, the new state goes to the next step's consumers through the
+//   exchange buffer of gru_sweep.hip (write-through stores + one monotone counter per (layer, step, row subgroup)).
+//   Per CU and step: 13 tiles x 32 KB of activations = 416 KB instead of 819-983 KB, and no launch boundary, ring prologue
+//   or drain between the steps.
+//
+// Schedule.  A row group is walked as TWO subgroups with counters of their own: while the workgroups of a (layer, row group)
+// -- 16 of them, one per unit slice, all waiting on each other -- finish subgroup B of step t, the hand-off of subgroup A is
+// already complete, so the counter round trip hides behind the other half's arithmetic.  Inside a subgroup the tiles are
+// software-pipelined: fragments of tile k + 2 are in flight while tile k + 1 multiplies and tile k's gate math runs.
+// Workgroup ids are dealt so that the 16 slices of a (layer, row group) share an XCD (ids are dealt round-robin over the 8
+// XCDs): the recurrent hand-off then stays inside one L2 (speed only; nothing relies on it).
+//
+// Payload LOADS are plain (L2-cached) loads: every exchange line is written once per launch and read only after its counter
+// says so, and a launch starts with clean caches, so no stale copy can exist; the 16 consumers of a line then share one
+// fetch.  Stores are write-through (`sc1`) and drained before the counter moves, exactly as in gru_sweep.hip.
+// Outputs are those of the diagonal launches (tile-native fp32 state, fp16 gate saves, row-major 16-bit copies, dropout-
+// applied copies from the same counter hash), so CE, backward and tests do not know which forward ran.
+// Reference op replaced: torch.nn.GRU forward (kgvae/model/models.py:121-127, 141).
+#include "sweep_sync.h"
+#include "../../include/ark_amd.h"
+
+#ifndef ARK_FAT_LD_AUX
+#define ARK_FAT_LD_AUX 0   // cache policy of the payload loads: 0 = plain (see above), 16 = sc1 (debugging aid)
+#endif
+
+namespace ark {
+
+struct GruFatArgs {
+  ArkGruSweep a;
+  int NG;          // row groups (each walked as two subgroups)
+  int xcd_pairs;   // 1: the NS slices of a (layer, row group) pair share an XCD
+};
+
+constexpr int kFatMaxTiles = 16;   // 16-row tiles per workgroup (both subgroups): bounds the LDS state array
+
+__device__ __forceinline__ u32x4 ld_pay(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, ARK_FAT_LD_AUX);
+}
+
+// D = 128 * KSW; UT 16-unit tiles per workgroup (US = 16 * UT units); 4 waves, wave w owns K-steps [w*KSW, (w+1)*KSW) of
+// both products
+template <int PREC, int PRECB, int KSW, int UT>
+__global__ __launch_bounds__(256) void gru_fat_fwd_kernel(GruFatArgs pa) {
+  using PT = PrecTraits<PREC>;
+  using PB = PrecTraits<PRECB>;
+  using h_t = typename PT::h_t;
+  using h8 = typename PT::h8;
+  using hb_t = typename PB::h_t;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ArkGruSweep& p = pa.a;
+  constexpr int D = 128 * KSW, US = 16 * UT, NS = D / US, NS16 = D / 16;
+  constexpr int TS = US + 8;                                  // row stride of the transposition tiles (halves)
+  constexpr int PART_B = 2 * 4 * 4 * UT * 64 * 16;            // [2 buffers][4 waves][4 accumulators][UT][64 lanes] f32x4
+  constexpr int STATE_B = kFatMaxTiles * UT * 64 * 16;        // [local tile][UT][64 lanes] f32x4: fp32 state of this workgroup's rows
+  constexpr int TILE_B = 16 * TS * 2;                         // one 16-row transposition tile
+  f32x4* part = reinterpret_cast<f32x4*>(smem);
+  f32x4* state = reinterpret_cast<f32x4*>(smem + PART_B);
+  char* tiles = smem + PART_B + STATE_B;                      // [2 buffers][4 arrays: h fwd | h*mask fwd | h bwd | h*mask bwd]
+  int* lflag = reinterpret_cast<int*>(smem + PART_B + STATE_B + 2 * 4 * TILE_B);
+
+  const int B = p.B, L = p.L, n = p.n_layers, NG = pa.NG;
+  const int RT = B >> 4, NSG = 2 * NG, NP = n * NG;
+  unsigned* sync = p.sync;
+  unsigned* cnt = p.sync + kSweepSyncHdr;
+  // workgroup -> (pair = layer * NG + row group, unit slice)
+  int pair, s;
+  if (pa.xcd_pairs) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    pair = xcd + 8 * (j / NS);
+    s = j % NS;
+  } else {
+    pair = blockIdx.x / NS;
+    s = blockIdx.x % NS;
+  }
+  const unsigned need = sweep_enter(sync, lflag, (unsigned)NS);
+  __syncthreads();
+  if (pair >= NP || *lflag != 0) {   // (block-uniform) a filler id of the XCD map, or a poisoned workspace: nothing to do
+    sweep_leave(sync);
+    return;
+  }
+  const int l = pair / NG, g = pair - l * NG;
+  const ArkGruSweepLayer& Ly = p.layer[l];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, kg = lane >> 4;
+
+  // this workgroup's weight rows as MFMA B fragments, for the whole recurrence
+  h8 wx[3][UT][KSW], wh[3][UT][KSW];
+  {
+    const h_t* wi = reinterpret_cast<const h_t*>(Ly.w_ih16);
+    const h_t* wr = reinterpret_cast<const h_t*>(Ly.w_hh16);
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+      for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+        for (int j = 0; j < KSW; ++j) {
+          const long o = (long)(gt * D + s * US + ut * 16 + r) * D + (wave * KSW + j) * 32 + kg * 8;
+          wx[gt][ut][j] = *reinterpret_cast<const h8*>(wi + o);
+          wh[gt][ut][j] = *reinterpret_cast<const h8*>(wr + o);
+        }
+  }
+  // epilogue mapping: thread -> (unit tile eut, MFMA lane ln, row half hf): rows 4*(ln>>4) + 2*hf + {0, 1}, unit ln & 15
+  const int eq = tid >> 1, hf = tid & 1;
+  const int eut = eq >> 6, ln = eq & 63;
+  const bool eact = eut < UT;                       // (UT = 1: the upper half of the workgroup has no element)
+  const int eu = s * US + (eact ? eut : 0) * 16 + (ln & 15);
+  const float br = Ly.b_ih[eu] + Ly.b_hh[eu], bz = Ly.b_ih[D + eu] + Ly.b_hh[D + eu];
+  const float bin = Ly.b_ih[2 * D + eu], bhn = Ly.b_hh[2 * D + eu];
+  const bool drop = Ly.drop_p > 0.f;
+  const bool below_drop = l > 0 && p.layer[l - 1].drop_p > 0.f;
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(Ly.drop_seed, p.hyper, Ly.drop_p);
+  const long slot = (long)B * D;                    // elements per timestep
+  const unsigned RG = (unsigned)(slot * 2);         // bytes of one exchange region == of one row-major 16-bit slot
+  const __amdgpu_buffer_rsrc_t rx = sweep_rsrc(p.x0_16, RG * (unsigned)L);
+  const __amdgpu_buffer_rsrc_t rh0 = sweep_rsrc(Ly.y16a, RG);
+  const __amdgpu_buffer_rsrc_t rex = sweep_rsrc(p.exch, RG * (unsigned)(2 * L * n));
+  // per-lane fragment offsets inside a 16-row tile (tile rt adds rt * 16 * D * 2 bytes in both layouts)
+  int voff_rm[KSW], voff_ex[KSW];
+#pragma unroll
+  for (int j = 0; j < KSW; ++j) {
+    const int ks = wave * KSW + j;
+    voff_rm[j] = (r * D + ks * 32 + kg * 8) * 2;
+    voff_ex[j] = ((ks * 2 + (kg >> 1)) * 16 + r) * 32 + (kg & 1) * 16;
+  }
+  const int tile_bytes = 16 * D * 2;
+  const int g_rt0 = (2 * g) * RT / NSG;             // first tile of this workgroup (local tile index = rt - g_rt0)
+
+  // fp32 state of the workgroup's rows: slot 0 of the tile-native state array
+  {
+    const int g_rt1 = (2 * g + 2) * RT / NSG;
+    if (eact)
+      for (int rt = g_rt0; rt < g_rt1; ++rt) {
+        const long o = (long)(rt * NS16 + s * UT + eut) * 256 + ln * 4 + 2 * hf;
+        reinterpret_cast<f32x2*>(state + ((rt - g_rt0) * UT + eut) * 64 + ln)[hf] = *reinterpret_cast<const f32x2*>(Ly.y_t + o);
+      }
+  }
+  __syncthreads();
+
+  auto load_tile = [&](int t, int rt, u32x4 (&xa)[KSW], u32x4 (&ha)[KSW]) {
+    const int to = rt * tile_bytes;
+    if (l == 0) {
+      const int so = (int)((unsigned)t * RG) + to;
+#pragma unroll
+      for (int j = 0; j < KSW; ++j) xa[j] = ld_pay(rx, voff_rm[j], so);
+    } else {
+      const int so = (int)((unsigned)(((l - 1) * L + t) * 2 + (below_drop ? 1 : 0)) * RG) + to;
+#pragma unroll
+      for (int j = 0; j < KSW; ++j) xa[j] = ld_pay(rex, voff_ex[j], so);
+    }
+    if (t == 0) {
+#pragma unroll
+      for (int j = 0; j < KSW; ++j) ha[j] = ld_pay(rh0, voff_rm[j], to);
+    } else {
+      const int so = (int)((unsigned)((l * L + (t - 1)) * 2) * RG) + to;
+#pragma unroll
+      for (int j = 0; j < KSW; ++j) ha[j] = ld_pay(rex, voff_ex[j], so);
+    }
+  };
+  auto multiply = [&](const u32x4 (&xa)[KSW], const u32x4 (&ha)[KSW], f32x4 (&acc)[4][UT]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int ut = 0; ut < UT; ++ut) acc[a][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+      const h8 a = __builtin_bit_cast(h8, xa[j]);
+#pragma unroll
+      for (int ut = 0; ut < UT; ++ut) {
+        acc[0][ut] = PT::mfma(a, wx[0][ut][j], acc[0][ut]);
+        acc[1][ut] = PT::mfma(a, wx[1][ut][j], acc[1][ut]);
+        acc[2][ut] = PT::mfma(a, wx[2][ut][j], acc[2][ut]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+      const h8 a = __builtin_bit_cast(h8, ha[j]);
+#pragma unroll
+      for (int ut = 0; ut < UT; ++ut) {
+        acc[0][ut] = PT::mfma(a, wh[0][ut][j], acc[0][ut]);
+        acc[1][ut] = PT::mfma(a, wh[1][ut][j], acc[1][ut]);
+        acc[3][ut] = PT::mfma(a, wh[2][ut][j], acc[3][ut]);
+      }
+    }
+  };
+  auto put_part = [&](int buf, const f32x4 (&acc)[4][UT]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int ut = 0; ut < UT; ++ut) part[(((buf * 4 + wave) * 4 + a) * UT + ut) * 64 + lane] = acc[a][ut];
+  };
+  // gate math of tile rt (partials in part[buf]) by all threads; leaves the 16-bit copies in the transposition tiles [buf]
+  auto epilogue = [&](int t, int rt, int buf) {
+    if (!eact) return;
+    f32x2 sum[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      sum[a] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sum[a] += reinterpret_cast<const f32x2*>(part + (((buf * 4 + w) * 4 + a) * UT + eut) * 64 + ln)[hf];
+    }
+    f32x2* st = reinterpret_cast<f32x2*>(state + ((rt - g_rt0) * UT + eut) * 64 + ln) + hf;
+    const f32x2 hp = *st;
+    f32x2 rr, zz, nn, hn, h;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rr[i] = fast_sigmoid(sum[0][i] + br);
+      zz[i] = fast_sigmoid(sum[1][i] + bz);
+      hn[i] = sum[3][i] + bhn;
+      nn[i] = fast_tanh(sum[2][i] + bin + rr[i] * hn[i]);
+      h[i] = nn[i] + zz[i] * (hp[i] - nn[i]);   // (1-z) n + z h_prev
+    }
+    *st = h;
+    const long o = (long)(rt * NS16 + s * UT + eut) * 256 + ln * 4 + 2 * hf;   // tile-native offset inside a slot
+    *reinterpret_cast<f32x2*>(Ly.y_t + (long)(t + 1) * slot + o) = h;
+    if (Ly.save_r) {
+      const long so = (long)t * slot + o;
+      *reinterpret_cast<half2_t*>(reinterpret_cast<_Float16*>(Ly.save_r) + so) = half2_t{(_Float16)rr[0], (_Float16)rr[1]};
+      *reinterpret_cast<half2_t*>(reinterpret_cast<_Float16*>(Ly.save_z) + so) = half2_t{(_Float16)zz[0], (_Float16)zz[1]};
+      *reinterpret_cast<half2_t*>(reinterpret_cast<_Float16*>(Ly.save_n) + so) = half2_t{(_Float16)nn[0], (_Float16)nn[1]};
+      *reinterpret_cast<half2_t*>(reinterpret_cast<_Float16*>(Ly.save_hn) + so) = half2_t{(_Float16)hn[0], (_Float16)hn[1]};
+    }
+    char* tb = tiles + buf * 4 * TILE_B;
+    const int row = 4 * (ln >> 4) + 2 * hf, col = eut * 16 + (ln & 15);
+    h_t* ta = reinterpret_cast<h_t*>(tb);
+    hb_t* tbw = reinterpret_cast<hb_t*>(tb + 2 * TILE_B);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ta[(row + i) * TS + col] = PT::cvt(h[i]);
+      tbw[(row + i) * TS + col] = PB::cvt(h[i]);
+    }
+    if (drop) {
+      const f32x4 m4 = dropout_quad(dc, (uint64_t)((long)(p.t0 + t) * slot + (o - 2 * hf)) >> 2);
+      const float m0 = hf ? m4[2] : m4[0], m1 = hf ? m4[3] : m4[1];
+      h_t* tda = reinterpret_cast<h_t*>(tb + TILE_B);
+      hb_t* tdb = reinterpret_cast<hb_t*>(tb + 3 * TILE_B);
+      tda[row * TS + col] = PT::cvt(h[0] * m0);
+      tda[(row + 1) * TS + col] = PT::cvt(h[1] * m1);
+      tdb[row * TS + col] = PB::cvt(h[0] * m0);
+      tdb[(row + 1) * TS + col] = PB::cvt(h[1] * m1);
+    }
+  };
+  // the 16-bit copies of tile rt leave the transposition tiles [buf]: wave 0 the state (own layer's next step: exchange copy
+  // 0, and the row-major forward-type array), wave 1 the dropout-applied copy (layer above: exchange copy 1, and its row-major
+  // array), waves 2 / 3 the two backward-type arrays; every 128-byte line of the exchange buffer is written whole
+  auto store_tile = [&](int t, int rt, int buf) {
+    if (lane >= 32 * UT) return;
+    const int sut = lane >> 5, srow = (lane & 31) >> 1, half = lane & 1;
+    const char* tb = tiles + (buf * 4 + wave) * TILE_B;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(tb + (srow * TS + sut * 16 + half * 8) * 2);
+    const long go = ((long)t * B + rt * 16 + srow) * D + s * US + sut * 16 + half * 8;   // row-major element offset, slot t
+    const int xo = ((rt * NS16 + s * UT + sut) * 16 + srow) * 32 + half * 16;            // exchange byte offset inside a region
+    if (wave == 0) {
+      st_sc1(v, rex, xo, (int)((unsigned)((l * L + t) * 2) * RG));
+      *reinterpret_cast<u32x4*>(reinterpret_cast<h_t*>(Ly.y16a) + go + slot) = v;
+    } else if (wave == 1) {
+      if (drop) {
+        st_sc1(v, rex, xo, (int)((unsigned)((l * L + t) * 2 + 1) * RG));
+        *reinterpret_cast<u32x4*>(reinterpret_cast<h_t*>(Ly.yd16a) + go) = v;
+      }
+    } else if (wave == 2) {
+      if (Ly.y16b) *reinterpret_cast<u32x4*>(reinterpret_cast<hb_t*>(Ly.y16b) + go + slot) = v;
+    } else {
+      if (drop && Ly.yd16b) *reinterpret_cast<u32x4*>(reinterpret_cast<hb_t*>(Ly.yd16b) + go) = v;
+    }
+  };
+
+  bool dead = false;
+  for (int t = 0; t < L && !dead; ++t) {
+    for (int hs = 0; hs < 2; ++hs) {
+      const int q = 2 * g + hs;
+      const int r0 = q * RT / NSG, r1 = (q + 1) * RT / NSG, nt = r1 - r0;
+      if (wave == 0) {
+        bool ok = true;
+        const unsigned code = (unsigned)(blockIdx.x << 12 | (t & 2047) << 1 | hs);
+        unsigned* cown = cnt + (((long)l * L + (t - 1)) * NSG + q) * kSweepCntStride;
+        unsigned* cbel = cnt + (((long)(l - 1) * L + t) * NSG + q) * kSweepCntStride;
+        if (t > 0 && l > 0) ok = sweep_wait2(cown, cbel, need, sync, code);
+        else if (t > 0) ok = sweep_wait(cown, need, sync, code);
+        else if (l > 0) ok = sweep_wait(cbel, need, sync, code | 0x80000000u);
+        if (!ok && lane == 0) *lflag = 1;
+      }
+      __syncthreads();
+      if (*lflag) { dead = true; break; }   // uniform: every wave reads the same word behind the barrier
+
+      // fragments two tiles ahead of the multiply, the multiply one tile ahead of the gate math.  Two fragment buffers take
+      // turns (the tile loop is unrolled by two so that neither is ever copied: a copy would wait for the load in flight)
+      u32x4 xaP[KSW], haP[KSW], xaQ[KSW], haQ[KSW];
+      f32x4 acc[4][UT];
+      load_tile(t, r0, xaP, haP);
+      if (nt > 1) load_tile(t, r0 + 1, xaQ, haQ);
+      multiply(xaP, haP, acc);
+      put_part(0, acc);
+      if (nt > 2) load_tile(t, r0 + 2, xaP, haP);
+      __syncthreads();
+      // iteration k: 16-bit copies of tile k-1 leave, tile k+1 multiplies (buffer X), tile k+3 is requested into X, tile k's
+      // gate math runs, tile k+1's partials go to LDS
+#define ARK_FAT_ITER(K, XA, HA)                                        \
+      {                                                                \
+        const int k_ = (K);                                            \
+        if (k_ > 0) store_tile(t, r0 + k_ - 1, (k_ - 1) & 1);          \
+        if (k_ + 1 < nt) multiply(XA, HA, acc);                        \
+        if (k_ + 3 < nt) load_tile(t, r0 + k_ + 3, XA, HA);            \
+        epilogue(t, r0 + k_, k_ & 1);                                  \
+        if (k_ + 1 < nt) put_part((k_ + 1) & 1, acc);                  \
+        __syncthreads();                                               \
+      }
+      for (int k = 0; k < nt; k += 2) {
+        ARK_FAT_ITER(k, xaQ, haQ)
+        if (k + 1 < nt) ARK_FAT_ITER(k + 1, xaP, haP)
+      }
+#undef ARK_FAT_ITER
+      store_tile(t, r1 - 1, (nt - 1) & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_fetch_add(cnt + (((long)l * L + t) * NSG + q) * kSweepCntStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  sweep_leave(sync);
+}
+
+template <int PREC, int PRECB, int KSW, int UT>
+static int launch_fat(const GruFatArgs& p, unsigned grid, unsigned valid, hipStream_t st) {
+  constexpr int US = 16 * UT;
+  constexpr int LDS = 2 * 4 * 4 * UT * 64 * 16 + kFatMaxTiles * UT * 64 * 16 + 2 * 4 * 16 * (US + 8) * 2 + 64;
+  static_assert(LDS <= 160 * 1024, "LDS budget");   // (one workgroup per CU by registers: 4 waves of ~400 VGPRs)
+  auto kern = gru_fat_fwd_kernel<PREC, PRECB, KSW, UT>;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+  (void)once;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return ARK_ERR_ARG;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return ARK_ERR_ARG;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, LDS) != hipSuccess || per_cu < 1) return ARK_ERR_SHAPE;
+  if ((long)valid > (long)cus * per_cu || (long)grid > (long)cus * per_cu) return ARK_ERR_SHAPE;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, p);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ark
+
+// row groups the forward of (n_layers, B, D) would use on the current device; 0 = unsupported shape / does not fit
+static int fat_row_groups(int n_layers, int B, int D) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (n_layers <= 0 || n_layers > ARK_SWEEP_MAX_LAYERS || B <= 0 || B % 16 != 0 || (D != 512 && D != 1024)) return 0;
+  const int ns = D == 512 ? 16 : 64, rt = B / 16;
+  int ng = cus / (n_layers * ns);
+  if (ng > rt / 2) ng = rt / 2;                       // every subgroup needs a tile
+  if (ng <= 0) return 0;
+  for (int g = 0; g < ng; ++g)                        // tiles per workgroup <= the LDS state array
+    if ((2 * g + 2) * rt / (2 * ng) - (2 * g) * rt / (2 * ng) > ark::kFatMaxTiles) return 0;
+  return ng;
+}
+extern "C" int ark_gru_fat_row_groups(int n_layers, int B, int D) { return fat_row_groups(n_layers, B, D); }
+extern "C" long ark_gru_fat_sync_words(int n_layers, int B, int D, int L) {
+  const int ng = fat_row_groups(n_layers, B, D);
+  return ark::kSweepSyncHdr + (long)n_layers * L * 2 * (ng > 0 ? ng : 1) * ark::kSweepCntStride;
+}
+
+extern "C" int ark_gru_fat_fwd(int prec, int prec_b, const ArkGruSweep* a, void* stream) {
+  using namespace ark;
+  if (!a || a->n_layers <= 0 || a->n_layers > ARK_SWEEP_MAX_LAYERS || a->B <= 0 || a->D <= 0 || a->L <= 0) return ARK_ERR_ARG;
+  if (!a->x0_16 || !a->exch || !a->sync || a->t0 < 0) return ARK_ERR_ARG;
+  const int D = a->D, B = a->B, L = a->L, n = a->n_layers;
+  if (L > 2047 || 2.0 * n * L * B * D * 2 >= 2147483648.0) return ARK_ERR_SHAPE;   // 32-bit buffer offsets
+  const int ng = fat_row_groups(n, B, D);
+  if (ng == 0) return ARK_ERR_SHAPE;
+  for (int l = 0; l < n; ++l) {
+    const ArkGruSweepLayer& y = a->layer[l];
+    if (!y.w_ih16 || !y.w_hh16 || !y.b_ih || !y.b_hh || !y.y_t || !y.y16a) return ARK_ERR_ARG;
+    if (y.drop_p < 0.f || y.drop_p >= 1.f || (y.drop_p > 0.f && (!y.yd16a || !a->hyper))) return ARK_ERR_ARG;
+    if (y.save_r && (!y.save_z || !y.save_n || !y.save_hn)) return ARK_ERR_ARG;
+  }
+  GruFatArgs p;
+  p.a = *a;
+  p.NG = ng;
+  const int ns = D == 512 ? 16 : 64, np = n * ng;
+  const unsigned valid = (unsigned)(np * ns);
+  // XCD map: pairs x, x + 8, ... on XCD x, each with its ns slices; needs ns * ceil(np / 8) <= 32 CUs of an XCD
+  const int per_xcd = ns * ((np + 7) / 8);
+  p.xcd_pairs = per_xcd <= 32 ? 1 : 0;
+  const unsigned grid = p.xcd_pairs ? (unsigned)(8 * per_xcd) : valid;
+  hipStream_t st = (hipStream_t)stream;
+#define ARK_FAT_GO(PF, PBK)                                                          \
+  do {                                                                               \
+    if (D == 512) return launch_fat<PF, PBK, 4, 2>(p, grid, valid, st);              \
+    return launch_fat<PF, PBK, 8, 1>(p, grid, valid, st);                            \
+  } while (0)
+  if (prec == PREC_F16 && prec_b == PREC_BF16) ARK_FAT_GO(PREC_F16, PREC_BF16);
+  if (prec == PREC_F16 && prec_b == PREC_F16) ARK_FAT_GO(PREC_F16, PREC_F16);
+  if (prec == PREC_BF16 && prec_b == PREC_BF16) ARK_FAT_GO(PREC_BF16, PREC_BF16);
+#undef ARK_FAT_GO
+  return ARK_ERR_ARG;
+}

@@ -187,6 +187,9 @@ class Engine:
         self.diag_chains = max(1, int(cfg.get("ark_diag_chains", 2)))
         # small batches of long sequences: the whole forward recurrence as ONE persistent launch (csrc/gru_sweep.hip);
         # "auto" = where the diagonal launches are all fixed cost (see _use_sweep)
+        # full batches: the forward recurrence as ONE weights-stationary persistent launch (csrc/gru_fat.hip); "auto" = where
+        # its grid fits the chip and the small-batch sweep does not apply (see _use_fat)
+        self.fat = cfg.get("ark_fat", "auto")
         self.sweep = cfg.get("ark_sweep", "auto")
         self.sweep_bwd = bool(cfg.get("ark_sweep_bwd", True))   # (0: persistent forward, diagonal backward)
         self.ce_dw_after_latent = bool(cfg.get("ark_ce_dw_after_latent", True))
@@ -775,7 +778,7 @@ class Engine:
     def _skip_x0(self, w, B, Lq):
         """True where no kernel reads the 16-bit embedding rows X0: the forward diagonals take layer 0's input projection from
         x_tab, the backward takes dW_ih0 / dW_tok from the token sums; the persistent sweep still streams X0"""
-        return bool(w.get("xtab") and w.get("emb_gemm") and not self._use_sweep(B, Lq))
+        return bool(w.get("xtab") and w.get("emb_gemm") and not self._use_sweep(B, Lq) and not self._use_fat(B, Lq))
 
     def _decoder_forward_v2(self, w, seq, ld_seq, B, Lq, use_drop, save=True, project=True):
         """fast decoder forward: token gather -> layer-diagonal GRU sweep -> tied vocabulary projection
@@ -844,6 +847,49 @@ class Engine:
                 raise L.ArkError(f"ark_sweep=1: {self.n} x {B // 16} x {self.D // 16} workgroups cannot be co-resident")
             return True
         return fits and Lq >= 32
+
+    def _use_fat(self, B, Lq):
+        """the weights-stationary forward (ark_gru_fat_fwd): D in {512, 1024}, all n * (D / units) * row-groups workgroups
+        co-resident, one per CU; taken for batches of >= 256 rows that the small-batch sweep does not serve"""
+        if self.fat in (0, False, "0", "off") or not self.use_dma or self.D not in (512, 1024) or B % 16 != 0:
+            return False
+        if self.n > L.SWEEP_MAX_LAYERS or Lq > 2047 or 2.0 * self.n * Lq * B * self.D * 2 >= 2 ** 31:
+            return False
+        fits = L.lib().ark_gru_fat_row_groups(L.i32(self.n), L.i32(B), L.i32(self.D)) > 0
+        if self.fat in (1, True, "1", "on"):
+            if not fits:
+                raise L.ArkError(f"ark_fat=1: the weights-stationary forward of {self.n} x {B} x {self.D} does not fit the chip")
+            return not self._use_sweep(B, Lq)
+        return fits and B >= 256 and not self._use_sweep(B, Lq)
+
+    def _fat_fwd(self, w, B, Lq, use_drop, save=True):
+        """the forward recurrence of all layers and steps as ONE weights-stationary launch (ark_gru_fat_fwd); same inputs
+        and outputs as the diagonal launches"""
+        D, n, p = self.D, self.n, self.p
+        key = ("fat", Lq)
+        if key not in w:
+            sy = torch.zeros(L.fat_sync_words(n, B, D, Lq), device=self.device, dtype=torch.int32)
+            self.__dict__.setdefault("_sweep_sync_all", []).append(sy)
+            w[key] = (torch.empty(2 * n * Lq * B * D, device=self.device, dtype=torch.int16), sy)
+        exch, sync = w[key]
+        a = L.GruSweep()
+        for l in range(n):
+            drop = use_drop and l < n - 1
+            y = a.layer[l]
+            y.w_ih16, y.w_hh16 = L.dptr(self.wih16[l]), L.dptr(self.whh16[l])
+            y.b_ih, y.b_hh = L.dptr(p[f"dec.gru.bias_ih_l{l}"]), L.dptr(p[f"dec.gru.bias_hh_l{l}"])
+            y.y_t, y.y16a, y.y16b = L.dptr(w["Y"][l]), L.dptr(w["Y16a"][l]), L.dptr(w["Y16b"][l])
+            y.yd16a = L.dptr(w["Yd16a"][l] if drop else None)
+            y.yd16b = L.dptr(w["Yd16b"][l] if drop else None)
+            if save:
+                y.save_r, y.save_z = L.dptr(w["SR"][l]), L.dptr(w["SZ"][l])
+                y.save_n, y.save_hn = L.dptr(w["SN"][l]), L.dptr(w["SHN"][l])
+            y.drop_seed = self._layer_seed(l)
+            y.drop_p = self.p_drop if drop else 0.0
+        a.x0_16, a.exch, a.sync, a.hyper = L.dptr(w["X0a"]), L.dptr(exch), L.dptr(sync), L.dptr(self.hyper)
+        a.n_layers, a.B, a.D, a.L, a.t0 = n, B, D, Lq, 0
+        import ctypes
+        _call("ark_gru_fat_fwd", L.i32(self.prec_fwd), L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
 
     def _sweep_wgs(self, B):
         """workgroups (= CUs) a persistent sweep of this batch occupies"""
@@ -953,6 +999,9 @@ class Engine:
         The batch is split into independent row-block chains on parallel queues (_chains)."""
         if self._use_sweep(B, Lq):
             self._sweep_fwd(w, B, Lq, use_drop, save)
+            return
+        if self._use_fat(B, Lq):
+            self._fat_fwd(w, B, Lq, use_drop, save)
             return
         self._run_chains(B, lambda b0, Bc: self._diag_chain(w, B, b0, Bc, Lq, use_drop, save))
 
