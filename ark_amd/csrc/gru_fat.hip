@@ -43,8 +43,25 @@ struct GruFatArgs {
   int xcd_pairs;   // 1: the NS slices of a (layer, row group) pair share an XCD
 };
 
+// Diagnostic build only (-DARK_FAT_STAMPS, tools/fat_stamps.py): 100-MHz ticks thread 0 of every workgroup spends per phase,
+// summed over the launch: [0] waiting for the counters, [1] first fragments + first multiply, [2] the tile loop,
+// [3] last copies + store drain + publish, [4] tiles walked
+#ifdef ARK_FAT_STAMPS
+__device__ unsigned long long ark_fat_stamp_buf[512 * 8];
+#define FAT_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (tid == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); facc_[i] += n_ - flast_; flast_ = n_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FAT_STAMP(i) do {} while (0)
+#endif
+
 constexpr int kFatMaxTiles = 16;   // 16-row tiles per workgroup (both subgroups): bounds the LDS state array
 
+// Payload loads are ordinary (compiler-tracked) buffer loads, and hipcc's wait insertion cannot count them across the tile
+// loop (loads two tiles ahead, a varying number of stores in between): it waits for `vmcnt(0)` in front of every multiply.
+// In the first build that wait sat right behind the write-through stores of the previous tile (1.5 us per tile, 287 us per
+// forward against 228 for the diagonal launches); the multiply now heads the iteration.  Tried and dropped: hand-issued
+// loads (inline asm into AGPR tuples + counted waits: the register allocator parks an asm output in a scratch tuple and
+// copies it home at once, i.e. before the data has landed); the walk fully unrolled (exact counts in straight-line code,
+// but with all 256 VGPRs in use the unrolled body spills and the scheduler sinks the prefetch next to its use).
 __device__ __forceinline__ u32x4 ld_pay(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, ARK_FAT_LD_AUX);
 }
@@ -205,8 +222,13 @@ __global__ __launch_bounds__(256) void gru_fat_fwd_kernel(GruFatArgs pa) {
       for (int ut = 0; ut < UT; ++ut) part[(((buf * 4 + wave) * 4 + a) * UT + ut) * 64 + lane] = acc[a][ut];
   };
   // gate math of tile rt (partials in part[buf]) by all threads; leaves the 16-bit copies in the transposition tiles [buf]
+  // (The stores of this function are UNCONDITIONAL for UT = 2 on purpose: hipcc can only let a multiply wait for ITS fragments
+  //  -- `vmcnt(N)` with N = what was provably issued after them -- if it can prove how many stores lie in between; with the gate
+  //  saves behind `if (save_r)` it proved none and every tile waited for the write-through stores issued just before it.)
   auto epilogue = [&](int t, int rt, int buf) {
-    if (!eact) return;
+    if constexpr (UT == 1) {
+      if (!eact) return;
+    }
     f32x2 sum[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -228,8 +250,8 @@ __global__ __launch_bounds__(256) void gru_fat_fwd_kernel(GruFatArgs pa) {
     *st = h;
     const long o = (long)(rt * NS16 + s * UT + eut) * 256 + ln * 4 + 2 * hf;   // tile-native offset inside a slot
     *reinterpret_cast<f32x2*>(Ly.y_t + (long)(t + 1) * slot + o) = h;
-    if (Ly.save_r) {
-      const long so = (long)t * slot + o;
+    {
+      const long so = (long)t * slot + o;   // (the host requires the four save arrays)
       *reinterpret_cast<half2_t*>(reinterpret_cast<_Float16*>(Ly.save_r) + so) = half2_t{(_Float16)rr[0], (_Float16)rr[1]};
       *reinterpret_cast<half2_t*>(reinterpret_cast<_Float16*>(Ly.save_z) + so) = half2_t{(_Float16)zz[0], (_Float16)zz[1]};
       *reinterpret_cast<half2_t*>(reinterpret_cast<_Float16*>(Ly.save_n) + so) = half2_t{(_Float16)nn[0], (_Float16)nn[1]};
@@ -280,9 +302,13 @@ __global__ __launch_bounds__(256) void gru_fat_fwd_kernel(GruFatArgs pa) {
     }
   };
 
+#ifdef ARK_FAT_STAMPS
+  unsigned long long facc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast_ = __builtin_amdgcn_s_memrealtime();
+#endif
   bool dead = false;
   for (int t = 0; t < L && !dead; ++t) {
     for (int hs = 0; hs < 2; ++hs) {
+      FAT_STAMP(5);
       const int q = 2 * g + hs;
       const int r0 = q * RT / NSG, r1 = (q + 1) * RT / NSG, nt = r1 - r0;
       if (wave == 0) {
@@ -297,9 +323,12 @@ __global__ __launch_bounds__(256) void gru_fat_fwd_kernel(GruFatArgs pa) {
       }
       __syncthreads();
       if (*lflag) { dead = true; break; }   // uniform: every wave reads the same word behind the barrier
+      FAT_STAMP(0);
 
       // fragments two tiles ahead of the multiply, the multiply one tile ahead of the gate math.  Two fragment buffers take
-      // turns (the tile loop is unrolled by two so that neither is ever copied: a copy would wait for the load in flight)
+      // turns (the tile loop is unrolled by two so that neither is ever copied: a copy would wait for the load in flight).
+      // hipcc cannot count the loads across this loop and waits for `vmcnt(0)` in front of every multiply (see the note on
+      // ld_pay), so the multiply comes FIRST in an iteration: what is in flight then was issued a whole tile ago.
       u32x4 xaP[KSW], haP[KSW], xaQ[KSW], haQ[KSW];
       f32x4 acc[4][UT];
       load_tile(t, r0, xaP, haP);
@@ -308,14 +337,13 @@ __global__ __launch_bounds__(256) void gru_fat_fwd_kernel(GruFatArgs pa) {
       put_part(0, acc);
       if (nt > 2) load_tile(t, r0 + 2, xaP, haP);
       __syncthreads();
-      // iteration k: 16-bit copies of tile k-1 leave, tile k+1 multiplies (buffer X), tile k+3 is requested into X, tile k's
-      // gate math runs, tile k+1's partials go to LDS
+      FAT_STAMP(1);
 #define ARK_FAT_ITER(K, XA, HA)                                        \
       {                                                                \
         const int k_ = (K);                                            \
-        if (k_ > 0) store_tile(t, r0 + k_ - 1, (k_ - 1) & 1);          \
         if (k_ + 1 < nt) multiply(XA, HA, acc);                        \
         if (k_ + 3 < nt) load_tile(t, r0 + k_ + 3, XA, HA);            \
+        if (k_ > 0) store_tile(t, r0 + k_ - 1, (k_ - 1) & 1);          \
         epilogue(t, r0 + k_, k_ & 1);                                  \
         if (k_ + 1 < nt) put_part((k_ + 1) & 1, acc);                  \
         __syncthreads();                                               \
@@ -325,13 +353,22 @@ __global__ __launch_bounds__(256) void gru_fat_fwd_kernel(GruFatArgs pa) {
         if (k + 1 < nt) ARK_FAT_ITER(k + 1, xaP, haP)
       }
 #undef ARK_FAT_ITER
+      FAT_STAMP(2);
+#ifdef ARK_FAT_STAMPS
+      if (tid == 0) facc_[4] += nt;
+#endif
       store_tile(t, r1 - 1, (nt - 1) & 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
       __syncthreads();
       if (tid == 0)
         __hip_atomic_fetch_add(cnt + (((long)l * L + t) * NSG + q) * kSweepCntStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      FAT_STAMP(3);
     }
   }
+#ifdef ARK_FAT_STAMPS
+  if (tid == 0 && blockIdx.x < 512)
+    for (int i_ = 0; i_ < 8; ++i_) ark_fat_stamp_buf[blockIdx.x * 8 + i_] = facc_[i_];
+#endif
   sweep_leave(sync);
 }
 
@@ -386,7 +423,7 @@ extern "C" int ark_gru_fat_fwd(int prec, int prec_b, const ArkGruSweep* a, void*
     const ArkGruSweepLayer& y = a->layer[l];
     if (!y.w_ih16 || !y.w_hh16 || !y.b_ih || !y.b_hh || !y.y_t || !y.y16a) return ARK_ERR_ARG;
     if (y.drop_p < 0.f || y.drop_p >= 1.f || (y.drop_p > 0.f && (!y.yd16a || !a->hyper))) return ARK_ERR_ARG;
-    if (y.save_r && (!y.save_z || !y.save_n || !y.save_hn)) return ARK_ERR_ARG;
+    if (!y.save_r || !y.save_z || !y.save_n || !y.save_hn) return ARK_ERR_ARG;   // (unconditional stores: see the kernel)
   }
   GruFatArgs p;
   p.a = *a;
@@ -409,3 +446,9 @@ extern "C" int ark_gru_fat_fwd(int prec, int prec_b, const ArkGruSweep* a, void*
 #undef ARK_FAT_GO
   return ARK_ERR_ARG;
 }
+
+#ifdef ARK_FAT_STAMPS
+extern "C" int ark_debug_fat_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ark::ark_fat_stamp_buf), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

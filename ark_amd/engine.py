@@ -187,8 +187,10 @@ class Engine:
         self.diag_chains = max(1, int(cfg.get("ark_diag_chains", 2)))
         # small batches of long sequences: the whole forward recurrence as ONE persistent launch (csrc/gru_sweep.hip);
         # "auto" = where the diagonal launches are all fixed cost (see _use_sweep)
-        # full batches: the forward recurrence as ONE weights-stationary persistent launch (csrc/gru_fat.hip); "auto" = where
-        # its grid fits the chip and the small-batch sweep does not apply (see _use_fat)
+        # full batches: the forward recurrence as ONE weights-stationary persistent launch (csrc/gru_fat.hip).  Parity-green but
+        # SLOWER than the diagonal launches on MI355X (syn-paths B = 1024: 283 us against 218 us per forward, DESIGN.md section 6:
+        # one wave per SIMD can keep ~64 KB of fragment loads in flight per CU, the three LDS rings of the diagonal launches
+        # 120 KB), so it is an opt-in experiment: `ark_fat: 1`; "auto" = the layer-diagonal launches
         self.fat = cfg.get("ark_fat", "auto")
         self.sweep = cfg.get("ark_sweep", "auto")
         self.sweep_bwd = bool(cfg.get("ark_sweep_bwd", True))   # (0: persistent forward, diagonal backward)
@@ -860,7 +862,7 @@ class Engine:
             if not fits:
                 raise L.ArkError(f"ark_fat=1: the weights-stationary forward of {self.n} x {B} x {self.D} does not fit the chip")
             return not self._use_sweep(B, Lq)
-        return fits and B >= 256 and not self._use_sweep(B, Lq)
+        return False   # ("auto": measured slower than the diagonal launches -- see __init__)
 
     def _fat_fwd(self, w, B, Lq, use_drop, save=True):
         """the forward recurrence of all layers and steps as ONE weights-stationary launch (ark_gru_fat_fwd); same inputs
@@ -1001,7 +1003,7 @@ class Engine:
             self._sweep_fwd(w, B, Lq, use_drop, save)
             return
         if self._use_fat(B, Lq):
-            self._fat_fwd(w, B, Lq, use_drop, save)
+            self._fat_fwd(w, B, Lq, use_drop, True)   # (always writes the gate saves)
             return
         self._run_chains(B, lambda b0, Bc: self._diag_chain(w, B, b0, Bc, Lq, use_drop, save))
 

@@ -123,7 +123,11 @@ def time_diag_kernels(eng, B, reps=8):
         sweeps = {"gru_sweep_fwd_kernel": (lambda: eng._diag_sweep(w, B, Lq, use_drop, True), 1),
                   "gru_sweep_bwd_kernel": (bwd_sweep, 1)}
     else:
-        sweeps = {"gru_diag_fwd_kernel": (lambda: eng._diag_sweep(w, B, Lq, use_drop, True), Lq + n - 1),
+        # full batches: the forward is ONE weights-stationary persistent launch (csrc/gru_fat.hip) where its grid fits the chip,
+        # else one launch per anti-diagonal; the backward is one launch per anti-diagonal
+        fat = eng._use_fat(B, Lq)
+        sweeps = {("gru_fat_fwd_kernel" if fat else "gru_diag_fwd_kernel"): (lambda: eng._diag_sweep(w, B, Lq, use_drop, True),
+                                                                            1 if fat else Lq + n - 1),
                   "gru_diag_bwd_kernel": (bwd_sweep, Lq + n - 1 + (1 if eng.mt == "SAIL" else 0))}
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
@@ -289,6 +293,8 @@ def other_workloads(dev, precision, dropout, mfma_peak):
                 times = time_diag_kernels(eng, B, reps=3)
                 ent["diag_kernels"] = {k: {"kernel_avg_us": kt * 1e6, "launches_per_step": n, "us_per_step": kt * 1e6 * n}
                                        for k, (kt, n) in times.items()}
+                if eng._use_fat(B, eng.L):
+                    ent["weights_stationary_forward"] = True
                 if eng._use_sweep(B, eng.L):
                     ent["persistent_sweep"] = {"workgroups": eng._sweep_wgs(B), "recurrence_steps": eng.L + eng.n - 1,
                                                "us_per_recurrence_step": {k: kt * 1e6 / (eng.L + eng.n - 1) for k, (kt, n) in times.items()}}
@@ -404,7 +410,8 @@ def main():
             chains = len(eng._chains(B))
             traffic = {k: v * chains for k, v in traffic.items()}
             kern = {}
-            alias = {"gru_sweep_fwd_kernel": "gru_diag_fwd_kernel", "gru_sweep_bwd_kernel": "gru_diag_bwd_kernel"}
+            alias = {"gru_sweep_fwd_kernel": "gru_diag_fwd_kernel", "gru_sweep_bwd_kernel": "gru_diag_bwd_kernel",
+                     "gru_fat_fwd_kernel": "gru_diag_fwd_kernel"}
             for name, (kt, launches) in times.items():
                 m = models[alias.get(name, name)]   # (the sweeps move the same algorithmic bytes as the launches they replace)
                 kern[name] = {"kernel_avg_us": kt * 1e6, "launches_per_step": launches, "us_per_step": kt * 1e6 * launches,

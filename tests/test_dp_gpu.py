@@ -183,4 +183,4 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1, out.stdout
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 256 and res["value"] > 0
-    assert res["roofline"]["kernel"] in ("gru_diag_fwd_kernel", "gru_diag_bwd_kernel")
+    assert res["roofline"]["kernel"] in ("gru_diag_fwd_kernel", "gru_diag_bwd_kernel", "gru_fat_fwd_kernel")

@@ -165,4 +165,6 @@ def test_fat_forward_refuses_what_does_not_fit():
     with pytest.raises(L.ArkError):
         eng._use_fat(8192, 10)                          # 512 row tiles: more than 16 per workgroup
     auto = make_engine(cfg, O.init_params(cfg, 0), "mixed")
-    assert auto._use_fat(1024, 10) and not auto._use_fat(64, 10) and not auto._use_fat(16, 100)
+    assert not auto._use_fat(1024, 10)                  # opt-in: measured slower than the diagonal launches
+    on = make_engine(dict(cfg, ark_fat=1), O.init_params(cfg, 0), "mixed")
+    assert on._use_fat(1024, 10) and on._use_fat(64, 10) and not on._use_fat(16, 100)   # (16 x 100: the small-batch sweep)
