@@ -112,7 +112,7 @@ class GruSweep(ctypes.Structure):
     """ArkGruSweep of include/ark_amd.h"""
     _fields_ = [("layer", GruSweepLayer * SWEEP_MAX_LAYERS), ("x0_16", ctypes.c_void_p), ("exch", ctypes.c_void_p),
                 ("sync", ctypes.c_void_p), ("hyper", ctypes.c_void_p), ("n_layers", ctypes.c_int), ("B", ctypes.c_int),
-                ("D", ctypes.c_int), ("L", ctypes.c_int), ("t0", ctypes.c_int), ("pad_", ctypes.c_int)]
+                ("D", ctypes.c_int), ("L", ctypes.c_int), ("t0", ctypes.c_int), ("wg_slices", ctypes.c_int)]
 
 
 class GruSweepBwdLayer(ctypes.Structure):
@@ -126,7 +126,7 @@ class GruSweepBwd(ctypes.Structure):
     """ArkGruSweepBwd of include/ark_amd.h"""
     _fields_ = [("layer", GruSweepBwdLayer * SWEEP_MAX_LAYERS), ("dy_t", ctypes.c_void_p), ("dh0", ctypes.c_void_p),
                 ("exch", ctypes.c_void_p), ("sync", ctypes.c_void_p), ("hyper", ctypes.c_void_p), ("n_layers", ctypes.c_int),
-                ("B", ctypes.c_int), ("D", ctypes.c_int), ("L", ctypes.c_int)]
+                ("B", ctypes.c_int), ("D", ctypes.c_int), ("L", ctypes.c_int), ("wg_slices", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
 class DiagTuning(ctypes.Structure):

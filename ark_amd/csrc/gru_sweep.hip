@@ -53,8 +53,11 @@ __device__ unsigned long long ark_sweep_stamp_buf[512 * 8];
 // 4 waves: wave w forms the partial products of K-steps [w*KSW, (w+1)*KSW) of BOTH operands (x_t W_ih^T, h_{t-1} W_hh^T);
 // wave 0 adds the partials, does the gate math and owns the state.  D = 128 * KSW; MT 16-row tiles per workgroup (the
 // weights in registers serve all of them: wd-movies, B = 256 x D = 128, fits the chip with MT = 2).
-template <int PREC, int PRECB, int KSW, int MT>
-__global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
+// WS: logical workgroups (unit slices) per PHYSICAL workgroup of 256 * WS threads.  WS = 2 packs two slices onto one CU
+// (waves 0-3 / 4-7: two per SIMD), so the sweep of wd-articles holds 48 CUs instead of 96 and the vocabulary CE beside it
+// gets 208: a sweep step is three memory round trips and 0.3 us of arithmetic, sharing a CU costs it next to nothing.
+template <int PREC, int PRECB, int KSW, int MT, int WS>
+__global__ __launch_bounds__(256 * WS) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
   using PT = PrecTraits<PREC>;
   using PB = PrecTraits<PRECB>;
   using h_t = typename PT::h_t;
@@ -65,18 +68,20 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
   constexpr int TS = 24;                                   // row stride of the 16 x 16 transposition tiles (halves)
   constexpr int TILE = 16 * TS * 2;                        // bytes of one such tile
   constexpr int PARTB = 3 * MT * 4 * 64 * 16;
-  f32x4* part = reinterpret_cast<f32x4*>(smem);            // [3 waves][MT][4 accumulators][64 lanes]
-  char* tiles = smem + PARTB;                              // [MT][h fwd type | h bwd type | h*mask fwd | h*mask bwd]
-  int* lflag = reinterpret_cast<int*>(smem + PARTB + MT * 4 * TILE);
+  const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);   // which of the WS slices of this physical workgroup
+  constexpr int SUBB = PARTB + MT * 4 * TILE;              // LDS of one slice
+  f32x4* part = reinterpret_cast<f32x4*>(smem + sub * SUBB);   // [3 waves][MT][4 accumulators][64 lanes]
+  char* tiles = smem + sub * SUBB + PARTB;                 // [MT][h fwd type | h bwd type | h*mask fwd | h*mask bwd]
+  int* lflag = reinterpret_cast<int*>(smem + WS * SUBB);
 
   const int D = p.D, B = p.B, L = p.L;
   const int NS = D >> 4, RBW = B / (16 * MT);
-  const int wg = blockIdx.x;
+  const int wg = blockIdx.x * WS + sub;                    // logical workgroup
   const int l = wg / (NS * RBW), rem = wg - l * (NS * RBW);
   const int rbw = rem / NS, s = rem - rbw * NS;
   const ArkGruSweepLayer& Ly = p.layer[l];
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);   // K-quarter inside the slice
   const int r = lane & 15, kg = lane >> 4;
   const int u = s * 16 + r;   // B-operand column / accumulator column of this lane
 
@@ -306,14 +311,25 @@ __global__ __launch_bounds__(256) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
 }
 
 template <class Kern, class Args>
-static int launch_persistent(Kern kern, const Args& p, unsigned grid, hipStream_t st);
+static int launch_persistent(Kern kern, const Args& p, unsigned grid, int ws, hipStream_t st);
 
+// `grid` counts LOGICAL workgroups (slices); two of them share a physical workgroup unless the caller asks for one per CU
 template <int PREC, int PRECB, int KSW, int MT>
 static int launch_sweep_fwd(const GruSweepArgs& p, unsigned grid, hipStream_t st) {
-  auto kern = gru_sweep_fwd_kernel<PREC, PRECB, KSW, MT>;
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
-  (void)once;
-  return launch_persistent(kern, p, grid, st);
+  // (two slices per workgroup = two waves per SIMD = 256 registers per lane: D = 512 with two row tiles does not fit them)
+  if (p.a.wg_slices == 1 || grid % 2 != 0 || (KSW == 4 && MT == 2)) {
+    auto kern = gru_sweep_fwd_kernel<PREC, PRECB, KSW, MT, 1>;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
+    (void)once;
+    return launch_persistent(kern, p, grid, 1, st);
+  }
+  if constexpr (!(KSW == 4 && MT == 2)) {
+    auto kern = gru_sweep_fwd_kernel<PREC, PRECB, KSW, MT, 2>;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
+    (void)once;
+    return launch_persistent(kern, p, grid / 2, 2, st);
+  }
+  return ARK_ERR_SHAPE;
 }
 
 
@@ -329,8 +345,8 @@ struct GruSweepBwdArgs {
   ArkGruSweepBwd a;
 };
 
-template <int PREC, int KSW, int MT>
-__global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) {
+template <int PREC, int KSW, int MT, int WS>
+__global__ __launch_bounds__(256 * WS) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) {
   using PT = PrecTraits<PREC>;
   using h_t = typename PT::h_t;
   using h8 = typename PT::h8;
@@ -340,19 +356,21 @@ __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) 
   constexpr int TS = 24;
   constexpr int PARTB = 3 * MT * 2 * 64 * 16;
   constexpr int TILE4 = 4 * 16 * TS * 2;                   // bytes of the four part tiles of one row tile
-  f32x4* part = reinterpret_cast<f32x4*>(smem);            // [3 waves][MT][2 accumulators][64 lanes]
-  char* tiles = smem + PARTB;                              // [MT][4 parts][16 rows][TS]
-  int* lflag = reinterpret_cast<int*>(smem + PARTB + MT * TILE4);
+  const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);   // (WS slices per physical workgroup: see the forward kernel)
+  constexpr int SUBB = PARTB + MT * TILE4;
+  f32x4* part = reinterpret_cast<f32x4*>(smem + sub * SUBB);   // [3 waves][MT][2 accumulators][64 lanes]
+  char* tiles = smem + sub * SUBB + PARTB;                 // [MT][4 parts][16 rows][TS]
+  int* lflag = reinterpret_cast<int*>(smem + WS * SUBB);
 
   const int D = p.D, B = p.B, L = p.L, n = p.n_layers;
   const int NS = D >> 4, RBW = B / (16 * MT);
-  const int wg = blockIdx.x;
+  const int wg = blockIdx.x * WS + sub;
   // the top layer starts the backward wavefront: give it the lowest workgroup ids
   const int l = n - 1 - wg / (NS * RBW), rem = wg % (NS * RBW);
   const int rbw = rem / NS, s = rem - rbw * NS;
   const ArkGruSweepBwdLayer& Ly = p.layer[l];
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
   const int r = lane & 15, kg = lane >> 4;
   const int u = s * 16 + r;
   const bool top = l == n - 1;
@@ -562,26 +580,37 @@ __global__ __launch_bounds__(256) void gru_sweep_bwd_kernel(GruSweepBwdArgs pa) 
 }
 
 template <class Kern, class Args>
-static int launch_persistent(Kern kern, const Args& p, unsigned grid, hipStream_t st) {
-  // every workgroup spins on others: all of them must be resident at once
+static int launch_persistent(Kern kern, const Args& p, unsigned grid, int ws, hipStream_t st) {
+  // every workgroup spins on others: all of them must be resident at once (`grid` physical workgroups of 256 * ws threads)
   int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess) return ARK_ERR_ARG;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return ARK_ERR_ARG;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, kSweepLds) != hipSuccess || per_cu < 1) return ARK_ERR_SHAPE;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256 * ws, kSweepLds) != hipSuccess || per_cu < 1) return ARK_ERR_SHAPE;
   if ((long)grid > (long)cus * per_cu) return ARK_ERR_SHAPE;
   // a plain launch, captured or not: residency is what the occupancy query above proves (nothing else may hold more
   // than 64 KB of LDS on the CUs this grid needs: the caller's business, see ark_amd.h); a failure is bounded and sticky
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kSweepLds, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * ws), kSweepLds, st, p);
   ARK_LAUNCH_CHECK();
   return 0;
 }
 
 template <int PREC, int KSW, int MT>
 static int launch_sweep_bwd(const GruSweepBwdArgs& p, unsigned grid, hipStream_t st) {
-  auto kern = gru_sweep_bwd_kernel<PREC, KSW, MT>;
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
-  (void)once;
-  return launch_persistent(kern, p, grid, st);
+  // (the backward keeps two weight panels AND two fragment sets in registers: at D = 512 that needs the 512 registers of a
+  //  lone wave per SIMD -- 58-126 spilled registers with two slices per workgroup -- so it stays one slice per workgroup)
+  if (p.a.wg_slices == 1 || grid % 2 != 0 || KSW == 4) {
+    auto kern = gru_sweep_bwd_kernel<PREC, KSW, MT, 1>;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
+    (void)once;
+    return launch_persistent(kern, p, grid, 1, st);
+  }
+  if constexpr (KSW != 4) {
+    auto kern = gru_sweep_bwd_kernel<PREC, KSW, MT, 2>;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
+    (void)once;
+    return launch_persistent(kern, p, grid / 2, 2, st);
+  }
+  return ARK_ERR_SHAPE;
 }
 
 }  // namespace ark
@@ -597,6 +626,14 @@ static int sweep_row_tiles(int n_layers, int B, int D) {
   return 0;
 }
 extern "C" int ark_gru_sweep_row_tiles(int n_layers, int B, int D) { return sweep_row_tiles(n_layers, B, D); }
+// CUs (= physical workgroups) the forward (backward = 1) sweep of this shape holds with `wg_slices` slices per workgroup
+extern "C" int ark_gru_sweep_cus(int n_layers, int B, int D, int backward, int wg_slices) {
+  const int mt = sweep_row_tiles(n_layers, B, D);
+  if (mt == 0) return 0;
+  const int logical = n_layers * (B / 16) * (D / 16) / mt;
+  const bool two = wg_slices != 1 && logical % 2 == 0 && (backward ? D != 512 : !(D == 512 && mt == 2));
+  return two ? logical / 2 : logical;
+}
 
 extern "C" long ark_gru_sweep_exch_bytes(int n_layers, int B, int D, int L) { return 2L * n_layers * L * B * D * 2; }
 extern "C" long ark_gru_sweep_sync_words(int n_layers, int B, int L) { return ark::kSweepSyncHdr + (long)n_layers * L * (B / 16) * ark::kSweepCntStride; }

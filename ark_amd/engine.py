@@ -194,6 +194,9 @@ class Engine:
         self.fat = cfg.get("ark_fat", "auto")
         self.sweep = cfg.get("ark_sweep", "auto")
         self.sweep_bwd = bool(cfg.get("ark_sweep_bwd", True))   # (0: persistent forward, diagonal backward)
+        # unit slices per physical sweep workgroup: 2 = two slices share a CU (half the CUs held; the kernels beside the sweep
+        # get the rest), 1 = one per CU
+        self.sweep_ws = 1 if int(cfg.get("ark_sweep_wg_slices", 2)) == 1 else 2
         self.ce_dw_after_latent = bool(cfg.get("ark_ce_dw_after_latent", True))
         self.ce_chunks = int(cfg.get("ark_ce_chunks", 4))   # time chunks of the sweep + CE pipeline (1: off)
         self._ce_dw_pending = None
@@ -893,10 +896,9 @@ class Engine:
         import ctypes
         _call("ark_gru_fat_fwd", L.i32(self.prec_fwd), L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
 
-    def _sweep_wgs(self, B):
-        """workgroups (= CUs) a persistent sweep of this batch occupies"""
-        mt = L.lib().ark_gru_sweep_row_tiles(L.i32(self.n), L.i32(B), L.i32(self.D))
-        return self.n * (B // 16) * (self.D // 16) // max(1, mt)
+    def _sweep_wgs(self, B, backward=False):
+        """CUs (= physical workgroups) the persistent forward / backward sweep of this batch holds"""
+        return int(L.lib().ark_gru_sweep_cus(L.i32(self.n), L.i32(B), L.i32(self.D), L.i32(1 if backward else 0), L.i32(self.sweep_ws)))
 
     def _sweep_fwd(self, w, B, Lq, use_drop, save=True, t0=0, t1=None):
         """the forward recurrence of all layers over the steps [t0, t1) (default: all) as ONE launch (ark_gru_sweep_fwd);
@@ -927,7 +929,7 @@ class Engine:
             y.drop_seed = self._layer_seed(l)
             y.drop_p = self.p_drop if drop else 0.0
         a.x0_16, a.exch, a.sync, a.hyper = L.dptr(at(w["X0a"])), L.dptr(exch), L.dptr(sync), L.dptr(self.hyper)
-        a.n_layers, a.B, a.D, a.L, a.t0 = n, B, D, Lc, t0
+        a.n_layers, a.B, a.D, a.L, a.t0, a.wg_slices = n, B, D, Lc, t0, self.sweep_ws
         import ctypes
         _call("ark_gru_sweep_fwd", L.i32(self.prec_fwd), L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
 
@@ -954,7 +956,7 @@ class Engine:
         a.dy_t = L.dptr(w["dYa"])
         a.dh0 = L.dptr(w["dH0"]) if self.mt == "SAIL" else 0
         a.exch, a.sync, a.hyper = L.dptr(exch), L.dptr(sync), L.dptr(self.hyper)
-        a.n_layers, a.B, a.D, a.L = n, B, D, Lq
+        a.n_layers, a.B, a.D, a.L, a.wg_slices = n, B, D, Lq, self.sweep_ws
         import ctypes
         _call("ark_gru_sweep_bwd", L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
 
@@ -1316,7 +1318,7 @@ class Engine:
                 # a persistent sweep that fills most of the chip cannot share it with this launch's one-workgroup-per-CU
                 # grid (measured, wd-movies: the sweep took 880 us beside it instead of 420): queue it behind the sweep,
                 # where it runs beside the short kernels of the latent / encoder backward instead
-                if side is not main and self._use_sweep(B, Lq) and self.sweep_bwd and self._sweep_wgs(B) > 128:
+                if side is not main and self._use_sweep(B, Lq) and self.sweep_bwd and self._sweep_wgs(B, backward=True) > 128:
                     ce_dw_later = ce_dw
                 elif side is not main and self._use_sweep(B, Lq) and self.sweep_bwd:
                     # a sweep that leaves most of the chip free (wd-articles: 96 CUs): the two run side by side, but the

@@ -216,10 +216,12 @@ typedef struct {
   int n_layers, B, D, L;
   int t0;                /* index of this launch's first step inside the whole sequence (a sequence swept in several launches
                           * passes arrays advanced by t0 steps): only the dropout hash offsets use it                    */
-  int pad_;
+  int wg_slices;         /* unit slices per physical workgroup: 0 / 2 = two (512 threads, half the CUs: the default), 1 = one */
 } ArkGruSweep;
 /* 16-row tiles per workgroup the sweeps would use on the current device: 1 or 2; 0 = the grid cannot be co-resident */
 int ark_gru_sweep_row_tiles(int n_layers, int B, int D);
+/* CUs (= physical workgroups) the forward (backward = 0) / backward (1) sweep of this shape holds; 0 = does not fit */
+int ark_gru_sweep_cus(int n_layers, int B, int D, int backward, int wg_slices);
 long ark_gru_sweep_exch_bytes(int n_layers, int B, int D, int L);
 long ark_gru_sweep_sync_words(int n_layers, int B, int L);
 int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* sweep, void* stream);
@@ -263,6 +265,8 @@ typedef struct {
   unsigned* sync;          /* workspace, ark_gru_sweep_sync_words() words (zeroed ONCE by the caller)   */
   const float* hyper;
   int n_layers, B, D, L;
+  int wg_slices;           /* as in ArkGruSweep */
+  int pad_;
 } ArkGruSweepBwd;
 long ark_gru_sweep_bwd_exch_bytes(int n_layers, int B, int D, int L);
 int ark_gru_sweep_bwd(int prec, const ArkGruSweepBwd* sweep, void* stream);

@@ -356,3 +356,35 @@ def test_a_failed_sweep_is_remembered_until_the_host_reads_it():
     torch.cuda.synchronize()
     assert eng.sweep_error() == (0, 0)
     assert rel_err(again, good) < 1e-5, (good, again)
+
+
+@pytest.mark.parametrize("D,B,T", [(128, 64, 12), (512, 16, 12), (256, 48, 11)])
+def test_two_slices_per_workgroup_change_nothing(D, B, T):
+    """`ark_sweep_wg_slices` (default 2: two unit slices share a 512-thread workgroup, the sweep holds half the CUs) is a
+    placement choice only: the same arithmetic per slice, so states, saves and panels are bit-identical to one slice per
+    workgroup (the bias-gradient and dh0 atomics land in another order)"""
+    from oracle import sail_oracle as O
+    cfg = _cfg(D, 16, 300, 5, T, True)
+    P = O.init_params(cfg, 1)
+    triples, seq = synth_batch(cfg, B, seed=5, padded=True)
+    torch.manual_seed(9)
+    eps = torch.randn(B, 16)
+    engs, outs = [], []
+    for ws in (1, 2):
+        eng = make_engine(dict(cfg, dec_dropout=0.1, ark_sweep=1, ark_sweep_wg_slices=ws), P, "mixed")
+        eng.set_hyper(beta=0.3)
+        eng.drop_seed = 4321
+        dev = eng.device
+        outs.append(eng.train_step(triples.to(dev), seq.to(dev), eps.to(dev)).cpu().numpy().copy())
+        torch.cuda.synchronize()
+        assert eng.sweep_error() == (0, 0)
+        engs.append(eng)
+    a, b = engs
+    assert b._sweep_wgs(B) * 2 == a._sweep_wgs(B)
+    for l in range(cfg["n_layers"]):
+        assert torch.equal(a.ws["Y"][l], b.ws["Y"][l]) and torch.equal(a.ws["SR"][l], b.ws["SR"][l]), l
+        assert torch.equal(a.ws["dG16"][l], b.ws["dG16"][l]), l
+    assert rel_err(float(outs[1][0]), float(outs[0][0])) < 1e-6
+    for k in a.g:
+        da, db = a.g[k].float(), b.g[k].float()
+        assert (da - db).norm().item() <= 1e-4 * da.norm().item() + 1e-9, k
