@@ -55,7 +55,8 @@ __device__ unsigned long long ark_sweep_stamp_buf[512 * 8];
 // weights in registers serve all of them: wd-movies, B = 256 x D = 128, fits the chip with MT = 2).
 // WS: logical workgroups (unit slices) per PHYSICAL workgroup of 256 * WS threads.  WS = 2 packs two slices onto one CU
 // (waves 0-3 / 4-7: two per SIMD), so the sweep of wd-articles holds 48 CUs instead of 96 and the vocabulary CE beside it
-// gets 208: a sweep step is three memory round trips and 0.3 us of arithmetic, sharing a CU costs it next to nothing.
+// gets 208.  Measured: NOT a win (wd-articles 7.13 -> 8.01 ms/step, wd-movies 1.93 -> 2.00): the two slices lengthen each
+// other's memory round trips, which is all a sweep step is made of.  Kept selectable (`wg_slices = 2`), default 1.
 template <int PREC, int PRECB, int KSW, int MT, int WS>
 __global__ __launch_bounds__(256 * WS) void gru_sweep_fwd_kernel(GruSweepArgs pa) {
   using PT = PrecTraits<PREC>;
@@ -317,7 +318,7 @@ static int launch_persistent(Kern kern, const Args& p, unsigned grid, int ws, hi
 template <int PREC, int PRECB, int KSW, int MT>
 static int launch_sweep_fwd(const GruSweepArgs& p, unsigned grid, hipStream_t st) {
   // (two slices per workgroup = two waves per SIMD = 256 registers per lane: D = 512 with two row tiles does not fit them)
-  if (p.a.wg_slices == 1 || grid % 2 != 0 || (KSW == 4 && MT == 2)) {
+  if (p.a.wg_slices != 2 || grid % 2 != 0 || (KSW == 4 && MT == 2)) {
     auto kern = gru_sweep_fwd_kernel<PREC, PRECB, KSW, MT, 1>;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
     (void)once;
@@ -598,7 +599,7 @@ template <int PREC, int KSW, int MT>
 static int launch_sweep_bwd(const GruSweepBwdArgs& p, unsigned grid, hipStream_t st) {
   // (the backward keeps two weight panels AND two fragment sets in registers: at D = 512 that needs the 512 registers of a
   //  lone wave per SIMD -- 58-126 spilled registers with two slices per workgroup -- so it stays one slice per workgroup)
-  if (p.a.wg_slices == 1 || grid % 2 != 0 || KSW == 4) {
+  if (p.a.wg_slices != 2 || grid % 2 != 0 || KSW == 4) {
     auto kern = gru_sweep_bwd_kernel<PREC, KSW, MT, 1>;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLds), true);
     (void)once;
@@ -631,7 +632,7 @@ extern "C" int ark_gru_sweep_cus(int n_layers, int B, int D, int backward, int w
   const int mt = sweep_row_tiles(n_layers, B, D);
   if (mt == 0) return 0;
   const int logical = n_layers * (B / 16) * (D / 16) / mt;
-  const bool two = wg_slices != 1 && logical % 2 == 0 && (backward ? D != 512 : !(D == 512 && mt == 2));
+  const bool two = wg_slices == 2 && logical % 2 == 0 && (backward ? D != 512 : !(D == 512 && mt == 2));
   return two ? logical / 2 : logical;
 }
 

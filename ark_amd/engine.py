@@ -194,9 +194,11 @@ class Engine:
         self.fat = cfg.get("ark_fat", "auto")
         self.sweep = cfg.get("ark_sweep", "auto")
         self.sweep_bwd = bool(cfg.get("ark_sweep_bwd", True))   # (0: persistent forward, diagonal backward)
-        # unit slices per physical sweep workgroup: 2 = two slices share a CU (half the CUs held; the kernels beside the sweep
-        # get the rest), 1 = one per CU
-        self.sweep_ws = 1 if int(cfg.get("ark_sweep_wg_slices", 2)) == 1 else 2
+        # unit slices per physical sweep workgroup: 1 = one per CU (default), 2 = two slices share a 512-thread workgroup (half
+        # the CUs held, the kernels beside the sweep get the rest).  Measured on MI355X, same box: wd-articles 7.13 -> 8.01
+        # ms/step, wd-movies 1.93 -> 2.00 with 2 -- a sweep step is three memory round trips, and two slices on one CU lengthen
+        # every one of them by more than the vocabulary CE gains from 208 instead of 160 CUs
+        self.sweep_ws = 2 if int(cfg.get("ark_sweep_wg_slices", 1)) == 2 else 1
         self.ce_dw_after_latent = bool(cfg.get("ark_ce_dw_after_latent", True))
         self.ce_chunks = int(cfg.get("ark_ce_chunks", 4))   # time chunks of the sweep + CE pipeline (1: off)
         self._ce_dw_pending = None

@@ -216,7 +216,7 @@ typedef struct {
   int n_layers, B, D, L;
   int t0;                /* index of this launch's first step inside the whole sequence (a sequence swept in several launches
                           * passes arrays advanced by t0 steps): only the dropout hash offsets use it                    */
-  int wg_slices;         /* unit slices per physical workgroup: 0 / 2 = two (512 threads, half the CUs: the default), 1 = one */
+  int wg_slices;         /* unit slices per physical workgroup: 0 / 1 = one (the default), 2 = two (512 threads, half the CUs) */
 } ArkGruSweep;
 /* 16-row tiles per workgroup the sweeps would use on the current device: 1 or 2; 0 = the grid cannot be co-resident */
 int ark_gru_sweep_row_tiles(int n_layers, int B, int D);
