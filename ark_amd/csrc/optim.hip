@@ -135,9 +135,18 @@ __device__ __forceinline__ AdamScalars adam_scalars(const float* hyper) {
   a.inv_sqrt_bc2 = 1.0f / sqrtf(hyper[ARK_HP_ADAM_BC2]);
   return a;
 }
-__device__ __forceinline__ f32x4 adam_quad(const AdamScalars& a, float* p, const float* g, float* m, float* v, long i) {
+// G16: the gradient is read from a bf16 buffer (the all-reduced transport copy of a data-parallel bucket) instead of the fp32
+// one -- what ark_uncast16 + this kernel did in two passes (72 MB less HBM traffic per step at syn-paths)
+template <bool G16>
+__device__ __forceinline__ f32x4 adam_quad(const AdamScalars& a, float* p, const void* g, float* m, float* v, long i) {
   f32x4 pp = *reinterpret_cast<f32x4*>(p + i);
-  const f32x4 gg = *reinterpret_cast<const f32x4*>(g + i) * a.gs;
+  f32x4 gg;
+  if constexpr (G16) {
+    const bf16x4 g4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(g) + i);
+    gg = f32x4{(float)g4[0], (float)g4[1], (float)g4[2], (float)g4[3]} * a.gs;
+  } else {
+    gg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g) + i) * a.gs;
+  }
   f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -151,7 +160,8 @@ __device__ __forceinline__ f32x4 adam_quad(const AdamScalars& a, float* p, const
   return pp;
 }
 
-__global__ __launch_bounds__(256) void adam_shadow_kernel(float* __restrict__ p, const float* __restrict__ g,
+template <bool G16>
+__global__ __launch_bounds__(256) void adam_shadow_kernel(float* __restrict__ p, const void* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, AdamJobs jobs,
                                                           const float* __restrict__ hyper) {
   __shared__ float tile[32][33];
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(256) void adam_shadow_kernel(float* __restrict__ p,
   const AdamScalars a = adam_scalars(hyper);
   if (jb.R == 0) {   // linear range, length jb.C (% 4 == 0)
     const long i = (long)t * 1024 + 4 * threadIdx.x;
-    if (i < jb.C) adam_quad(a, p, g, m, v, jb.off + i);
+    if (i < jb.C) adam_quad<G16>(a, p, g, m, v, jb.off + i);
     return;
   }
   const int tiles_c = (jb.C + 31) / 32;
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(256) void adam_shadow_kernel(float* __restrict__ p,
   f32x4 pp = {0.f, 0.f, 0.f, 0.f};
   if (r < jb.R && c < jb.C) {   // C % 4 == 0 (host-checked): the quad is whole
     const long e = (long)r * jb.C + c;
-    pp = adam_quad(a, p, g, m, v, jb.off + e);
+    pp = adam_quad<G16>(a, p, g, m, v, jb.off + e);
     if (jb.dst) {
       if (jb.prec == PREC_F16) {
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -215,9 +225,9 @@ extern "C" int ark_version(void) { return 200; }
 // Adam (as ark_adam_step) over the jobs' ranges of the flat buffers, writing the 16-bit weight shadows of
 // every matrix job from the updated values.  Job i: R[i] == 0 -> linear range [off[i], off[i] + C[i]);
 // else matrix [R[i], C[i]] at off[i] with optional plain (dst, prec) / transposed (dstT, precT, ldT) shadows.
-extern "C" int ark_adam_step_shadows(float* p, const float* g, float* m, float* v, int n_jobs, const int64_t* off,
-                                     const int* R, const int* C, void* const* dst, void* const* dstT, const int* prec,
-                                     const int* precT, const int* ldT, const float* hyper, void* stream) {
+static int adam_step_shadows_impl(float* p, const void* g, bool g16, float* m, float* v, int n_jobs, const int64_t* off,
+                                  const int* R, const int* C, void* const* dst, void* const* dstT, const int* prec,
+                                  const int* precT, const int* ldT, const float* hyper, void* stream) {
   using namespace ark;
   if (!p || !g || !m || !v || !hyper || n_jobs <= 0 || n_jobs > ARK_ADAM_MAX_JOBS || !off || !R || !C) return ARK_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
@@ -244,10 +254,27 @@ extern "C" int ark_adam_step_shadows(float* p, const float* g, float* m, float* 
     tiles += R[i] > 0 ? (long)((R[i] + 31) / 32) * ((C[i] + 31) / 32) : ((long)C[i] + 1023) / 1024;
     if (tiles > 0x7fffffffL) return ARK_ERR_SHAPE;
   }
-  hipLaunchKernelGGL(adam_shadow_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p, g, m, v, jobs, hyper);
+  if (g16) hipLaunchKernelGGL(adam_shadow_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p, g, m, v, jobs, hyper);
+  else hipLaunchKernelGGL(adam_shadow_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p, g, m, v, jobs, hyper);
   ARK_LAUNCH_CHECK();
   return 0;
 }
+
+extern "C" int ark_adam_step_shadows(float* p, const float* g, float* m, float* v, int n_jobs, const int64_t* off,
+                                     const int* R, const int* C, void* const* dst, void* const* dstT, const int* prec,
+                                     const int* precT, const int* ldT, const float* hyper, void* stream) {
+  return adam_step_shadows_impl(p, g, false, m, v, n_jobs, off, R, C, dst, dstT, prec, precT, ldT, hyper, stream);
+}
+
+// the same with the gradient read from a bf16 buffer g16 (same element offsets as the flat fp32 buffers): the all-reduced
+// transport copy of a data-parallel gradient bucket goes straight into the update, no widening pass in between
+extern "C" int ark_adam_step_shadows_g16(float* p, const void* g16, float* m, float* v, int n_jobs, const int64_t* off,
+                                         const int* R, const int* C, void* const* dst, void* const* dstT, const int* prec,
+                                         const int* precT, const int* ldT, const float* hyper, void* stream) {
+  if (reinterpret_cast<uintptr_t>(g16) & 7) return ARK_ERR_ALIGN;
+  return adam_step_shadows_impl(p, g16, true, m, v, n_jobs, off, R, C, dst, dstT, prec, precT, ldT, hyper, stream);
+}
+
 
 // up to 12 jobs: dst = cast(src [R,C]) in `prec`, dstT = cast(src^T [C,R]) in `precT` (either may be NULL)
 extern "C" int ark_weight_shadows(int n_jobs, const float* const* src, void* const* dst, void* const* dstT, const int* R,

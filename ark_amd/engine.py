@@ -211,6 +211,14 @@ class Engine:
         # all-reduce bf16 copies of the gradient buckets (half the bytes over xGMI; fp32 master gradients, weights and
         # moments; measured drift after 3 steps: mean < 1e-4, tests/test_dp_gpu.py).  `ark_dp_bf16: false` = fp32 buckets
         self.dp_bf16 = bool(cfg.get("ark_dp_bf16", True))
+        # order of the data-parallel step (SAIL, fast path).  "beside": the single-process order -- GRU weight gradients on the
+        # side queue beside the latent / encoder backward; both buckets complete at the end of the step, the encoder bucket's
+        # all-reduce is exposed, the decoder bucket's is pipelined into the next step.  "chain-first" (rounds 1-3): the
+        # dependent chain first, the GRU weight gradients after it so that the encoder bucket's all-reduce has something to
+        # hide under -- costs ~0.2 ms of compute on every rank before a byte moves
+        self.dp_order = str(cfg.get("ark_dp_order", "beside"))
+        if self.dp_order not in ("beside", "chain-first"):
+            raise L.ArkError(f"ark_dp_order: {self.dp_order!r} (beside | chain-first)")
         self._defer_wgrads = False
         self._fork_pending = None
         self._dlog16_only = False
@@ -367,10 +375,15 @@ class Engine:
         linear(cur, hi)
         return jobs
 
-    def _adam_launch(self, which):
+    def _adam_launch(self, which, g16=False):
+        """g16: the gradient comes from the bf16 transport buffer of the data-parallel buckets (no widening pass)"""
         st = L.cur_stream()
         if self.use_dma:
             for (n, off, R, C, dst, dstT, pf, pb, ldT) in self._adam_jobs[which]:
+                if g16:
+                    _call("ark_adam_step_shadows_g16", L.ptr(self.P), L.ptr(self._Gh), L.ptr(self.M), L.ptr(self.Vv), L.i32(n), off,
+                          R, C, dst, dstT, pf, pb, ldT, L.ptr(self.hyper), st)
+                    continue
                 _call("ark_adam_step_shadows", L.ptr(self.P), L.ptr(self.G), L.ptr(self.M), L.ptr(self.Vv), L.i32(n), off, R, C,
                       dst, dstT, pf, pb, ldT, L.ptr(self.hyper), st)
             if which in ("all", "dec"):   # (the bucket that holds W_tok and W_ih0)
@@ -1563,13 +1576,15 @@ class Engine:
         comes first and ticks the step counter, `dec` = [dec_grad_offset, total) follows with the same
         step scalars -- together exactly adam()."""
         off, tot = self.layout.dec_grad_offset, self.layout.total
+        fused = self.dp_bf16 and self.use_dma   # Adam reads the reduced bf16 bucket itself (ark_adam_step_shadows_g16)
         if which == "enc":
             _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
             self.adam_steps += 1
-            self._dp_unpack(0, off)
-        else:
+            if not fused:
+                self._dp_unpack(0, off)
+        elif not fused:
             self._dp_unpack(off, tot)
-        self._adam_launch(which)
+        self._adam_launch(which, g16=fused)
 
     def dp_flush(self):
         """Finish a pipelined data-parallel step: wait for the decoder bucket's all-reduce and apply its Adam
@@ -1643,6 +1658,14 @@ class Engine:
                 self.backward_encoder()
                 self._dp_pack(0, off)
                 yield (0, off)
+            return
+        if self.dp_order == "beside":
+            self.backward_decoder()   # (forks the GRU weight gradients + token-embedding gradient onto the side queue)
+            self.backward_encoder()   # (joins the side queue: every gradient is queued)
+            self._dp_pack(0, off)
+            yield (0, off)            # the encoder's parameters are needed first: its bucket goes out first
+            self._dp_pack(off, tot)
+            yield (off, tot)
             return
         self._defer_wgrads = True
         try:

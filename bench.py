@@ -171,15 +171,19 @@ def diag_byte_models(eng, B):
         dy = 4 * D if l == n - 1 else 0
         b_impl += Lq * (B * (up + 3 * D * 2 + dy + 4 * D + 4 * D + 8 * D + 4 * D * 2 + 4 * D) + wbytes)
     fl = cells * 2.0 * B * D * 6 * D
+    # small vocabularies: layer 0's input projection is a table row per token (W_tok W_ih0^T, Engine.xtab), not a product
+    tab = getattr(eng, "xtab", None) is not None and not eng._use_fat(B, Lq) and not eng._use_sweep(B, Lq)
+    fl_f = fl - (Lq * 2.0 * B * D * 3 * D if tab else 0.0)
     # operand bytes the workgroups pull from L2 into LDS by LDS-DMA (default tiles: forward 64 rows x 32 units = 96 weight
-    # rows over K = 2D; backward 32 rows x 64 columns over K = 3D from the layer above + 3D recurrent), summed over the step
-    f_dma = cells * ((B + 63) // 64) * (D // 32) * (64 + 96) * (2 * D) * 2
+    # rows over K = 2D -- K = D for layer 0 with the token table; backward 32 rows x 64 columns over K = 3D from the layer
+    # above + 3D recurrent), summed over the step
+    f_dma = (cells * 2 * D - (Lq * D if tab else 0)) * ((B + 63) // 64) * (D // 32) * (64 + 96) * 2
     b_dma = 0
     for l in range(n):
         for t in range(Lq):
             K = (3 * D if l < n - 1 else 0) + (3 * D if t < Lq - 1 else 0)
             b_dma += ((B + 31) // 32) * (D // 64) * (32 + 64) * K * 2
-    return {"gru_diag_fwd_kernel": dict(min=f_min, impl=f_impl, flops=fl, dma=f_dma),
+    return {"gru_diag_fwd_kernel": dict(min=f_min, impl=f_impl, flops=fl_f, dma=f_dma),
             "gru_diag_bwd_kernel": dict(min=b_min, impl=b_impl, flops=fl, dma=b_dma)}
 
 
@@ -282,11 +286,12 @@ def other_workloads(dev, precision, dropout, mfma_peak):
     out = {}
     for name, steps in (("syn-types", 100), ("wd-movies", 100), ("wd-articles", 30)):
         try:
-            r = time_workload(dev, name, precision, dropout, 0, steps, 10, 40)
+            r = time_workload(dev, name, precision, dropout, 0, steps, 10, 40)   # (40 settle + 10 warm-up steps, then `steps` timed)
             eng, cfg, B, dt = r["eng"], r["cfg"], r["B"], r["dt"]
             gps = B * steps / dt
             fl = flops_per_graph(cfg)
             ent = {"batch": B, "d_model": cfg["d_model"], "seq_len": cfg["seq_len"], "vocab": cfg["vocab_size"], "steps": steps,
+                   "warmup": 10, "settle_steps": 40,
                    "ms_per_step": dt / steps * 1e3, "graphs_per_s": gps, "model_tflops": gps * fl / 1e12,
                    "model_mfma_frac": gps * fl / 1e12 / mfma_peak, "final_loss": r["loss"][0]}
             if eng.ws["v2"]:
@@ -307,6 +312,40 @@ def other_workloads(dev, precision, dropout, mfma_peak):
         except Exception as e:   # a development leg must never take the headline line down
             out[name] = {"error": repr(e)}
     return out
+
+
+def dp_overhead_1rank(dev, args, extra, plain_ms):
+    """what the data-parallel SCHEDULE costs before a byte moves: the same workload through the N-rank code path (bucketed
+    gradient all-reduce over a ONE-rank RCCL group, bf16 transport, split / pipelined Adam, one hipGraph per bucket) against
+    the single-process step measured above, on this GPU, for both bucket orders (Engine.dp_order)."""
+    import torch
+    import torch.distributed as dist
+    res = {"plain_ms_per_step": plain_ms, "ranks": 1, "backend": "nccl (RCCL), one rank: no transfer, the schedule's own cost",
+           "steps": 200, "warmup": 20, "settle_steps": 100}
+    try:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        try:
+            for order in ("beside", "chain-first"):
+                r = time_workload(dev, args.workload, args.precision, args.dropout, args.batch, 200, 20, 100,
+                                  dict(extra, ark_dp_order=order), world=1, rank=0, dist=dist, use_dp=True)
+                ms = r["dt"] / 200 * 1e3
+                res[order.replace("-", "_") + "_ms_per_step"] = ms
+                res[order.replace("-", "_") + "_ratio"] = ms / plain_ms
+                log(f"dp schedule on one rank, order {order}: {ms:.3f} ms/step = {ms / plain_ms:.3f} x plain")
+                del r
+                torch.cuda.empty_cache()
+            res["default_order"] = "beside"
+            res["ratio"] = res["beside_ratio"]
+        finally:
+            dist.destroy_process_group()
+    except Exception as e:   # a diagnostic leg must never take the headline line down
+        res["error"] = repr(e)
+    return res
 
 
 def self_launch(args, argv):
@@ -465,6 +504,7 @@ def main():
         if not args.no_other and world == 1 and args.workload == "syn-paths" and not args.force_dist:
             del eng
             torch.cuda.empty_cache()
+            res["dp_overhead_1rank"] = dp_overhead_1rank(dev, args, extra, dt / args.steps * 1e3)
             res["other_workloads"] = other_workloads(dev, args.precision, args.dropout, mfma_peak)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, B, steps=args.cpu_steps, warmup=5)

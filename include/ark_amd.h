@@ -484,6 +484,11 @@ int ark_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const
 int ark_adam_step_shadows(float* p, const float* g, float* m, float* v, int n_jobs, const int64_t* off, const int* R,
                           const int* C, void* const* dst, void* const* dstT, const int* prec, const int* precT,
                           const int* ldT, const float* hyper, void* stream);
+/* the same with the gradient read from a bf16 buffer (element i of g16 = the gradient of flat element i): the all-reduced
+ * 16-bit transport copy of a data-parallel bucket feeds the update directly */
+int ark_adam_step_shadows_g16(float* p, const void* g16, float* m, float* v, int n_jobs, const int64_t* off, const int* R,
+                              const int* C, void* const* dst, void* const* dstT, const int* prec, const int* precT,
+                              const int* ldT, const float* hyper, void* stream);
 /* accumulate != 0: add into `out` (caller zeroed it, e.g. the whole gradient buffer at once) */
 int ark_colsum(const float* x, int64_t ld, int64_t batch_stride_in, float* out, int64_t batch_stride_out, int M,
                int N, int n_batch, int accumulate, void* stream);
