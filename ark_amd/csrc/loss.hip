@@ -358,6 +358,96 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
   }
 }
 
+// Phases 1-2 of latent_chain_bwd_kernel as a launch of their own, built for LATENCY (round 4: the fused kernel was 72-80 us
+// of mostly waiting -- one wave per SIMD walking Wz^T into LDS 20 dependent loads deep, then D / 64 dependent row loads, then
+// 2 x 20 x 3 dependent W_head loads -- for 31 MFLOP):
+//   dzp = dh0 * (1 - h0^2) (in place), dz = dzp Wz, dhead = d(beta * kl)/d(mu, logv) + dz through the reparameterisation
+// RW = 4 rows per workgroup, one wave per row; every load of a phase is in flight before the first use (Wz: D*Z/4/256
+// float4s per thread; the row: D / 64 values of dh0 and h0 per lane); Wz^T sits in LDS with row stride D + 1 (conflict-free).
+// The [B, 3D] phase (dA) follows as latent_dA_kernel on a 2-D grid.
+template <int ZT, int DU>
+__global__ __launch_bounds__(256) void latent_dz_head_kernel(float* __restrict__ dh0, const float* __restrict__ h0,
+                                                             const float* __restrict__ Wz, const float* __restrict__ head,
+                                                             const float* __restrict__ eps, const float* __restrict__ hyper,
+                                                             const float* __restrict__ ext_dhead, float* __restrict__ dhead,
+                                                             int B, int Z, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dz[];
+  float* zs = reinterpret_cast<float*>(smem_dz);   // Wz^T: [Z][D + 1]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int DS = D + 1;
+  const int b = (int)blockIdx.x * 4 + wave;
+  const bool valid = b < B;
+  const int bb = valid ? b : B - 1;
+  // this row's operands first (they are what the wave's dot products wait for), then the shared Wz tile
+  float hv[DU], gv[DU];
+#pragma unroll
+  for (int u = 0; u < DU; ++u) {
+    const int d = lane + 64 * u;
+    hv[u] = d < D ? h0[(long)bb * D + d] : 0.f;
+    gv[u] = d < D ? dh0[(long)bb * D + d] : 0.f;
+  }
+  {
+    const int N4 = (D * Z) >> 2;   // (D % 4 == 0: host check)
+    const f32x4* W4 = reinterpret_cast<const f32x4*>(Wz);
+    for (int base = threadIdx.x; base < N4; base += 256 * 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = base + 256 * u;
+        v[u] = q < N4 ? W4[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = base + 256 * u;
+        if (q < N4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * q + e;
+            zs[(i % Z) * DS + i / Z] = v[u][e];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float acc[ZT];
+#pragma unroll
+  for (int j = 0; j < ZT; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int u = 0; u < DU; ++u) {
+    const int d = lane + 64 * u;
+    if (d < D) {
+      const float g = gv[u] * (1.0f - hv[u] * hv[u]);
+      if (valid) dh0[(long)bb * D + d] = g;
+#pragma unroll
+      for (int j = 0; j < ZT; ++j)
+        if (j < Z) acc[j] += g * zs[j * DS + d];
+    }
+  }
+  float mydz = 0.f;
+#pragma unroll
+  for (int j = 0; j < ZT; ++j)
+    if (j < Z) {
+      const float a = wave_sum(acc[j]);
+      if (lane == j) mydz = a;
+    }
+  if (lane < Z && valid) {
+    const float ks = hyper[ARK_HP_BETA] * hyper[ARK_HP_KL_NORM];  // beta / (B_global * Z)
+    const float m = head[(long)b * 2 * Z + lane];
+    const float raw = head[(long)b * 2 * Z + Z + lane];
+    const float lv = fminf(fmaxf(raw, -10.0f), 10.0f);
+    float dmu = mydz + ks * m;
+    float dlv = mydz * (eps ? eps[(long)b * Z + lane] : 0.f) * 0.5f * expf(0.5f * lv) + ks * 0.5f * (expf(lv) - 1.0f);
+    if (raw < -10.0f || raw > 10.0f) dlv = 0.f;
+    if (ext_dhead) {
+      dmu += ext_dhead[(long)b * 2 * Z + lane];
+      dlv += ext_dhead[(long)b * 2 * Z + Z + lane];
+    }
+    dhead[(long)b * 2 * Z + lane] = dmu;
+    dhead[(long)b * 2 * Z + Z + lane] = dlv;
+  }
+}
+
 // The last phase of latent_chain_bwd_kernel as a launch of its own, for batches whose B/4 row workgroups would leave most
 // of the chip idle while each of them walks all H columns (syn-types B = 256: 64 workgroups, 224 us for 38 MFLOP):
 //   dA[b, c] = (sum_j dhead[b, j] W_head[j, c]) * gelu'(pre[b, c]), its 16-bit copy and column sums
@@ -816,6 +906,33 @@ extern "C" int ark_latent_chain_bwd(float* dh0, const float* h0, const float* w_
   if (lds > 150 * 1024) return ARK_ERR_SHAPE;
   // few row workgroups (B < 512) x many columns: the dA phase goes to a launch of its own with a 2-D grid (the chain kernel
   // runs with H = 0: its column loops are empty)
+  // small latent x wide decoder (syn-paths Z = 10, syn-types Z = 24): two launches built for latency -- per-row dz / dhead
+  // with every load of a phase in flight at once, then dA on a 2-D grid (72-80 us fused -> see profiles/r04_kernel_stats.csv)
+#ifndef ARK_NO_LATENT_DZ   // (A/B builds: tools/build_variant.sh nodz loss.hip -DARK_NO_LATENT_DZ)
+  if (Z <= 32 && D % 4 == 0 && D <= 1024 && B >= 64 && H >= 768) {
+    const size_t l2 = (size_t)Z * (D + 1) * sizeof(float);
+#define ARK_DZ(ZT, DU)                                                                                                       \
+    {                                                                                                                        \
+      static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_dz_head_kernel<ZT, DU>),            \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), true);         \
+      (void)once;                                                                                                            \
+      hipLaunchKernelGGL((latent_dz_head_kernel<ZT, DU>), dim3((B + 3) / 4), dim3(256), l2, st, dh0, h0, w_z, head, eps, hyper, \
+                         ext_dhead, dhead, B, Z, D);                                                                         \
+    }
+    if (l2 <= 150 * 1024) {
+      if (Z <= 16 && D <= 512) ARK_DZ(16, 8)
+      else if (Z <= 16) ARK_DZ(16, 16)
+      else if (D <= 512) ARK_DZ(32, 8)
+      else ARK_DZ(32, 16)
+#undef ARK_DZ
+      ARK_LAUNCH_CHECK();
+      hipLaunchKernelGGL(latent_dA_kernel, dim3((B + 7) / 8, (H + 255) / 256), dim3(256), 0, st, dhead, w_head, pre, dA, dA16, prec16,
+                         dA_colsum, B, 2 * Z, H);
+      ARK_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+#endif
   const bool split = Z <= 64 && (B + 3) / 4 < 128 && H >= 768;
   const int Hc = split ? 0 : H;
 #define ARK_LC(ZT)                                                                                                          \

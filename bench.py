@@ -60,7 +60,7 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("ARK_CPU_THREADS", "16"))))
 
 
-PMC_FILE = "profiles/r03_pmc_summary.json"   # committed PMC passes of this command (tools/profile_round.sh)
+PMC_FILE = "profiles/r04_pmc_summary.json"   # committed PMC passes of this command (tools/profile_round.sh)
 
 
 def log(*a):
@@ -304,7 +304,7 @@ def other_workloads(dev, precision, dropout, mfma_peak):
                     ent["persistent_sweep"] = {"workgroups": eng._sweep_wgs(B), "recurrence_steps": eng.L + eng.n - 1,
                                                "us_per_recurrence_step": {k: kt * 1e6 / (eng.L + eng.n - 1) for k, (kt, n) in times.items()}}
                 ent["diag_share_of_step"] = sum(v["us_per_step"] for v in ent["diag_kernels"].values()) / (dt / steps * 1e6)
-            ent["kernel_profile"] = f"profiles/r03_{name}_kernel_stats.csv"
+            ent["kernel_profile"] = f"profiles/r04_{name}_kernel_stats.csv"
             out[name] = ent
             log(f'{name}: {ent["ms_per_step"]:.3f} ms/step, {gps:.0f} graphs/s')
             del eng, r

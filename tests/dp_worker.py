@@ -39,10 +39,12 @@ def main(rank, world, port, out_path, graph, steps, bf16=False, variant="sail"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    # variants: "sail" (pipelined two-bucket schedule), "nopipe" (ark_dp_pipeline: false), "ark" (decoder-only: one bucket),
-    # and the wd-shaped ones of case()
+    # variants: "sail" (pipelined two-bucket schedule, weight gradients beside the chain), "chainfirst" (the same with
+    # `ark_dp_order: chain-first`), "nopipe" (ark_dp_pipeline: false), "ark" (decoder-only: one bucket), and the wd-shaped
+    # ones of case()
     cfg, B, padded = case(variant)
-    cfg = dict(cfg, learning_rate=1e-3, ark_dp_bf16=bf16, ark_dp_pipeline=(variant != "nopipe"))
+    cfg = dict(cfg, learning_rate=1e-3, ark_dp_bf16=bf16, ark_dp_pipeline=(variant != "nopipe"),
+               ark_dp_order="chain-first" if variant == "chainfirst" else "beside")
     sail = cfg["model_type"] == "SAIL"
     P = O.init_params(cfg, 0)
     eng = Engine(cfg, dev, precision="mixed", world_size=world, rank=rank)

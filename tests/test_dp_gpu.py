@@ -24,6 +24,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("graph,bf16,variant", [(False, False, "sail"), (True, False, "sail"), (True, True, "sail"),
+                                                (True, True, "chainfirst"), (False, False, "chainfirst"),
                                                 (False, False, "nopipe"), (True, False, "nopipe"),
                                                 (False, False, "ark"), (True, False, "ark")])
 def test_two_process_data_parallel_matches_single_process(tmp_path, graph, bf16, variant):
