@@ -16,7 +16,7 @@
 namespace ark {
 
 constexpr int kAttnMaxChunks = 10;   // keys per lane: L <= 640
-constexpr int kAttnMaxDh = 384;      // head width: up to 6 columns per lane (t-SAIL encoder: 3 * 512 / 4 heads)
+constexpr int kAttnMaxDh = 768;      // head width: up to 12 columns per lane (t-SAIL encoder: 3 * 1024 / 4 heads)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // y = LayerNorm(x + res) * gamma + beta over the last dimension (biased variance, eps inside the root: nn.LayerNorm);
@@ -395,6 +395,62 @@ __global__ __launch_bounds__(256) void xattn_bcast_bwd_kernel(const float* __res
   }
 }
 
+// the same for WIDE rows (D > 1536: t-SAIL's 3 * d_model encoder at d_model = 1024): keeping g and xhat of a row in
+// registers would take 4 * D / 64 of them, so the row is walked twice (the second walk re-reads what the first left in L2)
+// and only the two per-column sums stay resident
+template <int CPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                                 const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                 float* __restrict__ ds, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, int rows, int D, int rows_per_wg) {
+  __shared__ float red[2][64 * CPL];   // (the four waves add into it one after the other: same lane -> same columns)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[CPL], ab[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) ag[k] = ab[k] = 0.f;
+  const int r0 = blockIdx.x * rows_per_wg;
+  for (int row = r0 + wave; row < min(rows, r0 + rows_per_wg); row += 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      if (c < D) {
+        const float g = dy[(long)row * D + c] * gamma[c];
+        s1 += g;
+        s2 += g * (s[(long)row * D + c] - mean) * rstd;
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      if (c < D) {
+        const float dyv = dy[(long)row * D + c];
+        const float xh = (s[(long)row * D + c] - mean) * rstd;
+        ds[(long)row * D + c] = rstd * (dyv * gamma[c] - s1 - xh * s2);
+        ag[k] += dyv * xh;
+        ab[k] += dyv;
+      }
+    }
+  }
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        if (w == 0) { red[0][lane + 64 * k] = ag[k]; red[1][lane + 64 * k] = ab[k]; }
+        else { red[0][lane + 64 * k] += ag[k]; red[1][lane + 64 * k] += ab[k]; }
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < D; c += 256) {
+    atomicAdd(&dgamma[c], red[0][c]);
+    atomicAdd(&dbeta[c], red[1][c]);
+  }
+}
+
 static int attn_check(const AttnArgs& p) {
   if (p.B <= 0 || p.L <= 0 || p.D <= 0 || p.H <= 0 || p.D % p.H != 0) return ARK_ERR_ARG;
   if (p.L > 64 * kAttnMaxChunks || p.dh > kAttnMaxDh || p.dh % 4 != 0) return ARK_ERR_SHAPE;
@@ -418,7 +474,7 @@ extern "C" int ark_layernorm_bwd(const float* dy, const float* s, const float* s
                                  float* dbeta, int rows, int D, void* stream) {
   using namespace ark;
   if (!dy || !s || !stats || !gamma || !ds || !dgamma || !dbeta || rows <= 0 || D <= 0) return ARK_ERR_ARG;
-  if (D > 64 * 24) return ARK_ERR_SHAPE;   // (3 * d_model of the widest shipped config fits: 3 * 512)
+  if (D > 64 * 48) return ARK_ERR_SHAPE;   // (3 * d_model at d_model = 1024: the reference's syn-types / syn-tipr YAML)
   int rpw = (rows + 511) / 512;            // ~512 workgroups, whole groups of 4 rows
   rpw = (rpw + 3) / 4 * 4;
   const unsigned grid = (unsigned)((rows + rpw - 1) / rpw);
@@ -429,7 +485,8 @@ extern "C" int ark_layernorm_bwd(const float* dy, const float* s, const float* s
   else if (D <= 256) ARK_LN_BWD(4);
   else if (D <= 512) ARK_LN_BWD(8);
   else if (D <= 1024) ARK_LN_BWD(16);
-  else ARK_LN_BWD(24);
+  else if (D <= 1536) ARK_LN_BWD(24);
+  else hipLaunchKernelGGL((layernorm_bwd_wide_kernel<48>), dim3(grid), dim3(256), 0, st, dy, s, stats, gamma, ds, dgamma, dbeta, rows, D, rpw);
 #undef ARK_LN_BWD
   ARK_LAUNCH_CHECK();
   return 0;

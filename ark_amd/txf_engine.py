@@ -116,9 +116,9 @@ class TxfEngine(Engine):
         self.H = cfg["n_heads"]
         widths = [self.D] + ([3 * self.D] if self.vae else [])
         for W in widths:
-            if W % self.H != 0 or (W // self.H) % 4 != 0 or W // self.H > 384 or W > 1536:
-                raise L.ArkError(f"{self.mt}: layer width {W} / n_heads {self.H}: head widths must be multiples of 4 up to 384, "
-                                 "layer widths at most 1536")
+            if W % self.H != 0 or (W // self.H) % 4 != 0 or W // self.H > 768 or W > 3072:
+                raise L.ArkError(f"{self.mt}: layer width {W} / n_heads {self.H}: head widths must be multiples of 4 up to 768, "
+                                 "layer widths at most 3072")
         self.Z = cfg.get("d_latent", 0) if self.vae else 0
         self.seq_len = cfg["seq_len"]
         self.L = self.seq_len - 1
@@ -157,7 +157,7 @@ class TxfEngine(Engine):
         self.use_dma = False
         self._shadow_ok = True
         self._dp_pending, self._dp_flush_graph = None, None
-        self.dp_bf16 = False
+        self.dp_bf16 = bool(cfg.get("ark_dp_bf16", True))   # bf16 transport of the gradient buckets (fp32 master gradients)
         self._graph_steps = {}
         # 16-bit precisions: the dense products run on the LDS-DMA engines (ark_gemm16 / ark_wgrad16) from 16-bit copies of
         # their operands cast per call -- the register-staged ark_gemm converts the same fp32 operands on the fly, to the same
@@ -530,6 +530,18 @@ class TxfEngine(Engine):
         """backward of the last forward; the gradient w.r.t. the logits sits in ws['logits'].  t-SAIL: the KL gradient is
         added inside the latent kernel (hyper BETA x KL_NORM); ext_dhead [B, 2Z] (optional) adds an external gradient
         w.r.t. (mu | logv), as the reference-style autograd path needs."""
+        for _ in self._backward_steps(ext_dhead):
+            pass
+
+    def dp_split(self):
+        """offset that splits the flat gradient buffer into the two data-parallel buckets of t-SAIL: [split, total) -- the
+        decoder layers and the output projection -- is complete after the decoder half of the backward pass, [0, split) --
+        encoder, heads, embeddings, z-projection -- after the latent / encoder half.  t-ARK: one bucket (0)."""
+        return self.layout.entries["dec.txf.layers.0.self_attn.in_proj_weight"][0] if self.vae else 0
+
+    def _backward_steps(self, ext_dhead=None):
+        """backward() as a generator with ONE seam: it yields after the decoder half when a latent / encoder half follows
+        (the data-parallel step starts the decoder bucket's all-reduce there)"""
         self.prec = self.prec_bwd
         w, B, Lq = self.ws, self._B, self._Lrun
         D, n, V, H = self.D, self.n, self.V, self.H
@@ -577,6 +589,8 @@ class TxfEngine(Engine):
         self._colsum(dy, D, g["dec.pos_emb.weight"], B, D, n_batch=Lq, bs_in=B * D, bs_out=D)
         if not (self.vae and self._enc_on):
             return
+        yield "decoder"
+        st = L.cur_stream()
         # ---- latent + encoder half (t-SAIL)
         Z, T = self.Z, self._T
         W3, Re = 3 * D, T * B
@@ -618,40 +632,84 @@ class TxfEngine(Engine):
         return w["e_scr"]
 
     # ------------------------------------------------------------------ whole step
+    def _dp_segments(self, triples, seq, eps, ce_count):
+        """the data-parallel step as a generator: every next() launches the work that completes one gradient bucket [lo, hi)
+        and yields it (packed into the bf16 transport buffer when `ark_dp_bf16`)"""
+        tot, split = self.layout.total, self.dp_split()
+        self.forward(triples if self.vae else None, seq, eps if self.vae else None, ce_count=ce_count)
+        two = False
+        for _ in self._backward_steps():
+            two = True
+            self._dp_pack(split, tot)
+            yield (split, tot)       # its all-reduce flies underneath the latent / encoder half
+        lo_hi = (0, split) if two else (0, tot)
+        self._dp_pack(*lo_hi)
+        yield lo_hi
+
     def train_step(self, triples, seq, eps=None, grad_sync=None, ce_count=None, dp=False):
-        """forward + loss + backward (+ gradient all-reduce) + Adam; returns out4 on the device"""
+        """forward + loss + backward (+ bucketed gradient all-reduce) + Adam; returns out4 on the device"""
         self._default_norms(seq.shape[0])
         if ce_count is not None:
             self.set_hyper(ce_count=ce_count)
-        self.forward(triples if self.vae else None, seq, eps if self.vae else None, ce_count=ce_count)
-        self.backward()
-        if dp:   # one bucket: the whole flat gradient buffer, summed over the ranks
+        if dp:
             import torch.distributed as dist
-            dist.all_reduce(self.G, op=dist.ReduceOp.SUM)
+            handles = []
+            for item in self._dp_segments(triples, seq, eps, ce_count):
+                handles.append((item, dist.all_reduce(self.dp_bucket(*item), op=dist.ReduceOp.SUM, async_op=True)))
+            self._dp_nseg = len(handles)
+            for item, h in handles:
+                h.wait()
+                self._dp_unpack(*item)
+        else:
+            self.forward(triples if self.vae else None, seq, eps if self.vae else None, ce_count=ce_count)
+            self.backward()
         if grad_sync is not None:
             grad_sync(self.G)
         self.adam()
         return self.ws["out4"]
 
     def capture_train_step(self, triples, seq, eps=None, ce_count=None, grad_sync=None, dp=False):
-        """the single-process train step (forward + loss + backward + Adam, ~200 short launches) as ONE hipGraph on
-        fixed-address inputs; returns replay().  Everything that changes per step lives on the device: dropout and noise
-        draw counters, Adam's step scalars, the CE count.  (Data parallel: not captured -- use train_step(dp=True).)"""
-        if dp or grad_sync is not None:
-            raise L.ArkError(f"{self.mt}: the captured train step is single-process; use train_step(dp=True)")
+        """the train step (forward + loss + backward + Adam, ~200 short launches) as hipGraphs on fixed-address inputs;
+        returns replay().  Single process: ONE graph.  Data parallel (`dp=True`): one graph per gradient bucket (t-SAIL: decoder
+        half | latent + encoder half; t-ARK: one), that bucket's asynchronous all-reduce launched right after its replay, then
+        one graph for [widen the reduced buckets, Adam].  Everything that changes per step lives on the device: dropout and
+        noise draw counters, Adam's step scalars, the CE count."""
+        if grad_sync is not None:
+            raise L.ArkError(f"{self.mt}: capture with a caller-supplied grad_sync is not supported; use dp=True")
         self._default_norms(seq.shape[0])
         if ce_count is not None:
             self.set_hyper(ce_count=ce_count)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):   # warm-up outside capture (allocates the workspace); this IS a step
-            self.train_step(triples, seq, eps, ce_count=ce_count)
+            self.train_step(triples, seq, eps, ce_count=ce_count, dp=dp)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         steps0 = self.adam_steps
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.train_step(triples, seq, eps, ce_count=ce_count)
+        graphs, segs = [], []
+        if dp:
+            gen = self._dp_segments(triples, seq, eps, ce_count)
+            for _ in range(self._dp_nseg):   # (counted by the eager warm-up step above)
+                box = []
+                gseg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gseg):
+                    box.append(next(gen))
+                graphs.append(gseg)
+                segs.append((gseg, box[0]))
+            assert next(gen, None) is None, "data-parallel schedule changed between warm-up and capture"
+
+            def tail():
+                for _, item in segs:
+                    self._dp_unpack(*item)
+                self.adam()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                tail()
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.train_step(triples, seq, eps, ce_count=ce_count)
+        graphs.append(g)
         self.adam_steps = steps0   # capture does not execute
         out4 = self.ws["out4"]
         gstream = torch.cuda.Stream(device=self.device)
@@ -663,27 +721,33 @@ class TxfEngine(Engine):
             if use is not cur:
                 use.wait_stream(cur)
             with torch.cuda.stream(use):
+                if dp:
+                    import torch.distributed as dist
+                    handles = []
+                    for gseg, item in segs:
+                        gseg.replay()
+                        handles.append(dist.all_reduce(self.dp_bucket(*item), op=dist.ReduceOp.SUM, async_op=True))
+                    for h in handles:
+                        h.wait()
                 g.replay()
             if use is not cur:
                 cur.wait_stream(use)
             self.adam_steps += 1
             return out4
 
-        self._graphs[("train", self.ws_key)] = [g]
+        self._graphs[("train", self.ws_key, bool(dp))] = graphs
         self._pinned.add(self.ws_key)
         return replay
 
     def graphed_train_step(self, triples, seq, ce_count=None, dp=False):
-        """train_step() through a cached hipGraph (single process; data parallel steps are launched eagerly)"""
-        if dp:
-            return self.train_step(triples, seq, ce_count=ce_count, dp=True)
+        """train_step() through cached hipGraphs (data parallel: one graph per gradient bucket, see capture_train_step)"""
         assert self.training, "graphed_train_step is a training-mode step"
-        key = (None if triples is None else tuple(triples.shape), tuple(seq.shape), ce_count is None)
+        key = (None if triples is None else tuple(triples.shape), tuple(seq.shape), ce_count is None, bool(dp))
         ent = self._graph_steps.get(key)
         if ent is None:
             tri_s = None if triples is None else triples.clone()
             seq_s = seq.clone()
-            replay = self.capture_train_step(tri_s, seq_s, None, ce_count=ce_count)
+            replay = self.capture_train_step(tri_s, seq_s, None, ce_count=ce_count, dp=dp)
             self._graph_steps[key] = (tri_s, seq_s, replay)
             return self.ws["out4"]
         tri_s, seq_s, replay = ent

@@ -26,6 +26,9 @@ def case(variant):
         return dict(_cfg(128, 64, 3000, 3, 12, True), dec_dropout=0.1 if variant.endswith("-drop") else 0.0), 64, True
     if variant == "wd-articles":
         return _cfg(512, 128, 2500, 6, 86, True), 16, True
+    if variant in ("tsail", "tark"):   # the Transformer variants (bucketed, captured steps of ark_amd.txf_engine)
+        _, cfg = load_golden("tsail_small" if variant == "tsail" else "tark_small")
+        return dict(cfg, dec_dropout=0.0, ark_txf_dropout=0.0), 64, False
     _, cfg = load_golden("ark_synpaths_b32_s0" if variant == "ark" else "sail_synpaths_b32_s0")
     return dict(cfg, dec_dropout=0.0), 128, False
 
@@ -47,7 +50,13 @@ def main(rank, world, port, out_path, graph, steps, bf16=False, variant="sail"):
                ark_dp_order="chain-first" if variant == "chainfirst" else "beside")
     sail = cfg["model_type"] == "SAIL"
     P = O.init_params(cfg, 0)
-    eng = Engine(cfg, dev, precision="mixed", world_size=world, rank=rank)
+    txf = cfg["model_type"].startswith("t-")
+    if txf:
+        from ark_amd.txf_engine import TxfEngine
+        eng = TxfEngine(cfg, dev, precision="mixed", world_size=world, rank=rank)
+        sail = cfg["model_type"] == "t-SAIL"
+    else:
+        eng = Engine(cfg, dev, precision="mixed", world_size=world, rank=rank)
     eng.load_params(P)
     eng.set_hyper(lr=1e-3, beta=0.5)
     Bl = B // world
@@ -89,8 +98,9 @@ def main(rank, world, port, out_path, graph, steps, bf16=False, variant="sail"):
     Bp = (Bl + 15) // 16 * 16
     # which paths this rank took, its sweep error words, its own non-PAD target count of the first batch, its
     # (token-loss / global count, kl) per step
-    info = torch.tensor([float(eng._use_sweep(Bp, Lq)), float(eng.fused_ce), float(eng._ce_chunks(Bp, Lq) is not None),
-                         float(eng.sweep_error()[0]), float((batches[0][1][sl][:, 1:] != 0).sum()), float(Bp)] +
+    paths = [0.0, 0.0, 0.0, 0.0] if txf else [float(eng._use_sweep(Bp, Lq)), float(eng.fused_ce),
+                                              float(eng._ce_chunks(Bp, Lq) is not None), float(eng.sweep_error()[0])]
+    info = torch.tensor(paths + [float((batches[0][1][sl][:, 1:] != 0).sum()), float(Bp)] +
                         [float(x) for l3 in losses for x in l3.cpu()])
     infos = [torch.empty_like(info) for _ in range(world)]
     dist.all_gather(infos, info)

@@ -45,7 +45,9 @@ def _single_process_reference(variant, steps, P0, bf16):
     from tests.dp_worker import case
     cfg, B, padded = case(variant)
     cfg = dict(cfg, learning_rate=1e-3)
-    sail = cfg["model_type"] == "SAIL"
+    sail = cfg["model_type"] in ("SAIL", "t-SAIL")
+    if cfg["model_type"].startswith("t-"):
+        from ark_amd.txf_engine import TxfEngine as Engine   # noqa: F811
     eng = Engine(cfg, "cuda:0", precision="mixed")
     eng.load_params(O.init_params(cfg, 0))
     eng.set_hyper(lr=1e-3, beta=0.5)
@@ -57,7 +59,7 @@ def _single_process_reference(variant, steps, P0, bf16):
         eng.train_step(tri.to(dev) if sail else None, seq.to(dev), eps.to(dev) if sail else None,
                        ce_count=int((seq[:, 1:] != 0).sum()))
     torch.cuda.synchronize()
-    assert eng.sweep_error() == (0, 0)
+    assert cfg["model_type"].startswith("t-") or eng.sweep_error() == (0, 0)
     ref = eng.P.detach().cpu()
     moved = (ref - O_flat(eng, O.init_params(cfg, 0))).abs().max().item()
     assert moved > 1e-3                  # the weights did train
@@ -106,6 +108,19 @@ def test_two_process_data_parallel_at_wd_shapes(tmp_path, graph, variant):
     if variant == "wd-articles":
         assert i0[5] == 16.0                                                     # the 8-graph shard ran padded to 16 rows
     _single_process_reference(variant, steps, P0, False)
+
+
+@pytest.mark.parametrize("graph,bf16,variant", [(False, False, "tsail"), (True, False, "tsail"), (True, True, "tsail"),
+                                                (True, False, "tark")])
+def test_two_process_data_parallel_transformer_variants(tmp_path, graph, bf16, variant):
+    """t-SAIL / t-ARK under two ranks: the bucketed step (t-SAIL: decoder bucket's all-reduce underneath the latent / encoder
+    half), eager and as one hipGraph per bucket + one for [widen, Adam] (round 3: eager only, one bucket), fp32 and bf16
+    transport; the ranks stay bit-identical and land on the weights of ONE process training on the full batch"""
+    steps = 3
+    res = _run_two_ranks(tmp_path, graph, bf16, variant, steps)
+    P0, P1 = res["P"]
+    assert res["adam_steps"] == steps and torch.equal(P0, P1)
+    _single_process_reference(variant, steps, P0, bf16)
 
 
 def test_two_process_data_parallel_with_dropout_on_the_sweep_path(tmp_path):
