@@ -301,8 +301,21 @@ def other_workloads(dev, precision, dropout, mfma_peak):
                 if eng._use_fat(B, eng.L):
                     ent["weights_stationary_forward"] = True
                 if eng._use_sweep(B, eng.L):
-                    ent["persistent_sweep"] = {"workgroups": eng._sweep_wgs(B), "recurrence_steps": eng.L + eng.n - 1,
-                                               "us_per_recurrence_step": {k: kt * 1e6 / (eng.L + eng.n - 1) for k, (kt, n) in times.items()}}
+                    steps_cp = eng.L + eng.n - 1
+                    ent["persistent_sweep"] = {"workgroups": eng._sweep_wgs(B), "recurrence_steps": steps_cp,
+                                               "us_per_recurrence_step": {k: kt * 1e6 / steps_cp for k, (kt, n) in times.items()}}
+                    # these kernels are bound by the serial dependency chain, not by HBM or MFMA: the critical path
+                    # is (L + n - 1) recurrence steps of t_step each; t_step is three dependent trips through the memory system
+                    # (drain of the write-through stores, the counter, the handed-off fragments) around ~0.3 us of MFMA work
+                    ent["roofline_sweeps"] = {
+                        k: {"bound": "critical path (latency)", "recurrence_steps": steps_cp, "t_step_us": kt * 1e6 / steps_cp,
+                            "achieved_us": kt * 1e6, "mfma_work_us_per_step": 0.3,
+                            "floor_us": steps_cp * 0.3, "frac_of_floor": steps_cp * 0.3 / (kt * 1e6),
+                            "phase_split_us_per_step": {"source": "profiles/r03_sweep_stamps.txt (stamped build, wd-articles layer 1)",
+                                                        "wait_counters": 1.58, "barrier": 0.07, "fragments_land": 0.64,
+                                                        "mfma_partials_barrier": 0.29, "reduce_gate_math_tiles": 0.57,
+                                                        "store_drain": 0.31, "atomic_bulk_stores_loop": 0.90}}
+                        for k, (kt, n) in times.items()}
                 ent["diag_share_of_step"] = sum(v["us_per_step"] for v in ent["diag_kernels"].values()) / (dt / steps * 1e6)
             ent["kernel_profile"] = f"profiles/r04_{name}_kernel_stats.csv"
             out[name] = ent
