@@ -16,7 +16,7 @@
 // MONOTONE over the launches that share a `sync` workspace: launch number e (the epoch word of the header, read by every
 // workgroup when it starts and bumped by the last workgroup to leave) waits for counter >= (e + 1) * NS, so no launch has
 // to zero anything in front of a sweep (round 3 did: inside a captured step that 60-KB fill queued behind whatever held
-// the CUs).  Every spin is bounded: after ~0.25 s without progress (or when another workgroup has given up) a workgroup
+// the CUs).  Every spin is bounded: after ~2 s without progress (or when another workgroup has given up) a workgroup
 // sets the error word and leaves, so a scheduling accident ends in an error code, not in a hung GPU.  The error word is
 // STICKY: no kernel ever clears it, every later sweep on the workspace leaves at once, and only ark_gru_sweep_sync_reset
 // (host, after the error has been read) makes the workspace usable again.  All workgroups must be co-resident: the host

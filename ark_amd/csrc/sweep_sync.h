@@ -10,7 +10,10 @@ namespace ark {
 typedef _Float16 shalf4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr unsigned long long kSweepTimeoutTicks = 25000000ull;   // s_memrealtime runs at 100 MHz: 0.25 s
+// s_memrealtime runs at 100 MHz: 2 s.  (0.25 s until round 4: with TWO processes on one card -- the data-parallel tests -- a
+// sweep was seen to give up although nothing was wrong: its queue is time-sliced against the other process's, and a wait that
+// straddles a slice is as long as the slice.  The bound only has to turn a real deadlock into an error instead of a hang.)
+constexpr unsigned long long kSweepTimeoutTicks = 200000000ull;
 constexpr int kSweepLds = 96 * 1024;                             // > half of a CU's LDS: one workgroup per CU
 constexpr int kSweepSyncHdr = 32;                                // words in front of the counters: [0] sticky error, [1] who / where,
                                                                  // [2] epoch = launches completed on this workspace, [3] workgroups

@@ -185,7 +185,7 @@ int ark_gru_diag_bwd(int prec, int n_roles, const ArkGruDiagBwdRole* roles, cons
  * waiting (sync[1] = its id << 12 | step): the outputs of that launch AND of every later launch on the workspace are
  * invalid -- the word is sticky, later sweeps leave at once -- until the caller has read it and called
  * ark_gru_sweep_sync_reset.  The launch is a plain one: the caller must not run anything beside it that keeps a CU from
- * offering 96 KB of LDS to one of its workgroups for longer than the 0.25-s spin bound (the grid needs n_layers *
+ * offering 96 KB of LDS to one of its workgroups for longer than the 2-s spin bound (the grid needs n_layers *
  * (B/16) * (D/16) / row_tiles CUs).
  * Reference: nn.GRU forward, kgvae/model/models.py:121-127. */
 #define ARK_SWEEP_MAX_LAYERS 4

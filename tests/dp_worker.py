@@ -98,6 +98,9 @@ def main(rank, world, port, out_path, graph, steps, bf16=False, variant="sail"):
     Bp = (Bl + 15) // 16 * 16
     # which paths this rank took, its sweep error words, its own non-PAD target count of the first batch, its
     # (token-loss / global count, kl) per step
+    if not txf and eng.sweep_error()[0]:
+        print(f"[dp_worker rank {rank}] sweep error {eng.sweep_error()} (workgroup {eng.sweep_error()[1] >> 12 & 0x7FFFF})",
+              file=sys.stderr, flush=True)
     paths = [0.0, 0.0, 0.0, 0.0] if txf else [float(eng._use_sweep(Bp, Lq)), float(eng.fused_ce),
                                               float(eng._ce_chunks(Bp, Lq) is not None), float(eng.sweep_error()[0])]
     info = torch.tensor(paths + [float((batches[0][1][sl][:, 1:] != 0).sum()), float(Bp)] +

@@ -167,4 +167,6 @@ def test_fat_forward_refuses_what_does_not_fit():
     auto = make_engine(cfg, O.init_params(cfg, 0), "mixed")
     assert not auto._use_fat(1024, 10)                  # opt-in: measured slower than the diagonal launches
     on = make_engine(dict(cfg, ark_fat=1), O.init_params(cfg, 0), "mixed")
-    assert on._use_fat(1024, 10) and on._use_fat(64, 10) and not on._use_fat(16, 100)   # (16 x 100: the small-batch sweep)
+    assert on._use_fat(1024, 10) and on._use_fat(64, 10)
+    with pytest.raises(L.ArkError):
+        on._use_fat(16, 100)                            # one row tile: no two subgroups to walk
