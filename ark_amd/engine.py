@@ -39,6 +39,12 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
+# Graph captures run in THREAD-LOCAL error mode: with torch.distributed initialised, ProcessGroupNCCL's watchdog thread polls
+# the completion events of earlier collectives; under the default (global) mode such a query from another thread while THIS
+# thread captures is "operation not permitted when stream is capturing" and the watchdog takes the process down (seen in
+# round 4: a second capture in a process that had already run RCCL collectives).
+CAPTURE_MODE = "thread_local"
+
 _calls = [0]   # library calls made so far (txf_engine: "nothing has run since the previous product")
 
 
@@ -1798,7 +1804,7 @@ class Engine:
 
         def cap(fn):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 fn()
             graphs.append(g)
             return g
@@ -1811,7 +1817,7 @@ class Engine:
             for _ in range(self._dp_nseg):   # (counted by the eager warm-up step above)
                 box = []
                 gseg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gseg):
+                with torch.cuda.graph(gseg, capture_error_mode=CAPTURE_MODE):
                     box.append(next(gen))
                 graphs.append(gseg)
                 segs.append((gseg, box[0]))

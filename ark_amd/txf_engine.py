@@ -22,7 +22,7 @@ from collections import OrderedDict
 import torch
 
 from . import _lib as L
-from .engine import Engine, HP, PREC, _call, _rup
+from .engine import CAPTURE_MODE, Engine, HP, PREC, _call, _rup
 from .engine import _calls as _launches   # library calls made so far (TxfEngine._cast: "nothing ran since the previous product")
 
 FF = 2048          # nn.Transformer*Layer default dim_feedforward (the reference never passes another)
@@ -692,7 +692,7 @@ class TxfEngine(Engine):
             for _ in range(self._dp_nseg):   # (counted by the eager warm-up step above)
                 box = []
                 gseg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gseg):
+                with torch.cuda.graph(gseg, capture_error_mode=CAPTURE_MODE):
                     box.append(next(gen))
                 graphs.append(gseg)
                 segs.append((gseg, box[0]))
@@ -703,11 +703,11 @@ class TxfEngine(Engine):
                     self._dp_unpack(*item)
                 self.adam()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 tail()
         else:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 self.train_step(triples, seq, eps, ce_count=ce_count)
         graphs.append(g)
         self.adam_steps = steps0   # capture does not execute

@@ -134,8 +134,9 @@ def time_diag_kernels(eng, B, reps=8):
         for name, (fn, launches) in sweeps.items():
             fn()
             torch.cuda.synchronize()
+            from ark_amd.engine import CAPTURE_MODE
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 fn()
             g.replay()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

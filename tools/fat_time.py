@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
-from ark_amd.engine import Engine
+from ark_amd.engine import Engine, CAPTURE_MODE
 from ark_amd import initlib
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -24,7 +24,7 @@ for fat in (0, 1, 0, 1):
         fn = lambda: eng._diag_sweep(w, B, Lq, True, True)
         fn(); torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             fn()
         for _ in range(5):
             g.replay()
