@@ -211,8 +211,10 @@ class Engine:
         self._pad_bufs = {}
         self._n_valid = 0
         self._side_used = False
-        self._dp_pending = None      # data parallel: the decoder bucket's reduction + Adam still owed (see dp_flush)
-        self._dp_flush_graph = None
+        self._dp_pending = None      # data parallel: event behind the decoder bucket's reduction + Adam on the update queue
+        self._dp_flush_graph = None  # (captured mode: that Adam as a graph)
+        self._dp_upd = None          # the update queue
+        self._dp_mode = False        # inside a pipelined data-parallel step (see _forward_steps)
         self.dp_pipeline = bool(cfg.get("ark_dp_pipeline", True))
         # all-reduce bf16 copies of the gradient buckets (half the bytes over xGMI; fp32 master gradients, weights and
         # moments; measured drift after 3 steps: mean < 1e-4, tests/test_dp_gpu.py).  `ark_dp_bf16: false` = fp32 buckets
@@ -404,6 +406,7 @@ class Engine:
         """update device-resident step scalars (tiny async fills, only when a value changes)"""
         for key, val in (("LR", lr), ("BETA", beta), ("KL_NORM", kl_norm), ("GRAD_SCALE", grad_scale)):
             if val is not None and self._hp.get(key) != float(val):
+                self.dp_flush()   # (a decoder-bucket update still on the update queue reads these scalars)
                 self._hp[key] = float(val)
                 self.hyper[HP[key]:HP[key] + 1].fill_(float(val))
         if ce_count is not None and self._hp.get("CE_COUNT") != float(ce_count):
@@ -598,10 +601,11 @@ class Engine:
             H = 3 * D
             if w["v2"]:
                 pf, pb = self.prec_fwd, self.prec_bwd
-                if self._dp_pending is None and self.fused_prologue:
+                skip = self._skip_x0(w, B, Lq)   # (small vocabulary, diagonal path: nobody reads the embedding rows)
+                if self.fused_prologue and (skip or (self._dp_pending is None and not self._dp_mode)):
                     # the decoder's token gather shares the encoder pool's launch (both only need the batch indices); not
-                    # while a pipelined data-parallel update of the token table is still owed (it lands at the seam)
-                    skip = self._skip_x0(w, B, Lq)   # (small vocabulary, diagonal path: nobody reads the embedding rows)
+                    # in a pipelined data-parallel step, whose update of the token table lands at the seam (unless only the
+                    # token ids are written: `skip`) -- a captured first segment must not read W_tok either
                     _call("ark_pool_gather_fwd16", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
                           L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.ptr(w["g16a"]), L.i32(pf), L.ptr(w["g16b"]), L.i32(pb), L.i32(B),
                           L.i32(T), L.i32(D), L.i64(-1 if self.pad_rid is None else self.pad_rid), L.ptr(seq), L.i64(ld_seq),
@@ -1578,33 +1582,50 @@ class Engine:
         self._shadow_ok = True
 
     def _adam_part(self, which):
-        """Adam (+ shadows) of ONE gradient bucket (pipelined data parallel): `enc` = [0, dec_grad_offset)
-        comes first and ticks the step counter, `dec` = [dec_grad_offset, total) follows with the same
-        step scalars -- together exactly adam()."""
+        """Adam (+ shadows) of ONE gradient bucket (pipelined data parallel), with the step scalars _dp_tick() left:
+        `enc` = [0, dec_grad_offset), `dec` = [dec_grad_offset, total) -- together exactly adam()."""
         off, tot = self.layout.dec_grad_offset, self.layout.total
         fused = self.dp_bf16 and self.use_dma   # Adam reads the reduced bf16 bucket itself (ark_adam_step_shadows_g16)
-        if which == "enc":
-            _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
-            self.adam_steps += 1
-            if not fused:
-                self._dp_unpack(0, off)
-        elif not fused:
-            self._dp_unpack(off, tot)
+        if not fused:
+            self._dp_unpack(*((0, off) if which == "enc" else (off, tot)))
         self._adam_launch(which, g16=fused)
 
+    def _dp_tick(self):
+        """advance the optimiser step scalars once for both bucket updates of a pipelined data-parallel step"""
+        _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
+        self.adam_steps += 1
+
+    def _dp_finish(self, h_enc, h_dec, adam_enc, adam_dec):
+        """the tail of a pipelined data-parallel step.  Current queue: wait for the encoder bucket's all-reduce, tick, Adam
+        of that bucket (the next step's encoder forward needs it).  UPDATE queue, concurrently: wait for the decoder
+        bucket's all-reduce, Adam of that bucket -- it runs as soon as its reduction lands, underneath Adam(enc) and the
+        next step's encoder forward, and is joined at that forward's seam (dp_flush).  Round 3 ran it AT the seam, on the
+        critical path (45 us of the one-rank cost of the schedule)."""
+        main = torch.cuda.current_stream()
+        if self._dp_upd is None:
+            self._dp_upd = torch.cuda.Stream(device=self.device)
+        h_enc.wait()
+        self._dp_tick()
+        ticked = torch.cuda.Event()
+        ticked.record(main)
+        self._dp_upd.wait_event(ticked)   # (both updates read the ticked scalars; everything of this step is queued before)
+        with torch.cuda.stream(self._dp_upd):
+            h_dec.wait()
+            adam_dec()
+            done = torch.cuda.Event()
+            done.record(self._dp_upd)
+        adam_enc()
+        self._dp_pending = done
+
     def dp_flush(self):
-        """Finish a pipelined data-parallel step: wait for the decoder bucket's all-reduce and apply its Adam
-        update.  Called automatically before anything reads the decoder parameters (the seam of the next
-        forward, adam(), load_params, mark_params_dirty); call it yourself before reading parameters
-        from outside the engine (checkpoints, state_dict)."""
+        """Join a pipelined data-parallel step: the current queue waits for the decoder bucket's update (its all-reduce +
+        Adam on the update queue).  Called automatically before anything reads or writes the decoder parameters or the step
+        scalars (the seam of the next forward, adam(), load_params, mark_params_dirty, set_hyper); call it yourself before
+        reading parameters from outside the engine (checkpoints, state_dict)."""
         if self._dp_pending is None:
             return
-        h, self._dp_pending = self._dp_pending, None
-        h.wait()
-        if self._dp_flush_graph is not None:
-            self._dp_flush_graph.replay()
-        else:
-            self._adam_part("dec")
+        ev, self._dp_pending = self._dp_pending, None
+        torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------ whole step
     def _pad_batch(self, triples, seq, eps):
@@ -1649,9 +1670,13 @@ class Engine:
         whole K = B*L alone), so per-layer launches cost more than the finer overlap returns
         (1-rank step 1.76 ms vs 1.5 ms).  Other configurations: decoder bucket, then encoder bucket."""
         tot, off = self.layout.total, self.layout.dec_grad_offset
-        fwd = self._forward_steps(triples, seq, eps, ce_count=ce_count)
-        next(fwd)
-        yield "seam"   # (encoder half done; the caller finishes the previous step's decoder bucket here)
+        self._dp_mode = bool(self.dp_pipeline)
+        try:
+            fwd = self._forward_steps(triples, seq, eps, ce_count=ce_count)
+            next(fwd)
+        finally:
+            self._dp_mode = False
+        yield "seam"   # (encoder half done; the caller joins the previous step's decoder-bucket update here)
         for _ in fwd:
             pass
         w = self.ws
@@ -1725,9 +1750,7 @@ class Engine:
             if self.dp_pipeline and grad_sync is None and set(handles) == {(0, off), (off, tot)}:
                 # Adam of the encoder bucket now; the decoder bucket's reduction keeps flying underneath it and
                 # the next step's encoder forward, and is finished in that forward's seam (dp_flush)
-                handles[(0, off)].wait()
-                self._adam_part("enc")
-                self._dp_pending = handles[(off, tot)]
+                self._dp_finish(handles[(0, off)], handles[(off, tot)], lambda: self._adam_part("enc"), lambda: self._adam_part("dec"))
                 return self.ws["out4"]
             for h in handles.values():
                 h.wait()
@@ -1867,9 +1890,8 @@ class Engine:
                         else:
                             handles[item] = dist.all_reduce(self.dp_bucket(*item), op=dist.ReduceOp.SUM, async_op=True)
                     if pipelined:
-                        handles[(0, off)].wait()
-                        gc.replay()
-                        self._dp_pending = handles[(off, tot)]
+                        self._dp_finish(handles[(0, off)], handles[(off, tot)], gc.replay, self._dp_flush_graph.replay)
+                        self.adam_steps -= 1   # (counted below, as for the other modes)
                     else:
                         for h in handles.values():
                             h.wait()

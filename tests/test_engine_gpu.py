@@ -395,7 +395,8 @@ def test_dp_schedule_two_virtual_ranks(dropout):
     gd = (ranks[0].G - full.G).abs().max().item()
     assert gd <= 3e-3 * full.G.abs().max().item(), gd
     ranks[0].adam()
-    ranks[1]._adam_part("enc")   # the pipelined step's two half updates must equal one adam()
+    ranks[1]._dp_tick()          # the pipelined step's tick + two half updates must equal one adam()
+    ranks[1]._adam_part("enc")
     ranks[1]._adam_part("dec")
     torch.cuda.synchronize()
     assert ranks[0].adam_steps == ranks[1].adam_steps == 1
