@@ -10,7 +10,7 @@
 // Attention is exact fp32 on the vector units: one wave per query row (scores: one key per lane; softmax by wave
 // reductions; context: one head column per lane), probabilities kept for the backward pass.  L is at most 640 here
 // (wd-articles: 637), head widths 8 ... 256.
-#include "common.h"
+#include "gemm_core.h"
 #include "../../include/ark_amd.h"
 
 namespace ark {
@@ -293,6 +293,161 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// SHORT sequences (L <= 16: the syn-* datasets' 10 decoder steps, t-SAIL's 3 encoder triples): ONE WAVE per (batch, head)
+// does the whole head -- Q, K, V (backward: + dO) of its L rows staged once in LDS (row stride dh + 1), the L x L scores one
+// (query, key) pair per lane, softmax one query per lane, context / dQ / dK / dV one head column per lane.  The kernels above
+// run one wave per QUERY ROW and re-read every K / V row of the head from global memory per query: at L = 10 that is 40 960
+// waves per attention and was 0.75 ms of a 3.9-ms t-ARK step.  Same arithmetic, same dropout indices (prow + j), same
+// probabilities array.  Only wave-level synchronisation: a wave's LDS accesses execute in program order.
+__device__ __forceinline__ void lds_wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnArgs p, int per_wave_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem_as[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (pair >= p.B * p.H) return;   // (whole wave; no block-wide barrier below)
+  const int b = pair / p.H, h = pair % p.H;
+  const int B = p.B, L = p.L, D = p.D, dh = p.dh, DS = dh + 1, LS = L + 1;
+  const long rs = 3L * D;
+  float* Qs = smem_as + (long)wave * per_wave_floats;
+  float* Ks = Qs + L * DS;
+  float* Vs = Ks + L * DS;
+  float* Ss = Vs + L * DS;   // [L][L + 1]: scores, then dropped probabilities
+  for (int t = 0; t < L; ++t) {
+    const float* row = p.qkv + ((long)t * B + b) * rs + h * dh;
+    for (int d = lane; d < dh; d += 64) {
+      Qs[t * DS + d] = row[d] * p.scale;
+      Ks[t * DS + d] = row[D + d];
+      Vs[t * DS + d] = row[2 * D + d];
+    }
+  }
+  lds_wave_sync();
+  for (int idx = lane; idx < L * L; idx += 64) {
+    const int i = idx / L, j = idx - i * L;
+    float sc = -INFINITY;
+    if ((!p.causal || j <= i) && (!p.kmask || p.kmask[(long)b * L + j])) {
+      float a = 0.f;
+      for (int d = 0; d < dh; ++d) a += Qs[i * DS + d] * Ks[j * DS + d];
+      sc = a;
+    }
+    Ss[i * LS + j] = sc;
+  }
+  lds_wave_sync();
+  const bool drop = p.drop_p > 0.f;
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(p.seed, p.hyper, p.drop_p);
+  if (lane < L) {
+    const int i = lane;
+    float m = -INFINITY;
+    for (int j = 0; j < L; ++j) m = fmaxf(m, Ss[i * LS + j]);
+    float sum = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float s0 = Ss[i * LS + j];
+      sum += (s0 == -INFINITY) ? 0.f : expf(s0 - m);
+    }
+    const float inv = 1.0f / sum;
+    const long prow = (((long)b * p.H + h) * L + i) * L;
+    for (int j = 0; j < L; ++j) {
+      const float s0 = Ss[i * LS + j];
+      const float pr = ((s0 == -INFINITY) ? 0.f : expf(s0 - m)) * inv;
+      p.probs[prow + j] = pr;
+      Ss[i * LS + j] = pr * attn_keep(dc, drop, prow + j);
+    }
+  }
+  lds_wave_sync();
+  for (int i = 0; i < L; ++i) {
+    float* o = p.out + ((long)i * B + b) * D + h * dh;
+    const int nk = p.causal ? i + 1 : L;
+    for (int d = lane; d < dh; d += 64) {
+      float acc = 0.f;
+      for (int j = 0; j < nk; ++j) acc += Ss[i * LS + j] * Vs[j * DS + d];
+      o[d] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnArgs p, int per_wave_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem_as[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (pair >= p.B * p.H) return;
+  const int b = pair / p.H, h = pair % p.H;
+  const int B = p.B, L = p.L, D = p.D, dh = p.dh, DS = dh + 1, LS = L + 1;
+  const long rs = 3L * D;
+  float* Qs = smem_as + (long)wave * per_wave_floats;
+  float* Ks = Qs + L * DS;
+  float* Vs = Ks + L * DS;
+  float* Gs = Vs + L * DS;    // dO
+  float* dS = Gs + L * DS;    // [L][L + 1]: dS * scale
+  float* Pm = dS + L * LS;    // [L][L + 1]: dropped probabilities
+  float* dl = Pm + L * LS;    // [L]: delta
+  for (int t = 0; t < L; ++t) {
+    const float* row = p.qkv + ((long)t * B + b) * rs + h * dh;
+    const float* g = p.dout + ((long)t * B + b) * D + h * dh;
+    const float* o = p.out + ((long)t * B + b) * D + h * dh;
+    float part = 0.f;
+    for (int d = lane; d < dh; d += 64) {
+      Qs[t * DS + d] = row[d];
+      Ks[t * DS + d] = row[D + d];
+      Vs[t * DS + d] = row[2 * D + d];
+      const float gv = g[d];
+      Gs[t * DS + d] = gv;
+      part += gv * o[d];
+    }
+    part = wave_sum(part);
+    if (lane == 0) dl[t] = part;
+  }
+  lds_wave_sync();
+  const bool drop = p.drop_p > 0.f;
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(p.seed, p.hyper, p.drop_p);
+  for (int idx = lane; idx < L * L; idx += 64) {
+    const int i = idx / L, j = idx - i * L;
+    float ds = 0.f, pm = 0.f;
+    if ((!p.causal || j <= i) && (!p.kmask || p.kmask[(long)b * L + j])) {
+      float a = 0.f;
+      for (int d = 0; d < dh; ++d) a += Gs[i * DS + d] * Vs[j * DS + d];
+      const long pidx = (((long)b * p.H + h) * L + i) * L + j;
+      const float pr = p.probs[pidx], keep = attn_keep(dc, drop, pidx);
+      ds = pr * (a * keep - dl[i]) * p.scale;
+      pm = pr * keep;
+    }
+    dS[i * LS + j] = ds;
+    Pm[i * LS + j] = pm;
+  }
+  lds_wave_sync();
+  for (int t = 0; t < L; ++t) {
+    float* dq = p.dqkv + ((long)t * B + b) * rs + h * dh;
+    for (int d = lane; d < dh; d += 64) {
+      float aq = 0.f, ak = 0.f, av = 0.f;
+      for (int u = 0; u < L; ++u) {
+        aq += dS[t * LS + u] * Ks[u * DS + d];     // dQ[t] = sum_j dS[t, j] K[j]
+        ak += dS[u * LS + t] * Qs[u * DS + d];     // dK[t] = sum_i dS[i, t] Q[i]
+        av += Pm[u * LS + t] * Gs[u * DS + d];     // dV[t] = sum_i Pm[i, t] dO[i]
+      }
+      dq[d] = aq;
+      dq[D + d] = ak;
+      dq[2 * D + d] = av;
+    }
+  }
+}
+
+// waves per workgroup of the short-sequence kernels (0: not eligible): per-wave LDS of the BACKWARD (the larger), <= 64 KB in all
+static int attn_small_waves(const AttnArgs& p, int* fwd_floats, int* bwd_floats) {
+  if (p.L > 16) return 0;
+  const int f = 3 * p.L * (p.dh + 1) + p.L * (p.L + 1);
+  const int bw = 4 * p.L * (p.dh + 1) + 2 * p.L * (p.L + 1) + p.L;
+  *fwd_floats = f;
+  *bwd_floats = bw;
+  const int per = bw * 4;
+  if (per > 64 * 1024) return 0;
+  return per * 4 <= 64 * 1024 ? 4 : per * 2 <= 64 * 1024 ? 2 : 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // t-SAIL encoder input (AutoRegEncoder.forward, reference models.py:80-86): x[(t, b)] = [E[h] | R[r] | E[t]] of triple t of
 // graph b (rows time-major over the TRIPLE index), kmask[b, t] = (r != pad_rid).  One wave per row.
 __global__ __launch_bounds__(256) void triple_gather_kernel(const int64_t* __restrict__ triples, const float* __restrict__ E,
@@ -451,6 +606,47 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float* __
   }
 }
 
+// ONE pass where the backward of a sublayer made four (copy, dropout, bias column sum, 16-bit cast of the product operand):
+//   v = x * keep-scale (drop_p > 0; the mask of `seed` and the current draw, element index row * cols + col as
+//       ark_dropout_apply on a buffer of that shape);   x_out (nullable, may alias x) = v;   out16 = cast(v);
+//   colsum[col] += sum_rows v  (nullable).
+// 4 waves per workgroup walk the rows of a 256-column slab, lane -> 4 consecutive columns (one dropout hash per quad).
+template <int PREC>
+__global__ __launch_bounds__(256) void prep16_kernel(const float* __restrict__ x, float* x_out, void* __restrict__ out16_,
+                                                     float* __restrict__ colsum, int rows, int cols, int rows_per_wg, float drop_p,
+                                                     uint64_t seed, const float* __restrict__ hyper) {
+  using PT = PrecTraits<PREC>;
+  using h_t = typename PT::h_t;
+  typedef h_t h4_t __attribute__((ext_vector_type(4)));
+  __shared__ f32x4 red[4][64];
+  h_t* out16 = reinterpret_cast<h_t*>(out16_);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+  const bool drop = drop_p > 0.f;
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(seed, hyper, drop_p);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < cols) {
+    for (int r = r0 + wave; r < r1; r += 4) {
+      const long i = (long)r * cols + c;
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+      if (drop) v = v * dropout_quad(dc, (uint64_t)i >> 2);
+      if (x_out) *reinterpret_cast<f32x4*>(x_out + i) = v;
+      *reinterpret_cast<h4_t*>(out16 + i) = h4_t{PT::cvt(v[0]), PT::cvt(v[1]), PT::cvt(v[2]), PT::cvt(v[3])};
+      acc += v;
+    }
+  }
+  if (!colsum) return;   // (uniform)
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < cols) {
+    const f32x4 t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(&colsum[c + e], t[e]);
+  }
+}
+
 static int attn_check(const AttnArgs& p) {
   if (p.B <= 0 || p.L <= 0 || p.D <= 0 || p.H <= 0 || p.D % p.H != 0) return ARK_ERR_ARG;
   if (p.L > 64 * kAttnMaxChunks || p.dh > kAttnMaxDh || p.dh % 4 != 0) return ARK_ERR_SHAPE;
@@ -504,6 +700,24 @@ extern "C" int ark_dropout_apply(float* x, int64_t n, float p, uint64_t seed, co
   return 0;
 }
 
+extern "C" int ark_prep16(int prec, const float* x, float* x_out, void* out16, float* colsum, int rows, int cols, float drop_p,
+                          uint64_t seed, const float* hyper, void* stream) {
+  using namespace ark;
+  if (!x || !out16 || rows <= 0 || cols <= 0) return ARK_ERR_ARG;
+  if (cols % 4 != 0) return ARK_ERR_SHAPE;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !hyper)) return ARK_ERR_ARG;
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x_out)) & 15) || (reinterpret_cast<uintptr_t>(out16) & 7)) return ARK_ERR_ALIGN;
+  int rpw = (rows + 159) / 160;   // ~160 row chunks x the 256-column slabs
+  rpw = (rpw + 3) / 4 * 4;
+  const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)((rows + rpw - 1) / rpw));
+  hipStream_t st = (hipStream_t)stream;
+  if (prec == PREC_F16) hipLaunchKernelGGL(prep16_kernel<PREC_F16>, grid, dim3(256), 0, st, x, x_out, out16, colsum, rows, cols, rpw, drop_p, seed, hyper);
+  else if (prec == PREC_BF16) hipLaunchKernelGGL(prep16_kernel<PREC_BF16>, grid, dim3(256), 0, st, x, x_out, out16, colsum, rows, cols, rpw, drop_p, seed, hyper);
+  else return ARK_ERR_ARG;
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ark_attn_fwd(const float* qkv, float* out, float* probs, const unsigned char* kmask, int B, int L, int D, int n_heads,
                             int causal, float drop_p, uint64_t seed, const float* hyper, void* stream) {
   using namespace ark;
@@ -512,6 +726,14 @@ extern "C" int ark_attn_fwd(const float* qkv, float* out, float* probs, const un
   int rc = attn_check(p);
   if (rc) return rc;
   p.scale = 1.0f / sqrtf((float)p.dh);
+  int ff = 0, bf = 0;
+  const int nw = attn_small_waves(p, &ff, &bf);
+  if (nw > 0) {   // short sequences: one wave per (batch, head)
+    hipLaunchKernelGGL(attn_small_fwd_kernel, dim3((unsigned)((B * n_heads + nw - 1) / nw)), dim3(64 * nw), (size_t)nw * ff * sizeof(float),
+                       (hipStream_t)stream, p, ff);
+    ARK_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * n_heads), (unsigned)((L + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
   ARK_LAUNCH_CHECK();
   return 0;
@@ -527,6 +749,14 @@ extern "C" int ark_attn_bwd(const float* qkv, const float* out, const float* pro
   int rc = attn_check(p);
   if (rc) return rc;
   p.scale = 1.0f / sqrtf((float)p.dh);
+  int ff = 0, bf = 0;
+  const int nw = attn_small_waves(p, &ff, &bf);
+  if (nw > 0) {   // short sequences: one wave per (batch, head); `dscore` is not used
+    hipLaunchKernelGGL(attn_small_bwd_kernel, dim3((unsigned)((B * n_heads + nw - 1) / nw)), dim3(64 * nw), (size_t)nw * bf * sizeof(float),
+                       (hipStream_t)stream, p, bf);
+    ARK_LAUNCH_CHECK();
+    return 0;
+  }
   const dim3 grid((unsigned)(B * n_heads), (unsigned)((L + 3) / 4));
   hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
   hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);

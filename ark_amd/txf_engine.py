@@ -299,7 +299,11 @@ class TxfEngine(Engine):
     def _gemm(self, a_lay, b_lay, epi, A, lda, Bm, ldb, C, ldc, M, N, K, C2=None, bias=None, aux=None, acc=0):
         KM, MM = L.LAY_KMAJ, L.LAY_MMAJ
         pr = self.prec
+        if getattr(self, "_prepared", None) is not None and self._prepared != A.data_ptr():
+            self._prepared = None
         if not self.fast_gemm or pr == L.PREC_F32 or C2 is not None:
+            if getattr(self, "_prepared", None) is not None:
+                raise L.ArkError("a prepared (dropout-applied, 16-bit) operand reached the register-staged product")
             return super()._gemm(a_lay, b_lay, epi, A, lda, Bm, ldb, C, ldc, M, N, K, C2=C2, bias=bias, aux=aux, acc=acc)
         st = L.cur_stream()
         if a_lay == KM and K % 64 == 0 and lda == K and ((b_lay == KM and ldb == K) or (b_lay == MM and ldb == N)):
@@ -329,7 +333,23 @@ class TxfEngine(Engine):
             if self._last_cast is not None:
                 self._last_cast[1] = _launches[0]
             return
+        if getattr(self, "_prepared", None) is not None:
+            raise L.ArkError("a prepared (dropout-applied, 16-bit) operand reached the register-staged product")
         return super()._gemm(a_lay, b_lay, epi, A, lda, Bm, ldb, C, ldc, M, N, K, C2=C2, bias=bias, aux=aux, acc=acc)
+
+    def _fast_ok(self, *dims):
+        """the products around an [R, N] gradient take the 16-bit LDS-DMA engines (whole 64-wide stages in every dimension)"""
+        return bool(self.fast_gemm and self.prec != L.PREC_F32 and all(d % 64 == 0 for d in dims))
+
+    def _prep(self, x, R, N, bias_grad, seed=None, x_out=None):
+        """ONE pass (ark_prep16) for what used to be copy + dropout + bias column sum + 16-bit cast: the 16-bit copy of
+        dropout(x) lands in the product-operand slot, so the products that follow take `x` as their A operand and find it
+        there; bias_grad (nullable) += column sums; x_out (nullable, may be x): the fp32 dropped values"""
+        out = self._buf("a", 2 * R * N)
+        _call("ark_prep16", L.i32(self.prec), L.ptr(x), L.ptr(x_out), L.ptr(out), L.ptr(bias_grad), L.i32(R), L.i32(N),
+              L.f32(self.p_drop if seed is not None else 0.0), L.u64(seed or 0), L.ptr(self.hyper), L.cur_stream())
+        self._last_cast = [(x.data_ptr(), R * N, self.prec, out.data_ptr()), _launches[0]]
+        self._prepared = x.data_ptr()   # (the fp32 tensor itself is NOT what the products must read: see _gemm)
 
     def _copy(self, dst, src):
         _call("ark_copy", L.ptr(dst), L.ptr(src), L.i64(src.numel() * src.element_size()), L.cur_stream())
@@ -364,7 +384,10 @@ class TxfEngine(Engine):
         """x -> LN(x + drop(W2 drop(relu(W1 x))))"""
         KM, p = L.LAY_KMAJ, self.p
         self._gemm(KM, KM, L.EPI_BIAS_RELU, x, W, p[pre + "linear1.weight"], W, d["f"], FF, R, FF, W, bias=p[pre + "linear1.bias"])
-        if drop:
+        if drop and self._fast_ok(R, FF, W):
+            # in place (positive exactly where ReLU fired AND the mask kept) AND as the 16-bit operand of linear2: one pass
+            self._prep(d["f"], R, FF, None, self._seed(stack, l, 2), x_out=d["f"])
+        elif drop:
             self._drop(d["f"], self._seed(stack, l, 2))   # in place: positive exactly where ReLU fired AND the mask kept
         self._gemm(KM, KM, L.EPI_BIAS, d["f"], FF, p[pre + "linear2.weight"], FF, d["g2"], W, R, W, FF, bias=p[pre + "linear2.bias"])
         if drop:
@@ -468,18 +491,25 @@ class TxfEngine(Engine):
         """dy = gradient of LN(x_in + drop(FF(x_in))) -> gradient w.r.t. x_in, returned in `ds`"""
         KM, MM, p, g = L.LAY_KMAJ, L.LAY_MMAJ, self.p, self.g
         self._ln_bwd(dy, d[s_key], d[st_key], pre + norm, ds, R, W)
+        fast = self._fast_ok(R, W, FF)
         dg2 = ds
-        if drop:
-            dg2 = tmp
-            self._copy(dg2, ds)
-            self._drop(dg2, self._seed(stack, l, 3))
-        self._colsum(dg2, W, g[pre + "linear2.bias"], R, W)
+        if fast:   # dropout + bias gradient + the products' 16-bit operand in ONE pass over ds (which stays the residual's)
+            self._prep(ds, R, W, g[pre + "linear2.bias"], self._seed(stack, l, 3) if drop else None)
+        else:
+            if drop:
+                dg2 = tmp
+                self._copy(dg2, ds)
+                self._drop(dg2, self._seed(stack, l, 3))
+            self._colsum(dg2, W, g[pre + "linear2.bias"], R, W)
         self._gemm(MM, MM, L.EPI_NONE, dg2, W, d["f"], FF, g[pre + "linear2.weight"], FF, W, FF, R, acc=1)
         # df = (dg2 W2) masked by ReLU (and by the feed-forward dropout: f is positive only where both let it through)
         self._gemm(KM, MM, L.EPI_MUL_RELU, dg2, W, p[pre + "linear2.weight"], FF, df, FF, R, FF, W, aux=d["f"])
-        if drop:
-            self._drop(df, self._seed(stack, l, 2))
-        self._colsum(df, FF, g[pre + "linear1.bias"], R, FF)
+        if fast:
+            self._prep(df, R, FF, g[pre + "linear1.bias"], self._seed(stack, l, 2) if drop else None)
+        else:
+            if drop:
+                self._drop(df, self._seed(stack, l, 2))
+            self._colsum(df, FF, g[pre + "linear1.bias"], R, FF)
         self._gemm(MM, MM, L.EPI_NONE, df, FF, x_in, W, g[pre + "linear1.weight"], W, FF, W, R, acc=1)
         self._gemm(KM, MM, L.EPI_NONE, df, FF, p[pre + "linear1.weight"], W, ds, W, R, W, FF, acc=1)   # + df W1 (residual already there)
         return ds
@@ -489,18 +519,25 @@ class TxfEngine(Engine):
         KM, MM, p, g = L.LAY_KMAJ, L.LAY_MMAJ, self.p, self.g
         a = pre + "self_attn."
         self._ln_bwd(dy, d["s1"], d["st1"], pre + "norm1", ds, R, W)
+        fast = self._fast_ok(R, W)
         dsa = ds
-        if drop:
-            dsa = tmp
-            self._copy(dsa, ds)
-            self._drop(dsa, self._seed(stack, l, 1))
-        self._colsum(dsa, W, g[a + "out_proj.bias"], R, W)
+        if fast:
+            self._prep(ds, R, W, g[a + "out_proj.bias"], self._seed(stack, l, 1) if drop else None)
+        else:
+            if drop:
+                dsa = tmp
+                self._copy(dsa, ds)
+                self._drop(dsa, self._seed(stack, l, 1))
+            self._colsum(dsa, W, g[a + "out_proj.bias"], R, W)
         self._gemm(MM, MM, L.EPI_NONE, dsa, W, d["att"], W, g[a + "out_proj.weight"], W, W, W, R, acc=1)
         self._gemm(KM, MM, L.EPI_NONE, dsa, W, p[a + "out_proj.weight"], W, scratch, W, R, W, W)            # d(att)
         _call("ark_attn_bwd", L.ptr(d["qkv"]), L.ptr(d["att"]), L.ptr(d["probs"]), L.ptr(scratch), L.ptr(dscore), L.ptr(dqkv), L.ptr(kmask),
               L.i32(B), L.i32(Ls), L.i32(W), L.i32(self.H), L.i32(1 if causal else 0), L.f32(self.p_drop if drop else 0.0),
               L.u64(self._seed(stack, l, 0)), L.ptr(self.hyper), L.cur_stream())
-        self._colsum(dqkv, 3 * W, g[a + "in_proj_bias"], R, 3 * W)
+        if fast:
+            self._prep(dqkv, R, 3 * W, g[a + "in_proj_bias"])
+        else:
+            self._colsum(dqkv, 3 * W, g[a + "in_proj_bias"], R, 3 * W)
         self._gemm(MM, MM, L.EPI_NONE, dqkv, 3 * W, x_in, W, g[a + "in_proj_weight"], W, 3 * W, W, R, acc=1)
         self._gemm(KM, MM, L.EPI_NONE, dqkv, 3 * W, p[a + "in_proj_weight"], W, ds, W, R, W, 3 * W, acc=1)
         return ds
@@ -512,11 +549,14 @@ class TxfEngine(Engine):
         a = pre + "multihead_attn."
         self._ln_bwd(dy, d["s2"], d["st2"], pre + "norm2", ds, R, W)
         dca = ds
-        if drop:
-            dca = tmp
-            self._copy(dca, ds)
-            self._drop(dca, self._seed(0, l, 5))
-        self._colsum(dca, W, g[a + "out_proj.bias"], R, W)
+        if self._fast_ok(R, W):
+            self._prep(ds, R, W, g[a + "out_proj.bias"], self._seed(0, l, 5) if drop else None)
+        else:
+            if drop:
+                dca = tmp
+                self._copy(dca, ds)
+                self._drop(dca, self._seed(0, l, 5))
+            self._colsum(dca, W, g[a + "out_proj.bias"], R, W)
         self._gemm(MM, MM, L.EPI_NONE, dca, W, d["ctx"], W, g[a + "out_proj.weight"], W, W, W, R, acc=1)
         self._gemm(KM, MM, L.EPI_NONE, dca, W, p[a + "out_proj.weight"], W, scratch, W, R, W, W)            # d(ctx)
         _call("ark_xattn_bcast_bwd", L.ptr(scratch), L.ptr(d["cs"]), L.ptr(dv), L.i32(B), L.i32(Ls), L.i32(W), L.i32(self.H), L.cur_stream())

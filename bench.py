@@ -362,6 +362,44 @@ def dp_overhead_1rank(dev, args, extra, plain_ms):
     return res
 
 
+def transformer_variants(dev, precision, dropout):
+    """development numbers of the Transformer variants at the syn-paths shape, B = 1024: captured train steps
+    (H2D of the batch excluded: fixed device inputs), 40 timed after 10 untimed"""
+    import torch
+    from ark_amd import initlib
+    from ark_amd.txf_engine import TxfEngine
+    out = {}
+    for mt in ("t-ARK", "t-SAIL"):
+        try:
+            cfg = dict(build_cfg(dropout, "syn-paths"), model_type=mt)
+            B = cfg["batch"]
+            eng = TxfEngine(cfg, dev, precision=precision)
+            eng.load_params(initlib.init_state(cfg, seed=0))
+            eng.set_hyper(lr=cfg["learning_rate"], beta=cfg["beta"])
+            tri, seq = synth_global_batch(cfg, B, 1)
+            tri, seq = tri.to(dev), seq.to(dev)
+            st = torch.cuda.Stream(device=dev)
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                step = eng.capture_train_step(tri, seq)
+                for _ in range(10):
+                    o4 = step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(40):
+                    o4 = step()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 40
+            out[mt] = {"batch": B, "ms_per_step": dt * 1e3, "graphs_per_s": B / dt, "steps": 40, "warmup": 10,
+                       "final_loss": float(o4[0]), "note": "16-bit MFMA products, exact-fp32 attention / LayerNorm on the vector units"}
+            log(f'{mt}: {dt * 1e3:.3f} ms/step')
+            del eng
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out[mt] = {"error": repr(e)}
+    return out
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) as children of this process --
     which has not touched the GPU -- and relay their exit code; rank 0's JSON line goes to our stdout."""
@@ -520,6 +558,8 @@ def main():
             torch.cuda.empty_cache()
             res["dp_overhead_1rank"] = dp_overhead_1rank(dev, args, extra, dt / args.steps * 1e3)
             res["other_workloads"] = other_workloads(dev, args.precision, args.dropout, mfma_peak)
+            if args.precision != "f32":
+                res["transformer_variants"] = transformer_variants(dev, args.precision, args.dropout)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, B, steps=args.cpu_steps, warmup=5)
             if B == 1024:   # the plumbing batch and the YAML batch beside it

@@ -328,6 +328,11 @@ int ark_token_sums16(int prec, const int64_t* seq, int64_t ld_seq, const void* x
                      void* scratch, int64_t scratch_bytes, int B, int L, int Vp, int n_cols, void* stream);
 int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, int M, int N, int accumulate, void* stream);
 int ark_cast16(int prec, const float* x, void* out, int64_t n, void* stream);
+/* one pass for what the backward of a Transformer sublayer made four passes of: v = x * dropout keep-scale (drop_p > 0: the
+ * mask ark_dropout_apply(seed) draws on a [rows, cols] buffer), x_out (nullable, may alias x) = v, out16 = cast(v) in `prec`,
+ * colsum[col] += sum over rows of v (nullable).  cols % 4 == 0. */
+int ark_prep16(int prec, const float* x, float* x_out, void* out16, float* colsum, int rows, int cols, float drop_p, uint64_t seed,
+               const float* hyper, void* stream);
 /* out[i] = (float)x16[i]: data-parallel gradient buckets reduced in 16 bits go back into the fp32 gradient buffer */
 int ark_uncast16(int prec, const void* x16, float* out, int64_t n, void* stream);
 int ark_to_tiled(const float* x, float* out, int rows, int ld, void* stream);

@@ -42,9 +42,11 @@ def test_layernorm_fwd_bwd_match_torch(rows, D, with_res):
     assert torch.allclose(db.double(), bd.grad, atol=1e-4 * rows ** 0.5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("B,Lq,D,H", [(3, 10, 32, 4), (2, 70, 128, 4), (1, 130, 512, 4), (2, 9, 1024, 4)])
+@pytest.mark.parametrize("B,Lq,D,H", [(3, 10, 32, 4), (2, 70, 128, 4), (1, 130, 512, 4), (2, 9, 1024, 4),
+                                      (70, 10, 512, 4), (5, 16, 64, 4), (3, 17, 64, 4)])
 def test_attention_fwd_bwd_match_torch(B, Lq, D, H):
-    """causal multi-head attention on time-major packed qkv rows against torch (fp64), forward and backward"""
+    """causal multi-head attention on time-major packed qkv rows against torch (fp64), forward and backward; L <= 16 runs the
+    one-wave-per-head kernels, longer sequences the one-wave-per-query ones"""
     from ark_amd import _lib as L
     torch.manual_seed(1)
     dh = D // H
@@ -449,3 +451,41 @@ def test_tsail_at_d_model_1024_matches_the_oracle():
         assert (got - want).norm().item() <= 2e-3 * nw, (k, (got - want).norm().item() / nw)
         checked += 1
     assert checked >= 30
+
+
+@pytest.mark.parametrize("name", ["tark_small", "tsail_small"])
+def test_fused_gradient_prep_matches_the_separate_passes(name):
+    """16-bit precisions with dropout ON: ark_prep16 (dropout + bias column sums + the products' 16-bit operand in one pass; the
+    feed-forward activation dropped in place and cast in one pass) against the separate copy / dropout / column-sum / cast
+    passes of `ark_txf_fast_gemm: 0` (register-staged products: the same 16-bit operand values): the same masks, so the
+    same loss and gradients up to summation order"""
+    from oracle import sail_oracle as O
+    from tests.parity_util import synth_batch
+    from ark_amd.txf_engine import TxfEngine
+    z, cfg = load_golden(name)
+    cfg = dict(cfg, dec_dropout=0.1, ark_txf_dropout=0.1)
+    assert cfg["d_model"] % 64 == 0
+    B = 128
+    P = O.init_params(cfg, int(z["seed"]))
+    leaves = dict(O.leaf_params(P))
+    tri, seq = synth_batch(cfg, B, seed=5)
+    torch.manual_seed(11)
+    eps = torch.randn(B, cfg.get("d_latent", 1))
+    vae = cfg["model_type"] == "t-SAIL"
+    outs, grads = [], []
+    for fast in (0, 1):
+        eng = TxfEngine(dict(cfg, ark_txf_fast_gemm=fast), "cuda:0", precision="mixed")
+        eng.load_params({k: t.detach() for k, t in leaves.items()})
+        eng.set_hyper(beta=0.5)
+        eng._default_norms(B)
+        eng.training = True
+        R = B * (cfg["seq_len"] - 1)
+        assert eng._fast_ok(R, cfg["d_model"]) == bool(fast)
+        w = eng.forward(tri.cuda() if vae else None, seq.cuda(), eps.cuda() if vae else None)
+        eng.backward()
+        outs.append(w["out4"].cpu().numpy().copy())
+        grads.append({k: v.double().cpu().clone() for k, v in eng.g.items()})
+    assert rel_err(float(outs[1][0]), float(outs[0][0])) < 2e-5, outs
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert (a - b).norm().item() <= 4e-3 * a.norm().item() + 1e-10, (k, (a - b).norm().item() / (a.norm().item() + 1e-30))
