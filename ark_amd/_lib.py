@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("ARK_AMD_LIB") or os.path.join(_HERE, "lib", "libark_a
 
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 LAY_KMAJ, LAY_MMAJ = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL_DGELU, EPI_MUL_AUX, EPI_BIAS_RELU, EPI_MUL_RELU = 0, 1, 2, 3, 4, 5, 6
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL_DGELU, EPI_MUL_AUX, EPI_BIAS_RELU, EPI_MUL_RELU, EPI_ADD = 0, 1, 2, 3, 4, 5, 6, 7
 
 _lib = None
 

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
           if (p.epi == ARK_EPI_MUL_DGELU) x *= dgelu_erf(p.aux[o]);
           if (p.epi == ARK_EPI_BIAS_RELU) x = fmaxf(x, 0.f);
           if (p.epi == ARK_EPI_MUL_RELU) x = p.aux[o] > 0.f ? x : 0.f;
+          if (p.epi == ARK_EPI_ADD) x += p.C[o];   // (each element belongs to exactly one lane of one workgroup)
           if (p.epi == ARK_EPI_BIAS_GELU) {
             x += p.bias[col];
             p.C[o] = x;            // pre-activation (fp32, kept for the backward pass)
@@ -318,7 +319,8 @@ static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const vo
   if (!A16 || !B16 || !C || M <= 0 || N <= 0 || K <= 0) return ARK_ERR_ARG;
   if (K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0) return ARK_ERR_SHAPE;
   if (((uintptr_t)A16 | (uintptr_t)B16) & 15) return ARK_ERR_ALIGN;
-  if (epi < ARK_EPI_NONE || epi > ARK_EPI_MUL_RELU) return ARK_ERR_ARG;
+  if (epi < ARK_EPI_NONE || epi > ARK_EPI_ADD) return ARK_ERR_ARG;
+  if (epi == ARK_EPI_ADD && (c_tiled || c16a || c16b || colsum)) return ARK_ERR_ARG;
   if ((epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_BIAS_RELU) && !bias) return ARK_ERR_ARG;
   if ((epi == ARK_EPI_MUL_AUX || epi == ARK_EPI_MUL_DGELU || epi == ARK_EPI_MUL_RELU) && !aux) return ARK_ERR_ARG;
   if (c_tiled && (epi == ARK_EPI_BIAS_RELU || epi == ARK_EPI_MUL_RELU)) return ARK_ERR_ARG;

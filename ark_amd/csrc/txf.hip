@@ -24,23 +24,34 @@ constexpr int kAttnMaxDh = 768;      // head width: up to 12 columns per lane (t
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ s_out, float* __restrict__ y,
-                                                            float* __restrict__ stats, int rows, int D, float eps) {
+                                                            float* __restrict__ stats, int rows, int D, float eps, float drop_p,
+                                                            uint64_t seed, const float* __restrict__ hyper) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + (long)row * D;
   const float* rr = res ? res + (long)row * D : nullptr;
+  // drop_p > 0: `res` is the sublayer output BEFORE its dropout -- the keep-scale of element row * D + c of the current draw
+  // (what ark_dropout_apply would have multiplied in a pass of its own) is applied on the way in
+  const bool drop = drop_p > 0.f && rr;
+  DropCtx dc{};
+  if (drop) dc = drop_ctx(seed, hyper, drop_p);
+  auto rv = [&](int c) -> float {
+    if (!rr) return 0.f;
+    const float v = rr[c];
+    return drop ? v * dropout_one(dc, (uint64_t)((long)row * D + c)) : v;
+  };
   float sum = 0.f;
-  for (int c = lane; c < D; c += 64) sum += xr[c] + (rr ? rr[c] : 0.f);
+  for (int c = lane; c < D; c += 64) sum += xr[c] + rv(c);
   const float mean = wave_sum(sum) / (float)D;
   float sq = 0.f;
   for (int c = lane; c < D; c += 64) {
-    const float d = xr[c] + (rr ? rr[c] : 0.f) - mean;
+    const float d = xr[c] + rv(c) - mean;
     sq += d * d;
   }
   const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
   for (int c = lane; c < D; c += 64) {
-    const float v = xr[c] + (rr ? rr[c] : 0.f);
+    const float v = xr[c] + rv(c);
     if (s_out) s_out[(long)row * D + c] = v;
     y[(long)row * D + c] = (v - mean) * rstd * gamma[c] + beta[c];
   }
@@ -657,13 +668,20 @@ static int attn_check(const AttnArgs& p) {
 
 }  // namespace ark
 
-extern "C" int ark_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* s_out, float* y,
-                                 float* stats, int rows, int D, float eps, void* stream) {
+extern "C" int ark_layernorm_fwd_drop(const float* x, const float* res, const float* gamma, const float* beta, float* s_out, float* y,
+                                      float* stats, int rows, int D, float eps, float drop_p, uint64_t seed, const float* hyper,
+                                      void* stream) {
   if (!x || !gamma || !beta || !y || !stats || rows <= 0 || D <= 0) return ARK_ERR_ARG;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!hyper || !res))) return ARK_ERR_ARG;
   hipLaunchKernelGGL(ark::layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
-                     beta, s_out, y, stats, rows, D, eps);
+                     beta, s_out, y, stats, rows, D, eps, drop_p, seed, hyper);
   ARK_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int ark_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* s_out, float* y,
+                                 float* stats, int rows, int D, float eps, void* stream) {
+  return ark_layernorm_fwd_drop(x, res, gamma, beta, s_out, y, stats, rows, D, eps, 0.f, 0, nullptr, stream);
 }
 
 extern "C" int ark_layernorm_bwd(const float* dy, const float* s, const float* stats, const float* gamma, float* ds, float* dgamma,

@@ -310,7 +310,10 @@ class TxfEngine(Engine):
             # C[M,N] (+)= A[M,K] op(B): B is [N,K] (KM) or [K,N] (MM: its transposed 16-bit copy is made)
             A16 = self._cast("a", A, M * K, pr)
             B16 = self._cast("b", Bm, N * K, pr) if b_lay == KM else self._cast_t("b", Bm, K, N, pr)
-            if acc:
+            if acc and epi == L.EPI_NONE and ldc == N:   # C += A op(B) in the product's own epilogue
+                _call("ark_gemm16", L.i32(pr), L.i32(L.EPI_ADD), L.ptr(A16), L.i64(K), L.ptr(B16), L.i64(K), L.ptr(C), L.i64(ldc),
+                      L.ptr(None), L.ptr(None), L.i32(M), L.i32(N), L.i32(K), L.i32(0), st)
+            elif acc:
                 tmp = self._buf("c", 4 * M * N)
                 _call("ark_gemm16", L.i32(pr), L.i32(epi), L.ptr(A16), L.i64(K), L.ptr(B16), L.i64(K), L.ptr(tmp), L.i64(N),
                       L.ptr(bias), L.ptr(aux), L.i32(M), L.i32(N), L.i32(K), L.i32(0), st)
@@ -357,9 +360,11 @@ class TxfEngine(Engine):
     def _drop(self, x, seed):
         _call("ark_dropout_apply", L.ptr(x), L.i64(x.numel()), L.f32(self.p_drop), L.u64(seed), L.ptr(self.hyper), L.cur_stream())
 
-    def _ln_fwd(self, x, sub, pre, s, y, st, R, W):
-        _call("ark_layernorm_fwd", L.ptr(x), L.ptr(sub), L.ptr(self.p[pre + ".weight"]), L.ptr(self.p[pre + ".bias"]), L.ptr(s), L.ptr(y),
-              L.ptr(st), L.i32(R), L.i32(W), L.f32(LN_EPS), L.cur_stream())
+    def _ln_fwd(self, x, sub, pre, s, y, st, R, W, drop_seed=None):
+        """y = LN(x + sub); drop_seed: `sub` has NOT been through its dropout yet -- the kernel applies that mask on the way in"""
+        _call("ark_layernorm_fwd_drop", L.ptr(x), L.ptr(sub), L.ptr(self.p[pre + ".weight"]), L.ptr(self.p[pre + ".bias"]), L.ptr(s),
+              L.ptr(y), L.ptr(st), L.i32(R), L.i32(W), L.f32(LN_EPS), L.f32(self.p_drop if drop_seed is not None else 0.0),
+              L.u64(drop_seed or 0), L.ptr(self.hyper), L.cur_stream())
 
     def _ln_bwd(self, dy, s, st, pre, ds, R, W):
         _call("ark_layernorm_bwd", L.ptr(dy), L.ptr(s), L.ptr(st), L.ptr(self.p[pre + ".weight"]), L.ptr(ds), L.ptr(self.g[pre + ".weight"]),
@@ -375,9 +380,7 @@ class TxfEngine(Engine):
               L.i32(1 if causal else 0), L.f32(self.p_drop if drop else 0.0), L.u64(self._seed(stack, l, 0)), L.ptr(self.hyper),
               L.cur_stream())
         self._gemm(KM, KM, L.EPI_BIAS, d["att"], W, p[a + "out_proj.weight"], W, d["sa"], W, R, W, W, bias=p[a + "out_proj.bias"])
-        if drop:
-            self._drop(d["sa"], self._seed(stack, l, 1))
-        self._ln_fwd(x, d["sa"], pre + "norm1", d["s1"], d["x1"], d["st1"], R, W)
+        self._ln_fwd(x, d["sa"], pre + "norm1", d["s1"], d["x1"], d["st1"], R, W, self._seed(stack, l, 1) if drop else None)
         return d["x1"]
 
     def _ff_fwd(self, d, x, pre, norm, R, W, drop, stack, l, s_key, x_key, st_key):
@@ -390,9 +393,7 @@ class TxfEngine(Engine):
         elif drop:
             self._drop(d["f"], self._seed(stack, l, 2))   # in place: positive exactly where ReLU fired AND the mask kept
         self._gemm(KM, KM, L.EPI_BIAS, d["f"], FF, p[pre + "linear2.weight"], FF, d["g2"], W, R, W, FF, bias=p[pre + "linear2.bias"])
-        if drop:
-            self._drop(d["g2"], self._seed(stack, l, 3))
-        self._ln_fwd(x, d["g2"], pre + norm, d[s_key], d[x_key], d[st_key], R, W)
+        self._ln_fwd(x, d["g2"], pre + norm, d[s_key], d[x_key], d[st_key], R, W, self._seed(stack, l, 3) if drop else None)
         return d[x_key]
 
     def _cross_attn_fwd(self, d, x, mem, pre, R, W, B, Ls, drop, l):
@@ -404,9 +405,7 @@ class TxfEngine(Engine):
         _call("ark_xattn_bcast_fwd", L.ptr(d["vmem"]), L.ptr(d["ctx"]), L.ptr(d["cs"]), L.i32(B), L.i32(Ls), L.i32(W), L.i32(self.H),
               L.f32(self.p_drop if drop else 0.0), L.u64(self._seed(0, l, 4)), L.ptr(self.hyper), L.cur_stream())
         self._gemm(KM, KM, L.EPI_BIAS, d["ctx"], W, p[a + "out_proj.weight"], W, d["ca"], W, R, W, W, bias=p[a + "out_proj.bias"])
-        if drop:
-            self._drop(d["ca"], self._seed(0, l, 5))
-        self._ln_fwd(x, d["ca"], pre + "norm2", d["s2"], d["x2"], d["st2"], R, W)
+        self._ln_fwd(x, d["ca"], pre + "norm2", d["s2"], d["x2"], d["st2"], R, W, self._seed(0, l, 5) if drop else None)
         return d["x2"]
 
     # ------------------------------------------------------------------ forward

@@ -34,6 +34,7 @@ extern "C" {
 #define ARK_EPI_MUL_AUX 4   /* C = acc * aux[row,col]                    */
 #define ARK_EPI_BIAS_RELU 5 /* C = max(acc + bias[col], 0)   (Transformer feed-forward, nn.TransformerEncoderLayer default activation) */
 #define ARK_EPI_MUL_RELU 6  /* C = aux[row,col] > 0 ? acc : 0 (its backward: aux = the activation) */
+#define ARK_EPI_ADD 7       /* C += acc  (ark_gemm16 only, row-major C: a gradient that joins a residual's)  */
 
 int ark_version(void);
 
@@ -433,6 +434,10 @@ int ark_argmax_rows(const float* x, int64_t ld, int64_t* out, int rows, int V, v
 /* y = LayerNorm(x + res) * gamma + beta (res nullable); s_out (nullable) = x + res; stats[row] = (mean, rstd) */
 int ark_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* s_out, float* y,
                       float* stats, int rows, int D, float eps, void* stream);
+/* the same with the sublayer output's dropout applied on the way in: `res` is the output BEFORE dropout, the keep-scale of
+ * element row * D + col of the current draw (the mask ark_dropout_apply(seed) would draw on that buffer) multiplies it */
+int ark_layernorm_fwd_drop(const float* x, const float* res, const float* gamma, const float* beta, float* s_out, float* y,
+                           float* stats, int rows, int D, float eps, float drop_p, uint64_t seed, const float* hyper, void* stream);
 /* ds = dL/d(x + res) from dy, the saved sum s and stats; dgamma / dbeta ACCUMULATE (+=) */
 int ark_layernorm_bwd(const float* dy, const float* s, const float* stats, const float* gamma, float* ds, float* dgamma,
                       float* dbeta, int rows, int D, void* stream);
