@@ -43,6 +43,25 @@ def test_argument_errors_are_negative_codes_without_touching_the_gpu():
     assert lib.ark_adam_step(null, null, null, null, ctypes.c_int64(0), null, null) < 0
 
 
+def test_vocabulary_split_count_follows_the_cu_budget():
+    """ark_vocab_ce_fwd_splits is host arithmetic: the split count times the row tiles stays within the CUs the caller
+    leaves to the cross-entropy (the chunk pipeline passes the CUs a resident sweep does not hold), and row counts that
+    fill the chip on their own are not split"""
+    lib = ctypes.CDLL(os.path.join(ROOT, "ark_amd", "lib", "libark_amd.so"))
+    f = lib.ark_vocab_ce_fwd_splits
+    # wd-articles: 16 sequences x 259 steps, V = 60 943, D = 512; one quarter of the steps as a chunk
+    whole = f(16 * 259, 60943, 512, 0)
+    assert 2 <= whole <= 16 and (16 * 259 + 63) // 64 * whole <= 256 * 2
+    chunk_rows = 16 * 65
+    for budget in (256, 160, 96, 32):
+        nv = f(chunk_rows, 60943, 512, budget)
+        assert 1 <= nv <= 16
+        assert nv == 1 or (60943 + 63) // 64 // nv >= 32          # a split keeps at least 32 vocabulary tiles
+    assert f(chunk_rows, 60943, 512, 96) <= f(chunk_rows, 60943, 512, 256)   # a smaller budget never splits finer
+    assert f(1024 * 10, 55, 512, 0) == 1 and f(256 * 64, 60943, 512, 0) == 1   # small vocabulary / chip-filling rows
+    assert f(chunk_rows, 60943, 96, 0) == 1 and f(chunk_rows + 3, 60943, 512, 0) == 1   # shapes the fused kernel lacks
+
+
 @pytest.mark.parametrize("name", ["sail_tiny", "sail_tiny_pad", "ark_tiny"])
 def test_state_dict_keys_order_and_init_match_reference(name):
     """same keys in the same order as the reference's state_dict, same initial values under the seed"""
