@@ -235,6 +235,8 @@ int ark_gru_sweep_sync_reset(unsigned* sync, long words, void* stream);
  * layer-diagonal launches, whose weight panels pass through LDS once per cell).  D in {512, 1024}, B % 16 == 0;
  * ark_gru_fat_row_groups() > 0 says the grid fits the chip (one workgroup per CU, all co-resident) -- otherwise
  * ARK_ERR_SHAPE.  `exch`: ark_gru_sweep_exch_bytes() bytes; `sync`: ark_gru_fat_sync_words() words, zeroed once.
+ * `wg_slices` == 3 (D = 512 only) selects the second build of the kernel: activations through an LDS-DMA ring with counted
+ * waits, eight role-specialised waves (measured slower than the default build).
  * Reference: nn.GRU forward, kgvae/model/models.py:121-127. */
 int ark_gru_fat_row_groups(int n_layers, int B, int D);
 long ark_gru_fat_sync_words(int n_layers, int B, int D, int L);

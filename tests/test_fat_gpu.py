@@ -13,9 +13,9 @@ from tests.test_configs_gpu import _cfg
 pytestmark = pytest.mark.gpu
 
 
-def _pair(cfg, B, P, drop):
+def _pair(cfg, B, P, drop, kernel="regs"):
     a = make_engine(dict(cfg, dec_dropout=drop, ark_fat=0, ark_sweep=0), P, "mixed")
-    b = make_engine(dict(cfg, dec_dropout=drop, ark_fat=1, ark_sweep=0), P, "mixed")
+    b = make_engine(dict(cfg, dec_dropout=drop, ark_fat=1, ark_fat_kernel=kernel, ark_sweep=0), P, "mixed")
     Lq = cfg["seq_len"] - 1
     assert not a._use_fat(B, Lq) and b._use_fat(B, Lq)
     for eng in (a, b):
@@ -30,14 +30,19 @@ def _pair(cfg, B, P, drop):
                                             (512, 16, 48, 5, True),       # 3 row tiles: one row group, padded graphs
                                             (512, 32, 528, 4, True)])     # 33 row tiles: uneven subgroups
 @pytest.mark.parametrize("drop", [0.0, 0.1])
-def test_fat_forward_matches_diagonal_launches(D, Z, B, T, padded, drop):
+@pytest.mark.parametrize("kernel", ["regs", "ring"])
+def test_fat_forward_matches_diagonal_launches(D, Z, B, T, padded, drop, kernel):
+    """kernel: "regs" = fragments straight into registers; "ring" = the D = 512 build with an LDS-DMA landing ring, counted
+    waits and role-specialised waves (eight waves; three subgroups per row group; a continuous tile stream with bubbles)"""
     from oracle import sail_oracle as O
+    if kernel == "ring" and D != 512:
+        pytest.skip("the LDS-ring kernel is a D = 512 build")
     cfg = _cfg(D, Z, 49, 3, T, padded)
     P = O.init_params(cfg, 1)
     triples, seq = synth_batch(cfg, B, seed=5, padded=padded)
     torch.manual_seed(9)
     eps = torch.randn(B, Z)
-    a, b = _pair(cfg, B, P, drop)
+    a, b = _pair(cfg, B, P, drop, kernel)
     dev = a.device
     args = (triples.to(dev), seq.to(dev), eps.to(dev))
     oa = a.train_step(*args).cpu().numpy()
@@ -77,7 +82,8 @@ def test_fat_forward_matches_diagonal_launches(D, Z, B, T, padded, drop):
         assert (da - db).norm().item() <= 5e-3 * da.norm().item() + 1e-9, k
 
 
-def test_fat_forward_elbo_is_the_oracles_and_survives_capture():
+@pytest.mark.parametrize("kernel", ["regs", "ring"])
+def test_fat_forward_elbo_is_the_oracles_and_survives_capture(kernel):
     """the benchmarked shape: ELBO within north_star's 1e-4 of the CPU oracle; replays of a captured step that contains the
     persistent launch reproduce the eager step; twelve consecutive steps stay on the diagonal path's trajectory (monotone
     epoch counters: nothing is zeroed between the launches)"""
@@ -89,7 +95,7 @@ def test_fat_forward_elbo_is_the_oracles_and_survives_capture():
     torch.manual_seed(4)
     eps = torch.randn(B, cfg["d_latent"])
     want = float(O.sail_elbo(P, triples, seq, eps, 0.3, cfg)[0])
-    a, b = _pair(cfg, B, P, 0.0)
+    a, b = _pair(cfg, B, P, 0.0, kernel)
     dev = b.device
     args = (triples.to(dev), seq.to(dev), eps.to(dev))
     out = b.eval_loss(*args).cpu().numpy()

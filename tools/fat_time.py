@@ -10,8 +10,8 @@ from ark_amd import initlib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 wl = sys.argv[2] if len(sys.argv) > 2 else "syn-paths"
 dev = torch.device("cuda:0")
-for fat in (0, 1, 0, 1):
-    cfg = dict(bench.build_cfg(0.1, wl), ark_fat=fat)
+for fat, kern in ((0, "-"), (1, "ring"), (1, "regs"), (0, "-"), (1, "ring")):
+    cfg = dict(bench.build_cfg(0.1, wl), ark_fat=fat, ark_fat_kernel=kern)
     eng = Engine(cfg, dev, precision="mixed")
     eng.load_params(initlib.init_state(cfg, seed=0))
     tr, sq = bench.synth_global_batch(cfg, B, seed=1)
@@ -36,6 +36,6 @@ for fat in (0, 1, 0, 1):
                 g.replay()
             e1.record(); e1.synchronize()
             ts.append(e0.elapsed_time(e1) / 20 * 1e3)
-    print(f"{wl} B={B} fat={fat} use_fat={eng._use_fat(B, Lq)}: forward recurrence {min(ts):.1f} us (runs: {' '.join(f'{t:.1f}' for t in ts)}) err={eng.sweep_error()}", flush=True)
+    print(f"{wl} B={B} fat={fat} kernel={kern} use_fat={eng._use_fat(B, Lq)}: forward recurrence {min(ts):.1f} us (runs: {' '.join(f'{t:.1f}' for t in ts)}) err={eng.sweep_error()}", flush=True)
     del eng
     torch.cuda.empty_cache()
