@@ -163,6 +163,8 @@ class TxfEngine(Engine):
         # their operands cast per call -- the register-staged ark_gemm converts the same fp32 operands on the fly, to the same
         # 16-bit values, several times slower
         self.fast_gemm = bool(cfg.get("ark_txf_fast_gemm", True)) and self.prec_fwd != L.PREC_F32
+        # self-attention longer than 16 positions on the matrix cores, flash style (no [B, H, L, L] arrays): csrc/attn_mfma.hip
+        self.flash = bool(cfg.get("ark_txf_flash", True))
         self._scratch = {}
         self._last_cast = None   # (only consecutive _gemm calls may share an operand copy: anything else resets it)
         self._graphs = {}
@@ -183,13 +185,22 @@ class TxfEngine(Engine):
         probabilities, 5 cross-attention output"""
         return (self.drop_seed + 7919 * (8 * (2 * layer + stack) + site) + 104729 * self.rank) & 0xFFFFFFFFFFFFFFFF
 
+    def _flash_ok(self, W, Ls):
+        """self-attention of width W over Ls positions on the matrix cores (csrc/attn_mfma.hip)?  16-bit products only (the
+        exact-fp32 mode keeps the vector-unit kernels); short sequences keep the one-wave-per-head kernels"""
+        dh = W // self.H
+        return bool(self.flash) and self.prec_fwd != L.PREC_F32 and Ls > 16 and dh % 32 == 0 and dh <= 384
+
     def _layer_bufs(self, R, W, B, Ls, cross):
         dev = self.device
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         d = {k: f(R, c) for k, c in (("qkv", 3 * W), ("att", W), ("sa", W), ("s1", W), ("x1", W), ("f", FF), ("g2", W), ("s2", W),
                                     ("x2", W))}
         d["st1"], d["st2"] = f(R, 2), f(R, 2)
-        d["probs"] = f(B * self.H * Ls * Ls)
+        if self._flash_ok(W, Ls):   # matrix-core attention: one log-sum-exp per (batch, head, query) instead of [B, H, L, L]
+            d["lse"] = f(B * self.H * ((Ls + 63) // 64 * 64))
+        else:
+            d["probs"] = f(B * self.H * Ls * Ls)
         if cross:
             d.update({"ctx": f(R, W), "cs": f(R, self.H), "ca": f(R, W), "s3": f(R, W), "x3": f(R, W), "st3": f(R, 2),
                       "vmem": f(B, W)})
@@ -234,7 +245,8 @@ class TxfEngine(Engine):
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         w = {"v2": False, "_R": R, "X0": f(R, D)}
         w["dec"] = [self._layer_bufs(R, D, B, Lq, self.vae) for _ in range(n)]
-        w["dscore"] = f(B * H * Lq * Lq)
+        w["dscore"] = None if self._flash_ok(D, Lq) else f(B * H * Lq * Lq)
+        w["delta"] = f(B * H * ((max(Lq, T) + 63) // 64 * 64)) if (self._flash_ok(D, Lq) or (self.vae and self._flash_ok(3 * D, T))) else None
         w["dA"], w["dB"], w["dC"] = f(R, D), f(R, D), f(R, D)
         w["dqkv"], w["df"] = f(R, 3 * D), f(R, FF)
         if self.vae:
@@ -242,7 +254,7 @@ class TxfEngine(Engine):
             w["E0"] = f(Re, W3)
             w["kmask"] = torch.ones(B, T, device=dev, dtype=torch.uint8)
             w["enc"] = [self._layer_bufs(Re, W3, B, T, False) for _ in range(self.n_enc)]
-            w["e_dscore"] = f(B * H * T * T)
+            w["e_dscore"] = None if self._flash_ok(W3, T) else f(B * H * T * T)
             w["eA"], w["eB"], w["eC"] = f(Re, W3), f(Re, W3), f(Re, W3)
             w["e_dqkv"], w["e_df"] = f(Re, 3 * W3), f(Re, FF)
             w["g"], w["inv_cnt"], w["dg"] = f(B, W3), f(B), f(B, W3)
@@ -376,9 +388,14 @@ class TxfEngine(Engine):
         KM, p = L.LAY_KMAJ, self.p
         a = pre + "self_attn."
         self._gemm(KM, KM, L.EPI_BIAS, x, W, p[a + "in_proj_weight"], W, d["qkv"], 3 * W, R, 3 * W, W, bias=p[a + "in_proj_bias"])
-        _call("ark_attn_fwd", L.ptr(d["qkv"]), L.ptr(d["att"]), L.ptr(d["probs"]), L.ptr(kmask), L.i32(B), L.i32(Ls), L.i32(W), L.i32(self.H),
-              L.i32(1 if causal else 0), L.f32(self.p_drop if drop else 0.0), L.u64(self._seed(stack, l, 0)), L.ptr(self.hyper),
-              L.cur_stream())
+        if "lse" in d:
+            _call("ark_attn_flash_fwd", L.i32(self.prec_fwd), L.ptr(d["qkv"]), L.ptr(d["att"]), L.ptr(d["lse"]), L.ptr(kmask), L.i32(B),
+                  L.i32(Ls), L.i32(W), L.i32(self.H), L.i32(1 if causal else 0), L.f32(self.p_drop if drop else 0.0),
+                  L.u64(self._seed(stack, l, 0)), L.ptr(self.hyper), L.cur_stream())
+        else:
+            _call("ark_attn_fwd", L.ptr(d["qkv"]), L.ptr(d["att"]), L.ptr(d["probs"]), L.ptr(kmask), L.i32(B), L.i32(Ls), L.i32(W),
+                  L.i32(self.H), L.i32(1 if causal else 0), L.f32(self.p_drop if drop else 0.0), L.u64(self._seed(stack, l, 0)),
+                  L.ptr(self.hyper), L.cur_stream())
         self._gemm(KM, KM, L.EPI_BIAS, d["att"], W, p[a + "out_proj.weight"], W, d["sa"], W, R, W, W, bias=p[a + "out_proj.bias"])
         self._ln_fwd(x, d["sa"], pre + "norm1", d["s1"], d["x1"], d["st1"], R, W, self._seed(stack, l, 1) if drop else None)
         return d["x1"]
@@ -530,9 +547,15 @@ class TxfEngine(Engine):
             self._colsum(dsa, W, g[a + "out_proj.bias"], R, W)
         self._gemm(MM, MM, L.EPI_NONE, dsa, W, d["att"], W, g[a + "out_proj.weight"], W, W, W, R, acc=1)
         self._gemm(KM, MM, L.EPI_NONE, dsa, W, p[a + "out_proj.weight"], W, scratch, W, R, W, W)            # d(att)
-        _call("ark_attn_bwd", L.ptr(d["qkv"]), L.ptr(d["att"]), L.ptr(d["probs"]), L.ptr(scratch), L.ptr(dscore), L.ptr(dqkv), L.ptr(kmask),
-              L.i32(B), L.i32(Ls), L.i32(W), L.i32(self.H), L.i32(1 if causal else 0), L.f32(self.p_drop if drop else 0.0),
-              L.u64(self._seed(stack, l, 0)), L.ptr(self.hyper), L.cur_stream())
+        if "lse" in d:
+            _call("ark_attn_flash_bwd", L.i32(self.prec_bwd), L.ptr(d["qkv"]), L.ptr(d["att"]), L.ptr(d["lse"]), L.ptr(scratch),
+                  L.ptr(self.ws["delta"]), L.ptr(dqkv), L.ptr(kmask), L.i32(B), L.i32(Ls), L.i32(W), L.i32(self.H),
+                  L.i32(1 if causal else 0), L.f32(self.p_drop if drop else 0.0), L.u64(self._seed(stack, l, 0)), L.ptr(self.hyper),
+                  L.cur_stream())
+        else:
+            _call("ark_attn_bwd", L.ptr(d["qkv"]), L.ptr(d["att"]), L.ptr(d["probs"]), L.ptr(scratch), L.ptr(dscore), L.ptr(dqkv),
+                  L.ptr(kmask), L.i32(B), L.i32(Ls), L.i32(W), L.i32(self.H), L.i32(1 if causal else 0),
+                  L.f32(self.p_drop if drop else 0.0), L.u64(self._seed(stack, l, 0)), L.ptr(self.hyper), L.cur_stream())
         if fast:
             self._prep(dqkv, R, 3 * W, g[a + "in_proj_bias"])
         else:

@@ -455,6 +455,18 @@ int ark_attn_fwd(const float* qkv, float* out, float* probs, const unsigned char
 int ark_attn_bwd(const float* qkv, const float* out, const float* probs, const float* dout, float* dscore, float* dqkv,
                  const unsigned char* kmask, int B, int L, int D, int n_heads, int causal, float drop_p, uint64_t seed,
                  const float* hyper, void* stream);
+/* The same attention on the matrix cores, flash style (csrc/attn_mfma.hip): scores and probabilities never exist in memory.
+ * Forward: out and lse [B, H, Lp] (log2-domain log-sum-exp per query; Lp = L rounded up to 64: ark_attn_flash_stat_floats()
+ * floats); backward: dqkv from dout, recomputing the probabilities twice (query side, key side); `delta` is scratch of the
+ * same size as lse.  Operands are converted to `prec` (ARK_PREC_F16 / ARK_PREC_BF16) while staged; statistics and
+ * accumulators fp32; the dropout masks are those of ark_attn_fwd / ark_attn_bwd under the same seed.  Any L; dh % 32 == 0,
+ * dh <= 384.  Reference: F.scaled_dot_product_attention inside the stock Transformer layers, models.py:73-74, 104-105, 355-356 */
+long ark_attn_flash_stat_floats(int B, int L, int n_heads);
+int ark_attn_flash_fwd(int prec, const float* qkv, float* out, float* lse, const unsigned char* kmask, int B, int L, int D,
+                       int n_heads, int causal, float drop_p, uint64_t seed, const float* hyper, void* stream);
+int ark_attn_flash_bwd(int prec, const float* qkv, const float* out, const float* lse, const float* dout, float* delta,
+                       float* dqkv, const unsigned char* kmask, int B, int L, int D, int n_heads, int causal, float drop_p,
+                       uint64_t seed, const float* hyper, void* stream);
 /* ---- t-SAIL (reference: AutoRegEncoder / AutoRegDecoder, kgvae/model/models.py:66-114) ----------------------------------
  * encoder input rows (t, b) over the TRIPLE index: x = [E[h] | R[r] | E[t]], kmask[b, t] = (r != pad_rid) (nullable) */
 int ark_triple_gather(const int64_t* triples, const float* E, const float* R, float* x, unsigned char* kmask, int B, int T, int D,
