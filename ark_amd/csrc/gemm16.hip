@@ -310,6 +310,21 @@ __global__ __launch_bounds__(256) void to_tiled_kernel(const float* __restrict__
   }
 }
 
+// the inverse: tile-native fp32 -> row-major [rows, ld] (the fused vocabulary CE writes dY tile-native; the Transformer
+// backward reads gradients row-major)
+__global__ __launch_bounds__(256) void from_tiled_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int ld) {
+  const long n4 = (long)rows * ld / 4;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
+    const long tile = q >> 6;
+    const int lane = (int)(q & 63);
+    const int tr = (int)(tile / (ld >> 4)), tc = (int)(tile % (ld >> 4));
+    const int row0 = tr * 16 + 4 * (lane >> 4), col = tc * 16 + (lane & 15);
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[q];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[(long)(row0 + i) * ld + col] = v[i];
+  }
+}
+
 }  // namespace ark
 
 static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
@@ -449,6 +464,18 @@ extern "C" int ark_to_tiled(const float* x, float* out, int rows, int ld, void* 
   long blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(to_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, rows, ld);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ark_from_tiled(const float* x, float* out, int rows, int ld, void* stream) {
+  using namespace ark;
+  if (!x || !out || rows <= 0 || ld <= 0) return ARK_ERR_ARG;
+  if (rows % 16 != 0 || ld % 16 != 0) return ARK_ERR_SHAPE;
+  long n4 = (long)rows * ld / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(from_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, rows, ld);
   ARK_LAUNCH_CHECK();
   return 0;
 }

@@ -498,19 +498,28 @@ __global__ __launch_bounds__(256) void triple_scatter_kernel(const int64_t* __re
 }
 
 // masked mean over the sequence axis of time-major rows: g[b] = sum_t m[b,t] x[(t,b)] / max(1, sum_t m[b,t])  (models.py:86-91)
+// Workgroup (b, 64 columns): the four waves take t = w, w + 4, ... each (with one workgroup per graph and one thread walking
+// all T rows of a column the 16 graphs x 212 triples of wd-articles took 600 us for 20 MB), partials meet in LDS in wave order.
 __global__ __launch_bounds__(256) void seq_pool_fwd_kernel(const float* __restrict__ x, const unsigned char* __restrict__ kmask,
                                                            float* __restrict__ g, float* __restrict__ inv_cnt, int B, int T, int W) {
-  const int b = blockIdx.x;
+  __shared__ float part[4][64];
+  __shared__ int cnts[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane;
   int cnt = 0;
-  for (int t = 0; t < T; ++t) cnt += (!kmask || kmask[(long)b * T + t]) ? 1 : 0;
-  const float ic = 1.0f / (float)max(cnt, 1);
-  for (int c = threadIdx.x; c < W; c += 256) {
-    float a = 0.f;
-    for (int t = 0; t < T; ++t)
-      if (!kmask || kmask[(long)b * T + t]) a += x[((long)t * B + b) * W + c];
-    g[(long)b * W + c] = a * ic;
+  float a = 0.f;
+  for (int t = wave; t < T; t += 4) {
+    const bool on = !kmask || kmask[(long)b * T + t];
+    cnt += on ? 1 : 0;
+    if (on && c < W) a += x[((long)t * B + b) * W + c];
   }
-  if (threadIdx.x == 0) inv_cnt[b] = ic;
+  part[wave][lane] = a;
+  if (lane == 0) cnts[wave] = cnt;
+  __syncthreads();
+  if (wave != 0) return;
+  const float ic = 1.0f / (float)max(cnts[0] + cnts[1] + cnts[2] + cnts[3], 1);
+  if (c < W) g[(long)b * W + c] = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) * ic;
+  if (lane == 0 && blockIdx.y == 0) inv_cnt[b] = ic;
 }
 
 __global__ __launch_bounds__(256) void seq_pool_bwd_kernel(const float* __restrict__ dg, const unsigned char* __restrict__ kmask,
@@ -552,13 +561,16 @@ __global__ __launch_bounds__(256) void xattn_bcast_fwd_kernel(const float* __res
 // dv[b, h*dh + d] = sum_t c[t, b, h] * dctx[(t, b), h*dh + d]
 __global__ __launch_bounds__(256) void xattn_bcast_bwd_kernel(const float* __restrict__ dctx, const float* __restrict__ cscale,
                                                               float* __restrict__ dv, int B, int L, int D, int H) {
-  const int b = blockIdx.x, dh = D / H;
-  for (int c = threadIdx.x; c < D; c += 256) {
-    const int h = c / dh;
-    float a = 0.f;
-    for (int t = 0; t < L; ++t) a += cscale[((long)t * B + b) * H + h] * dctx[((long)t * B + b) * D + c];
-    dv[(long)b * D + c] = a;
-  }
+  __shared__ float part[4][64];   // workgroup (b, 64 columns), the time axis split over the waves as in seq_pool_fwd_kernel
+  const int b = blockIdx.x, dh = D / H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane;
+  const int h = min(c, D - 1) / dh;
+  float a = 0.f;
+  if (c < D)
+    for (int t = wave; t < L; t += 4) a += cscale[((long)t * B + b) * H + h] * dctx[((long)t * B + b) * D + c];
+  part[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && c < D) dv[(long)b * D + c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 // the same for WIDE rows (D > 1536: t-SAIL's 3 * d_model encoder at d_model = 1024): keeping g and xhat of a row in
@@ -802,7 +814,7 @@ extern "C" int ark_triple_scatter(const int64_t* triples, const float* dx, float
 
 extern "C" int ark_seq_pool_fwd(const float* x, const unsigned char* kmask, float* g, float* inv_cnt, int B, int T, int W, void* stream) {
   if (!x || !g || !inv_cnt || B <= 0 || T <= 0 || W <= 0) return ARK_ERR_ARG;
-  hipLaunchKernelGGL(ark::seq_pool_fwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, kmask, g, inv_cnt, B, T, W);
+  hipLaunchKernelGGL(ark::seq_pool_fwd_kernel, dim3((unsigned)B, (unsigned)((W + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, kmask, g, inv_cnt, B, T, W);
   ARK_LAUNCH_CHECK();
   return 0;
 }
@@ -829,7 +841,7 @@ extern "C" int ark_xattn_bcast_fwd(const float* v, float* ctx, float* cscale, in
 
 extern "C" int ark_xattn_bcast_bwd(const float* dctx, const float* cscale, float* dv, int B, int L, int D, int n_heads, void* stream) {
   if (!dctx || !cscale || !dv || B <= 0 || L <= 0 || D <= 0 || n_heads <= 0 || D % n_heads != 0) return ARK_ERR_ARG;
-  hipLaunchKernelGGL(ark::xattn_bcast_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dctx, cscale, dv, B, L, D, n_heads);
+  hipLaunchKernelGGL(ark::xattn_bcast_bwd_kernel, dim3((unsigned)B, (unsigned)((D + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dctx, cscale, dv, B, L, D, n_heads);
   ARK_LAUNCH_CHECK();
   return 0;
 }

@@ -165,6 +165,10 @@ class TxfEngine(Engine):
         self.fast_gemm = bool(cfg.get("ark_txf_fast_gemm", True)) and self.prec_fwd != L.PREC_F32
         # self-attention longer than 16 positions on the matrix cores, flash style (no [B, H, L, L] arrays): csrc/attn_mfma.hip
         self.flash = bool(cfg.get("ark_txf_flash", True))
+        # large vocabularies: output projection FUSED with the cross-entropy (csrc/vocab_ce.hip, as in the GRU engine): the
+        # [B*L, V] logits and their gradient never exist in the train / eval-loss steps (2.5 GB at wd-articles)
+        self.fused_ce = bool(cfg.get("ark_fused_ce", self.prec_fwd != L.PREC_F32 and self.V >= 2048 and self.D in (64, 128, 256, 512)))
+        self._fused_step = False
         self._scratch = {}
         self._last_cast = None   # (only consecutive _gemm calls may share an operand copy: anything else resets it)
         self._graphs = {}
@@ -264,7 +268,8 @@ class TxfEngine(Engine):
             w["kl"] = torch.zeros(1, device=dev)
             w["eps0"] = torch.zeros(B, Z, device=dev)
             w["mem"], w["dmem"], w["dv"] = f(B, D), f(B, D), f(B, D)
-        w["logits"] = torch.zeros(R, self.ldl, device=dev)
+        if not (self.fused_ce and R % 16 == 0):   # (the fused path allocates them on first use: model(seq), generation)
+            w["logits"] = torch.zeros(R, self.ldl, device=dev)
         w["row_loss"] = f(R)
         w["out4"] = torch.zeros(4, device=dev)
         if len(self._ws_cache) >= 8:
@@ -275,7 +280,23 @@ class TxfEngine(Engine):
         return w
 
     def _logits(self, w):
+        if "logits" not in w:
+            w["logits"] = torch.zeros(w["_R"], self.ldl, device=self.device)
         return w["logits"]
+
+    def _fused_ce_bufs(self, w, R):
+        """operands and outputs of the fused vocabulary CE: 16-bit copies of the top activations and of the output weight
+        (forward type), log-sum-exp, tile-native dY, the vocabulary-split scratch"""
+        if "ce_y16" not in w:
+            D, V, dev = self.D, self.V, self.device
+            w["ce_y16"] = torch.empty(R * D, device=dev, dtype=torch.int16)
+            w["ce_lse"] = torch.empty(R, device=dev)
+            w["ce_dY"] = torch.empty(R * D, device=dev)
+            ns = int(L.lib().ark_vocab_ce_fwd_splits(L.i32(R), L.i32(V), L.i32(D), L.i32(0)))
+            w["ce_ws"] = torch.empty(ns * (R * D + 4 * R), device=dev) if ns > 1 else None
+        if getattr(self, "_ce_w16", None) is None:
+            self._ce_w16 = torch.empty(self.V * self.D, device=self.device, dtype=torch.int16)
+        return w["ce_y16"], self._ce_w16, w["ce_lse"], w["ce_dY"], w["ce_ws"]
 
     # ------------------------------------------------------------------ dense products, 16-bit fast path
     def _buf(self, slot, nbytes):
@@ -490,14 +511,31 @@ class TxfEngine(Engine):
             else:
                 x = self._ff_fwd(d, x, pre, "norm2", R, D, use_drop, 0, l, "s2", "x2", "st2")
         self._top = x
-        self._gemm(KM, KM, L.EPI_BIAS, x, D, p["dec.out.weight"], D, w["logits"], self.ldl, R, V, D, bias=p["dec.out.bias"])
+        fused = self.fused_ce and with_loss and R % 16 == 0
+        self._fused_step = bool(fused and with_dlogits)
+        if not fused:
+            logits = self._logits(w)
+            self._gemm(KM, KM, L.EPI_BIAS, x, D, p["dec.out.weight"], D, logits, self.ldl, R, V, D, bias=p["dec.out.bias"])
         if with_loss:
             if ce_count is None:
                 _call("ark_count_targets", L.ptr(seq), L.i64(ld_seq), L.i32(B), L.i32(Lq), L.ptr(self.hyper), st)
                 self._hp.pop("CE_COUNT", None)
-            _call("ark_ce_fwd_bwd", L.ptr(w["logits"]), L.i64(self.ldl), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper),
-                  L.ptr(w["row_loss"]), L.ptr(w["logits"] if with_dlogits else None), L.ptr(None), L.i32(0), L.i64(0), L.i32(B),
-                  L.i32(Lq), L.i32(V), st)
+            if fused:
+                y16, w16, lse, dY, ws = self._fused_ce_bufs(w, R)
+                _call("ark_cast16", L.i32(self.prec_fwd), L.ptr(x), L.ptr(y16), L.i64(R * D), st)
+                _call("ark_cast16", L.i32(self.prec_fwd), L.ptr(p["dec.out.weight"]), L.ptr(w16), L.i64(V * D), st)
+                if with_dlogits and ws is not None:   # few rows: the vocabulary sweep split over workgroups + one merging launch
+                    _call("ark_vocab_ce_fwd_ws", L.i32(self.prec_fwd), L.ptr(y16), L.ptr(w16), L.ptr(p["dec.out.bias"]), L.ptr(seq),
+                          L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(lse), L.ptr(dY), L.ptr(ws), L.i64(ws.numel()),
+                          L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), L.i32(0), st)
+                else:
+                    _call("ark_vocab_ce_fwd", L.i32(self.prec_fwd), L.ptr(y16), L.ptr(w16), L.ptr(p["dec.out.bias"]), L.ptr(seq),
+                          L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(lse), L.ptr(dY if with_dlogits else None),
+                          L.i32(B), L.i32(Lq), L.i32(V), L.i32(D), st)
+            else:
+                _call("ark_ce_fwd_bwd", L.ptr(logits), L.i64(self.ldl), L.ptr(seq), L.i64(ld_seq), L.ptr(self.hyper),
+                      L.ptr(w["row_loss"]), L.ptr(logits if with_dlogits else None), L.ptr(None), L.i32(0), L.i64(0), L.i32(B),
+                      L.i32(Lq), L.i32(V), st)
             _call("ark_loss_finalize", L.ptr(w["row_loss"]), L.i32(R), L.ptr(w["kl"] if enc_on else None), L.ptr(self.hyper),
                   L.ptr(w["out4"]), st)
         return w
@@ -615,12 +653,21 @@ class TxfEngine(Engine):
         ld_seq = seq.shape[1]
         drop = self._used_drop
         self._zero(self.G)
-        dlog = w["logits"]
-        self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
-        self._gemm(MM, MM, L.EPI_NONE, dlog, self.ldl, self._top, D, g["dec.out.weight"], D, V, D, R, acc=1)
         bufs = [w["dA"], w["dB"], w["dC"]]
         dy = bufs[0]
-        self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, dy, D, R, D, V)
+        if self._fused_step:
+            # dW_out += dlogits^T y and db_out += colsum(dlogits) with dlogits recomputed from the log-sum-exp; dY came out of
+            # the forward sweep (tile-native: one small pass turns it row-major)
+            y16, w16, lse, dY, _ = self._fused_ce_bufs(w, R)
+            _call("ark_vocab_ce_dw", L.i32(self.prec_fwd), L.ptr(y16), L.ptr(w16), L.ptr(p["dec.out.bias"]), L.ptr(seq), L.i64(ld_seq),
+                  L.ptr(self.hyper), L.ptr(lse), L.ptr(g["dec.out.weight"]), L.ptr(g["dec.out.bias"]), L.i32(B), L.i32(Lq), L.i32(V),
+                  L.i32(D), st)
+            _call("ark_from_tiled", L.ptr(dY), L.ptr(dy), L.i32(R), L.i32(D), st)
+        else:
+            dlog = self._logits(w)
+            self._colsum(dlog, self.ldl, g["dec.out.bias"], R, V)
+            self._gemm(MM, MM, L.EPI_NONE, dlog, self.ldl, self._top, D, g["dec.out.weight"], D, V, D, R, acc=1)
+            self._gemm(KM, MM, L.EPI_NONE, dlog, self.ldl, p["dec.out.weight"], D, dy, D, R, D, V)
         if self.vae:
             self._zero(w["dmem"])
 
@@ -843,7 +890,7 @@ class TxfEngine(Engine):
             w = self.forward(None, prefix.contiguous(), None, with_loss=False, L_run=t, z_given=z, decode_ws=True)
         finally:
             self.training = was
-        return w["logits"][(t - 1) * B:t * B, :self.V]
+        return self._logits(w)[(t - 1) * B:t * B, :self.V]
 
     def decode_begin(self, *a, **k):
         raise L.ArkError(f"{self.mt} has no incremental decoder state: use prefix_logits()")

@@ -339,6 +339,8 @@ int ark_prep16(int prec, const float* x, float* x_out, void* out16, float* colsu
 /* out[i] = (float)x16[i]: data-parallel gradient buckets reduced in 16 bits go back into the fp32 gradient buffer */
 int ark_uncast16(int prec, const void* x16, float* out, int64_t n, void* stream);
 int ark_to_tiled(const float* x, float* out, int rows, int ld, void* stream);
+/* the inverse: tile-native fp32 -> row-major [rows, ld] (rows % 16 == 0, ld % 16 == 0) */
+int ark_from_tiled(const float* x, float* out, int rows, int ld, void* stream);
 
 /* ---- embeddings (reference: models.py:47-58 encoder gather+concat+masked mean; :138,:343
  *      decoder token / position lookup; autograd embedding_backward) --------------------------- */

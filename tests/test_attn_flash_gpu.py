@@ -161,3 +161,35 @@ def test_transformer_train_step_with_and_without_flash_attention(mt, B, T, D, dr
     for k in grads[0]:
         a, b = grads[0][k], grads[1][k]
         assert (a - b).norm().item() <= 2.5e-2 * a.norm().item() + 1e-7, (k, (a - b).norm().item(), a.norm().item())
+
+
+@pytest.mark.parametrize("mt,B,T", [("t-ARK", 8, 13), ("t-SAIL", 16, 7)])
+def test_transformer_fused_vocabulary_ce(mt, B, T):
+    """V >= 2048: the output projection fused with the cross-entropy (no [B*L, V] logits; vocab_ce.hip, vocabulary-split
+    forward for the few rows of these batches) against the logits path of the same engine: loss, the gradient of the output
+    layer and every gradient below it; the logits API still works afterwards (lazily allocated buffer)"""
+    from oracle import sail_oracle as O
+    from tests.test_configs_gpu import _cfg
+    from tests.parity_util import synth_batch
+    from ark_amd.txf_engine import TxfEngine
+    cfg = dict(_cfg(128, 16, 3000, 3, T, True), model_type=mt, dec_dropout=0.0, ark_txf_dropout=0.0)
+    assert cfg["vocab_size"] >= 2048
+    P = O.init_params(cfg, 6)
+    triples, seq = synth_batch(cfg, B, seed=12, padded=True)
+    outs, grads, evs = [], [], []
+    for fused in (0, 1):
+        eng = TxfEngine(dict(cfg, ark_fused_ce=fused), torch.device("cuda:0"), precision="mixed")
+        eng.load_params(P)
+        eng.set_hyper(lr=1e-3, beta=0.3)
+        tri = triples.cuda() if mt == "t-SAIL" else None
+        out = eng.train_step(tri, seq.cuda()).cpu().numpy().copy()
+        torch.cuda.synchronize()
+        assert eng._fused_step == bool(fused) and ("logits" in eng.ws) == (not fused)
+        outs.append(out)
+        grads.append({k: v.float().clone() for k, v in eng.g.items()})
+        evs.append(eng.eval_loss(tri, seq.cuda()).cpu().numpy().copy())   # (no dY: the forward-only form of the kernel)
+    assert rel_err(float(outs[1][0]), float(outs[0][0])) < 2e-4, outs
+    assert rel_err(float(evs[1][0]), float(evs[0][0])) < 2e-3, evs           # (after one Adam step of each engine)
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert (a - b).norm().item() <= 3e-2 * a.norm().item() + 1e-7, (k, (a - b).norm().item(), a.norm().item())
