@@ -369,9 +369,12 @@ def transformer_variants(dev, precision, dropout):
     from ark_amd import initlib
     from ark_amd.txf_engine import TxfEngine
     out = {}
-    for mt in ("t-ARK", "t-SAIL"):
+    for mt, wl, nt, nw in (("t-ARK", "syn-paths", 40, 10), ("t-SAIL", "syn-paths", 40, 10),
+                           # the wd-articles shape (16 graphs x 637 tokens, V = 60 943): matrix-core flash attention, fused CE
+                           ("t-ARK", "wd-articles", 12, 4), ("t-SAIL", "wd-articles", 12, 4)):
+        name = mt if wl == "syn-paths" else f"{mt}@{wl}"
         try:
-            cfg = dict(build_cfg(dropout, "syn-paths"), model_type=mt)
+            cfg = dict(build_cfg(dropout, wl), model_type=mt)
             B = cfg["batch"]
             eng = TxfEngine(cfg, dev, precision=precision)
             eng.load_params(initlib.init_state(cfg, seed=0))
@@ -382,21 +385,23 @@ def transformer_variants(dev, precision, dropout):
             st.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st):
                 step = eng.capture_train_step(tri, seq)
-                for _ in range(10):
+                for _ in range(nw):
                     o4 = step()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(40):
+                for _ in range(nt):
                     o4 = step()
                 torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / 40
-            out[mt] = {"batch": B, "ms_per_step": dt * 1e3, "graphs_per_s": B / dt, "steps": 40, "warmup": 10,
-                       "final_loss": float(o4[0]), "note": "16-bit MFMA products, exact-fp32 attention / LayerNorm on the vector units"}
-            log(f'{mt}: {dt * 1e3:.3f} ms/step')
+                dt = (time.perf_counter() - t0) / nt
+            out[name] = {"batch": B, "seq_len": cfg["seq_len"], "ms_per_step": dt * 1e3, "graphs_per_s": B / dt, "steps": nt, "warmup": nw,
+                         "final_loss": float(o4[0]),
+                         "note": "16-bit MFMA products; attention: one-wave-per-head fp32 kernels for L <= 16, matrix-core flash kernels "
+                                 "beyond; fused vocabulary CE for V >= 2048; fp32 LayerNorm"}
+            log(f'{name}: {dt * 1e3:.3f} ms/step')
             del eng
             torch.cuda.empty_cache()
         except Exception as e:
-            out[mt] = {"error": repr(e)}
+            out[name] = {"error": repr(e)}
     return out
 
 

@@ -1,9 +1,11 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 O=gpurun_out; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_attn_flash_gpu.py tests/test_txf_gpu.py -q -p no:cacheprovider -x > $O/r4z_tests.log 2>&1; rc=$?
-tail -30 $O/r4z_tests.log
-echo "pytest rc=$rc"
-if [ $rc -ne 0 ]; then exit 1; fi
-timeout -k 10 500 python tools/txf_wd_time.py t-SAIL > $O/r4z_txf_wd.log 2>&1; tail -5 $O/r4z_txf_wd.log
-timeout -k 10 300 python tools/txf_wd_time.py t-ARK >> $O/r4z_txf_wd.log 2>&1; tail -4 $O/r4z_txf_wd.log
+timeout -k 10 600 python bench.py --no-cpu-baseline --steps 200 > $O/r4z_bench.json 2> $O/r4z_bench.err; rc=$?
+grep "bench\]" $O/r4z_bench.err | tail -16
+echo "rc=$rc"
+python - <<PY
+import json
+d = json.load(open("$O/r4z_bench.json"))
+print(d["ms_per_step"], json.dumps(d.get("transformer_variants", d.get("other_workloads", {}).get("transformer_variants")), indent=0)[:1500])
+PY
