@@ -26,6 +26,11 @@ def case(variant):
         return dict(_cfg(128, 64, 3000, 3, 12, True), dec_dropout=0.1 if variant.endswith("-drop") else 0.0), 64, True
     if variant == "wd-articles":
         return _cfg(512, 128, 2500, 6, 86, True), 16, True
+    if variant in ("tsail-long", "tark-long"):
+        # 40 decoder positions (t-SAIL: 13 triples at width 3 D), V = 3 008: the matrix-core flash attention and the fused
+        # vocabulary CE under the bucketed step; padded graphs, unequal per-rank target counts
+        mt = "t-SAIL" if variant == "tsail-long" else "t-ARK"
+        return dict(_cfg(128, 16, 3000, 3, 13, True), model_type=mt, dec_dropout=0.0, ark_txf_dropout=0.0), 32, True
     if variant in ("tsail", "tark"):   # the Transformer variants (bucketed, captured steps of ark_amd.txf_engine)
         _, cfg = load_golden("tsail_small" if variant == "tsail" else "tark_small")
         return dict(cfg, dec_dropout=0.0, ark_txf_dropout=0.0), 64, False

@@ -193,3 +193,24 @@ def test_transformer_fused_vocabulary_ce(mt, B, T):
     for k in grads[0]:
         a, b = grads[0][k], grads[1][k]
         assert (a - b).norm().item() <= 3e-2 * a.norm().item() + 1e-7, (k, (a - b).norm().item(), a.norm().item())
+
+
+def test_prefix_logits_with_flash_attention():
+    """generation re-runs the prefix per token (TxfEngine.prefix_logits, ONE decode workspace at full length whose layers
+    carry the log-sum-exp buffers): prefixes shorter and longer than 16 positions through the matrix-core kernels agree with
+    the vector-unit kernels (mixed precision, logits of the next position)"""
+    from oracle import sail_oracle as O
+    from tests.test_configs_gpu import _cfg
+    from tests.parity_util import synth_batch
+    from ark_amd.txf_engine import TxfEngine
+    cfg = dict(_cfg(128, 16, 60, 3, 13, True), model_type="t-ARK", dec_dropout=0.0)
+    P = O.init_params(cfg, 7)
+    _, seq = synth_batch(cfg, 5, seed=13, padded=True)
+    got = []
+    for flash in (0, 1):
+        eng = TxfEngine(dict(cfg, ark_txf_flash=flash), torch.device("cuda:0"), precision="mixed")
+        eng.load_params(P)
+        got.append([eng.prefix_logits(seq[:, :t].cuda()).float().cpu().clone() for t in (3, 16, 17, 40)])
+    for a, b in zip(*got):
+        assert torch.isfinite(b).all()
+        assert (a - b).abs().max().item() < 2e-2 * (a.abs().max().item() + 1.0), (a - b).abs().max().item()

@@ -111,7 +111,7 @@ def test_two_process_data_parallel_at_wd_shapes(tmp_path, graph, variant):
 
 
 @pytest.mark.parametrize("graph,bf16,variant", [(False, False, "tsail"), (True, False, "tsail"), (True, True, "tsail"),
-                                                (True, False, "tark")])
+                                                (True, False, "tark"), (True, False, "tsail-long"), (False, False, "tark-long")])
 def test_two_process_data_parallel_transformer_variants(tmp_path, graph, bf16, variant):
     """t-SAIL / t-ARK under two ranks: the bucketed step (t-SAIL: decoder bucket's all-reduce underneath the latent / encoder
     half), eager and as one hipGraph per bucket + one for [widen, Adam] (round 3: eager only, one bucket), fp32 and bf16

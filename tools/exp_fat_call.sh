@@ -1,11 +1,6 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 O=gpurun_out; mkdir -p $O
-timeout -k 10 600 python bench.py --no-cpu-baseline --steps 200 > $O/r4z_bench.json 2> $O/r4z_bench.err; rc=$?
-grep "bench\]" $O/r4z_bench.err | tail -16
-echo "rc=$rc"
-python - <<PY
-import json
-d = json.load(open("$O/r4z_bench.json"))
-print(d["ms_per_step"], json.dumps(d.get("transformer_variants", d.get("other_workloads", {}).get("transformer_variants")), indent=0)[:1500])
-PY
+timeout -k 10 900 python -m pytest tests/test_attn_flash_gpu.py tests/test_dp_gpu.py -q -p no:cacheprovider -x -k "flash or transformer" > $O/r4z_dp_tests.log 2>&1; rc=$?
+tail -25 $O/r4z_dp_tests.log
+echo "pytest rc=$rc"
