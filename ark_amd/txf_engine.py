@@ -359,13 +359,19 @@ class TxfEngine(Engine):
             if self._last_cast is not None:
                 self._last_cast[1] = _launches[0]
             return
-        if (a_lay == MM and b_lay == MM and acc and epi == L.EPI_NONE and M % 64 == 0 and N % 64 == 0 and K % 64 == 0
-                and lda == M and ldb == N):
-            # weight gradient C[M,N] += A[K,M]^T B[K,N] (K = rows of the batch)
+        if a_lay == MM and b_lay == MM and acc and epi == L.EPI_NONE and M % 64 == 0 and N % 64 == 0 and lda == M and ldb == N:
+            # weight gradient C[M,N] += A[K,M]^T B[K,N] (K = rows of the batch).  The LDS-DMA engine walks K in stages of 64:
+            # a row count that is not a multiple (wd-articles: 16 x 637 = 10 192) gets zero rows behind its 16-bit copies
+            Kp = (K + 63) // 64 * 64
+            self._buf("a", 2 * Kp * M)
+            self._buf("b", 2 * Kp * N)
             A16 = self._cast("a", A, K * M, pr)
             B16 = self._cast("b", Bm, K * N, pr)
+            if Kp != K:
+                self._zero(A16[2 * K * M:2 * Kp * M])
+                self._zero(B16[2 * K * N:2 * Kp * N])
             _call("ark_wgrad16", L.i32(pr), L.ptr(A16), L.i64(M), L.ptr(B16), L.i64(N), L.ptr(C), L.i64(ldc), L.i32(M), L.i32(N),
-                  L.i32(K), None, st)
+                  L.i32(Kp), None, st)
             if self._last_cast is not None:
                 self._last_cast[1] = _launches[0]
             return
@@ -373,15 +379,17 @@ class TxfEngine(Engine):
             raise L.ArkError("a prepared (dropout-applied, 16-bit) operand reached the register-staged product")
         return super()._gemm(a_lay, b_lay, epi, A, lda, Bm, ldb, C, ldc, M, N, K, C2=C2, bias=bias, aux=aux, acc=acc)
 
-    def _fast_ok(self, *dims):
-        """the products around an [R, N] gradient take the 16-bit LDS-DMA engines (whole 64-wide stages in every dimension)"""
+    def _fast_ok(self, rows, *dims):
+        """the products around a [rows, N] gradient take the 16-bit LDS-DMA engines (whole 64-wide stages in every feature
+        dimension; any row count: as the M dimension rows are clamped, as the K dimension of a weight gradient they are
+        zero-padded in the 16-bit copies, see _gemm)"""
         return bool(self.fast_gemm and self.prec != L.PREC_F32 and all(d % 64 == 0 for d in dims))
 
     def _prep(self, x, R, N, bias_grad, seed=None, x_out=None):
         """ONE pass (ark_prep16) for what used to be copy + dropout + bias column sum + 16-bit cast: the 16-bit copy of
         dropout(x) lands in the product-operand slot, so the products that follow take `x` as their A operand and find it
         there; bias_grad (nullable) += column sums; x_out (nullable, may be x): the fp32 dropped values"""
-        out = self._buf("a", 2 * R * N)
+        out = self._buf("a", 2 * ((R + 63) // 64 * 64) * N)   # (room for the zero rows a weight gradient pads K with)
         _call("ark_prep16", L.i32(self.prec), L.ptr(x), L.ptr(x_out), L.ptr(out), L.ptr(bias_grad), L.i32(R), L.i32(N),
               L.f32(self.p_drop if seed is not None else 0.0), L.u64(seed or 0), L.ptr(self.hyper), L.cur_stream())
         self._last_cast = [(x.data_ptr(), R * N, self.prec, out.data_ptr()), _launches[0]]

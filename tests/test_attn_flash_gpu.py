@@ -214,3 +214,34 @@ def test_prefix_logits_with_flash_attention():
     for a, b in zip(*got):
         assert torch.isfinite(b).all()
         assert (a - b).abs().max().item() < 2e-2 * (a.abs().max().item() + 1.0), (a - b).abs().max().item()
+
+
+@pytest.mark.parametrize("mt,B,T", [("t-ARK", 6, 13), ("t-SAIL", 5, 30)])
+def test_row_counts_that_are_not_multiples_of_64_take_the_fast_products(mt, B, T):
+    """rows = B * L = 240 (t-ARK) / 455 and 150 (t-SAIL decoder / encoder): the weight gradients walk the rows as their K
+    dimension in stages of 64 -- the 16-bit operand copies are zero-padded -- against the register-staged products of the same
+    engine (`ark_txf_fast_gemm: 0`: the same 16-bit operand values, formed on the fly); dropout on, so the fused
+    dropout / column-sum / cast pass (`ark_prep16`) feeds the padded products too"""
+    from oracle import sail_oracle as O
+    from tests.test_configs_gpu import _cfg
+    from tests.parity_util import synth_batch
+    from ark_amd.txf_engine import TxfEngine
+    cfg = dict(_cfg(128, 16, 300, 3, T, True), model_type=mt, dec_dropout=0.1, ark_txf_dropout=0.1)
+    P = O.init_params(cfg, 8)
+    triples, seq = synth_batch(cfg, B, seed=14, padded=True)
+    assert (B * (cfg["seq_len"] - 1)) % 64 != 0
+    outs, grads = [], []
+    for fast in (0, 1):
+        eng = TxfEngine(dict(cfg, ark_txf_fast_gemm=fast), torch.device("cuda:0"), precision="mixed")
+        eng.load_params(P)
+        eng.set_hyper(lr=1e-3, beta=0.3)
+        eng.drop_seed = 21
+        tri = triples.cuda() if mt == "t-SAIL" else None
+        outs.append(eng.train_step(tri, seq.cuda()).cpu().numpy().copy())
+        torch.cuda.synchronize()
+        grads.append({k: v.float().clone() for k, v in eng.g.items()})
+    assert rel_err(float(outs[1][0]), float(outs[0][0])) < 5e-5, outs
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert torch.isfinite(b).all(), k
+        assert (a - b).norm().item() <= 5e-3 * a.norm().item() + 1e-7, (k, (a - b).norm().item(), a.norm().item())
