@@ -91,6 +91,13 @@ __device__ __forceinline__ H8 vc_tr_frag(const char* img0, int rbase, int dt, in
 
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
+// ONE barrier per stage (round 4): the barrier that publishes stage s also says every wave has finished reading stage s - 1,
+// whose slot is refilled at once (NSLOT - 1 stages in flight, as before) -- the second barrier of the loop and the LDS drain
+// in front of it are gone.  At D = 128 a stage is ~0.3 us of matrix work and the loop was bound by its fixed cost per stage.
+#ifndef ARK_VC_ONEBAR
+#define ARK_VC_ONEBAR 1
+#endif
+
 // ring depth by model width: a stage is 64 rows x D 16-bit elements (8 KB per 64 of D); narrow models afford four slots
 // -- three stages in flight per workgroup -- and need them: at D = 128 a step is ~0.3 us of matrix work behind ~1 us of
 // LDS-DMA latency with one stage in flight
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + min(v0 + ln, V - 1)),
                                      (__attribute__((address_space(3))) void*)(slot + STAGE + wave * kVcAux), 4, 0, 0);
   };
-  for (int s = s0; s < s0 + NSLOT && s < s1; ++s) issue(s);
+  for (int s = s0; s < s0 + NSLOT - ARK_VC_ONEBAR && s < s1; ++s) issue(s);
 
   float m2 = -INFINITY, lsum = 0.f, picked = 0.f;   // running max (log2 domain), this LANE's partial sum, target logit
   f32x4 U[WITH_DY ? DT : 1];
@@ -162,9 +169,12 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
     for (int dt = 0; dt < DT; ++dt) U[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (int s = s0; s < s1; ++s) {
-    vc_wait_stages<LPS>(min(NSLOT - 1, s1 - 1 - s));
+    vc_wait_stages<LPS>(min(NSLOT - 1 - ARK_VC_ONEBAR, s1 - 1 - s));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#if ARK_VC_ONEBAR
+    if (s + NSLOT - 1 < s1) issue(s + NSLOT - 1);   // into the slot of stage s - 1: every wave is past its reads of it
+#endif
     const char* base = smem + ((s - s0) % NSLOT) * SLOT;
     f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -218,12 +228,14 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
       for (int dt = 0; dt < DT; ++dt) U[dt] = PT::mfma(vc_tr_frag<h8>(base, vh * 32, dt, lane), pf, U[dt]);
     }
     m2 = mn;
+#if !ARK_VC_ONEBAR
     if (s + NSLOT < s1) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       issue(s + NSLOT);
     }
+#endif
   }
   // this lane's row sum over the 4 token quarters held by the lanes c, c+16, c+32, c+48
   lsum += __shfl_xor(lsum, 16, 64);
@@ -385,16 +397,19 @@ __global__ __launch_bounds__(128 * VG) void vocab_ce_dw_kernel(VocabCeArgs p) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.seq + (long)b * p.ld_seq + t + 1),
                                      (__attribute__((address_space(3))) void*)(aux + kVcAux), 4, 0, 0);
   };
-  for (int s = 0; s < NSLOT && s < nsteps; ++s) issue(s);
+  for (int s = 0; s < NSLOT - ARK_VC_ONEBAR && s < nsteps; ++s) issue(s);
 
   f32x4 dWt[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) dWt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dbv = 0.f;
   for (int s = 0; s < nsteps; ++s) {
-    vc_wait_stages<LPS>(min(NSLOT - 1, nsteps - 1 - s));
+    vc_wait_stages<LPS>(min(NSLOT - 1 - ARK_VC_ONEBAR, nsteps - 1 - s));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#if ARK_VC_ONEBAR
+    if (s + NSLOT - 1 < nsteps) issue(s + NSLOT - 1);
+#endif
     const char* base = smem + (s % NSLOT) * SLOT;
     f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -433,12 +448,14 @@ __global__ __launch_bounds__(128 * VG) void vocab_ce_dw_kernel(VocabCeArgs p) {
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dWt[dt] = PT::mfma(vc_tr_frag<h8>(base, rh * 32, dt, lane), gf, dWt[dt]);
+#if !ARK_VC_ONEBAR
     if (s + NSLOT < nsteps) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       issue(s + NSLOT);
     }
+#endif
   }
   dbv += __shfl_xor(dbv, 16, 64);
   dbv += __shfl_xor(dbv, 32, 64);
