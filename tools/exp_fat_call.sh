@@ -1,14 +1,9 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 O=gpurun_out; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gemm_gpu.py -q -p no:cacheprovider -x -k "vocab" > $O/r4z_vc_tests.log 2>&1; rc=$?
-tail -5 $O/r4z_vc_tests.log
+timeout -k 10 1000 python -m pytest tests -q -m gpu -p no:cacheprovider > $O/r4z_all_tests.log 2>&1; rc=$?
+tail -3 $O/r4z_all_tests.log
 echo "pytest rc=$rc"
 if [ $rc -ne 0 ]; then exit 1; fi
-for i in 1 2; do
-for v in default vc2bar; do
-  if [ $v = default ]; then unset ARK_AMD_LIB; else export ARK_AMD_LIB=$PWD/ark_amd/lib/variants/$v/libark_amd.so; fi
-  echo "== $v movies"; timeout -k 10 120 python tools/vc_time.py 2>&1 | grep " us"
-  echo "== $v articles"; timeout -k 10 120 python tools/vc_time.py articles 2>&1 | grep " us"
-done
-done
+bash tools/profile_round.sh r04b_wd-movies wd-movies stats-only && bash tools/profile_round.sh r04b_wd-articles wd-articles stats-only
+for w in wd-movies wd-articles; do timeout -k 10 200 python bench.py --workload $w --no-other --no-cpu-baseline --steps 100 --warmup 20 --settle 100 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', round(d['ms_per_step'],4))"; done
