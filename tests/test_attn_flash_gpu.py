@@ -245,3 +245,22 @@ def test_row_counts_that_are_not_multiples_of_64_take_the_fast_products(mt, B, T
         a, b = grads[0][k], grads[1][k]
         assert torch.isfinite(b).all(), k
         assert (a - b).norm().item() <= 5e-3 * a.norm().item() + 1e-7, (k, (a - b).norm().item(), a.norm().item())
+
+
+@pytest.mark.parametrize("mt", ["t-SAIL", "t-ARK"])
+def test_wd_movies_shape_through_the_train_entry_point(tmp_path, mt):
+    """`python -m kgvae.experiments.train` on the wd-movies YAML (V = 24 101, 70 decoder positions, padded graphs) with a
+    Transformer model type: flash attention in decoder (and encoder), fused vocabulary CE, captured steps, validation and
+    the posterior-bits log of the loop -- two epochs, finite parameters, a falling training loss"""
+    import os
+    import yaml
+    from kgvae.experiments import train as T
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "configs", "sail_wd-movies.yaml")))
+    cfg.update(model_type=mt, n_layers=2, num_epochs=2, batch_size=32, save_every=2, compression_log_every=1, verify_every=100,
+               learning_rate=1e-3, precision="mixed", synthetic_sizes={"n_train": 128, "n_val": 32, "n_test": 32},
+               dump_final_params=str(tmp_path / "P"))
+    cpath = tmp_path / "c.yaml"
+    yaml.safe_dump(cfg, open(cpath, "w"))
+    T.main(["--config", str(cpath), "--checkpoint-dir", str(tmp_path / "ck")])
+    assert torch.isfinite(torch.load(str(tmp_path / "P.rank0.pt"), weights_only=True)).all()
