@@ -94,6 +94,9 @@ constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 // ONE barrier per stage (round 4): the barrier that publishes stage s also says every wave has finished reading stage s - 1,
 // whose slot is refilled at once (NSLOT - 1 stages in flight, as before) -- the second barrier of the loop and the LDS drain
 // in front of it are gone.  At D = 128 a stage is ~0.3 us of matrix work and the loop was bound by its fixed cost per stage.
+// (Measured and not kept: the refill's pieces spread over the first product's k-steps instead of issued as one block behind
+// the barrier -- wd-articles forward 1.97 -> 2.02 ms, weight gradient 1.75 -> 1.91 ms: a piece between MFMAs stalls its wave
+// with LDS reads queued behind it.)
 #ifndef ARK_VC_ONEBAR
 #define ARK_VC_ONEBAR 1
 #endif
