@@ -60,6 +60,10 @@ def _oracle(name):
 
 # mixed (the shipped mode: fp16 forward / bf16 backward MFMA operands) is held to north_star's 1e-4 on the ELBO at the YAML
 # batch sizes (measured on MI355X: syn-types 3.2e-5, wd-movies 2.6e-6, wd-articles 1.5e-6 / 1.1e-6)
+# relative L2 error of every gradient tensor (measured on MI355X: f32 <= 1.4e-5, mixed <= 4.5e-3 over the four shapes)
+L2TOL = {"f32": 1e-4, "mixed": 1.2e-2}
+
+
 @pytest.mark.parametrize("precision,ltol,gtol", [("f32", 2e-5, 2e-3), ("mixed", 1e-4, 6e-2)])
 @pytest.mark.parametrize("name", list(SHAPES))
 def test_other_configs_match_oracle(name, precision, ltol, gtol):
@@ -80,10 +84,16 @@ def test_other_configs_match_oracle(name, precision, ltol, gtol):
         want["enc.r_emb.weight"] = want["enc.r_emb.weight"].clone()
         want["enc.e_emb.weight"][cfg["pad_eid"]] = 0
         want["enc.r_emb.weight"][cfg["pad_rid"]] = 0
+    worst = 0.0
     for k, gw in want.items():
         got = eng.g[k].cpu()
         scale = gw.abs().max().item() + 1e-12
         err = (got - gw).abs().max().item()
         assert err <= gtol * scale, (k, err, scale)
+        # the max-norm bound above is dominated by single 16-bit roundings; over the whole tensor the error is held tighter
+        l2 = ((got - gw).norm() / (gw.norm() + 1e-30)).item()
+        worst = max(worst, l2)
+        assert l2 <= (L2TOL[precision] if gw.norm().item() > 1e-6 else 1.0), (k, l2)
+    print(f"[{name} {precision}] worst relative L2 gradient error {worst:.2e}")
     del eng
     torch.cuda.empty_cache()
