@@ -39,6 +39,28 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   return cdf + x * pdf;
 }
 
+// GELU / GELU' for the 16-bit-operand product epilogues (gemm16.hip): erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7,
+// i.e. fp32 rounding noise) on the hardware exp2 / rcp -- 14 instructions where erff + expf + a division took ~90, which one
+// workgroup per CU cannot hide; GELU' shares the exponential between the density and the erf.  The exact-fp32 mode
+// (gemm.hip) keeps erff.
+__device__ __forceinline__ void erf_parts(float x, float& erf_abs, float& e) {   // erf(|x| / sqrt 2), exp(-x^2 / 2)
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  erf_abs = fmaf(-poly, e, 1.0f);
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  float ea, e;
+  erf_parts(x, ea, e);
+  return 0.5f * x * (1.0f + copysignf(ea, x));
+}
+__device__ __forceinline__ float dgelu_fast(float x) {
+  float ea, e;
+  erf_parts(x, ea, e);
+  return fmaf(0.39894228040143267794f * x, e, 0.5f * (1.0f + copysignf(ea, x)));
+}
+
 // hardware transcendentals for the 16-bit-operand (mixed precision) GRU epilogues: v_exp_f32 / v_rcp_f32 are ~1 ulp,
 // far inside the fp16 operand rounding of that path; 4-5 instructions instead of ~25 (expf + division) / ~40 (tanhf).
 // The exact-fp32 path (gru.hip) keeps expf / tanhf.

@@ -6,6 +6,19 @@
 // nn.GRU input projection (kgvae/model/models.py:121-127), nn.Linear `out` (:128,142) and their
 // autograd input-gradients.
 #include "dma_core.h"
+// Diagnostic build only (-DARK_STAMPS, tools/wpk_stamps.py): 100-MHz real-time stamps per WAVE of the wave-private
+// K-slice kernel -- entry, ring primed, first slice landed, main loop done, rings free, tiles summed, stores drained.
+#ifdef ARK_STAMPS
+namespace ark { __device__ unsigned long long ark_wpk_stamp_buf[1024 * 8 * 8]; }
+#define WPK_STAMP(i)                                                                                         \
+  do {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024)                                                        \
+      ark::ark_wpk_stamp_buf[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  } while (0)
+#endif
+#include "wpk_core.h"
 #include "../../include/ark_amd.h"
 
 namespace ark {
@@ -17,6 +30,49 @@ struct Gemm16Args {
   void* c16a; void* c16b; int prec_a, prec_b;   // optional row-major 16-bit copies of the result (ld = ldc)
   float* colsum;   // optional: colsum[col] += sum over rows of the value written to C (bias gradient of a dpre output)
 };
+
+// epilogue of one 16 x 16 accumulator tile (MFMA C/D order: this lane holds rows row0 .. row0+3 of column col); returns the
+// lane's contribution to the column sum of what it wrote (bias gradient of a dpre output)
+__device__ __forceinline__ float g16_epilogue(const Gemm16Args& p, f32x4 v, int row0, int col) {
+  const int M = p.M, N = p.N;
+  if (row0 >= M || col >= N) return 0.f;   // (the column-sum shuffles run outside: all lanes take part)
+  if (p.epi == ARK_EPI_BIAS || p.epi == ARK_EPI_BIAS_RELU) v += p.bias[col];
+  if (p.c_tiled) {  // M % 16 == 0 and ldc % 16 == 0 (checked on the host): the quad is whole
+    const long o = tile_native_off(row0, col, (int)p.ldc);
+    if (p.epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
+    *reinterpret_cast<f32x4*>(p.C + o) = v;
+    return 0.f;
+  }
+  float cs = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (row0 + i >= M) break;
+    const long o = (long)(row0 + i) * p.ldc + col;
+    float x = v[i];
+    if (p.epi == ARK_EPI_MUL_AUX) x *= p.aux[o];
+    if (p.epi == ARK_EPI_MUL_DGELU) x *= dgelu_fast(p.aux[o]);
+    if (p.epi == ARK_EPI_BIAS_RELU) x = fmaxf(x, 0.f);
+    if (p.epi == ARK_EPI_MUL_RELU) x = p.aux[o] > 0.f ? x : 0.f;
+    if (p.epi == ARK_EPI_ADD) x += p.C[o];   // (each element belongs to exactly one lane of one workgroup)
+    if (p.epi == ARK_EPI_BIAS_GELU) {
+      x += p.bias[col];
+      p.C[o] = x;            // pre-activation (fp32, kept for the backward pass)
+      x = gelu_fast(x);      // the 16-bit copies carry the activation
+    } else {
+      if (p.C) p.C[o] = x;
+      cs += x;
+    }
+    if (p.c16a) put16(p.c16a, o, x, p.prec_a);
+    if (p.c16b) put16(p.c16b, o, x, p.prec_b);
+  }
+  return cs;
+}
+// the four lane groups of a wave hold different rows of the same column: fold them, one atomic per column per wave
+__device__ __forceinline__ void g16_colsum(const Gemm16Args& p, float cs, int col) {
+  cs += __shfl_xor(cs, 16, 64);
+  cs += __shfl_xor(cs, 32, 64);
+  if ((threadIdx.x & 63) < 16 && col < p.N) atomicAdd(&p.colsum[col], cs);
+}
 
 template <int PREC, int BM, int BN, int NBUF>
 __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
@@ -38,53 +94,95 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
 #pragma unroll
   for (int tm = 0; tm < G::TM; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < G::TN; ++tn) {
-      const int row0 = m0 + wm * G::WTM + tm * 16 + 4 * (lane >> 4);
-      const int col = n0 + wn * G::WTN + tn * 16 + (lane & 15);
-      if (row0 >= M || col >= N) continue;   // (the column-sum shuffles below run outside this loop: all lanes take part)
-      f32x4 v = acc[tm][tn];
-      if (p.epi == ARK_EPI_BIAS || p.epi == ARK_EPI_BIAS_RELU) v += p.bias[col];
-      if (p.c_tiled) {  // M % 16 == 0 and ldc % 16 == 0 (checked on the host): the quad is whole
-        const long o = tile_native_off(row0, col, (int)p.ldc);
-        if (p.epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
-        *reinterpret_cast<f32x4*>(p.C + o) = v;
-      } else {
-        float cs = 0.f;
+    for (int tn = 0; tn < G::TN; ++tn)
+      csum[tn] += g16_epilogue(p, acc[tm][tn], m0 + wm * G::WTM + tm * 16 + 4 * (lane >> 4), n0 + wn * G::WTN + tn * 16 + (lane & 15));
+  if (p.colsum && !p.c_tiled) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (row0 + i >= M) break;
-          const long o = (long)(row0 + i) * p.ldc + col;
-          float x = v[i];
-          if (p.epi == ARK_EPI_MUL_AUX) x *= p.aux[o];
-          if (p.epi == ARK_EPI_MUL_DGELU) x *= dgelu_erf(p.aux[o]);
-          if (p.epi == ARK_EPI_BIAS_RELU) x = fmaxf(x, 0.f);
-          if (p.epi == ARK_EPI_MUL_RELU) x = p.aux[o] > 0.f ? x : 0.f;
-          if (p.epi == ARK_EPI_ADD) x += p.C[o];   // (each element belongs to exactly one lane of one workgroup)
-          if (p.epi == ARK_EPI_BIAS_GELU) {
-            x += p.bias[col];
-            p.C[o] = x;            // pre-activation (fp32, kept for the backward pass)
-            x = gelu_erf(x);       // the 16-bit copies carry the activation
-          } else {
-            p.C[o] = x;
-            cs += x;
-          }
-          if (p.c16a) put16(p.c16a, o, x, p.prec_a);
-          if (p.c16b) put16(p.c16b, o, x, p.prec_b);
-        }
-        csum[tn] += cs;
+    for (int tn = 0; tn < G::TN; ++tn) g16_colsum(p, csum[tn], n0 + wn * G::WTN + tn * 16 + (lane & 15));
+  }
+}
+
+// 16-bit quad store (run-time element type)
+__device__ __forceinline__ void put16x4(void* base, long idx, f32x4 v, int prec) {
+  if (prec == PREC_F16) {
+    using PT = PrecTraits<PREC_F16>;
+    *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(base) + idx) = f16x4{PT::cvt(v[0]), PT::cvt(v[1]), PT::cvt(v[2]), PT::cvt(v[3])};
+  } else {
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + idx) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  }
+}
+
+// The same product on the wave-private K-slice engine (wpk_core.h): one workgroup per CU, BM x BN tile, every wave runs
+// the whole tile over its own K-slices, partial tiles summed through LDS and written in row-major quads;
+// M % BM == 0, N % BN == 0, K % 64 == 0, row-major C (nullable when a 16-bit copy is asked for: an input gradient that
+// is only read as the next product's operand), ldc % 4 == 0, 16-byte aligned C / aux / bias, 8-byte aligned copies.
+template <int PREC, int BM, int BN, int NW, int NSLOT>
+__global__ __launch_bounds__(64 * NW) void gemm16_wpk_kernel(Gemm16Args p) {
+  using G = WpkNT<PREC, BM, BN, NW, NSLOT>;
+  using h_t = typename G::h_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_m = p.M / BM;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int tm_, tn_;
+  wpk_tile_of(lid, tiles_m, p.tiles_n, 8, tm_, tn_);
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
+  WPK_STAMP(0);
+  f32x4 acc[G::TM][G::TN];
+#pragma unroll
+  for (int tm = 0; tm < G::TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < G::TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  G::run(acc, reinterpret_cast<const h_t*>(p.A) + (long)m0 * p.lda, p.lda, reinterpret_cast<const h_t*>(p.B) + (long)n0 * p.ldb,
+         p.ldb, p.K, lid, smem);
+  float* cs_lds = G::colsum_lds(smem);
+  const int epi = p.epi;
+  G::reduce_rows(acc, smem, [&](int row, int col, f32x4 v) {
+    const long o = (long)(m0 + row) * p.ldc + n0 + col;
+    if (epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_RELU || epi == ARK_EPI_BIAS_GELU) v += *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
+    if (epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
+    if (epi == ARK_EPI_MUL_DGELU) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= dgelu_fast(a[e]);
+    }
+    if (epi == ARK_EPI_BIAS_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (epi == ARK_EPI_MUL_RELU) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = a[e] > 0.f ? v[e] : 0.f;
+    }
+    if (epi == ARK_EPI_ADD) v += *reinterpret_cast<const f32x4*>(p.C + o);
+    if (p.C) *reinterpret_cast<f32x4*>(p.C + o) = v;   // BIAS_GELU: the pre-activation
+    if (epi == ARK_EPI_BIAS_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);   // the 16-bit copies carry the activation
+    } else if (p.colsum) {
+      // the 8 lanes l, l + 8, ... of a wave hold the same four columns of 8 different rows: fold them, then one LDS add
+      // per column and wave
+      f32x4 c = v;
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] += __shfl_xor(c[e], o, 64);
+      if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&cs_lds[col + e], c[e]);
       }
     }
-  if (p.colsum && !p.c_tiled) {
-    // the four lane groups of a wave hold different rows of the same columns: fold them, one atomic per column per wave
-#pragma unroll
-    for (int tn = 0; tn < G::TN; ++tn) {
-      float cs = csum[tn];
-      cs += __shfl_xor(cs, 16, 64);
-      cs += __shfl_xor(cs, 32, 64);
-      const int col = n0 + wn * G::WTN + tn * 16 + (lane & 15);
-      if ((lane >> 4) == 0 && col < N) atomicAdd(&p.colsum[col], cs);
-    }
+    if (p.c16a) put16x4(p.c16a, o, v, p.prec_a);
+    if (p.c16b) put16x4(p.c16b, o, v, p.prec_b);
+  });
+  if (p.colsum) {
+    __syncthreads();
+    if ((int)threadIdx.x < BN) atomicAdd(&p.colsum[n0 + threadIdx.x], cs_lds[threadIdx.x]);
   }
+#ifdef ARK_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (diagnostic build: the stores have left the wave)
+  WPK_STAMP(6);
+#endif
 }
 
 template <class K>
@@ -112,17 +210,52 @@ static void launch16_cfg(Gemm16Args p, hipStream_t st) {
 
 constexpr int g_g16_tile = ARK_G16_TILE;   // 0: heuristic below, 1: 64x64, 2: 128x64, 3: 128x128, 4: 32x64, 5: 64x32
 
+#ifndef ARK_WPK_WAVES
+#define ARK_WPK_WAVES 8
+#endif
+template <int PREC, int BM, int BN>
+static void launch16_wpk(Gemm16Args p, hipStream_t st) {
+  constexpr int NW = ARK_WPK_WAVES, NSLOT = NW == 8 ? 1 : 2;   // 160 KB of ring either way (64 x 96 tile)
+  using G = WpkNT<PREC, BM, BN, NW, NSLOT>;
+  static bool once = (allow_lds16(gemm16_wpk_kernel<PREC, BM, BN, NW, NSLOT>, G::LDS_BYTES), true); (void)once;
+  p.tiles_n = p.N / BN;
+  const long tiles = (long)(p.M / BM) * p.tiles_n;
+  hipLaunchKernelGGL((gemm16_wpk_kernel<PREC, BM, BN, NW, NSLOT>), dim3((unsigned)tiles), dim3(64 * NW), G::LDS_BYTES, st, p);
+}
+
+// engine: 0 = choose, 1 = the shared ring (dma_core.h), 2 = wave-private K-slices (wpk_core.h; ARK_ERR_SHAPE if the
+// shape does not fit it).  WPK wants one tile per CU: it is chosen when its 64 x 96 (or 32 x 96) tiling gives between
+// half a chip and two chips of workgroups and K is deep enough for every wave to own at least two slices.
+static int wpk_rows(const Gemm16Args& p) {
+  if (p.N % 96 != 0 || p.K % 64 != 0 || p.K < 512 || p.c_tiled || p.ldc % 4 != 0) return 0;
+  if (((uintptr_t)p.C | (uintptr_t)p.aux | (uintptr_t)p.bias) & 15) return 0;
+  if (((uintptr_t)p.c16a | (uintptr_t)p.c16b) & 7) return 0;
+  const long tn = p.N / 96;
+  if (p.M % 64 == 0 && (p.M / 64) * tn >= 128 && (p.M / 64) * tn <= 512) return 64;
+  if (p.M % 32 == 0 && (p.M / 32) * tn >= 128 && (p.M / 32) * tn <= 512) return 32;
+  return 0;
+}
+
 template <int PREC>
-static int launch16(Gemm16Args p, hipStream_t st) {
+static int launch16(Gemm16Args p, int engine, hipStream_t st) {
+  const int bm = wpk_rows(p);
+  if (engine == 2 && !bm) return ARK_ERR_SHAPE;
+#ifdef ARK_G16_NO_WPK   // (A/B builds: the library's own choice stays on the shared ring)
+  if (engine == 0) engine = 1;
+#endif
+  if (bm && engine != 1) {
+    if (bm == 64) launch16_wpk<PREC, 64, 96>(p, st); else launch16_wpk<PREC, 32, 96>(p, st);
+    ARK_LAUNCH_CHECK();
+    return 0;
+  }
   int tile = g_g16_tile;
   if (tile == 0) {
     // these products are latency-bound, not MFMA-bound: what counts is how many workgroups a CU can keep
-    // resident.  64x64 tiles unless that leaves fewer than two workgroups per CU (the [B,3D]x[3D,3D] encoder
-    // products at B = 1024: 384 tiles) -- then 32x64 tiles, 24 KB of LDS each (measured 1.221 -> 1.211 ms/step)
+    // resident.  64x64 tiles unless that leaves fewer than two workgroups per CU -- then 32x64 tiles, 24 KB of LDS each
     const long t64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     tile = (g_g16_force64 || t64 >= 512) ? 1 : 4;
   }
-  if (tile == 4) {   // small tiles: more workgroups resident per CU for the short-M encoder products
+  if (tile == 4) {   // small tiles: more workgroups resident per CU for short-M products
     if (g_g16_nbuf == 4) launch16_cfg<PREC, 32, 64, 4>(p, st); else launch16_cfg<PREC, 32, 64, 2>(p, st);
   } else if (tile == 5) {
     if (g_g16_nbuf == 4) launch16_cfg<PREC, 64, 32, 4>(p, st); else launch16_cfg<PREC, 64, 32, 2>(p, st);
@@ -329,9 +462,12 @@ __global__ __launch_bounds__(256) void from_tiled_kernel(const float* __restrict
 
 static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
                        int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled, void* c16a,
-                       void* c16b, int prec_b, float* colsum, void* stream) {
+                       void* c16b, int prec_b, float* colsum, int engine, void* stream) {
   using namespace ark;
-  if (!A16 || !B16 || !C || M <= 0 || N <= 0 || K <= 0) return ARK_ERR_ARG;
+  if (!A16 || !B16 || M <= 0 || N <= 0 || K <= 0) return ARK_ERR_ARG;
+  // C may be NULL when a 16-bit copy is asked for (the product is only read as the next product's 16-bit operand), except
+  // where C itself carries information the copies do not (BIAS_GELU: the pre-activation; ADD: the running sum)
+  if (!C && (!c16a || c_tiled || epi == ARK_EPI_BIAS_GELU || epi == ARK_EPI_ADD)) return ARK_ERR_ARG;
   if (K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0) return ARK_ERR_SHAPE;
   if (((uintptr_t)A16 | (uintptr_t)B16) & 15) return ARK_ERR_ALIGN;
   if (epi < ARK_EPI_NONE || epi > ARK_EPI_ADD) return ARK_ERR_ARG;
@@ -344,15 +480,17 @@ static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const vo
   if (colsum && epi == ARK_EPI_BIAS_GELU) return ARK_ERR_ARG;
   if (c16b && prec_b != PREC_F16 && prec_b != PREC_BF16) return ARK_ERR_ARG;
   Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0, c16a, c16b, prec, prec_b, colsum};
-  if (prec == PREC_F16) return launch16<PREC_F16>(p, (hipStream_t)stream);
-  if (prec == PREC_BF16) return launch16<PREC_BF16>(p, (hipStream_t)stream);
+  if (engine < 0 || engine > 2) return ARK_ERR_ARG;
+  if (engine == 2 && (((uintptr_t)A16 | (uintptr_t)B16) & 15)) return ARK_ERR_ALIGN;
+  if (prec == PREC_F16) return launch16<PREC_F16>(p, engine, (hipStream_t)stream);
+  if (prec == PREC_BF16) return launch16<PREC_BF16>(p, engine, (hipStream_t)stream);
   return ARK_ERR_ARG;
 }
 
 extern "C" int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
                           int64_t ldc, const float* bias, const float* aux, int M, int N, int K, int c_tiled,
                           void* stream) {
-  return gemm16_impl(prec, epi, A16, lda, B16, ldb, C, ldc, bias, aux, M, N, K, c_tiled, nullptr, nullptr, 0, nullptr, stream);
+  return gemm16_impl(prec, epi, A16, lda, B16, ldb, C, ldc, bias, aux, M, N, K, c_tiled, nullptr, nullptr, 0, nullptr, 0, stream);
 }
 
 // same product with row-major 16-bit copies of the result written by the epilogue: c16a in `prec`,
@@ -361,7 +499,15 @@ extern "C" int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const
 extern "C" int ark_gemm16_ex(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
                              int64_t ldc, const float* bias, const float* aux, void* c16a, void* c16b, int prec_b,
                              float* colsum, int M, int N, int K, void* stream) {
-  return gemm16_impl(prec, epi, A16, lda, B16, ldb, C, ldc, bias, aux, M, N, K, 0, c16a, c16b, prec_b, colsum, stream);
+  return gemm16_impl(prec, epi, A16, lda, B16, ldb, C, ldc, bias, aux, M, N, K, 0, c16a, c16b, prec_b, colsum, 0, stream);
+}
+
+// ark_gemm16_ex on a chosen engine (tests, A/B timing): 0 = the library's choice, 1 = shared ring, 2 = wave-private
+// K-slices (ARK_ERR_SHAPE unless M % 32 == 0, N % 96 == 0, K % 64 == 0, K >= 512 and the tiling fills half a chip)
+extern "C" int ark_gemm16_engine(int engine, int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb,
+                                 float* C, int64_t ldc, const float* bias, const float* aux, void* c16a, void* c16b,
+                                 int prec_b, float* colsum, int M, int N, int K, void* stream) {
+  return gemm16_impl(prec, epi, A16, lda, B16, ldb, C, ldc, bias, aux, M, N, K, 0, c16a, c16b, prec_b, colsum, engine, stream);
 }
 
 extern "C" int ark_tok_gather16(int prec_a, int prec_b, const int64_t* seq, int64_t ld_seq, const float* w_tok,
@@ -479,6 +625,12 @@ extern "C" int ark_from_tiled(const float* x, float* out, int rows, int ld, void
   ARK_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef ARK_STAMPS
+extern "C" int ark_debug_wpk_stamps(unsigned long long* host, int n_blocks) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ark::ark_wpk_stamp_buf), sizeof(unsigned long long) * 64 * (size_t)n_blocks);
+}
+#endif
 
 namespace ark {
 // h0 = tanh(z Wz^T + bz) written once for every GRU layer in every layout the LDS-DMA path reads:

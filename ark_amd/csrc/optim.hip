@@ -160,67 +160,137 @@ __device__ __forceinline__ f32x4 adam_quad(const AdamScalars& a, float* p, const
   return pp;
 }
 
+// store 4 consecutive 16-bit elements of run-time type
+__device__ __forceinline__ void put16_quad(void* base, long e, f32x4 x, int prec) {
+  if (prec == PREC_F16) {
+    using PT = PrecTraits<PREC_F16>;
+    *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(base) + e) = f16x4{PT::cvt(x[0]), PT::cvt(x[1]), PT::cvt(x[2]), PT::cvt(x[3])};
+  } else {
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + e) = bf16x4{(__bf16)x[0], (__bf16)x[1], (__bf16)x[2], (__bf16)x[3]};
+  }
+}
+
+// Round 5: a workgroup takes a 64 x 64 tile (a linear job: 4096 floats), FOUR quads per thread with all sixteen 16-byte
+// loads (p, g, m, v of the four quads) in flight before the first update -- round 4's 32 x 32 tiles kept four loads in
+// flight per thread and touched memory in 128-byte (fp32) / 64-byte (16-bit) row segments: 3.85 TB/s.  Now every access
+// of a wave-instruction is 256 contiguous bytes of a row (fp32), 128 (plain 16-bit copy) or 128 (transposed copy: 64
+// source rows of one column).
+constexpr int kAdamTile = 64;
 template <bool G16>
-__global__ __launch_bounds__(256) void adam_shadow_kernel(float* __restrict__ p, const void* __restrict__ g,
+__device__ __forceinline__ void adam_load(const float* p, const void* g, const float* m, const float* v, long i, f32x4& pp,
+                                          f32x4& gg, f32x4& mm, f32x4& vv) {
+  pp = *reinterpret_cast<const f32x4*>(p + i);
+  if constexpr (G16) {
+    const bf16x4 g4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(g) + i);
+    gg = f32x4{(float)g4[0], (float)g4[1], (float)g4[2], (float)g4[3]};
+  } else {
+    gg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g) + i);
+  }
+  mm = *reinterpret_cast<const f32x4*>(m + i);
+  vv = *reinterpret_cast<const f32x4*>(v + i);
+}
+__device__ __forceinline__ void adam_update(const AdamScalars& a, f32x4& pp, f32x4 gg, f32x4& mm, f32x4& vv) {
+  gg *= a.gs;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mm[e] = a.b1 * mm[e] + (1.0f - a.b1) * gg[e];
+    vv[e] = a.b2 * vv[e] + (1.0f - a.b2) * gg[e] * gg[e];
+    pp[e] -= a.step_size * (mm[e] / (sqrtf(vv[e]) * a.inv_sqrt_bc2 + a.eps));
+  }
+}
+
+template <bool G16>
+__global__ __launch_bounds__(256, 4) void adam_shadow_kernel(float* __restrict__ p, const void* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, AdamJobs jobs,
                                                           const float* __restrict__ hyper) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[kAdamTile][kAdamTile + 1];
   int ji = 0;
   for (int k = 1; k < jobs.n; ++k)
     if ((int)blockIdx.x >= jobs.j[k].tile0) ji = k;
   const AdamJob jb = jobs.j[ji];
   const int t = blockIdx.x - jb.tile0;
   const AdamScalars a = adam_scalars(hyper);
-  if (jb.R == 0) {   // linear range, length jb.C (% 4 == 0)
-    const long i = (long)t * 1024 + 4 * threadIdx.x;
-    if (i < jb.C) adam_quad<G16>(a, p, g, m, v, jb.off + i);
-    return;
-  }
-  const int tiles_c = (jb.C + 31) / 32;
-  const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
-  const int ty = threadIdx.x >> 3, tx4 = (threadIdx.x & 7) * 4;
-  const int r = r0 + ty, c = c0 + tx4;
-  f32x4 pp = {0.f, 0.f, 0.f, 0.f};
-  if (r < jb.R && c < jb.C) {   // C % 4 == 0 (host-checked): the quad is whole
-    const long e = (long)r * jb.C + c;
-    pp = adam_quad<G16>(a, p, g, m, v, jb.off + e);
-    if (jb.dst) {
-      if (jb.prec == PREC_F16) {
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        using PT = PrecTraits<PREC_F16>;
-        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(jb.dst) + e) = h4{PT::cvt(pp[0]), PT::cvt(pp[1]), PT::cvt(pp[2]), PT::cvt(pp[3])};
-      } else {
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(jb.dst) + e) = bf16x4{(__bf16)pp[0], (__bf16)pp[1], (__bf16)pp[2], (__bf16)pp[3]};
-      }
+  f32x4 pp[4], gg[4], mm[4], vv[4];
+  long idx[4];
+  bool ok[4];
+  if (jb.R == 0) {   // linear range, length jb.C (% 4 == 0): 4096 floats per workgroup
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long e = (long)t * 4096 + 1024 * i + 4 * threadIdx.x;
+      ok[i] = e < jb.C;
+      idx[i] = jb.off + e;
+    }
+  } else {
+    const int tiles_c = (jb.C + kAdamTile - 1) / kAdamTile;
+    const int r0 = (t / tiles_c) * kAdamTile, c0 = (t % tiles_c) * kAdamTile;
+    const int ty = threadIdx.x >> 4, c = c0 + (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + ty + 16 * i;
+      ok[i] = r < jb.R && c < jb.C;   // C % 4 == 0 (host-checked): the quad is whole
+      idx[i] = jb.off + (long)r * jb.C + c;
     }
   }
-  if (!jb.dstT) return;   // block-uniform
 #pragma unroll
-  for (int e = 0; e < 4; ++e) tile[ty][tx4 + e] = pp[e];
+  for (int i = 0; i < 4; ++i) {
+    pp[i] = gg[i] = mm[i] = vv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ok[i]) adam_load<G16>(p, g, m, v, idx[i], pp[i], gg[i], mm[i], vv[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!ok[i]) continue;
+    adam_update(a, pp[i], gg[i], mm[i], vv[i]);
+    *reinterpret_cast<f32x4*>(p + idx[i]) = pp[i];
+    *reinterpret_cast<f32x4*>(m + idx[i]) = mm[i];
+    *reinterpret_cast<f32x4*>(v + idx[i]) = vv[i];
+    if (jb.R != 0 && jb.dst) put16_quad(jb.dst, idx[i] - jb.off, pp[i], jb.prec);
+  }
+  if (jb.R == 0 || !jb.dstT) return;   // block-uniform
+  {
+    const int ty = threadIdx.x >> 4, tx4 = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[ty + 16 * i][tx4 + e] = pp[i][e];
+  }
   __syncthreads();
-  // transposed copy: thread -> column c0 + ty of the source tile, 4 consecutive source rows r0 + tx4 .. +3
-  const int cT = c0 + ty, rT = r0 + tx4;
-  if (cT < jb.C && rT < jb.R) {
+  // transposed copy: thread -> column c0 + ty + 16 i of the source tile, 4 consecutive source rows r0 + tx4 .. + 3
+  const int tiles_c = (jb.C + kAdamTile - 1) / kAdamTile;
+  const int r0 = (t / tiles_c) * kAdamTile, c0 = (t % tiles_c) * kAdamTile;
+  const int ty = threadIdx.x >> 4, tx4 = (threadIdx.x & 15) * 4;
+  const int rT = r0 + tx4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cl = ty + 16 * i, cT = c0 + cl;
+    if (cT >= jb.C || rT >= jb.R) continue;
     const long eT = (long)cT * jb.ldT + rT;   // ldT % 4 == 0 (host-checked): 8-byte aligned
-    const float x0 = tile[tx4][ty], x1 = tile[tx4 + 1][ty], x2 = tile[tx4 + 2][ty], x3 = tile[tx4 + 3][ty];
+    const f32x4 x = {tile[tx4][cl], tile[tx4 + 1][cl], tile[tx4 + 2][cl], tile[tx4 + 3][cl]};
     if (rT + 3 < jb.R) {
-      if (jb.precT == PREC_F16) {
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        using PT = PrecTraits<PREC_F16>;
-        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(jb.dstT) + eT) = h4{PT::cvt(x0), PT::cvt(x1), PT::cvt(x2), PT::cvt(x3)};
-      } else {
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(jb.dstT) + eT) = bf16x4{(__bf16)x0, (__bf16)x1, (__bf16)x2, (__bf16)x3};
-      }
+      put16_quad(jb.dstT, eT, x, jb.precT);
     } else {   // last rows of a matrix whose row count is not a multiple of 4 (e.g. a 55-token vocabulary)
-      const float xs[4] = {x0, x1, x2, x3};
-      for (int e = 0; e < 4 && rT + e < jb.R; ++e) put16(jb.dstT, eT + e, xs[e], jb.precT);
+      for (int e = 0; e < 4 && rT + e < jb.R; ++e) put16(jb.dstT, eT + e, x[e], jb.precT);
     }
   }
 }
 
 }  // namespace ark
 
-extern "C" int ark_version(void) { return 200; }
+extern "C" int ark_version(void) { return 210; }
+
+namespace ark {
+__global__ void stamp_kernel(unsigned long long* buf, int slot) {
+  if (threadIdx.x == 0) buf[slot] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the whole device
+}
+}  // namespace ark
+// Diagnostics (tools/step_stamps.py): buf[slot] = the device's 100-MHz real-time counter when this one-thread launch
+// runs, i.e. right after everything queued before it on `stream`.  Captured with the step, it gives the end time of every
+// launch of a replay without a profiler in the process (rocprofv3 stretches the two-queue parts of a captured step up to 2x).
+extern "C" int ark_stamp(unsigned long long* buf, int slot, void* stream) {
+  if (!buf || slot < 0) return ARK_ERR_ARG;
+  hipLaunchKernelGGL(ark::stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, buf, slot);
+  ARK_LAUNCH_CHECK();
+  return 0;
+}
 
 // Adam (as ark_adam_step) over the jobs' ranges of the flat buffers, writing the 16-bit weight shadows of
 // every matrix job from the updated values.  Job i: R[i] == 0 -> linear range [off[i], off[i] + C[i]);
@@ -251,7 +321,7 @@ static int adam_step_shadows_impl(float* p, const void* g, bool g16, float* m, f
     }
     jobs.j[i] = AdamJob{(long)off[i], R[i] > 0 ? d : nullptr, R[i] > 0 ? dT : nullptr, R[i], C[i], prec ? prec[i] : 0,
                         precT ? precT[i] : 0, ld, (int)tiles};
-    tiles += R[i] > 0 ? (long)((R[i] + 31) / 32) * ((C[i] + 31) / 32) : ((long)C[i] + 1023) / 1024;
+    tiles += R[i] > 0 ? (long)((R[i] + kAdamTile - 1) / kAdamTile) * ((C[i] + kAdamTile - 1) / kAdamTile) : ((long)C[i] + 4095) / 4096;
     if (tiles > 0x7fffffffL) return ARK_ERR_SHAPE;
   }
   if (g16) hipLaunchKernelGGL(adam_shadow_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p, g, m, v, jobs, hyper);

@@ -48,9 +48,17 @@ CAPTURE_MODE = "thread_local"
 _calls = [0]   # library calls made so far (txf_engine: "nothing has run since the previous product")
 
 
+_stamps = None   # diagnostics (tools/step_stamps.py): {"buf": uint64 device tensor, "log": [(library call, stream)]}
+
+
 def _call(name, *args):
     _calls[0] += 1
     L.check(getattr(L.lib(), name)(*args), name)
+    if _stamps is not None and len(_stamps["log"]) < _stamps["buf"].numel():
+        # every library call takes its stream last: a one-thread stamp launch right behind it on the same queue
+        st = args[-1]
+        _stamps["log"].append((name, getattr(st, "value", None)))
+        L.check(L.lib().ark_stamp(L.ptr(_stamps["buf"]), L.i32(len(_stamps["log"]) - 1), st), "ark_stamp")
 
 
 class ParamLayout:
@@ -242,6 +250,13 @@ class Engine:
         self.fused_latent = bool(cfg.get("ark_fused_latent", True))
         self.fused_prologue = bool(cfg.get("ark_fused_prologue", True))   # encoder pool + token gather as one launch
         self._x0_ready = False
+        # engine of the encoder's 16-bit products (csrc/gemm16.hip): 0 = the library's choice, 1 = shared ring, 2 = wave-private
+        # K-slices; forward and input-gradient products separately (the latter run beside the weight-gradient launch)
+        self.g16_fwd = int(cfg.get("ark_g16_fwd", 0))
+        # measured (same box, alternating): forward on the wave-private engine 1.103 -> 1.093 ms per step; the input
+        # gradients on it 1.093 -> 1.110 -- its workgroups want a CU's whole LDS and queue behind the weight-gradient
+        # launch's two 64-KB workgroups per CU, where the ring's 24-KB workgroups slip in beside them
+        self.g16_bwd = int(cfg.get("ark_g16_bwd", 1))
         self.early_dec_adam = bool(cfg.get("ark_early_dec_adam", True))
         self.early_mlp_adam = bool(cfg.get("ark_early_mlp_adam", True))
         self._adam_dec_early = False
@@ -626,7 +641,7 @@ class Engine:
             if w["v2"]:
                 a16 = w["g16a"]
                 for i in range(n):
-                    _call("ark_gemm16_ex", L.i32(pf), L.i32(L.EPI_BIAS_GELU), L.ptr(a16), L.i64(H), L.ptr(self.wm16[i]), L.i64(H),
+                    _call("ark_gemm16_engine", L.i32(self.g16_fwd), L.i32(pf), L.i32(L.EPI_BIAS_GELU), L.ptr(a16), L.i64(H), L.ptr(self.wm16[i]), L.i64(H),
                           L.ptr(w["pre"][i]), L.i64(H), L.ptr(p[f"enc.mlp.{2 * i}.bias"]), L.ptr(None), L.ptr(w["act16a"][i]),
                           L.ptr(w["act16b"][i]), L.i32(pb), L.ptr(None), L.i32(B), L.i32(H), L.i32(H), st)
                     a16 = w["act16a"][i]
@@ -1227,12 +1242,14 @@ class Engine:
                     self._colsum(dpre, H, g[f"enc.mlp.{2 * i}.bias"], B, H)
                 group.append((w["dpre16"][i], H, inp16, H, g[f"enc.mlp.{2 * i}.weight"], H, H, H, _rup(B, 64)))
                 if i > 0:
-                    _call("ark_gemm16_ex", L.i32(pb), L.i32(L.EPI_MUL_DGELU), L.ptr(w["dpre16"][i]), L.i64(H), L.ptr(self.wmT16[i]),
-                          L.i64(H), L.ptr(other), L.i64(H), L.ptr(None), L.ptr(w["pre"][i - 1]), L.ptr(w["dpre16"][i - 1]), L.ptr(None),
+                    # (no fp32 output: this gradient is only read as the next product's 16-bit operand)
+                    _call("ark_gemm16_engine", L.i32(self.g16_bwd), L.i32(pb), L.i32(L.EPI_MUL_DGELU), L.ptr(w["dpre16"][i]), L.i64(H), L.ptr(self.wmT16[i]),
+                          L.i64(H), L.ptr(None), L.i64(H), L.ptr(None), L.ptr(w["pre"][i - 1]), L.ptr(w["dpre16"][i - 1]), L.ptr(None),
                           L.i32(pb), L.ptr(g[f"enc.mlp.{2 * (i - 1)}.bias"]), L.i32(B), L.i32(H), L.i32(H), st)
                 else:
-                    _call("ark_gemm16", L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dpre16"][0]), L.i64(H), L.ptr(self.wmT16[0]), L.i64(H),
-                          L.ptr(other), L.i64(H), L.ptr(None), L.ptr(None), L.i32(B), L.i32(H), L.i32(H), L.i32(0), st)
+                    _call("ark_gemm16_engine", L.i32(self.g16_bwd), L.i32(pb), L.i32(L.EPI_NONE), L.ptr(w["dpre16"][0]), L.i64(H),
+                          L.ptr(self.wmT16[0]), L.i64(H), L.ptr(other), L.i64(H), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None),
+                          L.i32(pb), L.ptr(None), L.i32(B), L.i32(H), L.i32(H), st)
                 dpre, other = other, dpre
             for i0 in range(0, len(group), 8):
                 self._wgrad_group(group[i0:i0 + 8])

@@ -287,6 +287,14 @@ int ark_gemm16(int prec, int epi, const void* A16, int64_t lda, const void* B16,
 int ark_gemm16_ex(int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc,
                   const float* bias, const float* aux, void* c16a, void* c16b, int prec_b, float* colsum, int M, int N,
                   int K, void* stream);
+/* ark_gemm16_ex on a chosen engine (parity tests, A/B timing): 0 = the library's choice (what ark_gemm16 / _ex do),
+ * 1 = the shared two-barrier ring (csrc/dma_core.h), 2 = wave-private K-slices (csrc/wpk_core.h: one 64 x 96 or 32 x 96
+ * tile per CU, every wave streams its own K-slices, no barrier in the main loop; ARK_ERR_SHAPE unless M % 32 == 0,
+ * N % 96 == 0, K % 64 == 0, K >= 512 and the tiling gives 128 .. 512 workgroups).  Same products as nn.Linear forward /
+ * input gradient of the encoder MLP (kgvae/model/models.py:32-41,60). */
+int ark_gemm16_engine(int engine, int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
+                      int64_t ldc, const float* bias, const float* aux, void* c16a, void* c16b, int prec_b, float* colsum,
+                      int M, int N, int K, void* stream);
 /* C[M,N] = sum_k A[k,M] B[k,N]: weight gradients with fp32 or 16-bit stored operands */
 int ark_gemm_wgrad(int prec, const void* A, int a_is16, int64_t lda, const void* B, int b_is16, int64_t ldb, float* C,
                    int64_t ldc, int M, int N, int K, int accumulate, void* stream);
@@ -496,6 +504,9 @@ int ark_latent_bwd_ex(const float* dz, const float* head, const float* eps, cons
 int ark_normal_fill(float* out, int64_t n, uint64_t seed, float* hyper, void* stream);
 /* zero `nbytes` bytes (multiple of 4, 16-byte aligned start): a plain kernel, ordered like every other launch of the stream */
 int ark_zero(void* ptr, int64_t nbytes, void* stream);
+/* diagnostics: buf[slot] = the device's 100-MHz real-time counter once everything queued before on `stream` has run
+ * (a one-thread launch; tools/step_stamps.py captures one behind every launch of a train step) */
+int ark_stamp(unsigned long long* buf, int slot, void* stream);
 /* y[0:n] += a * x[0:n] */
 int ark_axpy(float* y, const float* x, int64_t n, float a, void* stream);
 /* device-to-device copy of `nbytes` bytes (multiple of 4, 16-byte aligned ends): a plain kernel */

@@ -770,7 +770,9 @@ def test_token_table_forward_agrees_with_the_streamed_input_projection(drop):
                 assert (da - db).norm().item() <= 5e-3 * da.norm().item() + 1e-9, k
     want = b.wtok16.view(torch.float16).float() @ b.wih16[0].view(torch.float16).float().t()
     assert (b.xtab - want).abs().max().item() < 1e-4      # the table follows the updated shadows
-    assert (a.P - b.P).abs().max().item() <= 3 * 1e-3 * 1.05 and (a.P - b.P).abs().mean().item() < 2e-5
+    # (three Adam steps of lr = 1e-3 in opposite directions where a near-zero gradient's sign differs, |m_hat / sqrt(v_hat)| a
+    # little over 1 in the first steps)
+    assert (a.P - b.P).abs().max().item() <= 3 * 1e-3 * 1.25 and (a.P - b.P).abs().mean().item() < 2e-5
 
 
 @pytest.mark.parametrize("top", [False, True])

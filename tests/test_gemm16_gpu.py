@@ -1,0 +1,97 @@
+"""Parity of the 16-bit-operand product engines behind ark_gemm16 / ark_gemm16_ex (ark_amd/csrc/gemm16.hip) against torch
+fp64 on the same rounded operands: the shared LDS-DMA ring (dma_core.h) and the wave-private K-slice engine (wpk_core.h)
+at the encoder shapes of the BASELINE configurations, every fused epilogue the encoder uses."""
+import pytest
+import torch
+
+from ark_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+H16 = {L.PREC_F16: torch.float16, L.PREC_BF16: torch.bfloat16}
+
+
+def run16(engine, prec, epi, M, N, K, seed=0, colsum=False, copies=True, no_c=False):
+    g = torch.Generator().manual_seed(seed)
+    dev = torch.device("cuda:0")
+    A = (torch.randn(M, K, generator=g) * 0.5).to(H16[prec])
+    B = (torch.randn(N, K, generator=g) * 0.5).to(H16[prec])
+    bias = torch.randn(N, generator=g)
+    aux = torch.randn(M, N, generator=g)
+    Ad, Bd, bias_d, aux_d = A.to(dev), B.to(dev), bias.to(dev), aux.to(dev)
+    C = None if no_c else torch.full((M, N), float("nan"), device=dev)
+    prec_b = L.PREC_BF16 if prec == L.PREC_F16 else L.PREC_F16
+    c16a = torch.zeros(M, N, dtype=H16[prec], device=dev) if copies else None
+    c16b = torch.zeros(M, N, dtype=H16[prec_b], device=dev) if copies else None
+    cs = torch.zeros(N, device=dev) if colsum else None
+    rc = L.lib().ark_gemm16_engine(L.i32(engine), L.i32(prec), L.i32(epi), L.ptr(Ad), L.i64(K), L.ptr(Bd), L.i64(K), L.ptr(C),
+                                   L.i64(N), L.ptr(bias_d), L.ptr(aux_d), L.ptr(c16a), L.ptr(c16b), L.i32(prec_b), L.ptr(cs),
+                                   L.i32(M), L.i32(N), L.i32(K), L.cur_stream())
+    torch.cuda.synchronize()
+    ref = A.double() @ B.double().t()
+    copy_ref = None
+    if epi in (L.EPI_BIAS, L.EPI_BIAS_GELU):
+        ref = ref + bias.double()
+    if epi == L.EPI_BIAS_GELU:
+        copy_ref = torch.nn.functional.gelu(ref)
+    if epi == L.EPI_MUL_DGELU:
+        x = aux.double().requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        ref = ref * x.grad
+    if copy_ref is None:
+        copy_ref = ref
+    return rc, (C.cpu().double() if C is not None else None), ref, c16a, c16b, copy_ref, cs
+
+
+WPK_SHAPES = [(1024, 1536, 1536),   # syn-paths encoder MLP, B = 1024: 64 x 96 tiles, one per CU
+              (256, 3072, 3072),    # syn-types (D = 1024), B = 256: 32 x 96 tiles
+              (512, 1536, 576),     # 128 tiles, nine slices: waves own 3 / 2 / 2 / 2
+              (2048, 1536, 512)]    # two rounds of workgroups, two slices per wave
+
+
+@pytest.mark.parametrize("prec", [L.PREC_F16, L.PREC_BF16])
+@pytest.mark.parametrize("epi", [L.EPI_NONE, L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_MUL_DGELU])
+@pytest.mark.parametrize("shape", WPK_SHAPES)
+@pytest.mark.parametrize("engine", [1, 2])
+def test_gemm16_engines_match_fp64(engine, shape, epi, prec):
+    M, N, K = shape
+    with_cs = epi in (L.EPI_NONE, L.EPI_MUL_DGELU)
+    rc, out, ref, c16a, c16b, copy_ref, cs = run16(engine, prec, epi, M, N, K, colsum=with_cs)
+    assert rc == 0
+    tol = 3e-5 * K ** 0.5 + 1e-5   # fp32 accumulation order only: both sides multiply the same 16-bit operands
+    assert (out - ref).abs().max().item() <= tol
+    for c16, eps in ((c16a, 2.0 ** -10 if prec == L.PREC_F16 else 2.0 ** -7), (c16b, 2.0 ** -7 if prec == L.PREC_F16 else 2.0 ** -10)):
+        err = (c16.cpu().double() - copy_ref).abs()
+        assert (err <= eps * copy_ref.abs() + tol).all()
+    if with_cs:
+        want = ref.sum(0)
+        assert (cs.cpu().double() - want).abs().max().item() <= 1e-4 * M ** 0.5 * ref.abs().max().item()
+
+
+def test_gemm16_engines_agree_bit_for_bit_is_not_required_but_close():
+    """the two engines sum the same products in different orders: equal to fp32 rounding"""
+    M, N, K = 1024, 1536, 1536
+    _, o1, _, a1, _, _, _ = run16(1, L.PREC_F16, L.EPI_BIAS_GELU, M, N, K, seed=3)
+    _, o2, _, a2, _, _, _ = run16(2, L.PREC_F16, L.EPI_BIAS_GELU, M, N, K, seed=3)
+    assert (o1 - o2).abs().max().item() <= 2e-4
+    assert (a1.float() - a2.float()).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("engine", [1, 2])
+def test_gemm16_without_the_fp32_output(engine):
+    """an input gradient that is only read as the next product's 16-bit operand: C = NULL, copy + column sums only"""
+    M, N, K = 1024, 1536, 1536
+    rc, out, ref, c16a, _, copy_ref, cs = run16(engine, L.PREC_BF16, L.EPI_MUL_DGELU, M, N, K, colsum=True, no_c=True)
+    assert rc == 0 and out is None
+    assert ((c16a.cpu().double() - copy_ref).abs() <= 2.0 ** -7 * copy_ref.abs() + 2e-3).all()
+    assert (cs.cpu().double() - ref.sum(0)).abs().max().item() <= 1e-4 * M ** 0.5 * ref.abs().max().item()
+    assert run16(engine, L.PREC_BF16, L.EPI_BIAS_GELU, M, N, K, no_c=True)[0] == -1   # the pre-activation IS the output
+
+
+def test_gemm16_wpk_refuses_shapes_it_cannot_tile():
+    rc = run16(2, L.PREC_F16, L.EPI_NONE, 1024, 1024, 1536)[0]   # N % 96 != 0
+    assert rc == -2
+    rc = run16(2, L.PREC_F16, L.EPI_NONE, 64, 96, 1536)[0]       # one tile: not a chip-filling product
+    assert rc == -2
+    rc = run16(0, L.PREC_F16, L.EPI_NONE, 64, 96, 1536)[0]       # ... which the library's own choice still serves
+    assert rc == 0
