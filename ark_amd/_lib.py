@@ -147,13 +147,6 @@ def sweep_sync_words(n_layers, B, Lq):
     return int(f(i32(n_layers), i32(B), i32(Lq)))
 
 
-def fat_sync_words(n_layers, B, D, Lq):
-    """words of the `sync` workspace of ark_gru_fat_fwd"""
-    f = lib().ark_gru_fat_sync_words
-    f.restype = ctypes.c_long
-    return int(f(i32(n_layers), i32(B), i32(D), i32(Lq)))
-
-
 def wgrad_tuning(**kw):
     """the library's measured defaults with the given fields replaced (a ctypes byref, ready to pass)"""
     t = WgradTuning()

@@ -259,138 +259,6 @@ struct DmaTile {
     });
   }
 
-  // Ping-pong runner for ONE large workgroup per CU (8 waves = two per SIMD).  A lone workgroup whose waves all run
-  // "issue LDS-DMA, read fragments, multiply" in lockstep behind one barrier executes those phases one after the other
-  // (measured: 128 x 64 forward tile 22.8 us per launch against 19.1 for three 64 x 32 workgroups per CU that overlap
-  // each other's phases although they stream 1.5x the bytes).  Here the two waves of every SIMD -- waves w and w + 4 --
-  // run the SAME program one barrier interval apart: while group 0 multiplies stage s out of registers, group 1 issues
-  // its LDS-DMA pieces and reads its fragments of stage s, then they swap.  The matrix pipe of every SIMD always has one
-  // wave feeding it, the vector-memory front end and the LDS serve the other.
-  //
-  //   interval      2s                 2s+1               2s+2
-  //   group 0   LOAD(s)            MATH(s)            LOAD(s+1)         LOAD(s) = issue one stage ahead, read stage s
-  //   group 1   MATH(s-1)          LOAD(s)            MATH(s)           MATH(s) = the stage's MFMAs from registers
-  //
-  // Ring protocol (NBUF >= 4 slots of one 64-wide k-image): in LOAD(s) group 0 issues its pieces of stage s+NBUF-2 (slot
-  // of stage s-2: group 1 finished reading it two intervals ago), group 1 those of stage s+NBUF-1 (slot of stage s-1:
-  // its own reads of it completed before its MATH(s-1)).  Stage s is first read in interval 2s, so every wave waits for
-  // ITS pieces of stage s+1 (counted vmcnt) before the barrier that closes interval 2s+1: group 0 at the end of
-  // MATH(s), group 1 at the end of LOAD(s).  Reads therefore always come one barrier after the wait that retires the
-  // data (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it").
-  template <int NSEG, class RMA, class RMB, class MM>
-  static __device__ __forceinline__ void run_pp(const Segs<NSEG>& sg, long lda, long ldb, RMA rma, RMB rmb, char* lds,
-                                                MM&& mm) {
-    static_assert(KI == 1 && EVEN_A && EVEN_B && NW == 8 && NBUF >= 4 && NBUF <= 5, "ping-pong ring: 8 waves, 4-5 slots, even piece dealing");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g1 = wave >= NW / 2 ? 1 : 0;   // waves w and w + 4 share a SIMD: the second half runs one interval behind
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int lr = lane & 15, lq = lane >> 4;
-    long ao[NPA], bo[NPB];
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-      const int q = wave + NW * i, j = q / (BM / 8), pr = q % (BM / 8);
-      const int row = 8 * pr + (lane >> 3);
-      ao[i] = rma(row) * lda + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
-    }
-#pragma unroll
-    for (int i = 0; i < NPB; ++i) {
-      const int q = wave + NW * i, j = q / (BN / 8), pr = q % (BN / 8);
-      const int row = 8 * pr + (lane >> 3);
-      bo[i] = rmb(row) * ldb + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
-    }
-    int cum[NSEG];
-    {
-      int c = 0;
-#pragma unroll
-      for (int i = 0; i < NSEG; ++i) { c += sg.K[i] / KS; cum[i] = c; }
-    }
-    int left = cum[NSEG - 1];
-    if (left <= 0) return;   // (block-uniform: every wave of the workgroup serves the same role)
-    int gi = 0, islot = 0;
-    auto issue_next = [&]() {
-      uint64_t A = reinterpret_cast<uint64_t>(sg.A[0]), B = reinterpret_cast<uint64_t>(sg.B[0]);
-      int start = 0;
-#pragma unroll
-      for (int i = 1; i < NSEG; ++i) {
-        const int in_i = __builtin_amdgcn_readfirstlane(gi >= cum[i - 1] ? 1 : 0);
-        A = s_select64(in_i, reinterpret_cast<uint64_t>(sg.A[i]), A);
-        B = s_select64(in_i, reinterpret_cast<uint64_t>(sg.B[i]), B);
-        start = s_select32(in_i, cum[i - 1], start);
-      }
-      const int ik = (gi - start) * KS;
-      const h_t* Ap = reinterpret_cast<const h_t*>(A) + ik;
-      const h_t* Bp = reinterpret_cast<const h_t*>(B) + ik;
-      char* base = lds + islot * STAGE_BYTES;
-#pragma unroll
-      for (int i = 0; i < NPA; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ap + ao[i]),
-                                         (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NPB; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bp + bo[i]),
-                                         (__attribute__((address_space(3))) void*)(base + A_STAGE + (wave + NW * i) * 1024), 16, 0, 0);
-      ++gi;
-      islot = (islot + 1 == NBUF) ? 0 : islot + 1;
-      --left;
-    };
-    // this wave's stages still in flight may number n: wait until at most n * LPS of its LDS-DMA instructions are out
-    auto wait_out = [&](int n) {
-      if (n >= 3) wait_vmcnt<3 * LPS>();
-      else if (n == 2) wait_vmcnt<2 * LPS>();
-      else if (n == 1) wait_vmcnt<LPS>();
-      else wait_vmcnt<0>();
-    };
-    {
-      const int ahead = NBUF - 2 + g1;   // stages issued before LOAD(0): group 0 issues stage s+NBUF-2 in LOAD(s), group 1 s+NBUF-1
-      const int pre = left < ahead ? left : ahead;
-      for (int s = 0; s < pre; ++s) issue_next();
-      wait_out(gi - 1);                  // stage 0 has landed (this wave's pieces)
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (g1) {                            // the stagger: group 1 sits out interval 0
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    int cslot = 0, g = 0;                // slot and global index of the stage being consumed
-    static_for<NSEG>([&](auto segc) {
-      const int ns = sg.K[decltype(segc)::value] / KS;
-      for (int s = 0; s < ns; ++s, ++g) {
-        // ---- LOAD(g): keep the ring full, fragments of stage g into registers
-        if (left > 0) issue_next();
-        const char* bufA = lds + cslot * STAGE_BYTES;
-        const char* bufB = bufA + A_STAGE;
-        h8 a[2][TM], b[2][TN];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-            a[s2][tm] = *reinterpret_cast<const h8*>(bufA + lds_off(wm * WTM + tm * 16 + lr, 4 * s2 + lq));
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            b[s2][tn] = *reinterpret_cast<const h8*>(bufB + lds_off(wn * WTN + tn * 16 + lr, 4 * s2 + lq));
-        }
-        if (g1) wait_out(gi - (g + 2));  // this wave's pieces of stage g+1 have landed
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- MATH(g)
-        __builtin_amdgcn_s_setprio(1);
-        mm(segc, a[0], b[0]);
-        mm(segc, a[1], b[1]);
-        __builtin_amdgcn_s_setprio(0);
-        if (!g1) wait_out(gi - (g + 2));
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        cslot = (cslot + 1 == NBUF) ? 0 : cslot + 1;
-      }
-    });
-    if (!g1) {                           // group 0 is one interval ahead: meet group 1's last barrier
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-
   // plain product: acc = A x B^T over K
   template <class RMA, class RMB>
   static __device__ __forceinline__ void run(f32x4 (&acc)[TM][TN], const h_t* A, long lda, RMA rma, const h_t* B,

@@ -71,8 +71,9 @@ struct GruDiagArgs {
 };
 
 // BM rows x BU hidden units (x 3 gates) per workgroup, WGM x (BU/16) waves; wave tile (BM/WGM) x 48 = 16 units x 3 gates.
-// MODE: 0 = two-barrier ring (small tiles, several workgroups per CU), 2 = ping-pong halves (ONE 8-wave workgroup per CU;
-// dma_core.h run_pp); 1 = single-barrier ring (run_segs<.., true>: measured, no instantiation shipped)
+// MODE: 0 = two-barrier ring (small tiles, several workgroups per CU); 1 = single-barrier ring (run_segs<.., true>: measured,
+// no instantiation shipped).  (Round 3's 128 x 64 ping-pong tile -- one 8-wave workgroup per CU, 21.8 us per launch against
+// 19.1 -- was removed in round 5 together with its runner.)
 template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU, int WGM = 2, int MODE = 0>
 __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruDiagArgs p) {
   constexpr int BN = 3 * BU, WGN = BU / 16, NTHR = 64 * WGM * WGN;
@@ -156,8 +157,7 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
     }
   };
   ARK_STAMP(1);
-  if constexpr (MODE == 2) G::template run_pp<2>(sg, (long)D, (long)D, rma, rmb, smem, mm);
-  else G::template run_segs<2, MODE == 1, ARK_FWD_AUXA, ARK_FWD_AUXB>(sg, (long)D, (long)D, rma, rmb, smem, mm);
+  G::template run_segs<2, MODE == 1, ARK_FWD_AUXA, ARK_FWD_AUXB>(sg, (long)D, (long)D, rma, rmb, smem, mm);
   ARK_STAMP(2);
 
   __syncthreads();   // ring is free: reuse it to assemble row-major 16-bit rows [BM][BU+pad]
@@ -275,20 +275,13 @@ static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t 
     if (tn.fwd_units == 0 && (long)p.n_roles * ((p.B + 31) / 32) * (p.D / 32) <= 96) units = 16;
   }
   if (tn.fwd_units == 16) { units = 16; rows = 32; ki2 = tn.fwd_ki == 2 && p.D % 128 == 0; }
-  if (rows == 128 && units != 64) rows = 64;   // 128-row tiles exist for 64-unit tiles only
   const int MT = (p.B + rows - 1) / rows, UT = p.D / units;
   // (measured and not kept: four ring slots instead of two for grids of at most one workgroup per CU -- wd-movies B=256,
   //  wd-articles B=16 -- 5.9 -> 6.2 us forward, 9.9 -> 13.6 us backward per launch)
   const bool deep = false;
   p.xcd_map = (tn.fwd_xcd && UT % 4 == 0 && MT % 2 == 0) ? 1 : 0;
   if (units == 64) {   // 8 waves
-    // 128 x 64 on 8 waves, ONE workgroup per CU: single-barrier ring, 3 or 4 slots of 40 KB (fwd_nbuf), refill before consume
-    // 128 x 64 on 8 waves, ONE workgroup per CU, ping-pong halves over a 4-slot ring (dma_core.h run_pp).  Measured on
-    // MI355X (syn-paths B = 1024, per launch): 21.8 us against 19.1-19.6 for the default three 64 x 32 workgroups per CU;
-    // the same tile on a single-barrier ring 22.8, on the two-barrier ring 24.6 -- kept selectable as the reference point
-    // of DESIGN.md section 6, not a default.
-    if (rows == 128) launch_diag<PREC, PRECB, 4, 1, 128, 64, 2, 2>(p, st);
-    else if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 64>(p, st);
+    if (ki2) launch_diag<PREC, PRECB, 2, 2, 64, 64>(p, st);
     else launch_diag<PREC, PRECB, 2, 1, 64, 64>(p, st);
   } else if (units == 16) {   // 2 waves
     // (measured on the wd-articles shape, B = 16, profiles/r03_deep_ring_sweep.txt / r03_helper_waves_sweep.txt: neither a
@@ -312,7 +305,7 @@ static int launch_diag_cfg(GruDiagArgs& p, const ArkDiagTuning& tn, hipStream_t 
 }
 
 static bool diag_tuning_ok(const ArkDiagTuning& t) {
-  return (t.fwd_rows == 32 || t.fwd_rows == 64 || t.fwd_rows == 128) && (t.fwd_ki == 1 || t.fwd_ki == 2) &&
+  return (t.fwd_rows == 32 || t.fwd_rows == 64) && (t.fwd_ki == 1 || t.fwd_ki == 2) &&
          (t.fwd_nbuf == 2 || t.fwd_nbuf == 4) && (t.fwd_units == 0 || t.fwd_units == 16 || t.fwd_units == 32 || t.fwd_units == 64) &&
          (t.bwd_rows == 32 || t.bwd_rows == 64) && (t.bwd_ki == 1 || t.bwd_ki == 2) && (t.bwd_nbuf == 2 || t.bwd_nbuf == 4) &&
          (t.bwd_xcd_rows == 1 || t.bwd_xcd_rows == 2 || t.bwd_xcd_rows == 4 || t.bwd_xcd_rows == 8) &&

@@ -1,4 +1,4 @@
-// Hand-off protocol shared by the persistent GRU kernels (gru_sweep.hip: small batches of long sequences; gru_fat.hip:
+// Hand-off protocol of the persistent GRU kernels (gru_sweep.hip: small batches of long sequences; until round 4 also gru_fat.hip:
 // the forward recurrence of a full batch with register-resident weights): write-through payload stores, one padded
 // MONOTONE counter per hand-off point, an epoch word per `sync` workspace, bounded spins and a STICKY error word.
 // See the header comment of gru_sweep.hip for the protocol and MI355X_MICROARCH.md (visibility section) for why it is valid.
@@ -17,7 +17,11 @@ constexpr unsigned long long kSweepTimeoutTicks = 200000000ull;
 constexpr int kSweepLds = 96 * 1024;                             // > half of a CU's LDS: one workgroup per CU
 constexpr int kSweepSyncHdr = 32;                                // words in front of the counters: [0] sticky error, [1] who / where,
                                                                  // [2] epoch = launches completed on this workspace, [3] workgroups
-                                                                 // of the running launch that have left
+                                                                 // of the running launch that have left; written with the error:
+                                                                 // [4] the counter value waited for, [5] / [6] the values last seen
+                                                                 // of the first / second counter polled (0xFFFFFFFF: not polled),
+                                                                 // [7] 100-MHz ticks spent in the wait that gave up; [8] signals per
+                                                                 // counter and launch (a counter's value = launches x [8] when idle)
 constexpr int kSweepCntStride = 32;                              // words per counter: each on a 128-byte line of its own (atomics and
                                                                  // polls of different (layer, step, row block) never queue on one line)
 
@@ -41,6 +45,12 @@ __device__ __forceinline__ bool sweep_wait(unsigned* cnt, unsigned need, unsigne
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (t0 == 0) t0 = now;
       else if (now - t0 > kSweepTimeoutTicks) {
+        // the record first, the error word last: need / seen tell a producer that never started this launch (its counter
+        // still holds the previous launch's final value) from one that was merely late
+        __hip_atomic_store(sync + 4, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + 5, __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + 6, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + 7, (unsigned)(now - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(sync + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
@@ -63,6 +73,10 @@ __device__ __forceinline__ bool sweep_wait2(unsigned* c0, unsigned* c1, unsigned
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (t0 == 0) t0 = now;
       else if (now - t0 > kSweepTimeoutTicks) {
+        __hip_atomic_store(sync + 4, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + 5, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + 6, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + 7, (unsigned)(now - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(sync + 1, code | ((int)(a - need) >= 0 ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
@@ -77,6 +91,7 @@ __device__ __forceinline__ bool sweep_wait2(unsigned* c0, unsigned* c1, unsigned
 // whether the workspace is poisoned by an earlier failure
 __device__ __forceinline__ unsigned sweep_enter(unsigned* sync, int* lflag, unsigned NS) {
   const unsigned e = __hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sync + 8, NS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the host's reading of [4]-[6])
   if (threadIdx.x == 0) *lflag = __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 1 : 0;
   return (e + 1u) * NS;
 }

@@ -136,7 +136,18 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   const int rg = wave % RG, vh = wave / RG;
   const int c = lane & 15, q = lane >> 4;
   const int R = p.R, V = p.V;
-  const int r = blockIdx.x * (16 * RG) + rg * 16 + c;
+  // (row block, vocabulary split) of this workgroup.  Round 5: with NV splits dividing the 8 XCDs, a split's workgroups are
+  // dealt to 8 / NV XCDs only (workgroup ids round-robin over the XCDs: id % 8), so an XCD's L2 streams 1 / NV of W_tok per
+  // launch instead of all of it -- wd-articles: 4 chunk launches x 8 XCDs x 62 MB = 2.1 GB of fabric reads per step against
+  // 62 MB of weights (placement is a speed matter only: any mapping that is a bijection is correct)
+  int rbk = blockIdx.x, vs = blockIdx.y;
+  const int NV = gridDim.y;
+  if (NV > 1 && 8 % NV == 0 && (gridDim.x * NV) % 8 == 0) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, k = 8 / NV, xcd = lin & 7;
+    vs = xcd / k;
+    rbk = (lin >> 3) * k + xcd % k;
+  }
+  const int r = rbk * (16 * RG) + rg * 16 + c;
   const int rc = min(r, R - 1);
   const h_t* Y = reinterpret_cast<const h_t*>(p.Y16);
   const h_t* W = reinterpret_cast<const h_t*>(p.W16);
@@ -152,7 +163,6 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   // the workgroups of blockIdx.y = vs sweep the tiles [s0, s1) of the vocabulary (gridDim.y > 1: few row blocks, e.g. 160 at
   // wd-articles B = 16 -- the splits fill the other CUs; partial results meet in vocab_ce_combine_kernel)
   const int nsteps = (V + 63) / 64;
-  const int NV = gridDim.y, vs = blockIdx.y;
   const int s0 = (int)((long)nsteps * vs / NV), s1 = (int)((long)nsteps * (vs + 1) / NV);
   auto issue = [&](int s) {
     char* slot = smem + ((s - s0) % NSLOT) * SLOT;

@@ -48,6 +48,17 @@ CAPTURE_MODE = "thread_local"
 _calls = [0]   # library calls made so far (txf_engine: "nothing has run since the previous product")
 
 
+def _ranks_on_this_device(world_size):
+    """how many ranks of this job share one GPU: 1 on a real node (one process per GPU); torchrun's LOCAL_WORLD_SIZE against
+    the visible devices otherwise (the two-process tests on a one-GPU box)"""
+    if world_size <= 1:
+        return 1
+    import os
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", world_size))
+    ndev = max(1, torch.cuda.device_count())
+    return max(1, -(-local // ndev))
+
+
 _stamps = None   # diagnostics (tools/step_stamps.py): {"buf": uint64 device tensor, "log": [(library call, stream)]}
 
 
@@ -162,8 +173,7 @@ class Engine:
         # fast path ("v2"): 16-bit operands streamed by LDS-DMA, layer-diagonal GRU kernels; needs 16-bit shadows of
         # the GEMM weights, refreshed with every optimiser step: W_ih, W_hh, W_tok, encoder MLP / heads in the forward
         # type; W_ih^T, W_hh^T, W_tok^T, W_mlp^T in the backward type
-        self.use_dma = (self.prec_fwd != L.PREC_F32 and self.prec_bwd != L.PREC_F32 and self.D % 64 == 0
-                        and not cfg.get("ark_no_dma", False))
+        self.use_dma = self.prec_fwd != L.PREC_F32 and self.prec_bwd != L.PREC_F32 and self.D % 64 == 0
         self.tune = L.diag_tuning(**dict(cfg.get("ark_diag_tuning") or {})) if self.use_dma else None
         self.wg_tune = L.wgrad_tuning(**dict(cfg.get("ark_wgrad_tuning") or {})) if self.use_dma else None
         if self.use_dma:
@@ -201,22 +211,18 @@ class Engine:
         self.diag_chains = max(1, int(cfg.get("ark_diag_chains", 2)))
         # small batches of long sequences: the whole forward recurrence as ONE persistent launch (csrc/gru_sweep.hip);
         # "auto" = where the diagonal launches are all fixed cost (see _use_sweep)
-        # full batches: the forward recurrence as ONE weights-stationary persistent launch (csrc/gru_fat.hip).  Parity-green but
-        # SLOWER than the diagonal launches on MI355X (syn-paths B = 1024: 283 us against 218 us per forward, DESIGN.md section 6:
-        # one wave per SIMD can keep ~64 KB of fragment loads in flight per CU, the three LDS rings of the diagonal launches
-        # 120 KB), so it is an opt-in experiment: `ark_fat: 1`; "auto" = the layer-diagonal launches
-        self.fat = cfg.get("ark_fat", "auto")
-        # D = 512 has a second build, `ark_fat_kernel: ring` (activations through an LDS-DMA ring, role-specialised waves):
-        # 327 us per forward against 288 us for "regs" and 218 us for the diagonal launches
-        self.fat_kernel = str(cfg.get("ark_fat_kernel", "regs"))
         self.sweep = cfg.get("ark_sweep", "auto")
+        # processes that share THIS device (data-parallel tests put two ranks on one card; a real rank owns its GPU): every one
+        # of them may hold a persistent sweep grid at the same time, and a sweep only makes progress once ALL its workgroups
+        # are resident -- the host therefore admits a sweep only if the grids of all co-located ranks fit the chip together
+        self.ranks_per_device = max(1, int(cfg.get("ark_ranks_per_device", 0)) or _ranks_on_this_device(world_size))
         self.sweep_bwd = bool(cfg.get("ark_sweep_bwd", True))   # (0: persistent forward, diagonal backward)
         # unit slices per physical sweep workgroup: 1 = one per CU (default), 2 = two slices share a 512-thread workgroup (half
         # the CUs held, the kernels beside the sweep get the rest).  Measured on MI355X, same box: wd-articles 7.13 -> 8.01
         # ms/step, wd-movies 1.93 -> 2.00 with 2 -- a sweep step is three memory round trips, and two slices on one CU lengthen
         # every one of them by more than the vocabulary CE gains from 208 instead of 160 CUs
         self.sweep_ws = 2 if int(cfg.get("ark_sweep_wg_slices", 1)) == 2 else 1
-        self.ce_dw_after_latent = bool(cfg.get("ark_ce_dw_after_latent", True))
+        self.ce_dw_after_latent = True   # (round 5: the A/B switches nothing sets became constants -- INTEGRATION.md lists what is left)
         self.ce_chunks = int(cfg.get("ark_ce_chunks", 4))   # time chunks of the sweep + CE pipeline (1: off)
         self._ce_dw_pending = None
         self._pad_bufs = {}
@@ -241,14 +247,14 @@ class Engine:
         self._defer_wgrads = False
         self._fork_pending = None
         self._dlog16_only = False
-        self.dlog16_only = bool(cfg.get("ark_dlog16_only", True))
-        self.h0_ride = bool(cfg.get("ark_h0_ride", True))
+        self.dlog16_only = True
+        self.h0_ride = True
         self._finalize = None
         self._defer_finalize = False   # set by train_step / _dp_steps around forward(): backward follows at once
         self.fork_after = int(cfg.get("ark_fork_after", 1))   # measured: 0 -> 1.281, 1 -> 1.266, 2 -> 1.296 ms/step
         self.overlap_wgrad = bool(cfg.get("ark_overlap_wgrad", True))
-        self.fused_latent = bool(cfg.get("ark_fused_latent", True))
-        self.fused_prologue = bool(cfg.get("ark_fused_prologue", True))   # encoder pool + token gather as one launch
+        self.fused_latent = True
+        self.fused_prologue = True   # encoder pool + token gather as one launch
         self._x0_ready = False
         # engine of the encoder's 16-bit products (csrc/gemm16.hip): 0 = the library's choice, 1 = shared ring, 2 = wave-private
         # K-slices; forward and input-gradient products separately (the latter run beside the weight-gradient launch)
@@ -257,12 +263,12 @@ class Engine:
         # gradients on it 1.093 -> 1.110 -- its workgroups want a CU's whole LDS and queue behind the weight-gradient
         # launch's two 64-KB workgroups per CU, where the ring's 24-KB workgroups slip in beside them
         self.g16_bwd = int(cfg.get("ark_g16_bwd", 1))
-        self.early_dec_adam = bool(cfg.get("ark_early_dec_adam", True))
-        self.early_mlp_adam = bool(cfg.get("ark_early_mlp_adam", True))
+        self.early_dec_adam = True
+        self.early_mlp_adam = True
         self._adam_dec_early = False
         self._adam_dec_done = False
         self._adam_mlp_done = False
-        self.emb_gemm = bool(cfg.get("ark_emb_gemm", True))
+        self.emb_gemm = True
         # large vocabularies: tied projection fused with the cross-entropy -- [B*L, V] logits / dlogits never exist
         # (csrc/vocab_ce.hip); small ones keep the three short launches (W_tok is a few KB there)
         self.fused_ce = bool(cfg.get("ark_fused_ce", self.use_dma and self.V >= 2048 and self.D in (64, 128, 256, 512)))
@@ -699,7 +705,9 @@ class Engine:
             # next chunk's sweep sat behind it -- 3 % overlap): sweep(k + 1) goes out BEFORE CE(k), so its co-resident
             # workgroups are on their CUs when the CE grid arrives, and the CE grid is capped at the CUs the sweep leaves
             # (`cu_budget`: a 512-thread CE workgroup owns a CU's whole register file), so neither order can starve the sweep.
-            free_cus = max(32, 256 - self._sweep_wgs(B))
+            # (co-located ranks -- the two-process tests -- each hold a sweep and a capped CE grid: split what is left)
+            free_cus = max(32, self._cu_count() // self.ranks_per_device - self._sweep_wgs(B))
+            self._check_beside_sweep(side_wgs=free_cus)
             done = []
             for k, (t0, t1) in enumerate(chunks):
                 self._sweep_fwd(w, B, Lq, use_drop, True, t0, t1)
@@ -826,7 +834,7 @@ class Engine:
     def _skip_x0(self, w, B, Lq):
         """True where no kernel reads the 16-bit embedding rows X0: the forward diagonals take layer 0's input projection from
         x_tab, the backward takes dW_ih0 / dW_tok from the token sums; the persistent sweep still streams X0"""
-        return bool(w.get("xtab") and w.get("emb_gemm") and not self._use_sweep(B, Lq) and not self._use_fat(B, Lq))
+        return bool(w.get("xtab") and w.get("emb_gemm") and not self._use_sweep(B, Lq))
 
     def _decoder_forward_v2(self, w, seq, ld_seq, B, Lq, use_drop, save=True, project=True):
         """fast decoder forward: token gather -> layer-diagonal GRU sweep -> tied vocabulary projection
@@ -890,55 +898,36 @@ class Engine:
         if self.D not in (128, 256, 512) or self.n > L.SWEEP_MAX_LAYERS or B % 16 != 0:
             return False
         fits = L.lib().ark_gru_sweep_row_tiles(L.i32(self.n), L.i32(B), L.i32(self.D)) > 0
+        shared_ok = True
+        if fits and self.ranks_per_device > 1:
+            # every co-located rank runs the same sweeps on its shard: all their grids must be resident together (one
+            # workgroup per CU each), or two partly resident grids starve each other until the bounded waits give up
+            grid = max(self._sweep_wgs(B), self._sweep_wgs(B, backward=True) if self.sweep_bwd else 0)
+            shared_ok = grid * self.ranks_per_device <= self._cu_count()
         if self.sweep in (1, True, "1", "on"):
             if not fits:
                 raise L.ArkError(f"ark_sweep=1: {self.n} x {B // 16} x {self.D // 16} workgroups cannot be co-resident")
+            if not shared_ok:
+                raise L.ArkError(f"ark_sweep=1: {self.ranks_per_device} ranks share this device and their sweep grids "
+                                 f"({self._sweep_wgs(B)} workgroups each, one per CU) do not fit its {self._cu_count()} CUs together")
             return True
-        return fits and Lq >= 32
+        return fits and shared_ok and Lq >= 32
 
-    def _use_fat(self, B, Lq):
-        """the weights-stationary forward (ark_gru_fat_fwd): D in {512, 1024}, all n * (D / units) * row-groups workgroups
-        co-resident, one per CU; taken for batches of >= 256 rows that the small-batch sweep does not serve"""
-        if self.fat in (0, False, "0", "off") or not self.use_dma or self.D not in (512, 1024) or B % 16 != 0:
-            return False
-        if self.n > L.SWEEP_MAX_LAYERS or Lq > 2047 or 2.0 * self.n * Lq * B * self.D * 2 >= 2 ** 31:
-            return False
-        fits = L.lib().ark_gru_fat_row_groups(L.i32(self.n), L.i32(B), L.i32(self.D)) > 0
-        if self.fat in (1, True, "1", "on"):
-            if not fits:
-                raise L.ArkError(f"ark_fat=1: the weights-stationary forward of {self.n} x {B} x {self.D} does not fit the chip")
-            return not self._use_sweep(B, Lq)
-        return False   # ("auto": measured slower than the diagonal launches -- see __init__)
+    def _cu_count(self):
+        return int(torch.cuda.get_device_properties(self.device).multi_processor_count)
 
-    def _fat_fwd(self, w, B, Lq, use_drop, save=True):
-        """the forward recurrence of all layers and steps as ONE weights-stationary launch (ark_gru_fat_fwd); same inputs
-        and outputs as the diagonal launches"""
-        D, n, p = self.D, self.n, self.p
-        key = ("fat", Lq)
-        if key not in w:
-            sy = torch.zeros(L.fat_sync_words(n, B, D, Lq), device=self.device, dtype=torch.int32)
-            self.__dict__.setdefault("_sweep_sync_all", []).append(sy)
-            w[key] = (torch.empty(2 * n * Lq * B * D, device=self.device, dtype=torch.int16), sy)
-        exch, sync = w[key]
-        a = L.GruSweep()
-        for l in range(n):
-            drop = use_drop and l < n - 1
-            y = a.layer[l]
-            y.w_ih16, y.w_hh16 = L.dptr(self.wih16[l]), L.dptr(self.whh16[l])
-            y.b_ih, y.b_hh = L.dptr(p[f"dec.gru.bias_ih_l{l}"]), L.dptr(p[f"dec.gru.bias_hh_l{l}"])
-            y.y_t, y.y16a, y.y16b = L.dptr(w["Y"][l]), L.dptr(w["Y16a"][l]), L.dptr(w["Y16b"][l])
-            y.yd16a = L.dptr(w["Yd16a"][l] if drop else None)
-            y.yd16b = L.dptr(w["Yd16b"][l] if drop else None)
-            if save:
-                y.save_r, y.save_z = L.dptr(w["SR"][l]), L.dptr(w["SZ"][l])
-                y.save_n, y.save_hn = L.dptr(w["SN"][l]), L.dptr(w["SHN"][l])
-            y.drop_seed = self._layer_seed(l)
-            y.drop_p = self.p_drop if drop else 0.0
-        a.x0_16, a.exch, a.sync, a.hyper = L.dptr(w["X0a"]), L.dptr(exch), L.dptr(sync), L.dptr(self.hyper)
-        a.n_layers, a.B, a.D, a.L, a.t0 = n, B, D, Lq, 0
-        a.wg_slices = 3 if self.fat_kernel == "ring" else 0   # (D = 512: 3 = the LDS-ring kernel)
-        import ctypes
-        _call("ark_gru_fat_fwd", L.i32(self.prec_fwd), L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
+    def _check_beside_sweep(self, side_wgs=0):
+        """refuse (ArkError) a step that could put something chip-filling beside a persistent sweep: the sweep's workgroups
+        spin on each other and must ALL stay resident.  (1) a gradient all-reduce that may still be in flight -- an RCCL
+        kernel holds its channels' CUs while it spins on its peers; the pipelined schedule joins it at the forward's seam,
+        before the decoder, so finding one pending here is a scheduling bug; (2) a side launch capped at `side_wgs`
+        one-per-CU workgroups (the chunked CE) that does not fit the CUs the sweeps of all co-located ranks leave."""
+        if self._dp_pending is not None:
+            raise L.ArkError("a gradient all-reduce may still be running: a persistent sweep must not share the chip with an "
+                             "RCCL kernel (join it first: Engine.dp_flush())")
+        if side_wgs and (self._sweep_wgs(self._B) + side_wgs) * self.ranks_per_device > self._cu_count():
+            raise L.ArkError(f"{side_wgs} one-per-CU workgroups beside a {self._sweep_wgs(self._B)}-workgroup sweep on "
+                             f"{self.ranks_per_device} rank(s) of this device exceed its {self._cu_count()} CUs")
 
     def _sweep_wgs(self, B, backward=False):
         """CUs (= physical workgroups) the persistent forward / backward sweep of this batch holds"""
@@ -949,6 +938,7 @@ class Engine:
         same inputs and outputs as the diagonal launches.  A later chunk starts from the state the previous one left in
         slot t0 of the state arrays."""
         D, n, p = self.D, self.n, self.p
+        self._check_beside_sweep()
         t1 = Lq if t1 is None else t1
         Lc = t1 - t0
         key = ("sweep", Lq, t0, t1)
@@ -981,6 +971,7 @@ class Engine:
         """the backward recurrence of all layers and steps (+ the initial-state gradient, SAIL) as ONE launch
         (ark_gru_sweep_bwd); same inputs and outputs as the backward diagonal launches"""
         D, n, g = self.D, self.n, self.g
+        self._check_beside_sweep()
         key = ("sweep_bwd", Lq)
         if key not in w:
             w[key] = (torch.empty(n * Lq * B * 4 * D, device=self.device, dtype=torch.int16), self._new_sweep_sync(B, Lq))
@@ -1005,40 +996,78 @@ class Engine:
         _call("ark_gru_sweep_bwd", L.i32(self.prec_bwd), ctypes.byref(a), L.cur_stream())
 
     def _new_sweep_sync(self, B, Lc):
-        """a zeroed sync workspace of a persistent sweep (header: sticky error word, detail, epoch, leave count; then one
-        padded monotone counter per (layer, step, row block)); registered so that sweep_error() sees every one of them"""
+        """a zeroed sync workspace of a persistent sweep (header: sticky error word, detail, epoch, leave count, the record of
+        the wait that gave up; then one padded monotone counter per (layer, step, row block)); registered by WEAK reference so
+        that sweep_error() sees every live one and a workspace evicted from the cache takes its sync words with it"""
+        import weakref
         sy = torch.zeros(L.sweep_sync_words(self.n, B, Lc), device=self.device, dtype=torch.int32)
-        self.__dict__.setdefault("_sweep_sync_all", []).append(sy)
+        self.__dict__.setdefault("_sweep_sync_all", []).append(weakref.ref(sy))
         return sy
 
+    def _live_sweep_syncs(self):
+        refs = self.__dict__.get("_sweep_sync_all", [])
+        live = [(r, r()) for r in refs]
+        self._sweep_sync_all = [r for r, t in live if t is not None]
+        return [t for _, t in live if t is not None]
+
     def sweep_error(self):
-        """(error word, detail) of the persistent sweeps: non-zero = a workgroup of SOME sweep since the last
-        clear_sweep_error() gave up waiting -- that launch's outputs and everything computed from them are invalid.  The
-        word is sticky: no launch clears it, later sweeps on the same workspace leave at once.  Synchronises."""
-        syncs = getattr(self, "_sweep_sync_all", [])
+        """(error word, detail) of the persistent sweeps: non-zero = a workgroup of SOME sweep since the workspaces were
+        last reset gave up waiting -- that launch's outputs and everything computed from them are invalid.  The word is
+        sticky: no launch clears it, later sweeps on the same workspace leave at once.  Synchronises."""
+        rec = self.sweep_error_record()
+        return (0, 0) if rec is None else (1, rec["detail"])
+
+    def sweep_error_record(self):
+        """None, or the record the workgroup that gave up left behind: who waited where for what, and what it last saw"""
+        syncs = self._live_sweep_syncs()
         if not syncs:
-            return 0, 0
-        v = torch.stack([sy[:2] for sy in syncs]).cpu()
-        for e, d in v.tolist():
-            if e != 0:
-                return int(e), int(d)
-        return 0, 0
+            return None
+        v = torch.stack([sy[:9] for sy in syncs]).cpu().tolist()
+        for h in v:
+            if h[0] != 0:
+                d, need, seen0, seen1, ticks, ns = h[1] & 0xFFFFFFFF, h[4] & 0xFFFFFFFF, h[5] & 0xFFFFFFFF, h[6] & 0xFFFFFFFF, h[7] & 0xFFFFFFFF, h[8]
+                behind = [(need - s) & 0xFFFFFFFF for s in (seen0, seen1) if s != 0xFFFFFFFF]
+                worst = max(behind) if behind else 0
+                # a counter idles at (launches completed) x ns; `need` is one launch further
+                verdict = ("its producers never signalled in this launch: they were not resident (another grid held their CUs) "
+                           "or were themselves stuck" if ns and worst >= ns else
+                           f"{ns - worst} of its {ns} producers had signalled: late, not absent" if ns else "no record")
+                return {"detail": d, "workgroup": d >> 12 & 0x7FFFF, "step": d & 4095, "second_dependency": bool(d >> 31),
+                        "epoch": h[2], "need": need, "seen": [seen0, seen1], "signals_per_counter": ns,
+                        "waited_s": ticks * 1e-8, "verdict": verdict}
+        return None
 
     def clear_sweep_error(self):
-        """make the sweep workspaces usable again after a reported failure (zeroes error words, epochs and counters)"""
-        for sy in getattr(self, "_sweep_sync_all", []):
+        """reset the sweep workspaces (error words, epochs, counters).  NOT a recovery: Adam has been applying updates
+        computed from invalid activations since the failure -- reload a checkpoint (or the initial weights) first."""
+        for sy in self._live_sweep_syncs():
             _call("ark_gru_sweep_sync_reset", L.ptr(sy), L.i64(sy.numel()), L.cur_stream())
 
-    def raise_on_sweep_error(self):
+    def sweep_error_flag(self):
+        """device tensor [1], 1.0 if any sweep workspace is poisoned: add it to what the ranks all-reduce anyway (MAX), so
+        that every rank of a data-parallel run raises together instead of one rank leaving the others in the next collective"""
+        syncs = self._live_sweep_syncs()
+        if not syncs:
+            return torch.zeros(1, device=self.device)
+        return torch.stack([sy[0] for sy in syncs]).ne(0).any().float().reshape(1)
+
+    def raise_on_sweep_error(self, flag=None):
         """fail loudly if a persistent sweep of ANY step since the last check gave up waiting (sticky error word: a
-        failure in step k of an epoch is still there after step n).  Call it where the step's scalars are read anyway.
-        The error is cleared before raising, so a caller that catches it can fall back (`ark_sweep: 0`) and go on."""
-        e, d = self.sweep_error()
-        if e:
-            self.clear_sweep_error()
-            raise L.ArkError(f"persistent GRU sweep gave up waiting (workgroup {d >> 12 & 0x7FFFF}, step {d & 4095}): "
-                             "the workgroups were not all resident or the device is wedged; every result since the last "
-                             "check is invalid.  Set ark_sweep: 0 to use the layer-diagonal launches")
+        failure in step k of an epoch is still there after step n).  Call it where the step's scalars are read anyway;
+        `flag`: the all-reduced (MAX) sweep_error_flag() of a data-parallel run -- every rank raises, whichever rank failed.
+        FATAL for the run: every optimiser step since the failure consumed invalid activations (the sticky word makes later
+        sweeps leave at once), so the parameters are corrupt -- reload a checkpoint, then clear_sweep_error()."""
+        rec = self.sweep_error_record()
+        if rec is None and not (flag is not None and float(flag) != 0.0):
+            return
+        if rec is None:
+            raise L.ArkError("a persistent GRU sweep gave up waiting on ANOTHER rank: the parameters of every rank are invalid "
+                             "since then (reload a checkpoint; ark_sweep: 0 selects the layer-diagonal launches)")
+        raise L.ArkError(f"persistent GRU sweep gave up waiting after {rec['waited_s']:.2f} s (workgroup {rec['workgroup']}, step "
+                         f"{rec['step']}, {'second' if rec['second_dependency'] else 'first'} dependency; counter needed {rec['need']}, "
+                         f"last seen {rec['seen']}, launch {rec['epoch']} on this workspace): {rec['verdict']}.  Every result since "
+                         "is invalid and the parameters are corrupt: reload a checkpoint, then clear_sweep_error(); "
+                         "ark_sweep: 0 selects the layer-diagonal launches")
 
     def _diag_sweep(self, w, B, Lq, use_drop, save=True):
         """Layer-diagonal forward recurrence: cells (l, d-l) of one anti-diagonal are independent -> ONE
@@ -1048,8 +1077,6 @@ class Engine:
         if self._use_sweep(B, Lq):
             self._sweep_fwd(w, B, Lq, use_drop, save)
             return
-        if self._use_fat(B, Lq):
-            self._fat_fwd(w, B, Lq, use_drop, True)   # (always writes the gate saves)
             return
         self._run_chains(B, lambda b0, Bc: self._diag_chain(w, B, b0, Bc, Lq, use_drop, save))
 

@@ -60,7 +60,7 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("ARK_CPU_THREADS", "16"))))
 
 
-PMC_FILE = "profiles/r04_pmc_summary.json"   # committed PMC passes of this command (tools/profile_round.sh)
+PMC_FILE = "profiles/r05_pmc_summary.json"   # committed PMC passes of this command (tools/profile_round.sh)
 
 
 def log(*a):
@@ -102,6 +102,32 @@ def cpu_baseline(cfg, B, steps=6, warmup=2):
                       f"{dt * 1e3:.1f} ms/step"}
 
 
+def elbo_parity(dev, cfg, B):
+    """|ELBO(HIP forward) - ELBO(CPU oracle)| / |ELBO(oracle)| on the same seed-initialised weights, batch and noise
+    (dropout off: an evaluation forward), for the shipped `mixed` mode (fp16 forward operands) and for LITERAL bf16 forward
+    operands (BASELINE configs[1] says "bf16"): the number beside north_star's 1e-4 bar.  Part of the cpu_baseline leg:
+    the oracle is the checker here, never the thing measured."""
+    import torch
+    from oracle import sail_oracle as O
+    from ark_amd.engine import Engine
+    c = dict(cfg, dec_dropout=0.0)
+    P = O.init_params(c, 0)
+    triples, seq = synth_global_batch(c, B, 1)
+    torch.manual_seed(1000)
+    eps = torch.randn(B, c["d_latent"])
+    with torch.no_grad():
+        ref = float(O.sail_elbo(P, triples, seq, eps, c["beta"], c)[0])
+    out = {"batch": B, "oracle_elbo": ref, "bar": 1e-4}
+    for prec in ("mixed", "bf16"):
+        eng = Engine(c, dev, precision=prec)
+        eng.load_params(P)
+        eng.set_hyper(beta=c["beta"])
+        got = float(eng.eval_loss(triples.to(dev), seq.to(dev), eps.to(dev))[0])
+        out[prec] = {"elbo": got, "elbo_rel_err": abs(got - ref) / abs(ref)}
+        del eng
+    return out
+
+
 def time_diag_kernels(eng, B, reps=8):
     """average launch duration of the two layer-diagonal GRU kernels (forward, BPTT), measured live with HIP
     events on the launch stream.  Each sweep replays the real step's launch sequence (every anti-diagonal,
@@ -123,11 +149,8 @@ def time_diag_kernels(eng, B, reps=8):
         sweeps = {"gru_sweep_fwd_kernel": (lambda: eng._diag_sweep(w, B, Lq, use_drop, True), 1),
                   "gru_sweep_bwd_kernel": (bwd_sweep, 1)}
     else:
-        # full batches: the forward is ONE weights-stationary persistent launch (csrc/gru_fat.hip) where its grid fits the chip,
-        # else one launch per anti-diagonal; the backward is one launch per anti-diagonal
-        fat = eng._use_fat(B, Lq)
-        sweeps = {("gru_fat_fwd_kernel" if fat else "gru_diag_fwd_kernel"): (lambda: eng._diag_sweep(w, B, Lq, use_drop, True),
-                                                                            1 if fat else Lq + n - 1),
+        # full batches: one launch per anti-diagonal of the (layer, time) grid, both directions
+        sweeps = {"gru_diag_fwd_kernel": (lambda: eng._diag_sweep(w, B, Lq, use_drop, True), Lq + n - 1),
                   "gru_diag_bwd_kernel": (bwd_sweep, Lq + n - 1 + (1 if eng.mt == "SAIL" else 0))}
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
@@ -173,8 +196,12 @@ def diag_byte_models(eng, B):
         b_impl += Lq * (B * (up + 3 * D * 2 + dy + 4 * D + 4 * D + 8 * D + 4 * D * 2 + 4 * D) + wbytes)
     fl = cells * 2.0 * B * D * 6 * D
     # small vocabularies: layer 0's input projection is a table row per token (W_tok W_ih0^T, Engine.xtab), not a product
-    tab = getattr(eng, "xtab", None) is not None and not eng._use_fat(B, Lq) and not eng._use_sweep(B, Lq)
+    tab = getattr(eng, "xtab", None) is not None and not eng._use_sweep(B, Lq)
     fl_f = fl - (Lq * 2.0 * B * D * 3 * D if tab else 0.0)
+    if tab:   # layer 0 reads neither x_t nor W_ih0: one pass over the fp32 table [V, 3D] and the token ids per launch instead
+        cut = Lq * (B * D * 2 + 3 * D * D * 2) - Lq * (eng.V * 3 * D * 4 + B * 4)
+        f_min -= cut
+        f_impl -= cut
     # operand bytes the workgroups pull from L2 into LDS by LDS-DMA (default tiles: forward 64 rows x 32 units = 96 weight
     # rows over K = 2D -- K = D for layer 0 with the token table; backward 32 rows x 64 columns over K = 3D from the layer
     # above + 3D recurrent), summed over the step
@@ -299,8 +326,6 @@ def other_workloads(dev, precision, dropout, mfma_peak):
                 times = time_diag_kernels(eng, B, reps=3)
                 ent["diag_kernels"] = {k: {"kernel_avg_us": kt * 1e6, "launches_per_step": n, "us_per_step": kt * 1e6 * n}
                                        for k, (kt, n) in times.items()}
-                if eng._use_fat(B, eng.L):
-                    ent["weights_stationary_forward"] = True
                 if eng._use_sweep(B, eng.L):
                     steps_cp = eng.L + eng.n - 1
                     ent["persistent_sweep"] = {"workgroups": eng._sweep_wgs(B), "recurrence_steps": steps_cp,
@@ -312,13 +337,13 @@ def other_workloads(dev, precision, dropout, mfma_peak):
                         k: {"bound": "critical path (latency)", "recurrence_steps": steps_cp, "t_step_us": kt * 1e6 / steps_cp,
                             "achieved_us": kt * 1e6, "mfma_work_us_per_step": 0.3,
                             "floor_us": steps_cp * 0.3, "frac_of_floor": steps_cp * 0.3 / (kt * 1e6),
-                            "phase_split_us_per_step": {"source": "profiles/r03_sweep_stamps.txt (stamped build, wd-articles layer 1)",
+                            "phase_split_us_per_step": {"source": "profiles/r05_sweep_stamps.txt (stamped build, wd-articles, the layer that paces the sweep; round-4 hand-off protocol: monotone epochs)",
                                                         "wait_counters": 1.58, "barrier": 0.07, "fragments_land": 0.64,
                                                         "mfma_partials_barrier": 0.29, "reduce_gate_math_tiles": 0.57,
                                                         "store_drain": 0.31, "atomic_bulk_stores_loop": 0.90}}
                         for k, (kt, n) in times.items()}
                 ent["diag_share_of_step"] = sum(v["us_per_step"] for v in ent["diag_kernels"].values()) / (dt / steps * 1e6)
-            ent["kernel_profile"] = f"profiles/r04_{name}_kernel_stats.csv"
+            ent["kernel_profile"] = f"profiles/r05_{name}_kernel_stats.csv"
             out[name] = ent
             log(f'{name}: {ent["ms_per_step"]:.3f} ms/step, {gps:.0f} graphs/s')
             del eng, r
@@ -355,6 +380,26 @@ def dp_overhead_1rank(dev, args, extra, plain_ms):
                 torch.cuda.empty_cache()
             res["default_order"] = "beside"
             res["ratio"] = res["beside_ratio"]
+            # the shapes whose recurrences run as PERSISTENT SWEEPS (BASELINE configs 4, 5 are data-parallel configurations):
+            # one rank of the same RCCL group, default order -- a sweep's co-resident workgroups and a live RCCL communicator in
+            # one captured schedule (Engine._check_beside_sweep refuses a step that could run them side by side)
+            for wl, nt in (("wd-movies", 60), ("wd-articles", 20)):
+                try:
+                    r0 = time_workload(dev, wl, args.precision, args.dropout, 0, nt, 10, 20, dict(extra))
+                    p_ms = r0["dt"] / nt * 1e3
+                    del r0
+                    torch.cuda.empty_cache()
+                    r = time_workload(dev, wl, args.precision, args.dropout, 0, nt, 10, 20, dict(extra), world=1, rank=0, dist=dist,
+                                      use_dp=True)
+                    ms = r["dt"] / nt * 1e3
+                    res[wl] = {"plain_ms_per_step": p_ms, "dp_ms_per_step": ms, "ratio": ms / p_ms, "steps": nt,
+                               "persistent_sweeps": bool(r["eng"]._use_sweep(r["B"], r["eng"].L)),
+                               "sweep_error": r["eng"].sweep_error()[0]}
+                    log(f"dp schedule on one rank, {wl}: {ms:.3f} ms/step = {ms / p_ms:.3f} x plain")
+                    del r
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    res[wl] = {"error": repr(e)}
         finally:
             dist.destroy_process_group()
     except Exception as e:   # a diagnostic leg must never take the headline line down
@@ -494,10 +539,10 @@ def main():
             traffic = {}
             try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE x2 + WRITE_SIZE)
                 pm = json.load(open(os.path.join(ROOT, PMC_FILE)))
-                for k, v in pm.items():
-                    for name in times:
-                        if name in k:
-                            traffic[name] = v["hbm_bytes_corrected"]
+                for name in times:   # several instantiations of one kernel template: the one the step launches most
+                    rows = [v for k, v in pm.items() if name in k]
+                    if rows:
+                        traffic[name] = max(rows, key=lambda v: v["launches"])["hbm_bytes_corrected"]
             except Exception:
                 pass
             # unit of the roofline object = ONE anti-diagonal of the full batch.  With row-block chains (Engine._chains) that is
@@ -506,8 +551,7 @@ def main():
             chains = len(eng._chains(B))
             traffic = {k: v * chains for k, v in traffic.items()}
             kern = {}
-            alias = {"gru_sweep_fwd_kernel": "gru_diag_fwd_kernel", "gru_sweep_bwd_kernel": "gru_diag_bwd_kernel",
-                     "gru_fat_fwd_kernel": "gru_diag_fwd_kernel"}
+            alias = {"gru_sweep_fwd_kernel": "gru_diag_fwd_kernel", "gru_sweep_bwd_kernel": "gru_diag_bwd_kernel"}
             for name, (kt, launches) in times.items():
                 m = models[alias.get(name, name)]   # (the sweeps move the same algorithmic bytes as the launches they replace)
                 kern[name] = {"kernel_avg_us": kt * 1e6, "launches_per_step": launches, "us_per_step": kt * 1e6 * launches,
@@ -567,6 +611,11 @@ def main():
                 res["transformer_variants"] = transformer_variants(dev, args.precision, args.dropout)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, B, steps=args.cpu_steps, warmup=5)
+            if args.workload == "syn-paths":
+                try:
+                    res["elbo_parity"] = elbo_parity(dev, cfg, B)
+                except Exception as e:   # a diagnostic leg must never take the headline line down
+                    res["elbo_parity"] = {"error": repr(e)}
             if B == 1024:   # the plumbing batch and the YAML batch beside it
                 for b2 in (32, 256):
                     c2 = cpu_baseline(cfg, b2, steps=20, warmup=5)

@@ -128,7 +128,7 @@ typedef struct {
 /* speed-only tile / ring choices of the two diagonal kernels; passed per call (NULL = the measured defaults of
  * ark_diag_tuning_default), so the library keeps no mutable state */
 typedef struct {
-  int fwd_rows;      /* 32 | 64 | 128 (128: 64-unit tiles only: ONE 8-wave workgroup per CU, ping-pong halves on a 4-slot ring) */
+  int fwd_rows;      /* 32 | 64 */
   int fwd_ki;        /* 64-wide k-images per ring stage: 1 | 2                                  */
   int fwd_nbuf;      /* ring slots: 2 | 4                                                       */
   int fwd_xcd;       /* XCD-aware tile order: 0 | 1                                             */
@@ -228,19 +228,6 @@ long ark_gru_sweep_sync_words(int n_layers, int B, int L);
 int ark_gru_sweep_fwd(int prec, int prec_b, const ArkGruSweep* sweep, void* stream);
 /* zero a sync workspace (error word, epoch, counters) on the stream: after allocation and after a reported failure */
 int ark_gru_sweep_sync_reset(unsigned* sync, long words, void* stream);
-/* Weights-stationary forward recurrence of a FULL batch (csrc/gru_fat.hip): the same inputs, outputs, `exch` / `sync`
- * protocol and error behaviour as ark_gru_sweep_fwd, for shapes where every workgroup walks MANY 16-row tiles per step:
- * workgroup (layer, 32-unit slice [16 at D = 1024], row group) keeps its 196 KB of W_ih / W_hh rows in registers for the
- * whole recurrence and streams only activations (416 KB per CU and step at syn-paths instead of the 819-983 KB of the
- * layer-diagonal launches, whose weight panels pass through LDS once per cell).  D in {512, 1024}, B % 16 == 0;
- * ark_gru_fat_row_groups() > 0 says the grid fits the chip (one workgroup per CU, all co-resident) -- otherwise
- * ARK_ERR_SHAPE.  `exch`: ark_gru_sweep_exch_bytes() bytes; `sync`: ark_gru_fat_sync_words() words, zeroed once.
- * `wg_slices` == 3 (D = 512 only) selects the second build of the kernel: activations through an LDS-DMA ring with counted
- * waits, eight role-specialised waves (measured slower than the default build).
- * Reference: nn.GRU forward, kgvae/model/models.py:121-127. */
-int ark_gru_fat_row_groups(int n_layers, int B, int D);
-long ark_gru_fat_sync_words(int n_layers, int B, int D, int L);
-int ark_gru_fat_fwd(int prec, int prec_b, const ArkGruSweep* sweep, void* stream);
 /* The backward pass of the same recurrence (BPTT: autograd of nn.GRU) as ONE launch: what L + n - 1 ark_gru_diag_bwd
  * launches and the initial-state roles compute.  Writes the gate-gradient panels dg16[l] = [dr | dz | dn | dn*r]
  * (row-major [L*B, 4D], backward type), adds the bias gradients and (dh0 non-NULL) the initial-state gradient

@@ -146,11 +146,15 @@ def train_epoch(model, dataset, config, device, b=1.0, lr=None, world=(0, 1), ma
         if max_steps and nb >= max_steps:
             break
     model.engine().dp_flush()    # pipelined data parallel: land the last step's decoder-bucket update
+    # a persistent GRU sweep that gave up waiting poisons its rank's parameters; its flag rides the epoch's all-reduce
+    # (a sum over ranks: > 0 on EVERY rank if any failed), so all ranks raise together -- a rank raising alone would
+    # leave the others waiting in their next collective until the RCCL timeout
+    red = torch.cat([sums, model.engine().sweep_error_flag()])
     if nranks > 1:
         import torch.distributed as dist
-        dist.all_reduce(sums)    # token-loss sums add up; ce/loss are re-derived below
-    s = sums.tolist()
-    model.engine().raise_on_sweep_error()   # (a persistent GRU sweep that gave up waiting: the epoch's numbers are void)
+        dist.all_reduce(red)     # token-loss sums add up; ce/loss are re-derived below
+    s = red.tolist()
+    model.engine().raise_on_sweep_error(flag=s[4])
     if nb == 0:
         return 0.0, 0.0, 0.0, 0.0
     if nranks > 1:
@@ -176,11 +180,12 @@ def validate(model, dataset, config, device, compute_compression=False, b=1.0, s
             continue
         tot[:4] += model.eval_loss(tb.to(device), sb.to(device), beta=b)
         tot[4] += 1
+    tot = torch.cat([tot, model.engine().sweep_error_flag()])   # (evaluation forwards of long sequences run the sweep too)
     if nranks > 1:
         import torch.distributed as dist
         dist.all_reduce(tot)
     t = (tot[:4] / tot[4].clamp(min=1)).tolist()
-    model.engine().raise_on_sweep_error()   # (evaluation forwards of long sequences run the persistent sweep too)
+    model.engine().raise_on_sweep_error(flag=float(tot[5]))
     res = [t[0], t[1], t[2], 0.0]
     if compute_compression and rank == 0:
         bits = model.posterior_bits(dataset, device, pad_id=config["special_tokens"]["PAD"],

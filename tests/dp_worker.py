@@ -19,9 +19,16 @@ def case(variant):
                           Z = 64, padded graphs of 1..12 triples (per-rank target counts differ), L = 37 -> the persistent
                           sweeps, V = 3 010 -> the fused / vocabulary-split CE; 32 graphs per rank
       wd-articles:        config 5's (configs/autoreg_wd-articles.yaml:5-11): D = 512, Z = 128, GLOBAL batch 16 -> 8 graphs
-                          per rank, padded to the 16-row tiles; L = 259 -> sweep + CE in time chunks"""
+                          per rank, padded to the 16-row tiles; L = 259 -> sweep + CE in time chunks
+      wd-movies-full / wd-articles-full: the two YAML shapes at their REAL vocabularies and lengths (V = 24 101, L = 70,
+                          B = 256; V = 60 943, L = 637, B = 16): the vocabulary split of the fused CE at the sizes it was
+                          built for, on two ranks"""
     from tests.parity_util import load_golden
-    from tests.test_configs_gpu import _cfg
+    from tests.test_configs_gpu import _cfg, SHAPES
+    if variant == "wd-movies-full":     # the YAML shape itself: V = 24 101, L = 70, GLOBAL batch 256 (128 graphs per rank)
+        return SHAPES["wd-movies"][0], SHAPES["wd-movies"][1], True
+    if variant == "wd-articles-full":   # V = 60 943, T = 212 -> L = 637, GLOBAL batch 16 (8-graph shards padded to 16 rows)
+        return SHAPES["wd-articles-full"][0], SHAPES["wd-articles-full"][1], True
     if variant.startswith("wd-movies"):
         return dict(_cfg(128, 64, 3000, 3, 12, True), dec_dropout=0.1 if variant.endswith("-drop") else 0.0), 64, True
     if variant == "wd-articles":

@@ -38,7 +38,7 @@ def test_two_process_data_parallel_matches_single_process(tmp_path, graph, bf16,
     _single_process_reference(variant, steps, P0, bf16)
 
 
-def _single_process_reference(variant, steps, P0, bf16):
+def _single_process_reference(variant, steps, P0, bf16, rare_rows=False):
     """ONE process training on the full global batch must land on the weights the ranks share"""
     from oracle import sail_oracle as O
     from ark_amd.engine import Engine
@@ -65,9 +65,33 @@ def _single_process_reference(variant, steps, P0, bf16):
     assert moved > 1e-3                  # the weights did train
     # Adam normalises the update: where a gradient is ~0 its rounded sign decides a full +-lr step, so the worst single
     # weight may differ by up to ~lr per step (3 steps x 1e-3); the mean below is the meaningful bar
-    assert (P0 - ref).abs().max().item() <= steps * 1e-3 * 1.05
+    # (rare_rows -- the real wd vocabularies: most embedding rows only see the softmax tail, gradients of ~1e-9 whose sign is
+    #  summation-order noise; such a weight moves +lr in one run and -lr in the other, 2 lr apart per step)
+    worst, mean = (P0 - ref).abs().max().item(), (P0 - ref).abs().mean().item()
+    assert worst <= (2 if rare_rows else 1) * steps * 1e-3 * 1.05, (worst, mean)
     # (bf16 transport of the gradient buckets, `ark_dp_bf16`: the reduced gradients carry 8 significant bits)
-    assert (P0 - ref).abs().mean().item() <= (1e-4 if bf16 else 2e-5)
+    assert mean <= (1e-4 if bf16 else 5e-5 if rare_rows else 2e-5), (worst, mean)
+
+
+@pytest.mark.parametrize("variant", ["wd-movies-full", "wd-articles-full"])
+def test_two_process_data_parallel_at_the_real_wd_vocabularies(tmp_path, variant):
+    """BASELINE configs 4 and 5 at the YAML sizes themselves -- V = 24 101 / L = 70 / global batch 256 and V = 60 943 /
+    L = 637 / global batch 16 (8-graph shards padded to the 16-row tiles) -- captured, two ranks on the one card, against
+    ONE process on the full batch: the vocabulary split of the fused CE (`vc_splits`, `cu_budget`) and the real sequence
+    length on more than one rank (round 4 ran V = 3 010 / 2 510, L = 37 / 259).  The persistent sweeps run on both ranks
+    only where their grids fit the chip TOGETHER (Engine._use_sweep, ranks_per_device = 2: wd-articles 2 x 96 workgroups
+    yes, wd-movies 2 x 192 no -> layer-diagonal launches there).
+    Reference: configs/autoreg_wd-movies.yaml:7-12, autoreg_wd-articles.yaml:5-11; partition: SURVEY.md section 8e."""
+    steps = 2
+    res = _run_two_ranks(tmp_path, True, False, variant, steps)
+    P0, P1 = res["P"]
+    assert res["adam_steps"] == steps and torch.equal(P0, P1)
+    i0, i1 = [t.tolist() for t in res["info"]]
+    for info in (i0, i1):
+        assert info[1] == 1.0 and info[3] == 0.0, info                          # fused CE ran, nobody gave up
+        assert info[0] == (1.0 if variant == "wd-articles-full" else 0.0), info  # sweeps only where both ranks' grids fit
+    assert i0[4] != i1[4]                                                        # unequal non-PAD target counts
+    _single_process_reference(variant, steps, P0, False, rare_rows=True)
 
 
 def _run_two_ranks(tmp_path, graph, bf16, variant, steps):
@@ -199,4 +223,4 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1, out.stdout
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 256 and res["value"] > 0
-    assert res["roofline"]["kernel"] in ("gru_diag_fwd_kernel", "gru_diag_bwd_kernel", "gru_fat_fwd_kernel")
+    assert res["roofline"]["kernel"] in ("gru_diag_fwd_kernel", "gru_diag_bwd_kernel")

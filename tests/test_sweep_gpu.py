@@ -222,7 +222,7 @@ def test_chunked_sweep_with_the_fused_ce_beside_it(nc):
         assert eng.sweep_error() == (0, 0)
         engs.append(eng)
     a, b = engs
-    assert len(b._sweep_sync_all) == nc + 1   # one counter workspace per forward chunk + the backward sweep's
+    assert len(b._live_sweep_syncs()) == nc + 1   # one counter workspace per forward chunk + the backward sweep's
     for l in range(cfg["n_layers"]):
         assert torch.equal(a.ws["Y"][l], b.ws["Y"][l]), l            # the same arithmetic, launch boundaries apart
         assert torch.equal(a.ws["SR"][l], b.ws["SR"][l]), l
@@ -316,8 +316,8 @@ def test_many_consecutive_sweep_steps_track_the_diagonal_path():
         lb += [float(step()[0]) for _ in range(5)]
     torch.cuda.synchronize()
     assert b.sweep_error() == (0, 0)
-    epochs = [int(sy[2]) for sy in b._sweep_sync_all]
-    assert min(epochs) >= 12 and all(int(sy[3]) == 0 for sy in b._sweep_sync_all), epochs
+    epochs = [int(sy[2]) for sy in b._live_sweep_syncs()]
+    assert min(epochs) >= 12 and all(int(sy[3]) == 0 for sy in b._live_sweep_syncs()), epochs
     assert la[-1] < la[0]
     for x, y in zip(la, lb):
         assert rel_err(y, x) < 2e-3, (la, lb)
@@ -326,7 +326,9 @@ def test_many_consecutive_sweep_steps_track_the_diagonal_path():
 def test_a_failed_sweep_is_remembered_until_the_host_reads_it():
     """sticky error word (round 3: the next step's zero launch erased it).  One counter of the forward sweep is poisoned
     so that step 2 of 4 times out; steps 3 and 4 leave at once; the failure is still there after step 4, raise_on_sweep_error
-    raises and clears, and the engine then works again."""
+    raises -- every time it is asked, until the host resets the workspaces: the failure is FATAL for the parameters (Adam
+    kept stepping on invalid activations), so recovery = reload the weights, clear_sweep_error(), go on.  The record says who
+    waited for what: here a producer whose counter never moved in this launch."""
     from oracle import sail_oracle as O
     from ark_amd import _lib as L
     cfg = _cfg(128, 16, 300, 5, 12, True)
@@ -340,22 +342,57 @@ def test_a_failed_sweep_is_remembered_until_the_host_reads_it():
     good = float(eng.train_step(*args)[0])
     torch.cuda.synchronize()
     assert eng.sweep_error() == (0, 0)
-    fwd_sync = eng._sweep_sync_all[0]
+    fwd_sync = eng._live_sweep_syncs()[0]
     fwd_sync[32 + 32 * 3].fill_(-1000)       # counter of (layer 0, step 0, row block 3): never reaches its target again
     for _ in range(3):
         eng.train_step(*args)
     torch.cuda.synchronize()
     e, d = eng.sweep_error()
     assert e != 0
-    with pytest.raises(L.ArkError):
-        eng.raise_on_sweep_error()
-    assert eng.sweep_error() == (0, 0)        # cleared by the raise: the workspaces are usable again
+    rec = eng.sweep_error_record()
+    assert rec["signals_per_counter"] > 0 and rec["need"] > 0 and "never signalled" in rec["verdict"], rec
+    assert float(eng.sweep_error_flag()) == 1.0
+    for _ in range(2):                        # sticky on the host side too: asking does not clear
+        with pytest.raises(L.ArkError, match="never signalled"):
+            eng.raise_on_sweep_error()
+    with pytest.raises(L.ArkError, match="ANOTHER rank"):
+        type(eng).raise_on_sweep_error(make_engine(dict(cfg, ark_sweep=0), P, "mixed"), flag=1.0)   # a healthy rank of the same run
+    eng.clear_sweep_error()
+    assert eng.sweep_error() == (0, 0) and float(eng.sweep_error_flag()) == 0.0
     eng.load_params(P)
     eng.reset_optimizer()
     again = float(eng.train_step(*args)[0])
     torch.cuda.synchronize()
     assert eng.sweep_error() == (0, 0)
     assert rel_err(again, good) < 1e-5, (good, again)
+
+
+def test_sweeps_of_co_located_ranks_must_fit_the_chip_together():
+    """a sweep makes progress only with ALL its workgroups resident (one per CU); when several ranks share a device (the
+    two-process tests) each holds such a grid: the host admits the sweep only if they fit together, `ark_sweep: 1` refuses
+    loudly, and a step that could run a sweep beside a pending all-reduce or an over-sized side launch is refused too"""
+    from oracle import sail_oracle as O
+    from ark_amd import _lib as L
+    cfg = _cfg(512, 128, 300, 5, 40, True)      # wd-articles-like: 3 x 1 x 32 = 96 workgroups per sweep
+    P = O.init_params(cfg, 1)
+    one = make_engine(cfg, P, "mixed")
+    assert one.ranks_per_device == 1 and one._use_sweep(16, 121)
+    two = make_engine(dict(cfg, ark_ranks_per_device=2), P, "mixed")
+    assert two._sweep_wgs(16) == 96 and two._use_sweep(16, 121)             # 2 x 96 <= 256
+    three = make_engine(dict(cfg, ark_ranks_per_device=3), P, "mixed")
+    assert not three._use_sweep(16, 121)                                     # 3 x 96 > 256: layer-diagonal launches
+    forced = make_engine(dict(cfg, ark_ranks_per_device=3, ark_sweep=1), P, "mixed")
+    with pytest.raises(L.ArkError, match="share this device"):
+        forced._use_sweep(16, 121)
+    # beside a sweep: a pending collective, or more one-per-CU workgroups than the sweeps of all co-located ranks leave
+    two._B = 16
+    two._check_beside_sweep(side_wgs=32)                                     # (96 + 32) x 2 = 256: fits
+    with pytest.raises(L.ArkError, match="exceed"):
+        two._check_beside_sweep(side_wgs=64)
+    two._dp_pending = torch.cuda.Event()
+    with pytest.raises(L.ArkError, match="all-reduce"):
+        two._check_beside_sweep()
+    two._dp_pending = None
 
 
 @pytest.mark.parametrize("D,B,T", [(128, 64, 12), (512, 16, 12), (256, 48, 11)])
