@@ -225,6 +225,7 @@ class Engine:
         self.ce_dw_after_latent = True   # (round 5: the A/B switches nothing sets became constants -- INTEGRATION.md lists what is left)
         self.ce_chunks = int(cfg.get("ark_ce_chunks", 4))   # time chunks of the sweep + CE pipeline (1: off)
         self._ce_dw_pending = None
+        self._wgrads_forked = False   # this step's GRU weight gradients are on the side queue (backward_decoder)
         self._pad_bufs = {}
         self._n_valid = 0
         self._side_used = False
@@ -1382,6 +1383,7 @@ class Engine:
                 self._finalize()
                 self._finalize = None
             ce_dw_later = ce_dw_beside = None
+            self._wgrads_forked = False
             if self._fused_ce_step:
                 # dW_tok and db_out from the recomputed softmax (no dlogits buffer): csrc/vocab_ce.hip
                 def ce_dw():
@@ -1429,9 +1431,10 @@ class Engine:
             # is forked off the main queue only after that launch (fork_after: 0 right after the diagonals,
             # 1 after the dh0 roles, 2 after the latent kernel as well)
             side.wait_stream(torch.cuda.current_stream())
+            self._wgrads_forked = True
             with torch.cuda.stream(side):
                 self._gru_wgrads(w, B, Lq, seq, use_drop, range(n), emb=True)
-                if self._adam_dec_early:
+                if self._adam_dec_early and self._ce_dw_pending is None:
                     # every gradient of the decoder bucket [dec_grad_offset, total) is now queued: its Adam (+ shadows,
                     # 40 % of the parameters, HBM-bound) runs here, underneath the latent / encoder backward chain
                     _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
@@ -1451,8 +1454,17 @@ class Engine:
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
                         ce_dw_later()
+                        if self._adam_dec_early and not self._adam_dec_done and self._wgrads_forked:   # (the fork left the update to us)
+                            _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
+                            self._adam_launch("dec")
+                            self._adam_dec_done = True
+                    self._side_used = True
                 # SAIL: behind the latent kernel, the head of the encoder chain (its one-per-CU grid leaves that kernel 4 CUs)
                 if self.mt == "SAIL" and self.ce_dw_after_latent and not self._defer_wgrads:
+                    # dW_tok / db_out of the tied projection are then written AFTER the weight-gradient fork: the decoder
+                    # bucket's early Adam must follow THEM, not the fork (rounds 3-4 queued it at the fork: a single-process
+                    # step at the wd-movies shape never trained dec.out.bias nor the output side of the tied embedding -- found
+                    # in round 5 by the two-rank test at the real vocabulary, whose data-parallel step has no early Adam)
                     self._ce_dw_pending = go
                 else:
                     go()
@@ -1492,8 +1504,9 @@ class Engine:
                 _call("ark_gru_diag_bwd", L.i32(self.prec_bwd), L.i32(len(chunk)), roles, L.ptr(self.hyper), L.i32(B),
                       L.i32(self.D), ctypes.byref(self.tune), L.cur_stream())
 
-    def _diag_bwd_chain(self, w, B, b0, Bc, Lq, use_drop):
-        """the backward diagonals of rows [b0, b0 + Bc); returns the layers whose initial-state role rode a diagonal"""
+    def _diag_bwd_chain(self, w, B, b0, Bc, Lq, use_drop, diagonals=None):
+        """the backward diagonals of rows [b0, b0 + Bc); returns the layers whose initial-state role rode a diagonal
+        (`diagonals`: a subset -- timing tools re-issue single launches)"""
         import ctypes
         D, n, g = self.D, self.n, self.g
         pb = self.prec_bwd
@@ -1503,7 +1516,7 @@ class Engine:
             _call("ark_gru_diag_bwd", L.i32(pb), L.i32(k), roles, L.ptr(self.hyper), L.i32(Bc), L.i32(D), tune, L.cur_stream())
 
         h0_done = set()
-        for e in range(Lq + n - 1):
+        for e in (range(Lq + n - 1) if diagonals is None else diagonals):
             cells = [l for l in range(n - 1, -1, -1) if 0 <= Lq - 1 - (e - (n - 1 - l)) < Lq]
             for c0 in range(0, len(cells), L.DIAG_MAX_ROLES):
                 roles = (L.GruDiagBwdRole * L.DIAG_MAX_ROLES)()

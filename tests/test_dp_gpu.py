@@ -68,6 +68,10 @@ def _single_process_reference(variant, steps, P0, bf16, rare_rows=False):
     # (rare_rows -- the real wd vocabularies: most embedding rows only see the softmax tail, gradients of ~1e-9 whose sign is
     #  summation-order noise; such a weight moves +lr in one run and -lr in the other, 2 lr apart per step)
     worst, mean = (P0 - ref).abs().max().item(), (P0 - ref).abs().mean().item()
+    if mean > 2e-5:   # (diagnostics: which tensors carry the difference)
+        for name, (off, shape, numel) in eng.layout.entries.items():
+            d = (P0[off:off + numel] - ref[off:off + numel]).abs()
+            print(f"  {name:32s} mean |diff| {d.mean().item():.2e}  max {d.max().item():.2e}  moved {(ref[off:off + numel] - O_flat(eng, O.init_params(cfg, 0))[off:off + numel]).abs().mean().item():.2e}")
     assert worst <= (2 if rare_rows else 1) * steps * 1e-3 * 1.05, (worst, mean)
     # (bf16 transport of the gradient buckets, `ark_dp_bf16`: the reduced gradients carry 8 significant bits)
     assert mean <= (1e-4 if bf16 else 5e-5 if rare_rows else 2e-5), (worst, mean)

@@ -367,6 +367,34 @@ def test_a_failed_sweep_is_remembered_until_the_host_reads_it():
     assert rel_err(again, good) < 1e-5, (good, again)
 
 
+def test_deferred_ce_weight_gradient_reaches_adam():
+    """wd-movies kind of step (a sweep that fills most of the chip: the fused CE's weight gradient is queued behind the
+    latent kernel): dW_tok / db_out must be in the gradient buffer BEFORE the decoder bucket's Adam.  Rounds 3-4 queued that
+    Adam (early, on the side queue) in front of them: `dec.out.bias` never moved in single-process training at this shape.
+    One step of the two-queue schedule against the same step with everything on one queue."""
+    from oracle import sail_oracle as O
+    cfg = _cfg(128, 64, 3000, 3, 12, True)
+    B = 256                                    # 3 x 8 x 8 = 192 workgroups per sweep (> 128: the deferral)
+    P = O.init_params(cfg, 0)
+    triples, seq = synth_batch(cfg, B, seed=7, padded=True)
+    torch.manual_seed(9)
+    eps = torch.randn(B, cfg["d_latent"])
+    outs = {}
+    for name, extra in (("two-queue", {}), ("serial", {"ark_overlap_wgrad": 0})):
+        eng = make_engine(dict(cfg, **extra), P, "mixed", lr=1e-3)
+        eng.set_hyper(beta=0.5)
+        assert eng._use_sweep(B, cfg["seq_len"] - 1) and eng._sweep_wgs(B, backward=True) > 128
+        dev = eng.device
+        eng.train_step(triples.to(dev), seq.to(dev), eps.to(dev), ce_count=int((seq[:, 1:] != 0).sum()))
+        torch.cuda.synchronize()
+        assert eng.sweep_error() == (0, 0)
+        outs[name] = {k: (v.detach().cpu() - P[k]) for k, v in eng.p.items() if k in ("dec.out.bias", "dec.tok_emb.weight")}
+    for k in ("dec.out.bias", "dec.tok_emb.weight"):
+        a, b = outs["two-queue"][k], outs["serial"][k]
+        assert b.abs().max().item() > 5e-4, k                      # one Adam step of lr = 1e-3 moved it
+        assert (a - b).abs().mean().item() <= 0.05 * b.abs().mean().item(), (k, (a - b).abs().mean().item(), b.abs().mean().item())
+
+
 def test_sweeps_of_co_located_ranks_must_fit_the_chip_together():
     """a sweep makes progress only with ALL its workgroups resident (one per CU); when several ranks share a device (the
     two-process tests) each holds such a grid: the host admits the sweep only if they fit together, `ark_sweep: 1` refuses

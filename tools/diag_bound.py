@@ -87,7 +87,22 @@ def main():
         for d in range(nd):
             main.wait_stream(pool[d])
 
+    def bwd_chain():        # the backward diagonals as the step runs them (two row-block chains)
+        eng._run_chains(B, lambda b0, Bc: eng._diag_bwd_chain(w, B, b0, Bc, Lq, True))
+
+    def bwd_free():         # every backward anti-diagonal on its own queue
+        main = torch.cuda.current_stream()
+        for d in range(nd):
+            pool[d].wait_stream(main)
+            with torch.cuda.stream(pool[d]):
+                eng._diag_bwd_chain(w, B, 0, B, Lq, True, diagonals=[d])
+        for d in range(nd):
+            main.wait_stream(pool[d])
+
     for rnd in range(3):
+        ba, bb = timed(bwd_chain, st), timed(bwd_free, st)
+        print(f"round {rnd}: BACKWARD recurrence: step's chains {ba:7.1f} us ({ba / nd:5.2f} per diagonal)   no dependencies {bb:7.1f} us "
+              f"({bb / nd:5.2f} per diagonal)", flush=True)
         ta, t1, tb, tc = timed(chain, st), timed(one_chain, st), timed(free, st), timed(free_halves, st)
         print(f"round {rnd}: forward recurrence, {nd} anti-diagonals, B = {B}: step's chains {ta:7.1f} us ({ta / nd:5.2f} per diagonal)   "
               f"one chain {t1:7.1f}   no dependencies {tb:7.1f} us ({tb / nd:5.2f} per diagonal)   "
