@@ -137,7 +137,7 @@ class DiagTuning(ctypes.Structure):
 
 class WgradTuning(ctypes.Structure):
     """ArkWgradTuning of include/ark_amd.h"""
-    _fields_ = [(k, ctypes.c_int) for k in ("tile", "nbuf", "target_wgs", "balance")]
+    _fields_ = [(k, ctypes.c_int) for k in ("tile", "nbuf", "target_wgs", "balance", "waves")]
 
 
 def sweep_sync_words(n_layers, B, Lq):

@@ -41,8 +41,11 @@ struct Wgrad16Group {
   int n_long, s_short;
 };
 
-template <int PREC, int BT, int NBUF>   // square BT x BT output tile; 8 waves as 2 (m) x 4 (n), wave tile BT/2 x BT/4
-__global__ __launch_bounds__(512) void wgrad16_kernel(Wgrad16Group grp) {
+// square BT x BT output tile; NWV = 8 waves as 2 (m) x 4 (n), wave tile BT/2 x BT/4, or NWV = 4 waves as 2 x 2, wave tile
+// BT/2 x BT/2 (round 5: the two workgroups of a CU then put ONE wave each on a SIMD -- partners that run out of step --
+// and a wave multiplies 32 tiles per stage instead of 16 between the same two barriers, reading a third fewer fragments)
+template <int PREC, int BT, int NBUF, int NWV_ = 8>
+__global__ __launch_bounds__(64 * NWV_) void wgrad16_kernel(Wgrad16Group grp) {
   int gtile = blockIdx.x, slice = blockIdx.y, nslice = gridDim.y;
   if (grp.n_long > 0 && (int)blockIdx.x < grp.n_long) {
     gtile = xcd_remap(blockIdx.x, grp.n_long);   // consecutive tiles share operand panels: keep them on one XCD
@@ -66,7 +69,8 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(Wgrad16Group grp) {
   using h_t = typename PT::h_t;
   // Two waves per SIMD: a wave may keep at most 16 LDS reads in flight, and one wave per SIMD left the
   // matrix cores idle during every fragment fetch (measured: 1.2 us per 64-k stage vs 0.46 us of LDS-DMA).
-  constexpr int NWV = 8;
+  constexpr int NWV = NWV_;
+  static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
   constexpr int RB = BT * 2;                 // bytes per k-row per operand
   constexpr int LPR = RB / 16;               // lanes (16-B chunks) per k-row
   constexpr int RPP = 64 / LPR;              // k-rows per 1-KB LDS-DMA piece
@@ -76,14 +80,15 @@ __global__ __launch_bounds__(512) void wgrad16_kernel(Wgrad16Group grp) {
   constexpr int OP_BYTES = 64 * RB;
   constexpr int STAGE = 2 * OP_BYTES;
   constexpr int LPS = 2 * PPW;
-  constexpr int WTM = BT / 2, WTN = BT / 4;  // wave tile
+  constexpr int WGN = NWV / 2;               // waves along n
+  constexpr int WTM = BT / 2, WTN = BT / WGN;  // wave tile
   constexpr int TA = WTM / 16, TB = WTN / 16;
   static_assert((NBUF - 1) * LPS <= 63, "vmcnt");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int bid = (grp.n == 1) ? xcd_remap(bid_raw, ntiles) : bid_raw;
   const int m0 = (bid / p.tiles_n) * BT, n0 = (bid % p.tiles_n) * BT;
   const int k_chunk = (grp.n_long > 0) ? ((p.K + nslice - 1) / nslice + 63) / 64 * 64 : p.k_chunk;
@@ -195,10 +200,10 @@ static void allow_lds_w(K kernel, int bytes) {
 }
 
 
-template <int PREC, int BT, int NBUF>
+template <int PREC, int BT, int NBUF, int NWV = 8>
 static void launch_wg(Wgrad16Group& g, const ArkWgradTuning& tn, hipStream_t st) {
   constexpr int LDS = NBUF * 2 * 64 * BT * 2;
-  static bool once = (allow_lds_w(wgrad16_kernel<PREC, BT, NBUF>, LDS), true); (void)once;
+  static bool once = (allow_lds_w(wgrad16_kernel<PREC, BT, NBUF, NWV>, LDS), true); (void)once;
   long tiles = 0;
   int kmax = 0;
   for (int i = 0; i < g.n; ++i) {
@@ -223,11 +228,11 @@ static void launch_wg(Wgrad16Group& g, const ArkWgradTuning& tn, hipStream_t st)
     if (s >= 2 && kmax / s >= 256) {
       g.n_long = kCUs;
       g.s_short = s;
-      hipLaunchKernelGGL((wgrad16_kernel<PREC, BT, NBUF>), dim3((unsigned)(kCUs + rest * s), 1), dim3(512), LDS, st, g);
+      hipLaunchKernelGGL((wgrad16_kernel<PREC, BT, NBUF, NWV>), dim3((unsigned)(kCUs + rest * s), 1), dim3(64 * NWV), LDS, st, g);
       return;
     }
   }
-  hipLaunchKernelGGL((wgrad16_kernel<PREC, BT, NBUF>), dim3((unsigned)tiles, (unsigned)split), dim3(512), LDS, st, g);
+  hipLaunchKernelGGL((wgrad16_kernel<PREC, BT, NBUF, NWV>), dim3((unsigned)tiles, (unsigned)split), dim3(64 * NWV), LDS, st, g);
 }
 
 template <int PREC>
@@ -235,10 +240,13 @@ static int launch_wg_prec(Wgrad16Group& g, const ArkWgradTuning* tuning, hipStre
   ArkWgradTuning tn;
   ark_wgrad_tuning_default(&tn);
   if (tuning) tn = *tuning;
-  if ((tn.tile != 64 && tn.tile != 128) || tn.nbuf < 2 || tn.nbuf > 4 || tn.target_wgs < 1) return ARK_ERR_ARG;
+  if ((tn.tile != 64 && tn.tile != 128) || tn.nbuf < 2 || tn.nbuf > 4 || tn.target_wgs < 1 || (tn.waves != 4 && tn.waves != 8)) return ARK_ERR_ARG;
   bool ok128 = tn.tile == 128;
   for (int i = 0; i < g.n; ++i) ok128 = ok128 && g.p[i].M % 128 == 0 && g.p[i].N % 128 == 0;
-  if (ok128) {
+  if (ok128 && tn.waves == 4) {
+    if (tn.nbuf == 2) launch_wg<PREC, 128, 2, 4>(g, tn, st);
+    else launch_wg<PREC, 128, 3, 4>(g, tn, st);
+  } else if (ok128) {
     if (tn.nbuf == 2) launch_wg<PREC, 128, 2>(g, tn, st);
     else if (tn.nbuf == 3) launch_wg<PREC, 128, 3>(g, tn, st);
     else launch_wg<PREC, 128, 4>(g, tn, st);
@@ -255,7 +263,7 @@ static int launch_wg_prec(Wgrad16Group& g, const ArkWgradTuning* tuning, hipStre
 // (240 whole-K tiles -> 480 half-K: same-box A/B 1.245 -> 1.202 ms/step), even dealing of 257..511 tiles over the CUs
 extern "C" void ark_wgrad_tuning_default(ArkWgradTuning* t) {
   if (!t) return;
-  t->tile = 128; t->nbuf = 2; t->target_wgs = 300; t->balance = 1;
+  t->tile = 128; t->nbuf = 2; t->target_wgs = 300; t->balance = 1; t->waves = 8;
 }
 
 static int check_one(const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int M, int N, int K) {

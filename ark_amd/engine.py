@@ -204,6 +204,8 @@ class Engine:
                 m0, m1 = self.layout.entries["enc.mlp.0.weight"][0], self.layout.entries["enc.mu.weight"][0]
                 self._adam_jobs["mlp"] = self._build_adam_jobs(m0, m1)
                 self._adam_jobs["enc_rest"] = self._build_adam_jobs((0, m0), (m1, off))   # (one launch)
+                self._adam_jobs["emb"] = self._build_adam_jobs(0, m0)        # entity / relation tables (wd-articles: 31 M parameters)
+                self._adam_jobs["heads"] = self._build_adam_jobs(m1, off)
         self._shadow_ok = False
         self._side = None
         self._chain_streams = []
@@ -268,7 +270,8 @@ class Engine:
         self.early_mlp_adam = True
         self._adam_dec_early = False
         self._adam_dec_done = False
-        self._adam_mlp_done = False
+        self._adam_mlp_done = self._adam_emb_done = False
+        self._ticked = None
         self.emb_gemm = True
         # large vocabularies: tied projection fused with the cross-entropy -- [B*L, V] logits / dlogits never exist
         # (csrc/vocab_ce.hip); small ones keep the three short launches (W_tok is a few KB there)
@@ -1310,6 +1313,13 @@ class Engine:
               L.ptr(g["enc.r_emb.weight"]), L.i32(B), L.i32(T), L.i32(D), L.i32(g["enc.e_emb.weight"].shape[0]),
               L.i32(g["enc.r_emb.weight"].shape[0]), L.i64(-1 if self.pad_eid is None else self.pad_eid),
               L.i64(-1 if self.pad_rid is None else self.pad_rid), st)
+        if self._adam_dec_early and self._adam_dec_done and self._ticked is not None and w["v2"] and "emb" in self._adam_jobs:
+            # the embedding tables' gradients are complete: their Adam goes out HERE, on the chain's own queue, beside whatever
+            # the side queue still holds (wd-articles: 31 M parameters, 156 us that used to wait behind the side queue's fused-CE
+            # weight gradient, GRU weight gradients and decoder-bucket Adam)
+            torch.cuda.current_stream().wait_event(self._ticked)
+            self._adam_launch("emb")
+            self._adam_emb_done = True
         self._join_side()
 
     def _join_side(self):
@@ -1379,6 +1389,13 @@ class Engine:
             if self.mt == "SAIL":
                 self._zero(w["dH0"])   # the initial-state roles add into it
             filled.record(side)   # (the first backward diagonal waits for this: nothing else goes in front of it)
+            if self._adam_dec_early and side is not main:
+                # the optimiser tick of THIS step, early: every Adam launch of the step -- decoder bucket, MLP block and the
+                # embedding tables, on whichever queue -- only has to follow this event (round 4 ticked on the side queue behind
+                # the weight gradients, so nothing could update before them)
+                _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
+                self._ticked = torch.cuda.Event()
+                self._ticked.record(side)
             if self._finalize is not None:   # loss scalars of this step (deferred by forward)
                 self._finalize()
                 self._finalize = None
@@ -1437,7 +1454,8 @@ class Engine:
                 if self._adam_dec_early and self._ce_dw_pending is None:
                     # every gradient of the decoder bucket [dec_grad_offset, total) is now queued: its Adam (+ shadows,
                     # 40 % of the parameters, HBM-bound) runs here, underneath the latent / encoder backward chain
-                    _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
+                    if self._ticked is None:
+                        _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
                     self._adam_launch("dec")
                     self._adam_dec_done = True
             self._side_used = side is not main
@@ -1455,7 +1473,8 @@ class Engine:
                     with torch.cuda.stream(side):
                         ce_dw_later()
                         if self._adam_dec_early and not self._adam_dec_done and self._wgrads_forked:   # (the fork left the update to us)
-                            _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
+                            if self._ticked is None:
+                                _call("ark_adam_tick", L.ptr(self.hyper), L.cur_stream())
                             self._adam_launch("dec")
                             self._adam_dec_done = True
                     self._side_used = True
@@ -1833,7 +1852,8 @@ class Engine:
         self._adam_dec_early = bool(self.early_dec_adam and grad_sync is None and self.use_dma and self.overlap_wgrad
                                     and self.mt == "SAIL" and self.fork_after >= 1)
         self._adam_dec_done = False
-        self._adam_mlp_done = False
+        self._adam_mlp_done = self._adam_emb_done = False
+        self._ticked = None
         try:
             self.forward(triples, seq, eps, ce_count=ce_count)
             if self.backward_decoder():
@@ -1843,10 +1863,23 @@ class Engine:
             self._adam_dec_early = False
         if grad_sync is not None:
             grad_sync(self.G)
-        if self._adam_dec_done:   # the decoder bucket was updated on the side queue (which ticked the step): the rest
+        ticked, self._ticked = self._ticked is not None, None
+        if self._adam_dec_done:   # the decoder bucket was updated on the side queue (the step is ticked): the rest
             self._adam_dec_done = False
-            self._adam_launch("enc_rest" if self._adam_mlp_done else "enc")
-            self._adam_mlp_done = False
+            if self._adam_mlp_done and self._adam_emb_done:
+                self._adam_launch("heads")
+            elif self._adam_mlp_done:
+                self._adam_launch("enc_rest")
+            else:
+                assert not self._adam_emb_done
+                self._adam_launch("enc")
+            self._adam_mlp_done = self._adam_emb_done = False
+            self.adam_steps += 1
+            self._shadow_ok = True
+        elif ticked:   # (ticked early, but no bucket went out early: everything now, without a second tick)
+            assert not self._adam_emb_done and not self._adam_mlp_done
+            self.dp_flush()
+            self._adam_launch("all")
             self.adam_steps += 1
             self._shadow_ok = True
         else:

@@ -293,6 +293,7 @@ typedef struct {
   int nbuf;        /* LDS-DMA ring slots: 2..4                                                               */
   int target_wgs;  /* split K over workgroups (fp32 atomics) until at least this many workgroups exist        */
   int balance;     /* 257..511 whole-K tiles: 256 whole tiles + the rest cut into k-slices, 1.x tiles per CU  */
+  int waves;       /* 8 | 4 waves per workgroup (128 x 128 tiles: wave tile 64 x 32 | 64 x 64)                  */
 } ArkWgradTuning;
 void ark_wgrad_tuning_default(ArkWgradTuning* t);
 int ark_wgrad16(int prec, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C, int64_t ldc, int M,

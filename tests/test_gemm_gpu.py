@@ -87,9 +87,9 @@ def test_gemm_bad_args():
 
 
 @pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_F16])
-@pytest.mark.parametrize("tile,nbuf", [(64, 4), (64, 2), (128, 3), (128, 2)])
+@pytest.mark.parametrize("tile,nbuf,waves", [(64, 4, 8), (64, 2, 8), (128, 3, 8), (128, 2, 8), (128, 2, 4), (128, 3, 4)])
 @pytest.mark.parametrize("shape", [(64, 64, 64), (192, 128, 640), (1536, 512, 2048), (128, 256, 10240)])
-def test_wgrad16_tr_read_kernel(prec, tile, nbuf, shape):
+def test_wgrad16_tr_read_kernel(prec, tile, nbuf, waves, shape):
     """C += A^T B with both operands reduction-major 16-bit (LDS-DMA + ds_read_b64_tr_b16)."""
     M, N, K = shape
     g = torch.Generator().manual_seed(5)
@@ -99,7 +99,7 @@ def test_wgrad16_tr_read_kernel(prec, tile, nbuf, shape):
     C0 = torch.randn(M, N, generator=g)
     dev = torch.device("cuda:0")
     Ad, Bd, C = A.to(dev), B.to(dev), C0.to(dev).clone()
-    tn = L.wgrad_tuning(tile=tile, nbuf=nbuf, target_wgs=512)
+    tn = L.wgrad_tuning(tile=tile, nbuf=nbuf, target_wgs=512, waves=waves)
     L.check(L.lib().ark_wgrad16(L.i32(prec), L.ptr(Ad), L.i64(M), L.ptr(Bd), L.i64(N), L.ptr(C), L.i64(N), L.i32(M), L.i32(N),
                                 L.i32(K), tn, L.cur_stream()), "ark_wgrad16")
     torch.cuda.synchronize()
