@@ -266,6 +266,10 @@ class Engine:
         # gradients on it 1.093 -> 1.110 -- its workgroups want a CU's whole LDS and queue behind the weight-gradient
         # launch's two 64-KB workgroups per CU, where the ring's 24-KB workgroups slip in beside them
         self.g16_bwd = int(cfg.get("ark_g16_bwd", 1))
+        self.pool_bwd_early = bool(cfg.get("ark_pool_bwd_early", True))
+        # sweep workloads (the side queue is the long one: fused-CE weight gradient beside the backward sweep): GRU weight
+        # gradients on a third queue, the latent reductions and the MLP block's Adam on the chain's own queue
+        self.wgrad_third_queue = bool(cfg.get("ark_wgrad_third_queue", True))   # embedding scatter in front of the MLP weight gradients
         self.early_dec_adam = True
         self.early_mlp_adam = True
         self._adam_dec_early = False
@@ -1232,6 +1236,8 @@ class Engine:
                 self._fork_pending()
             main = torch.cuda.current_stream()
             side = self._side_stream() if self.overlap_wgrad else main
+            if self._side_heavy():   # (the side queue is the long one: this reduction stays on the chain's queue)
+                side = main
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 ss = L.cur_stream()
@@ -1282,17 +1288,27 @@ class Engine:
                           L.ptr(self.wmT16[0]), L.i64(H), L.ptr(other), L.i64(H), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None),
                           L.i32(pb), L.ptr(None), L.i32(B), L.i32(H), L.i32(H), st)
                 dpre, other = other, dpre
+            pooled = False
+            if self.pool_bwd_early:
+                # the embedding scatter only needs the last input gradient: it goes out in front of the MLP weight gradients
+                # (with the embedding tables' Adam behind it) instead of behind them and the side queue's fork
+                self._enc_pool_bwd(w, dpre, B, T, st)
+                pooled = True
             for i0 in range(0, len(group), 8):
                 self._wgrad_group(group[i0:i0 + 8])
             if self._adam_dec_early and self._adam_dec_done and self._side is not None and self.early_mlp_adam:
                 # the MLP block of the encoder bucket (99 % of it) is complete: its Adam runs on the side queue (which
                 # already ticked the step for the decoder bucket) underneath the embedding scatter
                 main = torch.cuda.current_stream()
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
+                if self._side_heavy() and self._ticked is not None:
+                    main.wait_event(self._ticked)
                     self._adam_launch("mlp")
+                else:
+                    self._side.wait_stream(main)
+                    with torch.cuda.stream(self._side):
+                        self._adam_launch("mlp")
+                    self._side_used = True
                 self._adam_mlp_done = True
-                self._side_used = True
         else:
             self._gemm(MM, MM, L.EPI_NONE, w["dhead"], 2 * Z, w["act"][n - 1], H, g["enc.mu.weight"], H, 2 * Z, H, B, acc=1)
             self._gemm(KM, MM, L.EPI_MUL_DGELU, w["dhead"], 2 * Z, p["enc.mu.weight"], H, w["dA"], H, B, H, 2 * Z,
@@ -1308,7 +1324,21 @@ class Engine:
                 else:
                     self._gemm(KM, MM, L.EPI_NONE, dpre, H, p[f"enc.mlp.{2 * i}.weight"], H, other, H, B, H, H)
                 dpre, other = other, dpre
-        dg = dpre
+        if not (w["v2"] and pooled):
+            self._enc_pool_bwd(w, dpre, B, T, st)
+        self._join_side()
+
+    def _side_heavy(self):
+        """True where the side queue of the backward is the LONG one: a sweep workload whose fused-CE weight gradient runs
+        beside the backward sweep and outlasts it (wd-articles); small work then stays on the chain's own queue"""
+        return bool(self.wgrad_third_queue and getattr(self, "_fused_ce_step", False) and self.overlap_wgrad
+                    and self._use_sweep(self._B, self._Lrun) and self.sweep_bwd
+                    and self._sweep_wgs(self._B, backward=True) <= 128)
+
+    def _enc_pool_bwd(self, w, dg, B, T, st):
+        """embedding gradients of the encoder (scatter of the pooled input's gradient) and, in a single-process step whose
+        optimiser tick is already out, the Adam of the two embedding tables right behind it on the same queue"""
+        g, D = self.g, self.D
         _call("ark_enc_pool_bwd", L.ptr(self._triples), L.ptr(dg), L.ptr(w["inv_cnt"]), L.ptr(g["enc.e_emb.weight"]),
               L.ptr(g["enc.r_emb.weight"]), L.i32(B), L.i32(T), L.i32(D), L.i32(g["enc.e_emb.weight"].shape[0]),
               L.i32(g["enc.r_emb.weight"].shape[0]), L.i64(-1 if self.pad_eid is None else self.pad_eid),
@@ -1320,7 +1350,6 @@ class Engine:
             torch.cuda.current_stream().wait_event(self._ticked)
             self._adam_launch("emb")
             self._adam_emb_done = True
-        self._join_side()
 
     def _join_side(self):
         if self._side_used:
@@ -1449,8 +1478,19 @@ class Engine:
             # 1 after the dh0 roles, 2 after the latent kernel as well)
             side.wait_stream(torch.cuda.current_stream())
             self._wgrads_forked = True
+            if ce_dw_beside is not None and self.wgrad_third_queue and side is not main:
+                # the side queue still holds the fused-CE weight gradient that ran beside the sweep (wd-articles: ~400 us
+                # longer than the sweep): the GRU weight gradients and the token scatter only need the sweep's panels, so they
+                # go to a queue of their own and start now; the decoder bucket's Adam (side queue) waits for both
+                wq = self._wgrad_stream()
+                wq.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(wq):
+                    self._gru_wgrads(w, B, Lq, seq, use_drop, range(n), emb=True)
+                side.wait_stream(wq)
+            else:
+                with torch.cuda.stream(side):
+                    self._gru_wgrads(w, B, Lq, seq, use_drop, range(n), emb=True)
             with torch.cuda.stream(side):
-                self._gru_wgrads(w, B, Lq, seq, use_drop, range(n), emb=True)
                 if self._adam_dec_early and self._ce_dw_pending is None:
                     # every gradient of the decoder bucket [dec_grad_offset, total) is now queued: its Adam (+ shadows,
                     # 40 % of the parameters, HBM-bound) runs here, underneath the latent / encoder backward chain
@@ -1642,6 +1682,11 @@ class Engine:
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
+
+    def _wgrad_stream(self):
+        if getattr(self, "_wgq", None) is None:
+            self._wgq = torch.cuda.Stream(device=self.device)
+        return self._wgq
 
     def _wgrad_group(self, items):
         import ctypes
