@@ -233,7 +233,10 @@ __global__ __launch_bounds__(256) void attn_flash_q_kernel(FlashArgs p) {
         if (drop) k4 = fa_keep4(dc, prow + kt * 64 + 16 * vt + 4 * q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float pr = __builtin_amdgcn_exp2f(sv[vt * 4 + i] - lse2);   // (-inf -> 0)
+          // (a masked key has sv = -inf -> 0; a query whose keys are ALL masked -- an all-PAD graph -- also has lse2 = -inf:
+          //  -inf - -inf would be NaN, so the masked case is decided before the subtraction)
+          const float sve = sv[vt * 4 + i];
+          const float pr = sve == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sve - lse2);
           pj[vt * 4 + i] = pr * (G[vt][i] * k4[i] - delta);
         }
       }
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_flash_q_kernel(FlashArgs p) {
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
     if (!qlive) return;
-    const float il = 1.0f / lsum;
+    const float il = lsum > 0.f ? 1.0f / lsum : 0.f;   // (every key masked: context 0, lse -inf -- not 0 * inf)
     float* o = p.out + ((long)qi * B + b) * D + h * dh;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)

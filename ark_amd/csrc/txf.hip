@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     sc[c] = (sc[c] == -INFINITY) ? 0.f : expf(sc[c] - m);
     sum += sc[c];
   }
-  const float inv = 1.0f / wave_sum(sum);
+  const float tot = wave_sum(sum);
+  const float inv = tot > 0.f ? 1.0f / tot : 0.f;   // (a query whose keys are all masked -- an all-PAD graph: zero row, not NaN)
   const long prow = (((long)b * p.H + h) * L + i) * L;
 #pragma unroll
   for (int c = 0; c < kAttnMaxChunks; ++c) {
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnArgs p, int per
       const float s0 = Ss[i * LS + j];
       sum += (s0 == -INFINITY) ? 0.f : expf(s0 - m);
     }
-    const float inv = 1.0f / sum;
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;   // (all keys masked: zero row, not NaN)
     const long prow = (((long)b * p.H + h) * L + i) * L;
     for (int j = 0; j < L; ++j) {
       const float s0 = Ss[i * LS + j];

@@ -314,6 +314,11 @@ class TxfEngine(Engine):
         key = (x.data_ptr(), n, prec, out.data_ptr())
         if slot == "a" and self._last_cast is not None and self._last_cast[0] == key and self._last_cast[1] == _launches[0]:
             return out   # (valid only while NO other library call has run since that product)
+        if slot == "a" and getattr(self, "_prepared", None) == x.data_ptr():
+            # _prep() left the dropout-applied gradient ONLY in this 16-bit slot (the fp32 tensor is un-dropped): re-casting the
+            # raw tensor here would silently lose the mask from the backward pass
+            raise L.ArkError("the prepared (dropout-applied) 16-bit operand is no longer in its slot: a library call ran between "
+                             "_prep() and the products that consume it, or the slot was reallocated")
         _call("ark_cast16", L.i32(prec), L.ptr(x), L.ptr(out), L.i64(n), L.cur_stream())
         if slot == "a":
             self._last_cast = [key, None]
@@ -393,7 +398,8 @@ class TxfEngine(Engine):
         _call("ark_prep16", L.i32(self.prec), L.ptr(x), L.ptr(x_out), L.ptr(out), L.ptr(bias_grad), L.i32(R), L.i32(N),
               L.f32(self.p_drop if seed is not None else 0.0), L.u64(seed or 0), L.ptr(self.hyper), L.cur_stream())
         self._last_cast = [(x.data_ptr(), R * N, self.prec, out.data_ptr()), _launches[0]]
-        self._prepared = x.data_ptr()   # (the fp32 tensor itself is NOT what the products must read: see _gemm)
+        # (without x_out = x and with dropout on, the fp32 tensor itself is NOT what the products must read: see _gemm / _cast)
+        self._prepared = x.data_ptr() if not (x_out is x or seed is None) else None
 
     def _copy(self, dst, src):
         _call("ark_copy", L.ptr(dst), L.ptr(src), L.i64(src.numel() * src.element_size()), L.cur_stream())

@@ -95,6 +95,25 @@ def rel_err_t(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
+@pytest.mark.parametrize("prec", ["mixed", "bf16"])
+def test_flash_attention_with_an_all_masked_graph(prec):
+    """a batch row whose keys are ALL masked (an all-PAD graph in the encoder): context 0, gradients 0, nothing NaN -- for
+    that row and, above all, for the others (round 4: out = 0 * inf, exp2(-inf - -inf) in the backward)"""
+    B, Lq, D, H = 3, 70, 384, 4
+    qkv, dout, km = _inputs(B, Lq, D, True)
+    km[1, :] = 0                                        # graph 1: every key masked
+    pf, pb = (F16, BF16) if prec == "mixed" else (BF16, BF16)
+    out, dqkv, lse = _flash(pf, pb, qkv, dout, km, B, Lq, D, H, 0)
+    assert torch.isfinite(out).all() and torch.isfinite(dqkv).all()
+    rows1 = torch.arange(Lq, device="cuda") * B + 1     # rows (t, b = 1)
+    assert out[rows1].abs().max().item() == 0.0 and dqkv[rows1].abs().max().item() == 0.0
+    # the other graphs are what they are without graph 1
+    keep = torch.tensor([0, 2], device="cuda")
+    sel = (torch.arange(Lq, device="cuda")[:, None] * B + keep[None, :]).reshape(-1)
+    out2, dqkv2, _ = _flash(pf, pb, qkv[sel].contiguous(), dout[sel].contiguous(), km[keep].contiguous(), 2, Lq, D, H, 0)
+    assert (out[sel] - out2).abs().max().item() < 1e-5 and (dqkv[sel] - dqkv2).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("B,Lq,D,H,causal,masked", [(2, 70, 128, 4, 1, False), (2, 130, 512, 4, 1, False), (2, 100, 384, 4, 0, True),
                                                     (1, 259, 512, 4, 1, False)])
 def test_flash_attention_draws_the_masks_of_the_vector_kernels(B, Lq, D, H, causal, masked):

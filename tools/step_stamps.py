@@ -34,7 +34,10 @@ def main():
         cfg[k] = int(v)
     B = a.batch or bench.WORKLOADS[a.workload]["batch"]
     tri, seq = bench.synth_global_batch(cfg, B, 1)
+    cnt = float((seq[:, 1:] != 0).sum())          # as bench.py / the train loop: target count from the host, noise as an input
     tri, seq = tri.to(dev), seq.to(dev)
+    torch.manual_seed(1000)
+    eps = torch.randn(B, cfg["d_latent"], device=dev)
 
     def run(stamped):
         eng = E.Engine(cfg, dev, precision="mixed")
@@ -44,18 +47,18 @@ def main():
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
             if stamped:
-                eng.train_step(tri, seq, None)   # (workspaces, shadows: outside the log)
+                eng.train_step(tri, seq, eps, ce_count=cnt)   # (workspaces, shadows: outside the log)
                 torch.cuda.synchronize()
                 E._stamps = {"buf": buf, "log": []}
                 replay = None
                 try:
                     # capture_train_step runs one eager warm-up step first: its log entries are dropped below
-                    replay = eng.capture_train_step(tri, seq, None)
+                    replay = eng.capture_train_step(tri, seq, eps, ce_count=cnt)
                 finally:
                     log = E._stamps["log"]
                     E._stamps = None
             else:
-                replay = eng.capture_train_step(tri, seq, None)
+                replay = eng.capture_train_step(tri, seq, eps, ce_count=cnt)
             for _ in range(300):
                 replay()
             s.synchronize()
