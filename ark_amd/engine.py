@@ -644,6 +644,18 @@ class Engine:
                           L.ptr(p["dec.tok_emb.weight"]), L.ptr(None if skip else w["X0a"]), L.ptr(None if skip else w["X0b"]),
                           L.i32(Lq), L.i32(D), L.ptr(w["tok_tm"] if w["xtab"] else None), L.ptr(self.hyper if use_drop else None), st)
                     self._x0_ready = True
+                elif T >= 32:
+                    # (pipelined data parallel, large vocabulary: the gather of W_tok rows waits for the seam.)  Long graphs in a
+                    # small batch still want the pool of the fused launch -- a graph spread over column blocks and its triples
+                    # over waves: 20 us where one workgroup per graph takes 230 (wd-articles, T = 212) -- so that launch is
+                    # issued with its gather half reduced to writing the time-major token ids (it does not read W_tok then)
+                    if "tok_ids_scratch" not in w:
+                        w["tok_ids_scratch"] = torch.empty(B * Lq, device=self.device, dtype=torch.int32)
+                    _call("ark_pool_gather_fwd16", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
+                          L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.ptr(w["g16a"]), L.i32(pf), L.ptr(w["g16b"]), L.i32(pb), L.i32(B),
+                          L.i32(T), L.i32(D), L.i64(-1 if self.pad_rid is None else self.pad_rid), L.ptr(seq), L.i64(ld_seq),
+                          L.ptr(p["dec.tok_emb.weight"]), L.ptr(None), L.ptr(None), L.i32(Lq), L.i32(D),
+                          L.ptr(w["tok_tm"] if w["xtab"] else w["tok_ids_scratch"]), L.ptr(None), st)
                 else:
                     _call("ark_enc_pool_fwd16", L.ptr(triples), L.ptr(p["enc.e_emb.weight"]), L.ptr(p["enc.r_emb.weight"]),
                           L.ptr(w["g"]), L.ptr(w["inv_cnt"]), L.ptr(w["g16a"]), L.i32(pf), L.ptr(w["g16b"]), L.i32(pb), L.i32(B),
@@ -2050,11 +2062,23 @@ class Engine:
         self._pinned_B.add(seq.shape[0])
         return replay
 
+    def dp_prefers_eager(self, B, Lq):
+        """True where the data-parallel step should be launched eagerly instead of replayed from its segment graphs: the sweep
+        workloads, whose step is a few dozen LONG launches whose OVERLAP is what matters (sweep beside fused CE, both directions).
+        ROCm's graph executor re-deals the nodes of a captured segment to its own queues and then runs a launch with no open
+        dependency behind unrelated ones (seen in kernel traces: the CE weight gradient queued behind the whole encoder
+        backward instead of beside the sweep) -- measured on one rank at wd-articles: captured 8.4 ms, eager 7.0 (single-process
+        captured step: 6.4; there the same graph keeps the overlap).  Eager costs nothing here: ~100 launches per 7 ms."""
+        Bp = (B + 15) // 16 * 16
+        return bool(self.mt == "SAIL" and self.use_dma and self._use_sweep(Bp, Lq) and self._sweep_wgs(Bp) <= 128)
+
     def graphed_train_step(self, triples, seq, ce_count=None, dp=False):
         """train_step() through a cached hipGraph: the first call for a batch shape runs the step eagerly
         (that IS the step for this batch) and captures it on private input buffers; later calls copy the
         batch into those buffers and replay.  The latent noise is drawn inside the graph."""
         assert self.training, "graphed_train_step is a training-mode step"
+        if dp and self.dp_prefers_eager(seq.shape[0], seq.shape[1] - 1):
+            return self.train_step(triples, seq, None, ce_count=ce_count, dp=True)
         key = (None if triples is None else tuple(triples.shape), tuple(seq.shape), bool(dp), ce_count is None)
         ent = self._graph_steps.get(key)
         if ent is None:

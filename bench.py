@@ -268,7 +268,9 @@ def time_workload(dev, workload, precision, dropout, batch, steps, warmup, settl
     run_stream = torch.cuda.Stream(device=dev)
     run_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(run_stream):
-        if no_graph:
+        if no_graph or (use_dp and eng.dp_prefers_eager(B, cfg["seq_len"] - 1)):
+            # (data parallel at the sweep workloads: eager launches keep the sweep / CE overlap the segment graphs lose --
+            #  Engine.dp_prefers_eager; the training loop takes the same decision in graphed_train_step)
             def step():
                 return eng.train_step(tri_in, seq_in, eps_in, ce_count=ce_count, dp=use_dp)
         else:
