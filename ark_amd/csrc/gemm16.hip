@@ -231,8 +231,15 @@ static int wpk_rows(const Gemm16Args& p) {
   if (((uintptr_t)p.C | (uintptr_t)p.aux | (uintptr_t)p.bias) & 15) return 0;
   if (((uintptr_t)p.c16a | (uintptr_t)p.c16b) & 7) return 0;
   const long tn = p.N / 96;
+#ifdef ARK_WPK_PREFER64
   if (p.M % 64 == 0 && (p.M / 64) * tn >= 128 && (p.M / 64) * tn <= 512) return 64;
+#else
+  // 64-row tiles where they fill at least three quarters of the chip, else 32-row tiles (B = 256 x 3 D = 3072: 128 tiles of
+  // 64 rows would leave half the CUs idle; 256 tiles of 32 rows stream 786 instead of 983 KB each)
+  if (p.M % 64 == 0 && (p.M / 64) * tn >= 192 && (p.M / 64) * tn <= 512) return 64;
+#endif
   if (p.M % 32 == 0 && (p.M / 32) * tn >= 128 && (p.M / 32) * tn <= 512) return 32;
+  if (p.M % 64 == 0 && (p.M / 64) * tn >= 128 && (p.M / 64) * tn <= 512) return 64;
   return 0;
 }
 
