@@ -116,12 +116,12 @@ __device__ __forceinline__ void put16x4(void* base, long idx, f32x4 v, int prec)
 // the whole tile over its own K-slices, partial tiles summed through LDS and written in row-major quads;
 // M % BM == 0, N % BN == 0, K % 64 == 0, row-major C (nullable when a 16-bit copy is asked for: an input gradient that
 // is only read as the next product's operand), ldc % 4 == 0, 16-byte aligned C / aux / bias, 8-byte aligned copies.
-template <int PREC, int BM, int BN, int NW, int NSLOT>
+template <int PREC, int BM, int BN, int NW, int NSLOT, bool CLAMP = false>
 __global__ __launch_bounds__(64 * NW) void gemm16_wpk_kernel(Gemm16Args p) {
   using G = WpkNT<PREC, BM, BN, NW, NSLOT>;
   using h_t = typename G::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_m = p.M / BM;
+  const int tiles_m = (p.M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   int tm_, tn_;
   wpk_tile_of(lid, tiles_m, p.tiles_n, 8, tm_, tn_);
@@ -132,11 +132,12 @@ __global__ __launch_bounds__(64 * NW) void gemm16_wpk_kernel(Gemm16Args p) {
   for (int tm = 0; tm < G::TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < G::TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-  G::run(acc, reinterpret_cast<const h_t*>(p.A) + (long)m0 * p.lda, p.lda, reinterpret_cast<const h_t*>(p.B) + (long)n0 * p.ldb,
-         p.ldb, p.K, lid, smem);
+  G::template run<CLAMP>(acc, reinterpret_cast<const h_t*>(p.A) + (long)m0 * p.lda, p.lda,
+                         reinterpret_cast<const h_t*>(p.B) + (long)n0 * p.ldb, p.ldb, p.K, lid, smem, min(BM, p.M - m0), min(BN, p.N - n0));
   float* cs_lds = G::colsum_lds(smem);
   const int epi = p.epi;
   G::reduce_rows(acc, smem, [&](int row, int col, f32x4 v) {
+    if (CLAMP && (m0 + row >= p.M || n0 + col >= p.N)) return;   // (N % 4 == 0: a quad is inside or outside as a whole)
     const long o = (long)(m0 + row) * p.ldc + n0 + col;
     if (epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_RELU || epi == ARK_EPI_BIAS_GELU) v += *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
     if (epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_wpk_kernel(Gemm16Args p) {
   });
   if (p.colsum) {
     __syncthreads();
-    if ((int)threadIdx.x < BN) atomicAdd(&p.colsum[n0 + threadIdx.x], cs_lds[threadIdx.x]);
+    if ((int)threadIdx.x < BN && n0 + (int)threadIdx.x < p.N) atomicAdd(&p.colsum[n0 + threadIdx.x], cs_lds[threadIdx.x]);
   }
 #ifdef ARK_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (diagnostic build: the stores have left the wave)
@@ -223,6 +224,23 @@ static void launch16_wpk(Gemm16Args p, hipStream_t st) {
   hipLaunchKernelGGL((gemm16_wpk_kernel<PREC, BM, BN, NW, NSLOT>), dim3((unsigned)tiles), dim3(64 * NW), G::LDS_BYTES, st, p);
 }
 
+// few tiles, deep K (the latent heads: [1024 x 2Z] over K = 3D = 1536 -- 32 tiles whose 24 ring stages are a dependent chain
+// of ~0.5 us each): 32 x 64 tiles whose eight waves take three K-slices each; rows / columns beyond M / N are clamped
+template <int PREC>
+static void launch16_wpk_deep(Gemm16Args p, hipStream_t st) {
+  using G = WpkNT<PREC, 32, 64, 8, 1>;
+  static bool once = (allow_lds16(gemm16_wpk_kernel<PREC, 32, 64, 8, 1, true>, G::LDS_BYTES), true); (void)once;
+  p.tiles_n = (p.N + 63) / 64;
+  const long tiles = (long)((p.M + 31) / 32) * p.tiles_n;
+  hipLaunchKernelGGL((gemm16_wpk_kernel<PREC, 32, 64, 8, 1, true>), dim3((unsigned)tiles), dim3(512), G::LDS_BYTES, st, p);
+}
+static bool wpk_deep(const Gemm16Args& p) {
+  if (p.K % 64 != 0 || p.K < 1024 || p.c_tiled || p.ldc % 4 != 0 || p.N % 4 != 0) return false;
+  if (((uintptr_t)p.C | (uintptr_t)p.aux | (uintptr_t)p.bias) & 15) return false;
+  if (((uintptr_t)p.c16a | (uintptr_t)p.c16b) & 7) return false;
+  return (long)((p.M + 31) / 32) * ((p.N + 63) / 64) <= 64;
+}
+
 // engine: 0 = choose, 1 = the shared ring (dma_core.h), 2 = wave-private K-slices (wpk_core.h; ARK_ERR_SHAPE if the
 // shape does not fit it).  WPK wants one tile per CU: it is chosen when its 64 x 96 (or 32 x 96) tiling gives between
 // half a chip and two chips of workgroups and K is deep enough for every wave to own at least two slices.
@@ -246,12 +264,18 @@ static int wpk_rows(const Gemm16Args& p) {
 template <int PREC>
 static int launch16(Gemm16Args p, int engine, hipStream_t st) {
   const int bm = wpk_rows(p);
-  if (engine == 2 && !bm) return ARK_ERR_SHAPE;
+  const bool deep = !bm && wpk_deep(p);
+  if (engine == 2 && !bm && !deep) return ARK_ERR_SHAPE;
 #ifdef ARK_G16_NO_WPK   // (A/B builds: the library's own choice stays on the shared ring)
   if (engine == 0) engine = 1;
 #endif
   if (bm && engine != 1) {
     if (bm == 64) launch16_wpk<PREC, 64, 96>(p, st); else launch16_wpk<PREC, 32, 96>(p, st);
+    ARK_LAUNCH_CHECK();
+    return 0;
+  }
+  if (deep && engine != 1) {
+    launch16_wpk_deep<PREC>(p, st);
     ARK_LAUNCH_CHECK();
     return 0;
   }

@@ -46,7 +46,7 @@ struct WpkNT {
   static constexpr int PA = BM / 8, PB = BN / 8;     // 1-KB pieces per slice
   static constexpr int LPS = PA + PB;
   static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
-  static_assert(BM % 16 == 0 && BN % 32 == 0, "whole MFMA tiles, 32-column groups in the epilogue");
+  static_assert(BM % 16 == 0 && BN % 32 == 0 && (BM / 8) % 2 == 0, "whole MFMA tiles, 32-column groups in the epilogue, even A pieces");
   static_assert(NSLOT >= 1 && NSLOT <= 3 && NSLOT * LPS <= 63, "in-flight pieces must fit the 6-bit vmcnt");
 
   template <int N>
@@ -55,8 +55,11 @@ struct WpkNT {
   // acc += A[m0 .. m0+BM, :] x B[n0 .. n0+BN, :]^T over this wave's slices of [0, K) (K % 64 == 0); rows must exist.
   // rot: the slice this workgroup starts at (any value; slices are taken modulo K / 64): workgroups that share operand
   // panels in their XCD's L2 walk K out of step, so one's misses are the others' hits.
+  // a_rows / b_rows (> 0): rows of the tile that exist in memory -- the pieces of the rest re-read the last valid row (their
+  // products land in accumulator rows / columns the epilogue drops); 0 = the whole tile exists (no clamping code at all)
+  template <bool CLAMP = false>
   static __device__ __forceinline__ void run(f32x4 (&acc)[TM][TN], const h_t* A, long lda, const h_t* B, long ldb, int K,
-                                             int rot, char* lds) {
+                                             int rot, char* lds, int a_rows = 0, int b_rows = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -79,7 +82,18 @@ struct WpkNT {
       sl = sl >= NS ? sl - NS : sl;
       const long k0 = (long)sl * 64;
       char* slot = ring + (j % NSLOT) * SLOT;
-      if (q < PA)
+      if constexpr (CLAMP) {
+        const int sw = 8 * ((lane & 7) ^ ((4 * (q & 1) + (lane >> 4)) & 7));   // (PA is even: the parity of q is the piece's own)
+        if (q < PA) {
+          const int row = min(8 * q + (lane >> 3), a_rows - 1);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + k0 + (long)row * lda + sw),
+                                           (__attribute__((address_space(3))) void*)(slot + q * 1024), 16, 0, 0);
+        } else {
+          const int row = min(8 * (q - PA) + (lane >> 3), b_rows - 1);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + k0 + (long)row * ldb + sw),
+                                           (__attribute__((address_space(3))) void*)(slot + q * 1024), 16, 0, 0);
+        }
+      } else if (q < PA)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + k0 + (long)(8 * q) * lda + voa[q & 1]),
                                          (__attribute__((address_space(3))) void*)(slot + q * 1024), 16, 0, 0);
       else

@@ -88,10 +88,28 @@ def test_gemm16_without_the_fp32_output(engine):
     assert run16(engine, L.PREC_BF16, L.EPI_BIAS_GELU, M, N, K, no_c=True)[0] == -1   # the pre-activation IS the output
 
 
+@pytest.mark.parametrize("prec", [L.PREC_F16, L.PREC_BF16])
+@pytest.mark.parametrize("shape", [(1024, 20, 1536), (1000, 52, 1536), (256, 48, 3072), (96, 128, 1024)])
+@pytest.mark.parametrize("engine", [0, 1, 2])
+def test_gemm16_few_tiles_deep_k(engine, shape, prec):
+    """the latent heads' kind of product -- a handful of tiles over a deep K: 32 x 64 wave-private tiles whose eight waves
+    split K, rows and columns beyond M / N clamped on the way in and dropped on the way out"""
+    M, N, K = shape
+    rc, out, ref, c16a, c16b, copy_ref, cs = run16(engine, prec, L.EPI_BIAS, M, N, K, colsum=False)
+    assert rc == 0
+    tol = 3e-5 * K ** 0.5 + 1e-5
+    assert torch.isfinite(out).all() and (out - ref).abs().max().item() <= tol
+    err = (c16a.cpu().double() - copy_ref).abs()
+    assert (err <= (2.0 ** -10 if prec == L.PREC_F16 else 2.0 ** -7) * copy_ref.abs() + tol).all()
+    rc, out, ref, _, _, _, cs = run16(engine, prec, L.EPI_NONE, M, N, K, colsum=True, copies=False)
+    assert rc == 0 and (out - ref).abs().max().item() <= tol
+    assert (cs.cpu().double() - ref.sum(0)).abs().max().item() <= 1e-4 * M ** 0.5 * ref.abs().max().item()
+
+
 def test_gemm16_wpk_refuses_shapes_it_cannot_tile():
     rc = run16(2, L.PREC_F16, L.EPI_NONE, 1024, 1024, 1536)[0]   # N % 96 != 0
     assert rc == -2
-    rc = run16(2, L.PREC_F16, L.EPI_NONE, 64, 96, 1536)[0]       # one tile: not a chip-filling product
+    rc = run16(2, L.PREC_F16, L.EPI_NONE, 4096, 1024, 256)[0]    # shallow K, N % 96 != 0: neither flavour
     assert rc == -2
-    rc = run16(0, L.PREC_F16, L.EPI_NONE, 64, 96, 1536)[0]       # ... which the library's own choice still serves
+    rc = run16(0, L.PREC_F16, L.EPI_NONE, 4096, 1024, 256)[0]    # ... which the library's own choice still serves (ring)
     assert rc == 0
