@@ -267,6 +267,7 @@ class Engine:
         # launch's two 64-KB workgroups per CU, where the ring's 24-KB workgroups slip in beside them
         self.g16_bwd = int(cfg.get("ark_g16_bwd", 1))
         self.pool_bwd_early = bool(cfg.get("ark_pool_bwd_early", True))
+        self.ce_dw_last = bool(cfg.get("ark_ce_dw_last", True))   # a deferred fused-CE weight gradient behind the whole encoder backward
         # sweep workloads (the side queue is the long one: fused-CE weight gradient beside the backward sweep): GRU weight
         # gradients on a third queue, the latent reductions and the MLP block's Adam on the chain's own queue
         self.wgrad_third_queue = bool(cfg.get("ark_wgrad_third_queue", True))   # embedding scatter in front of the MLP weight gradients
@@ -1241,7 +1242,7 @@ class Engine:
                   L.ptr(self._eps), L.ptr(self.hyper), L.ptr(ext), L.ptr(p["enc.mu.weight"]), L.ptr(w["pre"][n - 1]),
                   L.ptr(w["dhead"]), L.ptr(w["dA"]), L.ptr(w["dpre16"][n - 1]), L.i32(pb),
                   L.ptr(g[f"enc.mlp.{2 * (n - 1)}.bias"]), L.i32(nv), L.i32(Z), L.i32(D), L.i32(H), st)
-            if self._ce_dw_pending is not None:
+            if self._ce_dw_pending is not None and not self.ce_dw_last:
                 self._ce_dw_pending()
                 self._ce_dw_pending = None
             if self._fork_pending is not None:
@@ -1338,6 +1339,12 @@ class Engine:
                 dpre, other = other, dpre
         if not (w["v2"] and pooled):
             self._enc_pool_bwd(w, dpre, B, T, st)
+        if self._ce_dw_pending is not None:
+            # the deferred fused-CE weight gradient (a sweep that fills most of the chip: wd-movies) goes out LAST: its
+            # one-per-CU, whole-register-file workgroups (1.5 rounds of ~240 us) kept the encoder backward's ten-microsecond
+            # launches off the chip for ~570 us when it was queued right behind the latent kernel (stamps, round 5)
+            self._ce_dw_pending()
+            self._ce_dw_pending = None
         self._join_side()
 
     def _side_heavy(self):
