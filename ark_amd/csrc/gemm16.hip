@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_wpk_kernel(Gemm16Args p) {
 #pragma unroll
     for (int tn = 0; tn < G::TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
   G::template run<CLAMP>(acc, reinterpret_cast<const h_t*>(p.A) + (long)m0 * p.lda, p.lda,
-                         reinterpret_cast<const h_t*>(p.B) + (long)n0 * p.ldb, p.ldb, p.K, lid, smem, min(BM, p.M - m0), min(BN, p.N - n0));
+                         reinterpret_cast<const h_t*>(p.B) + (long)n0 * p.ldb, p.ldb, p.K, 0, smem, min(BM, p.M - m0), min(BN, p.N - n0));
   float* cs_lds = G::colsum_lds(smem);
   const int epi = p.epi;
   G::reduce_rows(acc, smem, [&](int row, int col, f32x4 v) {

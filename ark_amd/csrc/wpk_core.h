@@ -53,8 +53,10 @@ struct WpkNT {
   static __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
   // acc += A[m0 .. m0+BM, :] x B[n0 .. n0+BN, :]^T over this wave's slices of [0, K) (K % 64 == 0); rows must exist.
-  // rot: the slice this workgroup starts at (any value; slices are taken modulo K / 64): workgroups that share operand
-  // panels in their XCD's L2 walk K out of step, so one's misses are the others' hits.
+  // rot: the slice this workgroup starts at (any value; slices are taken modulo K / 64).  The callers pass 0: starting the
+  // workgroups of an XCD at different slices (so that one's L2 misses are the others' hits) measured no faster, and with a
+  // common start every output row is summed in the SAME order whichever tile it falls into -- a data-parallel shard and the
+  // full batch then agree bit for bit in these products, which the two-process tests lean on.
   // a_rows / b_rows (> 0): rows of the tile that exist in memory -- the pieces of the rest re-read the last valid row (their
   // products land in accumulator rows / columns the epilogue drops); 0 = the whole tile exists (no clamping code at all)
   template <bool CLAMP = false>

@@ -72,7 +72,10 @@ def _single_process_reference(variant, steps, P0, bf16, rare_rows=False):
         for name, (off, shape, numel) in eng.layout.entries.items():
             d = (P0[off:off + numel] - ref[off:off + numel]).abs()
             print(f"  {name:32s} mean |diff| {d.mean().item():.2e}  max {d.max().item():.2e}  moved {(ref[off:off + numel] - O_flat(eng, O.init_params(cfg, 0))[off:off + numel]).abs().mean().item():.2e}")
-    assert worst <= (2 if rare_rows else 1) * steps * 1e-3 * 1.05, (worst, mean)
+    # (round 5: 2 lr per step for every variant.  The 1-lr bound of rounds 2-4 held only while the shards and the full batch
+    #  happened to round their near-zero gradients alike; any change of a product's summation order -- the latent heads moved to
+    #  the K-split engine -- moves which handful of weights flip.  A flip costs at most 2 lr per step; the MEAN is the pin.)
+    assert worst <= 2 * steps * 1e-3 * 1.05, (worst, mean)
     # (bf16 transport of the gradient buckets, `ark_dp_bf16`: the reduced gradients carry 8 significant bits)
     assert mean <= (1e-4 if bf16 else 5e-5 if rare_rows else 2e-5), (worst, mean)
 
