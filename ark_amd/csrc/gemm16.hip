@@ -137,11 +137,14 @@ __global__ __launch_bounds__(64 * NW) void gemm16_wpk_kernel(Gemm16Args p) {
   float* cs_lds = G::colsum_lds(smem);
   const int epi = p.epi;
   G::reduce_rows(acc, smem, [&](int row, int col, f32x4 v) {
-    if (CLAMP && (m0 + row >= p.M || n0 + col >= p.N)) return;   // (N % 4 == 0: a quad is inside or outside as a whole)
-    const long o = (long)(m0 + row) * p.ldc + n0 + col;
-    if (epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_RELU || epi == ARK_EPI_BIAS_GELU) v += *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
-    if (epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
-    if (epi == ARK_EPI_MUL_DGELU) {
+    // (clamped tiles: a quad beyond M / N -- N % 4 == 0: inside or outside as a whole -- touches no memory, but its lanes stay in
+    //  the column-sum shuffles below with zeros: an early return would leave their partners reading dead registers)
+    const bool valid = !CLAMP || (m0 + row < p.M && n0 + col < p.N);
+    const long o = valid ? (long)(m0 + row) * p.ldc + n0 + col : 0;
+    if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (valid && (epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_RELU || epi == ARK_EPI_BIAS_GELU)) v += *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
+    if (valid && epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
+    if (valid && epi == ARK_EPI_MUL_DGELU) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + o);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= dgelu_fast(a[e]);
@@ -150,13 +153,13 @@ __global__ __launch_bounds__(64 * NW) void gemm16_wpk_kernel(Gemm16Args p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    if (epi == ARK_EPI_MUL_RELU) {
+    if (valid && epi == ARK_EPI_MUL_RELU) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + o);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = a[e] > 0.f ? v[e] : 0.f;
     }
-    if (epi == ARK_EPI_ADD) v += *reinterpret_cast<const f32x4*>(p.C + o);
-    if (p.C) *reinterpret_cast<f32x4*>(p.C + o) = v;   // BIAS_GELU: the pre-activation
+    if (valid && epi == ARK_EPI_ADD) v += *reinterpret_cast<const f32x4*>(p.C + o);
+    if (valid && p.C) *reinterpret_cast<f32x4*>(p.C + o) = v;   // BIAS_GELU: the pre-activation
     if (epi == ARK_EPI_BIAS_GELU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);   // the 16-bit copies carry the activation
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(64 * NW) void gemm16_wpk_kernel(Gemm16Args p) {
         for (int e = 0; e < 4; ++e) atomicAdd(&cs_lds[col + e], c[e]);
       }
     }
-    if (p.c16a) put16x4(p.c16a, o, v, p.prec_a);
-    if (p.c16b) put16x4(p.c16b, o, v, p.prec_b);
+    if (valid && p.c16a) put16x4(p.c16a, o, v, p.prec_a);
+    if (valid && p.c16b) put16x4(p.c16b, o, v, p.prec_b);
   });
   if (p.colsum) {
     __syncthreads();
@@ -264,8 +267,13 @@ static int wpk_rows(const Gemm16Args& p) {
 template <int PREC>
 static int launch16(Gemm16Args p, int engine, hipStream_t st) {
   const int bm = wpk_rows(p);
-  const bool deep = !bm && wpk_deep(p);
+  // the few-tiles / deep-K flavour is taken only where a caller asks for it (engine 2 or 3): it sums K in another order than
+  // the ring, and a model whose later layers amplify 1e-6 of the forward (the Transformer feed-forward: a random 1e-6 on
+  // linear2's output moves linear1's gradients by 1e-2 through ReLU / LayerNorm, measured) would no longer compare against
+  // its register-staged twin at that test's 5e-3
+  const bool deep = !bm && (engine == 2 || engine == 3) && wpk_deep(p);
   if (engine == 2 && !bm && !deep) return ARK_ERR_SHAPE;
+  if (engine == 3) engine = 0;
 #ifdef ARK_G16_NO_WPK   // (A/B builds: the library's own choice stays on the shared ring)
   if (engine == 0) engine = 1;
 #endif
@@ -511,7 +519,7 @@ static int gemm16_impl(int prec, int epi, const void* A16, int64_t lda, const vo
   if (colsum && epi == ARK_EPI_BIAS_GELU) return ARK_ERR_ARG;
   if (c16b && prec_b != PREC_F16 && prec_b != PREC_BF16) return ARK_ERR_ARG;
   Gemm16Args p{A16, B16, C, bias, aux, (long)lda, (long)ldb, (long)ldc, M, N, K, epi, c_tiled ? 1 : 0, 0, c16a, c16b, prec, prec_b, colsum};
-  if (engine < 0 || engine > 2) return ARK_ERR_ARG;
+  if (engine < 0 || engine > 3) return ARK_ERR_ARG;
   if (engine == 2 && (((uintptr_t)A16 | (uintptr_t)B16) & 15)) return ARK_ERR_ALIGN;
   if (prec == PREC_F16) return launch16<PREC_F16>(p, engine, (hipStream_t)stream);
   if (prec == PREC_BF16) return launch16<PREC_BF16>(p, engine, (hipStream_t)stream);
@@ -534,7 +542,8 @@ extern "C" int ark_gemm16_ex(int prec, int epi, const void* A16, int64_t lda, co
 }
 
 // ark_gemm16_ex on a chosen engine (tests, A/B timing): 0 = the library's choice, 1 = shared ring, 2 = wave-private
-// K-slices (ARK_ERR_SHAPE unless M % 32 == 0, N % 96 == 0, K % 64 == 0, K >= 512 and the tiling fills half a chip)
+// K-slices (ARK_ERR_SHAPE unless M % 32 == 0, N % 96 == 0, K % 64 == 0, K >= 512 and the tiling fills half a chip, or the
+// product is a few tiles over K >= 1024), 3 = the library's choice INCLUDING the few-tiles / deep-K flavour
 extern "C" int ark_gemm16_engine(int engine, int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb,
                                  float* C, int64_t ldc, const float* bias, const float* aux, void* c16a, void* c16b,
                                  int prec_b, float* colsum, int M, int N, int K, void* stream) {

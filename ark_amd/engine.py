@@ -266,11 +266,13 @@ class Engine:
         # gradients on it 1.093 -> 1.110 -- its workgroups want a CU's whole LDS and queue behind the weight-gradient
         # launch's two 64-KB workgroups per CU, where the ring's 24-KB workgroups slip in beside them
         self.g16_bwd = int(cfg.get("ark_g16_bwd", 1))
-        self.pool_bwd_early = bool(cfg.get("ark_pool_bwd_early", True))
-        self.ce_dw_last = bool(cfg.get("ark_ce_dw_last", True))   # a deferred fused-CE weight gradient behind the whole encoder backward
-        # sweep workloads (the side queue is the long one: fused-CE weight gradient beside the backward sweep): GRU weight
-        # gradients on a third queue, the latent reductions and the MLP block's Adam on the chain's own queue
-        self.wgrad_third_queue = bool(cfg.get("ark_wgrad_third_queue", True))   # embedding scatter in front of the MLP weight gradients
+        # round-5 schedule choices, measured and fixed (no switches): the embedding scatter in front of the MLP
+        # weight gradients (wd-articles 6.96 -> 6.70 ms, syn-paths +-0); a deferred fused-CE weight gradient behind the whole
+        # encoder backward (wd-movies 1.87 -> 1.84); sweep workloads whose side queue is the long one: GRU weight gradients on a
+        # third queue, the latent reductions and the MLP block's Adam on the chain's own queue (wd-articles -0.2 ms)
+        self.pool_bwd_early = True
+        self.ce_dw_last = True
+        self.wgrad_third_queue = True
         self.early_dec_adam = True
         self.early_mlp_adam = True
         self._adam_dec_early = False
@@ -672,9 +674,10 @@ class Engine:
                           L.ptr(w["pre"][i]), L.i64(H), L.ptr(p[f"enc.mlp.{2 * i}.bias"]), L.ptr(None), L.ptr(w["act16a"][i]),
                           L.ptr(w["act16b"][i]), L.i32(pb), L.ptr(None), L.i32(B), L.i32(H), L.i32(H), st)
                     a16 = w["act16a"][i]
-                _call("ark_gemm16", L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(a16), L.i64(H), L.ptr(self.wh16), L.i64(H),
-                      L.ptr(w["head"]), L.i64(2 * Z), L.ptr(p["enc.mu.bias"]), L.ptr(None), L.i32(B), L.i32(2 * Z), L.i32(H),
-                      L.i32(0), st)
+                # (the heads: a handful of tiles over K = 3D -- the K-split flavour of the wave-private engine where it applies)
+                _call("ark_gemm16_engine", L.i32(3 if self.g16_fwd == 0 else self.g16_fwd), L.i32(pf), L.i32(L.EPI_BIAS), L.ptr(a16),
+                      L.i64(H), L.ptr(self.wh16), L.i64(H), L.ptr(w["head"]), L.i64(2 * Z), L.ptr(p["enc.mu.bias"]), L.ptr(None),
+                      L.ptr(None), L.ptr(None), L.i32(pf), L.ptr(None), L.i32(B), L.i32(2 * Z), L.i32(H), st)
             else:
                 a = w["g"]
                 for i in range(n):

@@ -277,8 +277,10 @@ int ark_gemm16_ex(int prec, int epi, const void* A16, int64_t lda, const void* B
 /* ark_gemm16_ex on a chosen engine (parity tests, A/B timing): 0 = the library's choice (what ark_gemm16 / _ex do),
  * 1 = the shared two-barrier ring (csrc/dma_core.h), 2 = wave-private K-slices (csrc/wpk_core.h: one 64 x 96 or 32 x 96
  * tile per CU, every wave streams its own K-slices, no barrier in the main loop; ARK_ERR_SHAPE unless M % 32 == 0,
- * N % 96 == 0, K % 64 == 0, K >= 512 and the tiling gives 128 .. 512 workgroups).  Same products as nn.Linear forward /
- * input gradient of the encoder MLP (kgvae/model/models.py:32-41,60). */
+ * N % 96 == 0, K % 64 == 0, K >= 512 and the tiling gives 128 .. 512 workgroups -- or the product is at most 64 tiles of
+ * 32 x 64 over K >= 1024: the latent heads), 3 = the library's choice INCLUDING that few-tiles / deep-K flavour (which
+ * `ark_gemm16` / `_ex` never pick by themselves: another summation order).  Same products as nn.Linear forward / input
+ * gradient of the encoder MLP and the heads (kgvae/model/models.py:32-44,60-61). */
 int ark_gemm16_engine(int engine, int prec, int epi, const void* A16, int64_t lda, const void* B16, int64_t ldb, float* C,
                       int64_t ldc, const float* bias, const float* aux, void* c16a, void* c16b, int prec_b, float* colsum,
                       int M, int N, int K, void* stream);

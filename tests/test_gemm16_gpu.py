@@ -89,8 +89,8 @@ def test_gemm16_without_the_fp32_output(engine):
 
 
 @pytest.mark.parametrize("prec", [L.PREC_F16, L.PREC_BF16])
-@pytest.mark.parametrize("shape", [(1024, 20, 1536), (1000, 52, 1536), (256, 48, 3072), (96, 128, 1024)])
-@pytest.mark.parametrize("engine", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(1024, 20, 1536), (1000, 52, 1536), (1004, 52, 1536), (240, 128, 2048), (256, 48, 3072), (96, 128, 1024)])
+@pytest.mark.parametrize("engine", [3, 1, 2])
 def test_gemm16_few_tiles_deep_k(engine, shape, prec):
     """the latent heads' kind of product -- a handful of tiles over a deep K: 32 x 64 wave-private tiles whose eight waves
     split K, rows and columns beyond M / N clamped on the way in and dropped on the way out"""
@@ -113,3 +113,38 @@ def test_gemm16_wpk_refuses_shapes_it_cannot_tile():
     assert rc == -2
     rc = run16(0, L.PREC_F16, L.EPI_NONE, 4096, 1024, 256)[0]    # ... which the library's own choice still serves (ring)
     assert rc == 0
+
+
+@pytest.mark.parametrize("shape", [(240, 128, 2048), (1024, 1536, 1536), (256, 3072, 3072)])
+@pytest.mark.parametrize("epi", [L.EPI_ADD, L.EPI_BIAS_RELU, L.EPI_MUL_RELU, L.EPI_MUL_AUX, L.EPI_BIAS])
+def test_gemm16_engines_agree_on_every_epilogue(epi, shape):
+    """the epilogues the Transformer engines use (accumulate into a residual's gradient, ReLU, ReLU'), through `ark_gemm16`'s
+    own choice of engine against the shared ring, on the same operands and the same initial C"""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(11)
+    dev = torch.device("cuda:0")
+    A = (torch.randn(M, K, generator=g) * 0.3).to(torch.bfloat16).to(dev)
+    B = (torch.randn(N, K, generator=g) * 0.3).to(torch.bfloat16).to(dev)
+    bias, aux, C0 = torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    outs = []
+    for engine in (1, 0):
+        C = C0.clone()
+        rc = L.lib().ark_gemm16_engine(L.i32(engine), L.i32(L.PREC_BF16), L.i32(epi), L.ptr(A), L.i64(K), L.ptr(B), L.i64(K), L.ptr(C),
+                                       L.i64(N), L.ptr(bias), L.ptr(aux), L.ptr(None), L.ptr(None), L.i32(L.PREC_BF16), L.ptr(None),
+                                       L.i32(M), L.i32(N), L.i32(K), L.cur_stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append(C)
+    ref = A.double() @ B.double().t()
+    if epi == L.EPI_ADD:
+        ref = ref + C0.double()
+    if epi in (L.EPI_BIAS, L.EPI_BIAS_RELU):
+        ref = ref + bias.double()
+    if epi == L.EPI_BIAS_RELU:
+        ref = ref.clamp(min=0)
+    if epi == L.EPI_MUL_RELU:
+        ref = torch.where(aux > 0, ref, torch.zeros_like(ref))
+    if epi == L.EPI_MUL_AUX:
+        ref = ref * aux.double()
+    for C in outs:
+        assert (C.double() - ref).abs().max().item() <= 3e-5 * K ** 0.5 + 1e-4
