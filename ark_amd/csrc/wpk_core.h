@@ -1,19 +1,20 @@
-// Wave-private K-slice engine ("WPK") for the chip-filling products of the step's tail and of the encoder:
-// ONE workgroup per CU owns a large output tile, and every one of its four waves runs the WHOLE tile over its own
-// K-slices (slice s belongs to wave s % 4) through a PRIVATE LDS-DMA ring -- no barrier and no cross-wave hand-off
-// anywhere in the main loop; the four partial tiles meet in LDS once, at the end.
+// Wave-private K-slice engine ("WPK") for the chip-filling products of the encoder (and any product of that kind):
+// ONE workgroup per CU owns a large output tile, and every one of its waves (eight: two per SIMD; four in the first build)
+// runs the WHOLE tile over its own K-slices (slice s belongs to wave s mod NW) through a PRIVATE LDS-DMA ring -- no barrier
+// and no cross-wave hand-off anywhere in the main loop; the partial tiles meet in LDS once, at the end.
 //
 // Why (round 5): the ring engine of dma_core.h shares every stage between the waves of a workgroup, so it needs two
 // barriers per 64-wide stage and small tiles (32 x 64 ... 128 x 128 split eight ways) whose phases only overlap across
 // three resident workgroups.  For the [1024 x 1536] x [1536 x 1536] encoder products that is 768 workgroups streaming
 // 221 MB from L2 into LDS for 12.6 MB of operands (864 KB per CU at ~48 GB/s per CU = 18 us), with three ds_read_b128 per
-// two MFMAs.  Here a CU streams each operand byte of its tile exactly once (64 x 96 tile: 480 KB per CU), a wave reads 20
-// fragments for 48 MFMAs, up to 160 KB of LDS-DMA are in flight per CU, and the waves drift apart by themselves: while
-// one multiplies, another issues its pieces and a third waits for data -- the phase overlap three small workgroups gave,
-// without their redundant bytes.
+// two MFMAs.  Here a CU streams each operand byte of its tile exactly once (64 x 96 tile: 480 KB per CU), a wave reads 10
+// fragments for 24 MFMAs, 160 KB of LDS-DMA are in flight per CU, and the waves drift apart by themselves: while one
+// multiplies, its SIMD partner issues its pieces or waits for data -- the phase overlap three small workgroups gave,
+// without their redundant bytes.  Measured: 18.1 -> 13-15 us per product (tools/wpk_stamps.py).
 //
-// Price: the whole tile's accumulators live in EVERY wave (BM x BN / 64 registers: 96 for 64 x 96, 256 for 128 x 128),
-// and a cross-wave sum through LDS at the end (the ring's space is reused).
+// Price: the whole tile's accumulators live in EVERY wave (BM x BN / 64 registers: 96 for 64 x 96), a cross-wave sum
+// through LDS at the end (the ring's space is reused), and ONE workgroup per CU (160 KB of LDS): beside a launch that
+// leaves less than that free (the weight gradients' two 64-KB workgroups per CU) such a workgroup waits for a whole CU.
 #pragma once
 #include "dma_core.h"
 
