@@ -231,3 +231,20 @@ def test_shipped_configs_are_the_reference_yamls_with_model_type_overridden():
             if k not in own:
                 assert got[k] == v, (name, k, got[k], v)
         assert got["model_type"] == "SAIL"
+
+
+def test_ranks_sharing_a_device_are_counted_from_the_launcher_environment(monkeypatch):
+    """Engine admits a persistent sweep only if the grids of all ranks on ITS device fit the chip together; the count comes from
+    torchrun's LOCAL_WORLD_SIZE and the visible devices (one process per GPU on a real node -> 1)"""
+    import torch
+    from ark_amd import engine as E
+    assert E._ranks_on_this_device(1) == 1
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert E._ranks_on_this_device(8) == 1            # a real 8-GPU node
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert E._ranks_on_this_device(8) == 8            # eight ranks rehearsed on one card
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    assert E._ranks_on_this_device(2) == 2            # the two-process tests
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert E._ranks_on_this_device(2) == 2            # (spawned without torchrun: every rank is local)

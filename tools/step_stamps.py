@@ -25,10 +25,14 @@ def main():
     ap.add_argument("--cfg", default="")
     ap.add_argument("--replays", type=int, default=200)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--model", default="SAIL", help="SAIL | t-ARK | t-SAIL (the Transformer engines: ark_amd/txf_engine.py)")
+    ap.add_argument("--by-call", action="store_true", help="also print the time per library call, summed over the step")
     a = ap.parse_args()
     from ark_amd import engine as E, initlib
     dev = torch.device("cuda", 0)
     cfg = bench.build_cfg(0.1, a.workload)
+    if a.model != "SAIL":
+        cfg.update(model_type=a.model, ark_txf_dropout=0.1)
     for kv in filter(None, a.cfg.split(",")):
         k, v = kv.split("=")
         cfg[k] = int(v)
@@ -40,7 +44,11 @@ def main():
     eps = torch.randn(B, cfg["d_latent"], device=dev)
 
     def run(stamped):
-        eng = E.Engine(cfg, dev, precision="mixed")
+        if a.model != "SAIL":
+            from ark_amd.txf_engine import TxfEngine
+            eng = TxfEngine(cfg, dev, precision="mixed")
+        else:
+            eng = E.Engine(cfg, dev, precision="mixed")
         eng.load_params(initlib.init_state(cfg, seed=0))
         eng.set_hyper(lr=1e-4, beta=0.1)
         buf = torch.zeros(4096, dtype=torch.int64, device=dev)
@@ -94,6 +102,15 @@ def main():
         rows.append((rel, qname[st], d, name))
     for rel, q, d, name in sorted(rows):
         print(f"{rel:9.2f}  {q}  +{d:7.2f}  {name}")
+    if a.by_call:
+        tot = {}
+        for rel, q, d, name in rows:
+            c = tot.setdefault(name, [0, 0.0])
+            c[0] += 1
+            c[1] += d
+        print("per library call (us since the previous stamp on the same queue, summed):")
+        for name, (k, us) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+            print(f"  {us:9.1f} us  {k:4d} x  {name}")
 
 
 if __name__ == "__main__":
