@@ -397,31 +397,36 @@ def dp_overhead_1rank(dev, args, extra, plain_ms):
                 torch.cuda.empty_cache()
             res["default_order"] = "beside"
             res["ratio"] = res["beside_ratio"]
-            # the shapes whose recurrences run as PERSISTENT SWEEPS (BASELINE configs 4, 5 are data-parallel configurations):
-            # one rank of the same RCCL group, default order -- a sweep's co-resident workgroups and a live RCCL communicator in
-            # one captured schedule (Engine._check_beside_sweep refuses a step that could run them side by side)
-            for wl, nt in (("wd-movies", 60), ("wd-articles", 20)):
-                try:
-                    r0 = time_workload(dev, wl, args.precision, args.dropout, 0, nt, 10, 20, dict(extra))
-                    p_ms = r0["dt"] / nt * 1e3
-                    del r0
-                    torch.cuda.empty_cache()
-                    r = time_workload(dev, wl, args.precision, args.dropout, 0, nt, 10, 20, dict(extra), world=1, rank=0, dist=dist,
-                                      use_dp=True)
-                    ms = r["dt"] / nt * 1e3
-                    res[wl] = {"plain_ms_per_step": p_ms, "dp_ms_per_step": ms, "ratio": ms / p_ms, "steps": nt,
-                               "persistent_sweeps": bool(r["eng"]._use_sweep(r["B"], r["eng"].L)),
-                               "sweep_error": r["eng"].sweep_error()[0]}
-                    log(f"dp schedule on one rank, {wl}: {ms:.3f} ms/step = {ms / p_ms:.3f} x plain")
-                    del r
-                    torch.cuda.empty_cache()
-                except Exception as e:
-                    res[wl] = {"error": repr(e)}
         finally:
             dist.destroy_process_group()
     except Exception as e:   # a diagnostic leg must never take the headline line down
         res["error"] = repr(e)
     return res
+
+
+def dp_overhead_sweep_workloads(args, plain):
+    """The same one-rank leg at the shapes whose recurrences run as PERSISTENT SWEEPS (BASELINE configs 4 and 5 are data-parallel
+    configurations): a sweep's co-resident workgroups and a live RCCL communicator in one schedule (Engine._check_beside_sweep
+    refuses a step that could run them side by side).  Each in a CHILD process (`bench.py --force-dist --workload ...`: the
+    N-rank entry with one rank) -- its own RCCL life cycle and, at wd-articles, the eager launches Engine.dp_prefers_eager
+    chooses there -- against the single-process step of `other_workloads`."""
+    import subprocess
+    out = {}
+    for wl, nt in (("wd-movies", 60), ("wd-articles", 20)):
+        try:
+            p_ms = plain[wl]["ms_per_step"]
+            cmd = [sys.executable, os.path.abspath(__file__), "--force-dist", "--workload", wl, "--no-other", "--no-cpu-baseline",
+                   "--steps", str(nt), "--warmup", "10", "--settle", "20", "--precision", args.precision, "--dropout", str(args.dropout)]
+            env = dict(os.environ, MASTER_PORT=str(29600 + (os.getpid() % 300)))
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            ms = d["ms_per_step"]
+            out[wl] = {"plain_ms_per_step": p_ms, "dp_ms_per_step": ms, "ratio": ms / p_ms, "steps": nt,
+                       "launch": "eager (Engine.dp_prefers_eager: the sweep workloads)"}
+            log(f"dp schedule on one rank, {wl}: {ms:.3f} ms/step = {ms / p_ms:.3f} x plain")
+        except Exception as e:   # a diagnostic leg must never take the headline line down
+            out[wl] = {"error": repr(e)}
+    return out
 
 
 def transformer_variants(dev, precision, dropout):
@@ -628,6 +633,7 @@ def main():
             torch.cuda.empty_cache()
             res["dp_overhead_1rank"] = dp_overhead_1rank(dev, args, extra, dt / args.steps * 1e3)
             res["other_workloads"] = other_workloads(dev, args.precision, args.dropout, mfma_peak)
+            res["dp_overhead_1rank"].update(dp_overhead_sweep_workloads(args, res["other_workloads"]))
             if args.precision != "f32":
                 res["transformer_variants"] = transformer_variants(dev, args.precision, args.dropout)
         if not args.no_cpu_baseline and world == 1:
