@@ -2080,7 +2080,9 @@ class Engine:
         backward instead of beside the sweep) -- measured on one rank at wd-articles: captured 8.4 ms, eager 7.0 (single-process
         captured step: 6.4; there the same graph keeps the overlap).  Eager costs nothing here: ~100 launches per 7 ms."""
         Bp = (B + 15) // 16 * 16
-        return bool(self.mt == "SAIL" and self.use_dma and self._use_sweep(Bp, Lq))   # (wd-movies: 2.05 captured, 2.00 eager)
+        # only where the sweep is the narrow one (<= 128 workgroups: wd-articles).  wd-movies (1.9 ms, ~150 launches): eager 1.88 ms
+        # against 1.92 captured on an idle host -- not worth leaving the host a third of a step for the rest of the loop
+        return bool(self.mt == "SAIL" and self.use_dma and self._use_sweep(Bp, Lq) and self._sweep_wgs(Bp) <= 128)
 
     def graphed_train_step(self, triples, seq, ce_count=None, dp=False):
         """train_step() through a cached hipGraph: the first call for a batch shape runs the step eagerly

@@ -272,7 +272,8 @@ def time_workload(dev, workload, precision, dropout, batch, steps, warmup, settl
     run_stream = torch.cuda.Stream(device=dev)
     run_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(run_stream):
-        if no_graph or (use_dp and eng.dp_prefers_eager(B, cfg["seq_len"] - 1)):
+        eager = bool(no_graph or (use_dp and eng.dp_prefers_eager(B, cfg["seq_len"] - 1)))
+        if eager:
             # (data parallel at the sweep workloads: eager launches keep the sweep / CE overlap the segment graphs lose --
             #  Engine.dp_prefers_eager; the training loop takes the same decision in graphed_train_step)
             def step():
@@ -321,7 +322,7 @@ def time_workload(dev, workload, precision, dropout, batch, steps, warmup, settl
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     return {"eng": eng, "cfg": cfg, "B": B, "Bg": Bg, "dt": dt, "loss": [float(x) for x in out4.cpu()],
-            "h2d_bytes": n_tri + n_seq + n_eps, "steps": steps, "dt_resident": dt_res}
+            "h2d_bytes": n_tri + n_seq + n_eps, "steps": steps, "dt_resident": dt_res, "eager": eager}
 
 
 def other_workloads(dev, precision, dropout, mfma_peak):
@@ -408,21 +409,22 @@ def dp_overhead_sweep_workloads(args, plain):
     """The same one-rank leg at the shapes whose recurrences run as PERSISTENT SWEEPS (BASELINE configs 4 and 5 are data-parallel
     configurations): a sweep's co-resident workgroups and a live RCCL communicator in one schedule (Engine._check_beside_sweep
     refuses a step that could run them side by side).  Each in a CHILD process (`bench.py --force-dist --workload ...`: the
-    N-rank entry with one rank) -- its own RCCL life cycle and, at wd-articles, the eager launches Engine.dp_prefers_eager
-    chooses there -- against the single-process step of `other_workloads`."""
+    N-rank entry with one rank) -- its own RCCL life cycle and the launch mode Engine.dp_prefers_eager chooses for the shape
+    (eager at wd-articles, segment graphs at wd-movies) -- against the single-process step of `other_workloads`."""
     import subprocess
     out = {}
-    for wl, nt in (("wd-movies", 60), ("wd-articles", 20)):
+    # (settle steps: the first ~100 steps of a fresh process run 10 % slower at wd-movies -- 2.13 ms after 20, 1.92 after 100 or 300)
+    for wl, nt, ns in (("wd-movies", 100, 100), ("wd-articles", 30, 30)):
         try:
             p_ms = plain[wl]["ms_per_step"]
             cmd = [sys.executable, os.path.abspath(__file__), "--force-dist", "--workload", wl, "--no-other", "--no-cpu-baseline",
-                   "--steps", str(nt), "--warmup", "10", "--settle", "20", "--precision", args.precision, "--dropout", str(args.dropout)]
+                   "--steps", str(nt), "--warmup", "10", "--settle", str(ns), "--precision", args.precision, "--dropout", str(args.dropout)]
             env = dict(os.environ, MASTER_PORT=str(29600 + (os.getpid() % 300)))
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             ms = d["ms_per_step"]
             out[wl] = {"plain_ms_per_step": p_ms, "dp_ms_per_step": ms, "ratio": ms / p_ms, "steps": nt,
-                       "launch": "eager (Engine.dp_prefers_eager: the sweep workloads)"}
+                       "launch": d.get("config", {}).get("launch")}
             log(f"dp schedule on one rank, {wl}: {ms:.3f} ms/step = {ms / p_ms:.3f} x plain")
         except Exception as e:   # a diagnostic leg must never take the headline line down
             out[wl] = {"error": repr(e)}
@@ -617,7 +619,8 @@ def main():
             "data": f"synthetic (IntelliGraphs {args.workload}-shaped, uniform ids; random-init weights)",
             "config": {"workload": f"autoreg_{args.workload} SAIL train step (H2D+fwd+ELBO+bwd+Adam)", "batch_per_gpu": B,
                        "global_batch": Bg, "d_model": cfg["d_model"], "d_latent": cfg["d_latent"], "n_layers": 3, "seq_len": cfg["seq_len"],
-                       "vocab": cfg["vocab_size"], "dec_dropout": args.dropout, "hipgraph": not args.no_graph, "settle_steps": args.settle,
+                       "vocab": cfg["vocab_size"], "dec_dropout": args.dropout, "hipgraph": not run["eager"],
+                       "launch": "eager" if run["eager"] else "hipGraph replay", "settle_steps": args.settle,
                        "h2d_bytes_per_step": h2d_bytes,
                        "h2d": "inside the timed region and on the dependent chain, every step (pinned host -> device on the run queue)",
                        "parallelism": f"dp{world}"},
