@@ -50,6 +50,49 @@ __device__ __forceinline__ int s_select32(int cond, int a, int b) {
   return r;
 }
 
+// ds_read_b64_tr_b16 through inline asm, for kernels whose LDS is filled by LDS-DMA.  The compiler's builtin
+// (__builtin_amdgcn_ds_read_tr16_b64_*) reaches the waitcnt pass without a memory operand it could prove disjoint from the
+// LDS-DMA destinations in flight, so the pass puts `s_waitcnt vmcnt(0)` in front of the first such read of every stage: the
+// whole ring is drained, including the stage issued a moment ago, and a ring of any depth runs as if it had one slot
+// (tools/isa_dma_waits.py lists these waits; round 5 found them in wgrad16, vocab_ce fwd and vocab_ce dw).
+// The asm form hands back registers the compiler believes READY: tr_wait<N>() -- s_waitcnt lgkmcnt(N) and a tie on every
+// register it covers -- has to sit between a read and the first use of its result (any use: a register copy counts).
+// N = reads issued AFTER the ones waited for that may stay in flight (LDS returns in order; extra LDS operations of the
+// compiler's own in the queue only make a counted wait stricter).
+typedef short tr16x4 __attribute__((ext_vector_type(4)));
+typedef short tr16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned lds_addr(const char* p) {   // byte address inside the workgroup's LDS
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF = 0>
+__device__ __forceinline__ tr16x4 lds_tr16(unsigned a) {
+  tr16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF = 0>
+__device__ __forceinline__ tr16x4 lds_tr16(const char* p) { return lds_tr16<OFF>(lds_addr(p)); }
+// a plain 16-byte fragment read in the same un-waited form (for loops that pipeline their fragment reads by hand: left to
+// the compiler, a read of a DMA-filled image was issued, waited for -- lgkmcnt(0) -- and used one at a time)
+template <int OFF = 0>
+__device__ __forceinline__ f32x4 lds_b128(unsigned a) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void tr_wait_cnt() {
+  static_assert(N >= 0, "count");
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory");
+}
+__device__ __forceinline__ void tr_tie(tr16x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void tr_tie(f32x4& v) { asm volatile("" : "+v"(v)); }
+template <class H8>
+__device__ __forceinline__ H8 tr_join(tr16x4 lo, tr16x4 hi) {
+  const tr16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(H8, v);
+}
+
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
   (f(std::integral_constant<int, I>{}), ...);
@@ -57,6 +100,26 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// NI un-waited LDS reads-and-uses, the reads G items ahead of their uses in two register sets:
+//   req(item, set, slot) issues the RPI asm reads of `item` into slot `slot` of set `set` (all three integral_constants);
+//   use(item, set, slot) ties those registers (tr_tie) and consumes them.
+template <int NI, int G, int RPI, class Req, class Use>
+__device__ __forceinline__ void lds_pipeline(Req&& req, Use&& use) {
+  static_assert(NI % G == 0, "items per group");
+  constexpr int NG = NI / G;
+  static_for<G>([&](auto t) { req(t, std::integral_constant<int, 0>{}, t); });
+  static_for<NG>([&](auto g) {
+    if constexpr (g + 1 < NG) {
+      static_for<G>([&](auto t) { req(std::integral_constant<int, (g + 1) * G + t>{}, std::integral_constant<int, (g + 1) & 1>{}, t); });
+      tr_wait_cnt<RPI * G>();
+    } else {
+      tr_wait_cnt<0>();
+    }
+    static_for<G>([&](auto t) { use(std::integral_constant<int, g * G + t>{}, std::integral_constant<int, g & 1>{}, t); });
+    __builtin_amdgcn_sched_barrier(0);
+  });
 }
 
 template <int PREC, int BM, int BN, int NBUF, int WGM, int WGN, int KI = 1>

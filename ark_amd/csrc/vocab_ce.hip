@@ -72,39 +72,98 @@ __device__ __forceinline__ void vc_issue_stage(const T* src, int D, RM rowmap, c
   }
 }
 
-// transposed fragment for the second product: element j of lane (i16 = lane&15, q = lane>>4) = image[row(q, j)][16*dt + i16]
-// with row(q, j) = rbase + 16*(j>>2) + 4q + (j&3)
-template <class H8>
-__device__ __forceinline__ H8 vc_tr_frag(const char* img0, int rbase, int dt, int lane) {
-  const int i16 = lane & 15, q = lane >> 4;
-  const int row = rbase + 4 * q + (i16 >> 2);
-  const int chunk = 2 * (dt & 3) + ((i16 & 3) >> 1), within = (i16 & 1) * 8;
-  const char* b = img0 + (dt >> 2) * kVcImg;
-  const vs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) vs16x4*)(b + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + within));
-  const int row2 = row + 16;
-  const vs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) vs16x4*)(b + row2 * 128 + ((chunk ^ ((row2 >> 1) & 7)) << 4) + within));
-  const vs16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(H8, v);
+// Both products of both kernels read their LDS operand through inline asm (lds_b128 / lds_tr16, dma_core.h), G fragments
+// ahead of the matrix instructions that consume them.  (Round 5.  The builtin transposed read drained the LDS-DMA ring at
+// every stage -- the waitcnt pass put vmcnt(0) in front of it -- and the compiler scheduled the plain reads of the first
+// product as read, lgkmcnt(0), one MFMA: every fragment paid its full LDS latency.)
+//
+// First product: S[b][t] += F(b, t, ks) x reg[ks] over the KSTEPS 32-wide steps of the model dimension; F = the plain
+// fragment (16 image rows `row0 + 16 t`, chunk 4 (ks & 1) + q of image ks >> 1) of block b.  a_even / a_odd: the lane's
+// byte address for even / odd ks in block 0, image 0, t = 0 (the swizzle folds the odd step's chunk bit into bit 6).
+template <class PT, int KSTEPS, int TM, int BLK, int G>
+__device__ __forceinline__ void vc_first_product(unsigned a_even, unsigned a_odd, const typename PT::h8 (&reg)[KSTEPS], f32x4 (&S)[TM][2]) {
+  using h8 = typename PT::h8;
+  f32x4 f[2][G];
+  lds_pipeline<KSTEPS * TM * 2, G, 1>(
+      [&](auto i, auto set, auto slot) {   // item i: ks = i / (2 TM), block (i / 2) % TM, t = i & 1
+        constexpr int ks = i / (2 * TM), b = (i / 2) % TM, t = i & 1;
+        f[set][slot] = lds_b128<b * BLK + (ks >> 1) * kVcImg + t * 2048>((ks & 1) ? a_odd : a_even);
+      },
+      [&](auto i, auto set, auto slot) {
+        constexpr int ks = i / (2 * TM), b = (i / 2) % TM, t = i & 1;
+        tr_tie(f[set][slot]);
+        S[b][t] = PT::mfma(__builtin_bit_cast(h8, f[set][slot]), reg[ks], S[b][t]);
+      });
 }
+// Second product: acc[dt] += sum over blocks b of F(b, dt) x bf[b] for the DT 16-wide tiles of the model dimension; F = the
+// TRANSPOSED fragment: element j of lane (i16 = lane&15, q = lane>>4) = image[row(q, j)][16*dt + i16] with
+// row(q, j) = rbase + 16*(j>>2) + 4q + (j&3) (two ds_read_b64_tr_b16, 16 image rows = 2048 B apart: same swizzle key).
+// a4[m]: the lane's byte address for tiles with dt & 3 == m in block 0, image 0.
+template <class PT, int DT, int NB, int BLK, int G>
+__device__ __forceinline__ void vc_second_product(const unsigned (&a4)[4], const typename PT::h8 (&bf)[NB], f32x4 (&acc)[DT]) {
+  using h8 = typename PT::h8;
+  tr16x4 f[2][G][2];
+  lds_pipeline<DT * NB, G, 2>(
+      [&](auto i, auto set, auto slot) {   // item i = (block i / DT, tile i % DT): consecutive products, different accumulators
+        constexpr int b = i / DT, dt = i % DT;
+        f[set][slot][0] = lds_tr16<b * BLK + (dt >> 2) * kVcImg>(a4[dt & 3]);
+        f[set][slot][1] = lds_tr16<b * BLK + (dt >> 2) * kVcImg + 2048>(a4[dt & 3]);
+      },
+      [&](auto i, auto set, auto slot) {
+        constexpr int b = i / DT, dt = i % DT;
+        tr_tie(f[set][slot][0]);
+        tr_tie(f[set][slot][1]);
+        acc[dt] = PT::mfma(tr_join<h8>(f[set][slot][0], f[set][slot][1]), bf[b], acc[dt]);
+      });
+}
+// the lane's fragment addresses inside the stage image at `base` (both kernels: `half` = the 32-row half of a block it works on)
+struct VcFragAddr { unsigned even, odd, tr[4]; };
+__device__ __forceinline__ VcFragAddr vc_frag_addr(const char* base, int half, int lane) {
+  VcFragAddr r;
+  const int c = lane & 15, q = lane >> 4;
+  const int row = half * 32 + c;   // first product: image row of fragment t = 0
+  const unsigned b0 = lds_addr(base);
+  r.even = b0 + row * 128 + (((q ^ (row >> 1)) & 7) << 4);
+  r.odd = b0 + row * 128 + ((((q ^ (row >> 1)) & 7) ^ 4) << 4);
+  const int rowt = half * 32 + 4 * q + (c >> 2);   // second product
+  const int key = (rowt >> 1) & 7, c0 = (c & 3) >> 1;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) r.tr[m] = b0 + rowt * 128 + (c & 1) * 8 + (((2 * m + c0) ^ key) << 4);
+  return r;
+}
+// fragments requested ahead: as many as the registers allow (D = 512 keeps 192 of a wave's 256 in accumulators and its row;
+// workgroups of more than 8 waves put three waves on a SIMD: 168 registers each)
+template <int DT, int NW> constexpr int vc_frag_group() { return DT >= 32 ? 2 : NW > 8 ? (DT >= 16 ? 2 : 4) : (DT >= 16 ? 4 : 8); }
 
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
 // ONE barrier per stage (round 4): the barrier that publishes stage s also says every wave has finished reading stage s - 1,
-// whose slot is refilled at once (NSLOT - 1 stages in flight, as before) -- the second barrier of the loop and the LDS drain
-// in front of it are gone.  At D = 128 a stage is ~0.3 us of matrix work and the loop was bound by its fixed cost per stage.
+// whose slot is refilled at once (NSLOT - 1 stages in flight) -- no second barrier, no LDS drain in front of it.
 // (Measured and not kept: the refill's pieces spread over the first product's k-steps instead of issued as one block behind
 // the barrier -- wd-articles forward 1.97 -> 2.02 ms, weight gradient 1.75 -> 1.91 ms: a piece between MFMAs stalls its wave
 // with LDS reads queued behind it.)
-#ifndef ARK_VC_ONEBAR
-#define ARK_VC_ONEBAR 1
-#endif
 
-// ring depth by model width: a stage is 64 rows x D 16-bit elements (8 KB per 64 of D); narrow models afford four slots
-// -- three stages in flight per workgroup -- and need them: at D = 128 a step is ~0.3 us of matrix work behind ~1 us of
-// LDS-DMA latency with one stage in flight
-template <int DCH> constexpr int vc_slots() { return DCH <= 2 ? 4 : DCH <= 4 ? 3 : 2; }
+// A stage is TM blocks of 64 rows of the streamed operand (64 tokens of W_tok forward, 64 rows of y in the weight gradient),
+// each DCH k-images.  Round 5: narrow models take SEVERAL blocks per stage -- at D = 128 a 64-row stage is 16 products per
+// wave between two barriers, behind a fixed cost per stage (barrier, the cross-lane maximum, waits for fragments that have
+// nothing to overlap with) several times as long; with TM blocks a wave has 2 TM independent accumulator chains in the
+// first product and one maximum / one barrier per 64 TM rows.  D = 512 keeps TM = 1 (registers: 192 of a wave's 256 hold
+// accumulators and its row).
+#ifndef ARK_VC_TM_CAP
+#define ARK_VC_TM_CAP 4
+#endif
+constexpr int vc_tm_cap(int dch) { return (dch <= 2 ? 4 : dch <= 4 ? 2 : 1) < ARK_VC_TM_CAP ? (dch <= 2 ? 4 : dch <= 4 ? 2 : 1) : ARK_VC_TM_CAP; }
+// ring depth by stage size (8 KB per image): small stages afford four slots -- three in flight per workgroup
+constexpr int vc_slots(int imgs) { return imgs <= 2 ? 4 : imgs <= 4 ? 3 : 2; }
+constexpr int vc_ring_bytes(int dch, int nw, int aux_per_wave, int tm) {
+  return vc_slots(dch * tm) * (tm * dch * kVcImg + nw * tm * aux_per_wave);
+}
+// blocks per stage: the most the cap and the 160 KB of LDS allow for NW waves with `aux_per_wave` bytes of side data per block
+constexpr int vc_tm(int dch, int nw, int aux_per_wave) {
+  int tm = vc_tm_cap(dch);
+  while (tm > 1 && vc_ring_bytes(dch, nw, aux_per_wave, tm) > 160 * 1024) tm /= 2;
+  return tm;
+}
 
 // wait until all but the youngest `k` stages (LPS LDS-DMA instructions each) of this wave have landed
 template <int LPS>
@@ -127,8 +186,10 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   using h8 = typename PT::h8;
   constexpr int D = 64 * DCH, KSTEPS = D / 32, DT = D / 16;
   constexpr int NW = 2 * RG;
-  constexpr int STAGE = DCH * kVcImg, SLOT = STAGE + NW * kVcAux, LPS = (8 * DCH + NW - 1) / NW + 1;
-  constexpr int NSLOT = vc_slots<DCH>();
+  constexpr int TM = vc_tm(DCH, NW, kVcAux), TS = 64 * TM;   // blocks / tokens per stage
+  constexpr int BLOCK = DCH * kVcImg, STAGE = TM * BLOCK, SLOT = STAGE + NW * TM * kVcAux;
+  constexpr int LPS = TM * ((8 * DCH + NW - 1) / NW + 1);
+  constexpr int NSLOT = vc_slots(DCH * TM);
   static_assert((NSLOT - 1) * LPS <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -162,18 +223,21 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
 
   // the workgroups of blockIdx.y = vs sweep the tiles [s0, s1) of the vocabulary (gridDim.y > 1: few row blocks, e.g. 160 at
   // wd-articles B = 16 -- the splits fill the other CUs; partial results meet in vocab_ce_combine_kernel)
-  const int nsteps = (V + 63) / 64;
+  const int nsteps = (V + TS - 1) / TS;
   const int s0 = (int)((long)nsteps * vs / NV), s1 = (int)((long)nsteps * (vs + 1) / NV);
   auto issue = [&](int s) {
     char* slot = smem + ((s - s0) % NSLOT) * SLOT;
-    const int v0 = s * 64;
-    vc_issue_stage<DCH, NW>(W, D, [=](int row) { return min(v0 + row, V - 1); }, slot, wave, lane);
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + min(v0 + ln, V - 1)),
-                                     (__attribute__((address_space(3))) void*)(slot + STAGE + wave * kVcAux), 4, 0, 0);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const int v0 = s * TS + 64 * b;
+      vc_issue_stage<DCH, NW>(W, D, [=](int row) { return min(v0 + row, V - 1); }, slot + b * BLOCK, wave, lane);
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + min(v0 + ln, V - 1)),
+                                       (__attribute__((address_space(3))) void*)(slot + STAGE + (wave * TM + b) * kVcAux), 4, 0, 0);
+    }
   };
-  for (int s = s0; s < s0 + NSLOT - ARK_VC_ONEBAR && s < s1; ++s) issue(s);
+  for (int s = s0; s < s0 + NSLOT - 1 && s < s1; ++s) issue(s);
 
   float m2 = -INFINITY, lsum = 0.f, picked = 0.f;   // running max (log2 domain), this LANE's partial sum, target logit
   f32x4 U[WITH_DY ? DT : 1];
@@ -182,73 +246,58 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
     for (int dt = 0; dt < DT; ++dt) U[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (int s = s0; s < s1; ++s) {
-    vc_wait_stages<LPS>(min(NSLOT - 1 - ARK_VC_ONEBAR, s1 - 1 - s));
+    vc_wait_stages<LPS>(min(NSLOT - 2, s1 - 1 - s));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-#if ARK_VC_ONEBAR
     if (s + NSLOT - 1 < s1) issue(s + NSLOT - 1);   // into the slot of stage s - 1: every wave is past its reads of it
-#endif
     const char* base = smem + ((s - s0) % NSLOT) * SLOT;
-    f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // this wave's tokens of the stage: the half vh (32 tokens) of each of its TM blocks
+    f32x4 S[TM][2];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-#pragma unroll
-      for (int vt = 0; vt < 2; ++vt) {
-        const h8 a = *reinterpret_cast<const h8*>(base + (ks >> 1) * kVcImg + lds_off(vh * 32 + 16 * vt + c, 4 * (ks & 1) + q));
-        S[vt] = PT::mfma(a, yf[ks], S[vt]);
-      }
-    }
-    const float* bw = reinterpret_cast<const float*>(base + STAGE + wave * kVcAux);
-    float sv[8];
+    for (int b = 0; b < TM; ++b) S[b][0] = S[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const VcFragAddr fa = vc_frag_addr(base, vh, lane);
+    vc_first_product<PT, KSTEPS, TM, BLOCK, vc_frag_group<DT, NW>()>(fa.even, fa.odd, yf, S);
+    const float* bw = reinterpret_cast<const float*>(base + STAGE + wave * TM * kVcAux);
+    constexpr int NE = 8 * TM;   // logits of this lane's row in the stage; element e = (block e >> 3, j = e & 7)
+    auto tok_of = [&](int e) { return 64 * (e >> 3) + vh * 32 + 16 * ((e & 7) >> 2) + 4 * q + (e & 3); };   // token inside the stage
+    float sv[NE];
     float mt = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int vloc = vh * 32 + 16 * (j >> 2) + 4 * q + (j & 3);
-      sv[j] = (S[j >> 2][j & 3] + bw[vloc]) * kLog2e;
-    }
+    for (int e = 0; e < NE; ++e) sv[e] = (S[e >> 3][(e & 7) >> 2][e & 3] + bw[tok_of(e)]) * kLog2e;
     // two rare cases, each behind a wave-uniform branch so that the common step pays nothing per element:
-    // the last tile reaches past V; some row's target token lives in this tile
+    // the last stage reaches past V; some row's target token lives in this stage
     if (s == nsteps - 1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (s * 64 + vh * 32 + 16 * (j >> 2) + 4 * q + (j & 3) >= V) sv[j] = -INFINITY;
+      for (int e = 0; e < NE; ++e)
+        if (s * TS + tok_of(e) >= V) sv[e] = -INFINITY;
     }
-    if (__any((int)(tgt >> 6) == s)) {
+    if (__any((int)(tgt / TS) == s)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if ((long)(s * 64 + vh * 32 + 16 * (j >> 2) + 4 * q + (j & 3)) == tgt) picked = sv[j];   // (log2 domain)
+      for (int e = 0; e < NE; ++e)
+        if ((long)(s * TS + tok_of(e)) == tgt) picked = sv[e];   // (log2 domain)
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) mt = fmaxf(mt, sv[j]);
+    for (int e = 0; e < NE; ++e) mt = fmaxf(mt, sv[e]);
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float mn = fmaxf(m2, mt);
-    const float ref = (mn == -INFINITY) ? 0.f : mn;     // (a half-tile beyond V has nothing to add)
+    const float ref = (mn == -INFINITY) ? 0.f : mn;     // (a stage half beyond V has nothing to add)
     const float scale = __builtin_amdgcn_exp2f(m2 - ref);   // m2 = -inf -> 0
-    float pj[8], ps = 0.f;
+    float ps = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { pj[j] = __builtin_amdgcn_exp2f(sv[j] - ref); ps += pj[j]; }
+    for (int e = 0; e < NE; ++e) { sv[e] = __builtin_amdgcn_exp2f(sv[e] - ref); ps += sv[e]; }
     lsum = lsum * scale + ps;
     if constexpr (WITH_DY) {
       if (__any(scale != 1.0f)) {   // wave-uniform: after the first tiles the running max rarely moves
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) U[dt] *= scale;
       }
-      h8 pf;
+      h8 pf[TM];   // (probabilities, <= 1: the plain conversion -- no saturation needed)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = PT::cvt(pj[j]);
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) U[dt] = PT::mfma(vc_tr_frag<h8>(base, vh * 32, dt, lane), pf, U[dt]);
+      for (int e = 0; e < NE; ++e) pf[e >> 3][e & 7] = (h_t)sv[e];
+      vc_second_product<PT, DT, TM, BLOCK, vc_frag_group<DT, NW>()>(fa.tr, pf, U);
     }
     m2 = mn;
-#if !ARK_VC_ONEBAR
-    if (s + NSLOT < s1) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      issue(s + NSLOT);
-    }
-#endif
   }
   // this lane's row sum over the 4 token quarters held by the lanes c, c+16, c+32, c+48
   lsum += __shfl_xor(lsum, 16, 64);
@@ -374,8 +423,10 @@ __global__ __launch_bounds__(128 * VG) void vocab_ce_dw_kernel(VocabCeArgs p) {
   using h8 = typename PT::h8;
   constexpr int D = 64 * DCH, KSTEPS = D / 32, DT = D / 16;
   constexpr int NW = 2 * VG;
-  constexpr int STAGE = DCH * kVcImg, SLOT = STAGE + NW * 2 * kVcAux, LPS = (8 * DCH + NW - 1) / NW + 2;   // per wave: lse[64] + target[64]
-  constexpr int NSLOT = vc_slots<DCH>();
+  constexpr int TM = vc_tm(DCH, NW, 2 * kVcAux), RS = 64 * TM;   // blocks / rows per stage
+  constexpr int BLOCK = DCH * kVcImg, STAGE = TM * BLOCK, SLOT = STAGE + NW * TM * 2 * kVcAux;   // per wave and block: lse[64] + target[64]
+  constexpr int LPS = TM * ((8 * DCH + NW - 1) / NW + 2);
+  constexpr int NSLOT = vc_slots(DCH * TM);
   static_assert((NSLOT - 1) * LPS <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -394,81 +445,70 @@ __global__ __launch_bounds__(128 * VG) void vocab_ce_dw_kernel(VocabCeArgs p) {
   const float bv = (v < V) ? p.bias[vc] * kLog2e : -INFINITY;   // tokens past V (last tile): exp2(-inf) = 0, no target matches
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  const int nsteps = (R + 63) / 64;
+  const int nsteps = (R + RS - 1) / RS;
   auto issue = [&](int s) {
     char* slot = smem + (s % NSLOT) * SLOT;
-    const int r0 = s * 64;
-    vc_issue_stage<DCH, NW>(Y, D, [=](int row) { return min(r0 + row, R - 1); }, slot, wave, lane);
-    // per-wave side data of the stage's 64 rows: lse and the target token (low dword of the int64)
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int rr = min(r0 + ln, R - 1);
-    const int t = rr / B, b = rr % B;
-    char* aux = slot + STAGE + wave * 2 * kVcAux;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lse + rr),
-                                     (__attribute__((address_space(3))) void*)aux, 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.seq + (long)b * p.ld_seq + t + 1),
-                                     (__attribute__((address_space(3))) void*)(aux + kVcAux), 4, 0, 0);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const int r0 = s * RS + 64 * b;
+      vc_issue_stage<DCH, NW>(Y, D, [=](int row) { return min(r0 + row, R - 1); }, slot + b * BLOCK, wave, lane);
+      // per-wave side data of the block's 64 rows: lse and the target token (low dword of the int64)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int rr = min(r0 + ln, R - 1);
+      const int t = rr / B, bb = rr % B;
+      char* aux = slot + STAGE + (wave * TM + b) * 2 * kVcAux;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lse + rr),
+                                       (__attribute__((address_space(3))) void*)aux, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.seq + (long)bb * p.ld_seq + t + 1),
+                                       (__attribute__((address_space(3))) void*)(aux + kVcAux), 4, 0, 0);
+    }
   };
-  for (int s = 0; s < NSLOT - ARK_VC_ONEBAR && s < nsteps; ++s) issue(s);
+  for (int s = 0; s < NSLOT - 1 && s < nsteps; ++s) issue(s);
 
   f32x4 dWt[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) dWt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dbv = 0.f;
   for (int s = 0; s < nsteps; ++s) {
-    vc_wait_stages<LPS>(min(NSLOT - 1 - ARK_VC_ONEBAR, nsteps - 1 - s));
+    vc_wait_stages<LPS>(min(NSLOT - 2, nsteps - 1 - s));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-#if ARK_VC_ONEBAR
     if (s + NSLOT - 1 < nsteps) issue(s + NSLOT - 1);
-#endif
     const char* base = smem + (s % NSLOT) * SLOT;
-    f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // this wave's rows of the stage: the half rh (32 rows) of each of its TM blocks
+    f32x4 S[TM][2];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const h8 a = *reinterpret_cast<const h8*>(base + (ks >> 1) * kVcImg + lds_off(rh * 32 + 16 * rt + c, 4 * (ks & 1) + q));
-        S[rt] = PT::mfma(a, wf[ks], S[rt]);
-      }
-    }
-    const float* lw = reinterpret_cast<const float*>(base + STAGE + wave * 2 * kVcAux);
-    const int* tw = reinterpret_cast<const int*>(base + STAGE + wave * 2 * kVcAux + kVcAux);
-    h8 gf;
+    for (int b = 0; b < TM; ++b) S[b][0] = S[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const VcFragAddr fa = vc_frag_addr(base, rh, lane);
+    vc_first_product<PT, KSTEPS, TM, BLOCK, vc_frag_group<DT, NW>()>(fa.even, fa.odd, wf, S);
+    constexpr int NE = 8 * TM;   // element e = (block e >> 3, j = e & 7): row 64 (e >> 3) + rloc(e) of the stage
+    auto rloc_of = [&](int e) { return rh * 32 + 16 * ((e & 7) >> 2) + 4 * q + (e & 3); };
+    h8 gf[TM];
     // per row: c_r = -lse_r (log2 domain), -inf for rows whose target is PAD (their gradient is zero) and, in the last
     // stage only, for the clamped copies of the last row; the target of such rows is set to -1 so no token matches it
-    float cr[8];
-    int tg[8];
+    float cr[NE];
+    int tg[NE];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int rloc = rh * 32 + 16 * (j >> 2) + 4 * q + (j & 3);
-      const int t0 = tw[rloc];
+    for (int e = 0; e < NE; ++e) {
+      const char* aux = base + STAGE + (wave * TM + (e >> 3)) * 2 * kVcAux;
+      const int t0 = reinterpret_cast<const int*>(aux + kVcAux)[rloc_of(e)];
       const bool dead = t0 == ARK_TOK_PAD;
-      cr[j] = dead ? -INFINITY : -lw[rloc] * kLog2e;
-      tg[j] = dead ? -1 : t0;
+      cr[e] = dead ? -INFINITY : -reinterpret_cast<const float*>(aux)[rloc_of(e)] * kLog2e;
+      tg[e] = dead ? -1 : t0;
     }
     if (s == nsteps - 1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (s * 64 + rh * 32 + 16 * (j >> 2) + 4 * q + (j & 3) >= R) { cr[j] = -INFINITY; tg[j] = -1; }
+      for (int e = 0; e < NE; ++e)
+        if (s * RS + 64 * (e >> 3) + rloc_of(e) >= R) { cr[e] = -INFINITY; tg[e] = -1; }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float g = __builtin_amdgcn_exp2f(__builtin_fmaf(S[j >> 2][j & 3], kLog2e, bv + cr[j])) - (tg[j] == v ? 1.0f : 0.f);
+    for (int e = 0; e < NE; ++e) {
+      const float g = __builtin_amdgcn_exp2f(__builtin_fmaf(S[e >> 3][(e & 7) >> 2][e & 3], kLog2e, bv + cr[e])) - (tg[e] == v ? 1.0f : 0.f);
       dbv += g;
-      gf[j] = PT::cvt(g);
+      gf[e >> 3][e & 7] = (h_t)g;   // (|g| <= 1: the plain conversion)
     }
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) dWt[dt] = PT::mfma(vc_tr_frag<h8>(base, rh * 32, dt, lane), gf, dWt[dt]);
-#if !ARK_VC_ONEBAR
-    if (s + NSLOT < nsteps) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      issue(s + NSLOT);
-    }
-#endif
+    vc_second_product<PT, DT, TM, BLOCK, vc_frag_group<DT, NW>()>(fa.tr, gf, dWt);
   }
   dbv += __shfl_xor(dbv, 16, 64);
   dbv += __shfl_xor(dbv, 32, 64);
@@ -501,7 +541,7 @@ static void vc_allow_lds(K kernel, int bytes) {
 
 template <int DCH, int NG>
 constexpr int vc_lds_bytes(int aux_per_wave) {
-  const int ring = vc_slots<DCH>() * (DCH * kVcImg + 2 * NG * aux_per_wave);
+  const int ring = vc_ring_bytes(DCH, 2 * NG, aux_per_wave, vc_tm(DCH, 2 * NG, aux_per_wave));
   const int comb = NG * (64 * DCH / 16) * 64 * 16 + NG * 3 * 64 * 4;
   return ring > comb ? ring : comb;
 }

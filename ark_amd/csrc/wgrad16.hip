@@ -131,17 +131,16 @@ __global__ __launch_bounds__(64 * NWV_) void wgrad16_kernel(Wgrad16Group grp) {
 
   // fragment addressing: lane = 16*g + 4*q + pp  ->  k-row 8g+q (+4), columns 4pp..4pp+3 of the 16-wide block
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-  auto frag = [&](const char* op, int s2, int col0) -> typename PT::h8 {
+  // (inline-asm reads: see lds_tr16 in dma_core.h -- the builtin gets an s_waitcnt vmcnt(0) in front of the first read of every
+  //  stage, which drains the ring: 101 us for the GRU group whatever the ring depth or wave layout)
+  auto frag = [&](const char* op, int s2, int col0, tr16x4& lo, tr16x4& hi) {
     const int k1 = 32 * s2 + 8 * g + q, k2 = k1 + 4;
     const int cb = (col0 * 2) / 16 + (pp >> 1);         // logical 16-B chunk of this lane's 8 bytes
     const int sub = (pp & 1) * 8;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(op + k1 * RB + ((cb ^ (tr_sw<RB>(k1) << 1)) << 4) + sub));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(op + k2 * RB + ((cb ^ (tr_sw<RB>(k2) << 1)) << 4) + sub));
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(typename PT::h8, v);
+    lo = lds_tr16(op + k1 * RB + ((cb ^ (tr_sw<RB>(k1) << 1)) << 4) + sub);
+    hi = lds_tr16(op + k2 * RB + ((cb ^ (tr_sw<RB>(k2) << 1)) << 4) + sub);
   };
+  using h8 = typename PT::h8;
 
   if (NS > 0) {
     const int pre = NS < NBUF ? NS : NBUF;
@@ -158,17 +157,32 @@ __global__ __launch_bounds__(64 * NWV_) void wgrad16_kernel(Wgrad16Group grp) {
       __builtin_amdgcn_sched_barrier(0);
       const char* opA = smem + (s % NBUF) * STAGE;
       const char* opB = opA + OP_BYTES;
+      // both 32-k halves of the stage are requested at once; the second half's reads land under the first half's products
+      tr16x4 fa[2][TA][2], fb[2][TB][2];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        typename PT::h8 a[TA], b[TB];
 #pragma unroll
-        for (int t = 0; t < TA; ++t) a[t] = frag(opA, s2, wm * WTM + t * 16);
+        for (int t = 0; t < TA; ++t) frag(opA, s2, wm * WTM + t * 16, fa[s2][t][0], fa[s2][t][1]);
 #pragma unroll
-        for (int t = 0; t < TB; ++t) b[t] = frag(opB, s2, wn * WTN + t * 16);
+        for (int t = 0; t < TB; ++t) frag(opB, s2, wn * WTN + t * 16, fb[s2][t][0], fb[s2][t][1]);
+      }
 #pragma unroll
-        for (int ta = 0; ta < TA; ++ta)
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (s2 == 0) tr_wait_cnt<2 * (TA + TB)>(); else tr_wait_cnt<0>();
 #pragma unroll
-          for (int tb = 0; tb < TB; ++tb) acc[ta][tb] = PT::mfma(a[ta], b[tb], acc[ta][tb]);
+        for (int t = 0; t < TA; ++t) { tr_tie(fa[s2][t][0]); tr_tie(fa[s2][t][1]); }
+#pragma unroll
+        for (int t = 0; t < TB; ++t) { tr_tie(fb[s2][t][0]); tr_tie(fb[s2][t][1]); }
+        h8 b[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) b[t] = tr_join<h8>(fb[s2][t][0], fb[s2][t][1]);
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta) {
+          const h8 a = tr_join<h8>(fa[s2][ta][0], fa[s2][ta][1]);
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb) acc[ta][tb] = PT::mfma(a, b[tb], acc[ta][tb]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (the first half's products stay in front of the second wait)
       }
       if (s + NBUF < NS) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
