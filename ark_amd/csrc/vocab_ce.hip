@@ -72,6 +72,36 @@ __device__ __forceinline__ void vc_issue_stage(const T* src, int D, RM rowmap, c
   }
 }
 
+// The same pieces for a block whose 64 rows all exist (every block but the last of the launch), from per-lane byte offsets
+// computed ONCE (models up to D = 256 have the registers): one instruction per piece -- the row clamp, the swizzle and the
+// 64-bit address arithmetic of vc_issue_stage were ~13 vector instructions per piece, 120 per wave and stage at D = 128.
+template <int DCH, int NW>
+struct VcPieces {
+  static constexpr int NP = 8 * DCH, PPW = (NP + NW - 1) / NW;
+  unsigned off[PPW];
+  __device__ __forceinline__ void init(int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      int piece = wave + NW * i;
+      if (piece >= NP) piece = 0;
+      const int j = piece >> 3, pr = piece & 7;
+      const int row = 8 * pr + (lane >> 3);
+      off[i] = 2u * (unsigned)(row * (64 * DCH) + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7)));
+    }
+  }
+  // block = address of the block's first row (wave-uniform)
+  __device__ __forceinline__ void issue(const char* block, char* slot, int wave) const {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      int piece = wave + NW * i;
+      if (piece >= NP) piece = 0;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(block + off[i]),
+                                       (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+    }
+  }
+};
+template <int DCH> constexpr bool vc_fast_issue() { return DCH <= 4; }
+
 // Both products of both kernels read their LDS operand through inline asm (lds_b128 / lds_tr16, dma_core.h), G fragments
 // ahead of the matrix instructions that consume them.  (Round 5.  The builtin transposed read drained the LDS-DMA ring at
 // every stage -- the waitcnt pass put vmcnt(0) in front of it -- and the compiler scheduled the plain reads of the first
@@ -116,19 +146,29 @@ __device__ __forceinline__ void vc_second_product(const unsigned (&a4)[4], const
         acc[dt] = PT::mfma(tr_join<h8>(f[set][slot][0], f[set][slot][1]), bf[b], acc[dt]);
       });
 }
-// the lane's fragment addresses inside the stage image at `base` (both kernels: `half` = the 32-row half of a block it works on)
-struct VcFragAddr { unsigned even, odd, tr[4]; };
-__device__ __forceinline__ VcFragAddr vc_frag_addr(const char* base, int half, int lane) {
+// the lane's fragment addresses relative to a stage image (both kernels: `half` = the 32-row half of a block it works on);
+// at(b0): the addresses inside the image at LDS byte address b0
+struct VcFragAddr {
+  unsigned even, odd, tr[4];
+  __device__ __forceinline__ VcFragAddr at(unsigned b0) const {
+    VcFragAddr r;
+    r.even = even + b0;
+    r.odd = odd + b0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) r.tr[m] = tr[m] + b0;
+    return r;
+  }
+};
+__device__ __forceinline__ VcFragAddr vc_frag_addr(int half, int lane) {
   VcFragAddr r;
   const int c = lane & 15, q = lane >> 4;
   const int row = half * 32 + c;   // first product: image row of fragment t = 0
-  const unsigned b0 = lds_addr(base);
-  r.even = b0 + row * 128 + (((q ^ (row >> 1)) & 7) << 4);
-  r.odd = b0 + row * 128 + ((((q ^ (row >> 1)) & 7) ^ 4) << 4);
+  r.even = row * 128 + (((q ^ (row >> 1)) & 7) << 4);
+  r.odd = row * 128 + ((((q ^ (row >> 1)) & 7) ^ 4) << 4);
   const int rowt = half * 32 + 4 * q + (c >> 2);   // second product
   const int key = (rowt >> 1) & 7, c0 = (c & 3) >> 1;
 #pragma unroll
-  for (int m = 0; m < 4; ++m) r.tr[m] = b0 + rowt * 128 + (c & 1) * 8 + (((2 * m + c0) ^ key) << 4);
+  for (int m = 0; m < 4; ++m) r.tr[m] = rowt * 128 + (c & 1) * 8 + (((2 * m + c0) ^ key) << 4);
   return r;
 }
 // fragments requested ahead: as many as the registers allow (D = 512 keeps 192 of a wave's 256 in accumulators and its row;
@@ -225,16 +265,26 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   // wd-articles B = 16 -- the splits fill the other CUs; partial results meet in vocab_ce_combine_kernel)
   const int nsteps = (V + TS - 1) / TS;
   const int s0 = (int)((long)nsteps * vs / NV), s1 = (int)((long)nsteps * (vs + 1) / NV);
+  VcPieces<DCH, NW> pieces;
+  if constexpr (vc_fast_issue<DCH>()) pieces.init(wave, lane);
+  const unsigned lane4 = 4u * lane;
   auto issue = [&](int s) {
     char* slot = smem + ((s - s0) % NSLOT) * SLOT;
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
       const int v0 = s * TS + 64 * b;
-      vc_issue_stage<DCH, NW>(W, D, [=](int row) { return min(v0 + row, V - 1); }, slot + b * BLOCK, wave, lane);
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + min(v0 + ln, V - 1)),
-                                       (__attribute__((address_space(3))) void*)(slot + STAGE + (wave * TM + b) * kVcAux), 4, 0, 0);
+      char* aux = slot + STAGE + (wave * TM + b) * kVcAux;
+      if (vc_fast_issue<DCH>() && v0 + 64 <= V) {
+        pieces.issue(reinterpret_cast<const char*>(W + (long)v0 * D), slot + b * BLOCK, wave);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(p.bias + v0) + lane4),
+                                         (__attribute__((address_space(3))) void*)aux, 4, 0, 0);
+      } else {
+        vc_issue_stage<DCH, NW>(W, D, [=](int row) { return min(v0 + row, V - 1); }, slot + b * BLOCK, wave, lane);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + min(v0 + ln, V - 1)),
+                                         (__attribute__((address_space(3))) void*)aux, 4, 0, 0);
+      }
     }
   };
   for (int s = s0; s < s0 + NSLOT - 1 && s < s1; ++s) issue(s);
@@ -245,25 +295,44 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) U[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  const VcFragAddr fo = vc_frag_addr(vh, lane);
+  // the bias of this lane's tokens: 4 consecutive floats per 16-token tile, at (vh * 32 + 16 * tile + 4 q) of the block's 64
+  const unsigned bias_off = STAGE + wave * TM * kVcAux + (vh * 32 + 4 * q) * 4;
   for (int s = s0; s < s1; ++s) {
     vc_wait_stages<LPS>(min(NSLOT - 2, s1 - 1 - s));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (s + NSLOT - 1 < s1) issue(s + NSLOT - 1);   // into the slot of stage s - 1: every wave is past its reads of it
-    const char* base = smem + ((s - s0) % NSLOT) * SLOT;
+    const unsigned sb = lds_addr(smem + ((s - s0) % NSLOT) * SLOT);
+    const VcFragAddr fa = fo.at(sb);
     // this wave's tokens of the stage: the half vh (32 tokens) of each of its TM blocks
+    // (requested in front of the first product's fragments, which wait for everything at their end -- where three waves share
+    //  a SIMD and its registers, behind it)
+    f32x4 bq[TM][2];
+    auto request_bias = [&]() {
+      static_for<TM>([&](auto b) {
+        bq[b][0] = lds_b128<b * kVcAux>(sb + bias_off);
+        bq[b][1] = lds_b128<b * kVcAux + 64>(sb + bias_off);
+      });
+    };
+    constexpr bool kBiasEarly = NW <= 8;
+    if constexpr (kBiasEarly) request_bias();
     f32x4 S[TM][2];
 #pragma unroll
     for (int b = 0; b < TM; ++b) S[b][0] = S[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const VcFragAddr fa = vc_frag_addr(base, vh, lane);
     vc_first_product<PT, KSTEPS, TM, BLOCK, vc_frag_group<DT, NW>()>(fa.even, fa.odd, yf, S);
-    const float* bw = reinterpret_cast<const float*>(base + STAGE + wave * TM * kVcAux);
+    if constexpr (!kBiasEarly) { request_bias(); tr_wait_cnt<0>(); }
     constexpr int NE = 8 * TM;   // logits of this lane's row in the stage; element e = (block e >> 3, j = e & 7)
     auto tok_of = [&](int e) { return 64 * (e >> 3) + vh * 32 + 16 * ((e & 7) >> 2) + 4 * q + (e & 3); };   // token inside the stage
-    float sv[NE];
-    float mt = -INFINITY;
+    float sv[NE];   // logit (natural units) until the maximum is known, then the probability relative to it
 #pragma unroll
-    for (int e = 0; e < NE; ++e) sv[e] = (S[e >> 3][(e & 7) >> 2][e & 3] + bw[tok_of(e)]) * kLog2e;
+    for (int b = 0; b < TM; ++b) {
+      tr_tie(bq[b][0]);
+      tr_tie(bq[b][1]);
+      const f32x4 t0 = S[b][0] + bq[b][0], t1 = S[b][1] + bq[b][1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sv[8 * b + i] = t0[i]; sv[8 * b + 4 + i] = t1[i]; }
+    }
     // two rare cases, each behind a wave-uniform branch so that the common step pays nothing per element:
     // the last stage reaches past V; some row's target token lives in this stage
     if (s == nsteps - 1) {
@@ -274,18 +343,19 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
     if (__any((int)(tgt / TS) == s)) {
 #pragma unroll
       for (int e = 0; e < NE; ++e)
-        if ((long)(s * TS + tok_of(e)) == tgt) picked = sv[e];   // (log2 domain)
+        if ((long)(s * TS + tok_of(e)) == tgt) picked = sv[e] * kLog2e;   // (log2 domain)
     }
+    float mt = -INFINITY;
 #pragma unroll
     for (int e = 0; e < NE; ++e) mt = fmaxf(mt, sv[e]);
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float mn = fmaxf(m2, mt);
+    const float mn = fmaxf(m2, mt * kLog2e);
     const float ref = (mn == -INFINITY) ? 0.f : mn;     // (a stage half beyond V has nothing to add)
     const float scale = __builtin_amdgcn_exp2f(m2 - ref);   // m2 = -inf -> 0
     float ps = 0.f;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) { sv[e] = __builtin_amdgcn_exp2f(sv[e] - ref); ps += sv[e]; }
+    for (int e = 0; e < NE; ++e) { sv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[e], kLog2e, -ref)); ps += sv[e]; }
     lsum = lsum * scale + ps;
     if constexpr (WITH_DY) {
       if (__any(scale != 1.0f)) {   // wave-uniform: after the first tiles the running max rarely moves
@@ -443,25 +513,45 @@ __global__ __launch_bounds__(128 * VG) void vocab_ce_dw_kernel(VocabCeArgs p) {
 #pragma unroll
   for (int s = 0; s < KSTEPS; ++s) wf[s] = *reinterpret_cast<const h8*>(W + (long)vc * D + 32 * s + 8 * q);
   const float bv = (v < V) ? p.bias[vc] * kLog2e : -INFINITY;   // tokens past V (last tile): exp2(-inf) = 0, no target matches
+  // the token the one-hot term compares targets with: PAD rows carry target PAD and no gradient, so the lane that owns the PAD
+  // token must never match (tokens past V neither)
+  const int vmatch = (v < V && v != ARK_TOK_PAD) ? v : -2;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   const int nsteps = (R + RS - 1) / RS;
+  VcPieces<DCH, NW> pieces;
+  if constexpr (vc_fast_issue<DCH>()) pieces.init(wave, lane);
+  const unsigned lane4 = 4u * lane;
+  // row -> (t, b) = (row / B, row % B) by a multiply: exact while row * B < 2^32
+  const unsigned magic = (unsigned)((0x100000000ull + (unsigned)B - 1) / (unsigned)B);
+  const bool fast_ok = vc_fast_issue<DCH>() && (unsigned long long)R * (unsigned)B < 0x100000000ull && (unsigned long long)B * p.ld_seq < 0x20000000ull;
   auto issue = [&](int s) {
     char* slot = smem + (s % NSLOT) * SLOT;
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
       const int r0 = s * RS + 64 * b;
-      vc_issue_stage<DCH, NW>(Y, D, [=](int row) { return min(r0 + row, R - 1); }, slot + b * BLOCK, wave, lane);
       // per-wave side data of the block's 64 rows: lse and the target token (low dword of the int64)
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const int rr = min(r0 + ln, R - 1);
-      const int t = rr / B, bb = rr % B;
       char* aux = slot + STAGE + (wave * TM + b) * 2 * kVcAux;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lse + rr),
-                                       (__attribute__((address_space(3))) void*)aux, 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.seq + (long)bb * p.ld_seq + t + 1),
-                                       (__attribute__((address_space(3))) void*)(aux + kVcAux), 4, 0, 0);
+      if (fast_ok && r0 + 64 <= R) {
+        pieces.issue(reinterpret_cast<const char*>(Y + (long)r0 * D), slot + b * BLOCK, wave);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(p.lse + r0) + lane4),
+                                         (__attribute__((address_space(3))) void*)aux, 4, 0, 0);
+        const unsigned rr = (unsigned)r0 + (lane4 >> 2);
+        const unsigned t = __umulhi(rr, magic), bb = rr - t * (unsigned)B;
+        const unsigned idx = bb * (unsigned)p.ld_seq + t + 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(p.seq) + 8ull * idx),
+                                         (__attribute__((address_space(3))) void*)(aux + kVcAux), 4, 0, 0);
+      } else {
+        vc_issue_stage<DCH, NW>(Y, D, [=](int row) { return min(r0 + row, R - 1); }, slot + b * BLOCK, wave, lane);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int rr = min(r0 + ln, R - 1);
+        const int t = rr / B, bb = rr % B;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lse + rr),
+                                         (__attribute__((address_space(3))) void*)aux, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.seq + (long)bb * p.ld_seq + t + 1),
+                                         (__attribute__((address_space(3))) void*)(aux + kVcAux), 4, 0, 0);
+      }
     }
   };
   for (int s = 0; s < NSLOT - 1 && s < nsteps; ++s) issue(s);
@@ -470,43 +560,78 @@ __global__ __launch_bounds__(128 * VG) void vocab_ce_dw_kernel(VocabCeArgs p) {
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) dWt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dbv = 0.f;
+  const VcFragAddr fo = vc_frag_addr(rh, lane);
+  // lse / target of this lane's rows: 4 consecutive dwords per 16-row tile, at (rh * 32 + 16 * tile + 4 q) of the block's 64
+  const unsigned aux_off = STAGE + wave * TM * 2 * kVcAux + (rh * 32 + 4 * q) * 4;
+  constexpr bool kAuxEarly = NW <= 8;   // (three waves on a SIMD: no registers to hold the side data across the first product)
   for (int s = 0; s < nsteps; ++s) {
     vc_wait_stages<LPS>(min(NSLOT - 2, nsteps - 1 - s));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (s + NSLOT - 1 < nsteps) issue(s + NSLOT - 1);
-    const char* base = smem + (s % NSLOT) * SLOT;
+    const unsigned sb = lds_addr(smem + (s % NSLOT) * SLOT);
+    const VcFragAddr fa = fo.at(sb);
     // this wave's rows of the stage: the half rh (32 rows) of each of its TM blocks
+    f32x4 lq[TM][2], tq[TM][2];   // lse and targets (as raw dwords) of those rows
+    auto request_aux = [&]() {
+      static_for<TM>([&](auto b) {
+        lq[b][0] = lds_b128<b * 2 * kVcAux>(sb + aux_off);
+        lq[b][1] = lds_b128<b * 2 * kVcAux + 64>(sb + aux_off);
+        tq[b][0] = lds_b128<b * 2 * kVcAux + kVcAux>(sb + aux_off);
+        tq[b][1] = lds_b128<b * 2 * kVcAux + kVcAux + 64>(sb + aux_off);
+      });
+    };
+    if constexpr (kAuxEarly) request_aux();
     f32x4 S[TM][2];
 #pragma unroll
     for (int b = 0; b < TM; ++b) S[b][0] = S[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const VcFragAddr fa = vc_frag_addr(base, rh, lane);
     vc_first_product<PT, KSTEPS, TM, BLOCK, vc_frag_group<DT, NW>()>(fa.even, fa.odd, wf, S);
+    if constexpr (!kAuxEarly) { request_aux(); tr_wait_cnt<0>(); }
     constexpr int NE = 8 * TM;   // element e = (block e >> 3, j = e & 7): row 64 (e >> 3) + rloc(e) of the stage
     auto rloc_of = [&](int e) { return rh * 32 + 16 * ((e & 7) >> 2) + 4 * q + (e & 3); };
     h8 gf[TM];
-    // per row: c_r = -lse_r (log2 domain), -inf for rows whose target is PAD (their gradient is zero) and, in the last
-    // stage only, for the clamped copies of the last row; the target of such rows is set to -1 so no token matches it
-    float cr[NE];
+    // per row: lse_r, +inf for rows whose target is PAD (their gradient is zero) and, in the last stage only, for the
+    // clamped copies of the last row (whose target is set to -1 so that no token matches it)
+    float ls[NE];
     int tg[NE];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const char* aux = base + STAGE + (wave * TM + (e >> 3)) * 2 * kVcAux;
-      const int t0 = reinterpret_cast<const int*>(aux + kVcAux)[rloc_of(e)];
-      const bool dead = t0 == ARK_TOK_PAD;
-      cr[e] = dead ? -INFINITY : -reinterpret_cast<const float*>(aux)[rloc_of(e)] * kLog2e;
-      tg[e] = dead ? -1 : t0;
+    for (int b = 0; b < TM; ++b) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        tr_tie(lq[b][h]);
+        tr_tie(tq[b][h]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = 8 * b + 4 * h + i;
+          const float tbits = tq[b][h][i];   // (a copy first: __builtin_bit_cast on the vector ELEMENT read element 0 every time)
+          tg[e] = __builtin_bit_cast(int, tbits);
+          ls[e] = tg[e] == ARK_TOK_PAD ? INFINITY : lq[b][h][i];
+        }
+      }
     }
     if (s == nsteps - 1) {
 #pragma unroll
       for (int e = 0; e < NE; ++e)
-        if (s * RS + 64 * (e >> 3) + rloc_of(e) >= R) { cr[e] = -INFINITY; tg[e] = -1; }
+        if (s * RS + 64 * (e >> 3) + rloc_of(e) >= R) { ls[e] = INFINITY; tg[e] = -1; }
+    }
+    // G = softmax - onehot: exp2((S - lse) log2e + b log2e); the one-hot term is rare (a row's target among this wave's 16
+    // tokens) and sits behind a wave-uniform branch
+    float g[NE];
+    unsigned long long hit = 0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      g[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[e >> 3][(e & 7) >> 2][e & 3] - ls[e], kLog2e, bv));
+      hit |= __ballot(tg[e] == vmatch);
+    }
+    if (hit) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+        if (tg[e] == vmatch) g[e] -= 1.0f;
     }
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-      const float g = __builtin_amdgcn_exp2f(__builtin_fmaf(S[e >> 3][(e & 7) >> 2][e & 3], kLog2e, bv + cr[e])) - (tg[e] == v ? 1.0f : 0.f);
-      dbv += g;
-      gf[e >> 3][e & 7] = (h_t)g;   // (|g| <= 1: the plain conversion)
+      dbv += g[e];
+      gf[e >> 3][e & 7] = (h_t)g[e];   // (|g| <= 1: the plain conversion)
     }
     vc_second_product<PT, DT, TM, BLOCK, vc_frag_group<DT, NW>()>(fa.tr, gf, dWt);
   }
@@ -632,9 +757,10 @@ static int vc_launch_dw_vg(const VocabCeArgs& p, hipStream_t st) {
 template <int PREC, int DCH>
 static int vc_launch_dw(const VocabCeArgs& p, hipStream_t st) {
   // (wd-movies, V = 24 101, standalone: 547 / 551 / 924 / 507 us at 3 / 4 / 5 / 6 token groups: one full round of 252 workgroups wins)
-  switch (DCH >= 8 ? 4 : vc_groups((p.V + 15) / 16, DCH <= 2 ? 6 : 5)) {
+  // (D = 256 with 10 waves: 168 registers per wave do not hold two blocks per stage)
+  switch (DCH >= 8 ? 4 : vc_groups((p.V + 15) / 16, DCH <= 2 ? 6 : 4)) {
     case 3: return vc_launch_dw_vg<PREC, DCH, 3>(p, st);
-    case 5: if constexpr (DCH <= 4) return vc_launch_dw_vg<PREC, DCH, 5>(p, st); else break;
+    case 5: if constexpr (DCH <= 2) return vc_launch_dw_vg<PREC, DCH, 5>(p, st); else break;
     case 6: if constexpr (DCH <= 2) return vc_launch_dw_vg<PREC, DCH, 6>(p, st); else break;
     default: break;
   }
