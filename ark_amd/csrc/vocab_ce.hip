@@ -48,6 +48,12 @@ struct VocabCeArgs {
 };
 
 constexpr int kVcImg = 64 * 128;   // one k-image: 64 rows x 128 B (64 16-bit elements of the reduction index)
+// Swizzle of an image row's eight 16-byte chunks: physical chunk = logical chunk ^ vc_key(row).  Bits 1-2 of the row in bits
+// 1-2 of the key serve BOTH kinds of fragment read: the 16 lanes of a ds_read_b128 cycle (rows {0-3, 12-15} with chunk ch and
+// rows {4-11} with chunk ch + 1) land on 64 different banks, and so do the 32 lanes of a ds_read_b64_tr_b16 cycle (rows
+// r .. r + 7, four lanes per row on a 32-byte chunk pair).  Round 5; with the key (row >> 1) & 7 of the other kernels' images
+// rows r and r + 2 met on the same chunk pair in the transposed reads: SQ_LDS_BANK_CONFLICT = 30 % of the LDS cycles.
+__device__ __forceinline__ int vc_key(int row) { return row & 6; }
 constexpr int kVcAux = 256;        // per-wave side data of a stage: 64 dwords
 
 // issue one ring stage: DCH k-images of 64 rows = 8*DCH one-KB pieces, dealt round-robin over the NW waves (every wave
@@ -66,7 +72,7 @@ __device__ __forceinline__ void vc_issue_stage(const T* src, int D, RM rowmap, c
     if (piece >= NP) piece = 0;
     const int j = piece >> 3, pr = piece & 7;
     const int row = 8 * pr + (lane >> 3);
-    const T* g = src + (long)rowmap(row) * D + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+    const T* g = src + (long)rowmap(row) * D + 64 * j + 8 * ((lane & 7) ^ vc_key(row));
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
   }
@@ -86,7 +92,7 @@ struct VcPieces {
       if (piece >= NP) piece = 0;
       const int j = piece >> 3, pr = piece & 7;
       const int row = 8 * pr + (lane >> 3);
-      off[i] = 2u * (unsigned)(row * (64 * DCH) + 64 * j + 8 * ((lane & 7) ^ ((row >> 1) & 7)));
+      off[i] = 2u * (unsigned)(row * (64 * DCH) + 64 * j + 8 * ((lane & 7) ^ vc_key(row)));
     }
   }
   // block = address of the block's first row (wave-uniform)
@@ -163,10 +169,10 @@ __device__ __forceinline__ VcFragAddr vc_frag_addr(int half, int lane) {
   VcFragAddr r;
   const int c = lane & 15, q = lane >> 4;
   const int row = half * 32 + c;   // first product: image row of fragment t = 0
-  r.even = row * 128 + (((q ^ (row >> 1)) & 7) << 4);
-  r.odd = row * 128 + ((((q ^ (row >> 1)) & 7) ^ 4) << 4);
+  r.even = row * 128 + ((q ^ vc_key(row)) << 4);
+  r.odd = row * 128 + (((q ^ vc_key(row)) ^ 4) << 4);
   const int rowt = half * 32 + 4 * q + (c >> 2);   // second product
-  const int key = (rowt >> 1) & 7, c0 = (c & 3) >> 1;
+  const int key = vc_key(rowt), c0 = (c & 3) >> 1;
 #pragma unroll
   for (int m = 0; m < 4; ++m) r.tr[m] = rowt * 128 + (c & 1) * 8 + (((2 * m + c0) ^ key) << 4);
   return r;
