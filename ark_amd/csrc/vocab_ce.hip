@@ -265,7 +265,12 @@ __global__ __launch_bounds__(128 * RG) void vocab_ce_fwd_kernel(VocabCeArgs p) {
   const int t = rc / p.B, b = rc % p.B;
   const long tgt = p.seq[(long)b * p.ld_seq + t + 1];
   const bool live = r < R && tgt != ARK_TOK_PAD;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on only LDS-DMA is outstanding (counted waits)
+  // from here on only LDS-DMA is outstanding (counted waits); the loaded registers are used here so that the compiler's own
+  // wait for them is not an s_waitcnt vmcnt(0) at their first use inside the loop
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(yf[s]));
+  { long t2 = tgt; asm volatile("" : "+v"(t2)); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // the workgroups of blockIdx.y = vs sweep the tiles [s0, s1) of the vocabulary (gridDim.y > 1: few row blocks, e.g. 160 at
   // wd-articles B = 16 -- the splits fill the other CUs; partial results meet in vocab_ce_combine_kernel)
@@ -522,6 +527,12 @@ __global__ __launch_bounds__(128 * VG) void vocab_ce_dw_kernel(VocabCeArgs p) {
   // the token the one-hot term compares targets with: PAD rows carry target PAD and no gradient, so the lane that owns the PAD
   // token must never match (tokens past V neither)
   const int vmatch = (v < V && v != ARK_TOK_PAD) ? v : -2;
+  // From here on only LDS-DMA is outstanding (counted waits).  The registers loaded above are USED here, so the compiler's
+  // own wait for them lands here too: left to their first use inside the loop it would be an s_waitcnt vmcnt(0) per stage,
+  // which drains the ring (tools/isa_dma_waits.py).
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(wf[s]));
+  { float t = bv; asm volatile("" : "+v"(t)); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   const int nsteps = (R + RS - 1) / RS;
