@@ -31,15 +31,38 @@ struct Gemm16Args {
   float* colsum;   // optional: colsum[col] += sum over rows of the value written to C (bias gradient of a dpre output)
 };
 
-// epilogue of one 16 x 16 accumulator tile (MFMA C/D order: this lane holds rows row0 .. row0+3 of column col); returns the
-// lane's contribution to the column sum of what it wrote (bias gradient of a dpre output)
-__device__ __forceinline__ float g16_epilogue(const Gemm16Args& p, f32x4 v, int row0, int col) {
+// What the epilogue of one 16 x 16 accumulator tile READS per lane (MFMA C/D order: this lane holds rows row0 .. row0+3 of
+// column col): the aux / old-C values of its four elements and its column's bias.  The kernel gathers these for ALL of a
+// lane's tiles in front of its first store (round 5): read inside the per-element loop, each load sat behind the previous
+// element's store -- which may alias it as far as the compiler knows -- and the epilogue was a chain of TM x TN x 4 memory
+// round trips (s_waitcnt vmcnt(0) after every load), longer than the product itself for the encoder's K = 512 input gradients.
+struct G16Pre { f32x4 x; float bias; };
+__device__ __forceinline__ G16Pre g16_preload(const Gemm16Args& p, int row0, int col) {
+  G16Pre q{f32x4{0.f, 0.f, 0.f, 0.f}, 0.f};
+  const int M = p.M, N = p.N, epi = p.epi;
+  if (row0 >= M || col >= N) return q;
+  if (epi == ARK_EPI_BIAS || epi == ARK_EPI_BIAS_RELU || epi == ARK_EPI_BIAS_GELU) q.bias = p.bias[col];
+  if (p.c_tiled) {
+    if (epi == ARK_EPI_MUL_AUX) q.x = *reinterpret_cast<const f32x4*>(p.aux + tile_native_off(row0, col, (int)p.ldc));
+    return q;
+  }
+  const float* src = (epi == ARK_EPI_MUL_AUX || epi == ARK_EPI_MUL_DGELU || epi == ARK_EPI_MUL_RELU) ? p.aux : epi == ARK_EPI_ADD ? p.C : nullptr;
+  if (src) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (row0 + i < M) q.x[i] = src[(long)(row0 + i) * p.ldc + col];
+  }
+  return q;
+}
+// epilogue of that tile from the gathered values; returns the lane's contribution to the column sum of what it wrote
+// (bias gradient of a dpre output)
+__device__ __forceinline__ float g16_epilogue(const Gemm16Args& p, f32x4 v, int row0, int col, const G16Pre& q) {
   const int M = p.M, N = p.N;
   if (row0 >= M || col >= N) return 0.f;   // (the column-sum shuffles run outside: all lanes take part)
-  if (p.epi == ARK_EPI_BIAS || p.epi == ARK_EPI_BIAS_RELU) v += p.bias[col];
+  if (p.epi == ARK_EPI_BIAS || p.epi == ARK_EPI_BIAS_RELU) v += q.bias;
   if (p.c_tiled) {  // M % 16 == 0 and ldc % 16 == 0 (checked on the host): the quad is whole
     const long o = tile_native_off(row0, col, (int)p.ldc);
-    if (p.epi == ARK_EPI_MUL_AUX) v *= *reinterpret_cast<const f32x4*>(p.aux + o);
+    if (p.epi == ARK_EPI_MUL_AUX) v *= q.x;
     *reinterpret_cast<f32x4*>(p.C + o) = v;
     return 0.f;
   }
@@ -49,13 +72,13 @@ __device__ __forceinline__ float g16_epilogue(const Gemm16Args& p, f32x4 v, int 
     if (row0 + i >= M) break;
     const long o = (long)(row0 + i) * p.ldc + col;
     float x = v[i];
-    if (p.epi == ARK_EPI_MUL_AUX) x *= p.aux[o];
-    if (p.epi == ARK_EPI_MUL_DGELU) x *= dgelu_fast(p.aux[o]);
+    if (p.epi == ARK_EPI_MUL_AUX) x *= q.x[i];
+    if (p.epi == ARK_EPI_MUL_DGELU) x *= dgelu_fast(q.x[i]);
     if (p.epi == ARK_EPI_BIAS_RELU) x = fmaxf(x, 0.f);
-    if (p.epi == ARK_EPI_MUL_RELU) x = p.aux[o] > 0.f ? x : 0.f;
-    if (p.epi == ARK_EPI_ADD) x += p.C[o];   // (each element belongs to exactly one lane of one workgroup)
+    if (p.epi == ARK_EPI_MUL_RELU) x = q.x[i] > 0.f ? x : 0.f;
+    if (p.epi == ARK_EPI_ADD) x += q.x[i];   // (each element belongs to exactly one lane of one workgroup)
     if (p.epi == ARK_EPI_BIAS_GELU) {
-      x += p.bias[col];
+      x += q.bias;
       p.C[o] = x;            // pre-activation (fp32, kept for the backward pass)
       x = gelu_fast(x);      // the 16-bit copies carry the activation
     } else {
@@ -91,11 +114,18 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
   float csum[G::TN];
 #pragma unroll
   for (int tn = 0; tn < G::TN; ++tn) csum[tn] = 0.f;
+  G16Pre pre[G::TM][G::TN];
 #pragma unroll
   for (int tm = 0; tm < G::TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < G::TN; ++tn)
-      csum[tn] += g16_epilogue(p, acc[tm][tn], m0 + wm * G::WTM + tm * 16 + 4 * (lane >> 4), n0 + wn * G::WTN + tn * 16 + (lane & 15));
+      pre[tm][tn] = g16_preload(p, m0 + wm * G::WTM + tm * 16 + 4 * (lane >> 4), n0 + wn * G::WTN + tn * 16 + (lane & 15));
+#pragma unroll
+  for (int tm = 0; tm < G::TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < G::TN; ++tn)
+      csum[tn] += g16_epilogue(p, acc[tm][tn], m0 + wm * G::WTM + tm * 16 + 4 * (lane >> 4), n0 + wn * G::WTN + tn * 16 + (lane & 15),
+                               pre[tm][tn]);
   if (p.colsum && !p.c_tiled) {
 #pragma unroll
     for (int tn = 0; tn < G::TN; ++tn) g16_colsum(p, csum[tn], n0 + wn * G::WTN + tn * 16 + (lane & 15));
