@@ -483,6 +483,45 @@ __global__ __launch_bounds__(256) void colsum16_kernel(const void* X_, long ld, 
   if (wave == 0 && col < N) atomicAdd(&out[col], red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
 }
 
+// the same sums with 16-byte loads: a lane owns 8 columns, a wave reads 1 KB of a row per instruction and keeps four rows in
+// flight (round 5: the kernel above issues one 2-byte load per lane and iteration and waits for it -- 15 us for the 42 MB
+// gate-gradient panel of syn-paths).  N % 8 == 0, ld % 8 == 0, 16-byte aligned X.
+template <int PREC>
+__global__ __launch_bounds__(256) void colsum16_wide_kernel(const void* X_, long ld, float* __restrict__ out, int M, int N, int rows_per_wg) {
+  using PT = PrecTraits<PREC>;
+  using H = typename PT::h_t;
+  using H8 = typename PT::h8;
+  const H* X = reinterpret_cast<const H*>(X_);
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 512 + lane * 8;
+  const int m0 = blockIdx.y * rows_per_wg, m1 = min(M, m0 + rows_per_wg);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < N) {
+    for (int r = m0 + wave; r < m1; r += 16) {
+      H8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = min(r + 4 * u, m1 - 1);   // (a row past the end re-reads the last one and is not added)
+        v[u] = *reinterpret_cast<const H8*>(X + (long)rr * ld + col);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + 4 * u < m1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[e] += (float)v[u][e];
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = s[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    const int cc = blockIdx.x * 512 + c;
+    if (cc < N) atomicAdd(&out[cc], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  }
+}
+
 template <int PREC>
 __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ x, void* out_, long n) {
   using H = typename PrecTraits<PREC>::h_t;
@@ -636,6 +675,18 @@ extern "C" int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, i
   if (!accumulate) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
     if (e != hipSuccess) return (int)e;
+  }
+  if (prec != PREC_F16 && prec != PREC_BF16) return ARK_ERR_ARG;
+  if (N % 8 == 0 && ld % 8 == 0 && ((uintptr_t)x16 & 15) == 0) {
+    int rows_per_wg = 256;
+    const int col_tiles = (N + 511) / 512;
+    // (syn-paths panel, 10 240 x 2 048: 15.1 / 12.8 / 14.4 / 21.7 us at 32 / 64 / 128 / 256 rows per workgroup -- 640 workgroups)
+    while (rows_per_wg > 16 && (long)col_tiles * ((M + rows_per_wg - 1) / rows_per_wg) < 600) rows_per_wg >>= 1;
+    dim3 grid(col_tiles, (M + rows_per_wg - 1) / rows_per_wg);
+    if (prec == PREC_F16) hipLaunchKernelGGL(colsum16_wide_kernel<PREC_F16>, grid, dim3(256), 0, st, x16, (long)ld, out, M, N, rows_per_wg);
+    else hipLaunchKernelGGL(colsum16_wide_kernel<PREC_BF16>, grid, dim3(256), 0, st, x16, (long)ld, out, M, N, rows_per_wg);
+    ARK_LAUNCH_CHECK();
+    return 0;
   }
   int rows_per_wg = 128;
   const int col_tiles = (N + 63) / 64;

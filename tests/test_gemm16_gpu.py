@@ -148,3 +148,26 @@ def test_gemm16_engines_agree_on_every_epilogue(epi, shape):
         ref = ref * aux.double()
     for C in outs:
         assert (C.double() - ref).abs().max().item() <= 3e-5 * K ** 0.5 + 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [L.PREC_F16, L.PREC_BF16])
+@pytest.mark.parametrize("M,N,ld,off", [(10240, 2048, 2048, 0), (1000, 520, 528, 0), (77, 2048, 2048, 0), (300, 100, 104, 0), (512, 512, 512, 3),
+                                        (64, 24101, 24104, 0)])
+def test_column_sums_of_a_16_bit_panel(prec, M, N, ld, off):
+    """ark_colsum16 (bias gradients from the 16-bit gradient panels) against fp64 sums: the 16-byte-load kernel (N, ld multiples
+    of 8, aligned base) and the element-wise one (anything else: N = 100, a base 6 bytes into an allocation), overwrite and
+    accumulate"""
+    dev = torch.device("cuda:0")
+    dt = torch.float16 if prec == L.PREC_F16 else torch.bfloat16
+    g = torch.Generator().manual_seed(M + N)
+    buf = (torch.randn(M * ld + 8, generator=g) * 0.5).to(dt).to(dev)
+    X = buf[off:off + M * ld].view(M, ld)
+    ref = X[:, :N].double().sum(dim=0).cpu()
+    out = torch.full((N,), 7.0, device=dev)
+    rc = L.lib().ark_colsum16(L.i32(prec), L.ptr(X), L.i64(ld), L.ptr(out), L.i32(M), L.i32(N), L.i32(0), L.cur_stream())
+    assert rc == 0
+    rc = L.lib().ark_colsum16(L.i32(prec), L.ptr(X), L.i64(ld), L.ptr(out), L.i32(M), L.i32(N), L.i32(1), L.cur_stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (out.double().cpu() - 2 * ref).abs().max().item() <= 2e-5 * M ** 0.5 + 1e-4
