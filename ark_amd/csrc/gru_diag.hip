@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruD
     mt = k / UT;
     ut = k % UT;
   }
-  const ArkGruDiagRole& R = p.role[role];
+  const ArkGruDiagRole R = p.role[role];   // (by value: the whole role in one burst of scalar loads, one wait)
   const int m0 = mt * BM, u0 = ut * BU;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(128 * WGM) void gru_diag_bwd_kernel(GruDiagBwdArgs 
     nt = kk % NT;
   }
   const int m0 = mt * BM, n0 = nt * BN;
-  const ArkGruDiagBwdRole& R = p.role[role];
+  const ArkGruDiagBwdRole R = p.role[role];   // (by value: the whole role in one burst of scalar loads, one wait -- by reference its fields came one dependent s_load at a time)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const bool fin = R.dh0 != nullptr;   // initial-state role: dh0 += carry + dgh_0 W_hh, nothing else
