@@ -458,9 +458,10 @@ __global__ __launch_bounds__(256) void latent_dA_kernel(const float* __restrict_
   constexpr int RW = 8;
   __shared__ float sh[RW][256];   // (2Z <= 256: host check)
   const int row0 = blockIdx.x * RW;
-  for (int i = threadIdx.x; i < RW * Z2; i += 256) {
-    const int r = i / Z2, j = i - r * Z2;
-    sh[r][j] = row0 + r < B ? dhead[(long)(row0 + r) * Z2 + j] : 0.f;
+  const int Z2p = (Z2 + 31) & ~31;   // (columns up to the next multiple of 32 are zero: the products below run in blocks of 32)
+  for (int i = threadIdx.x; i < RW * Z2p; i += 256) {
+    const int r = i / Z2p, j = i - r * Z2p;
+    sh[r][j] = (row0 + r < B && j < Z2) ? dhead[(long)(row0 + r) * Z2 + j] : 0.f;
   }
   __syncthreads();
   const int c = blockIdx.y * 256 + threadIdx.x;
@@ -471,11 +472,17 @@ __global__ __launch_bounds__(256) void latent_dA_kernel(const float* __restrict_
     acc[r] = 0.f;
     pv[r] = row0 + r < B ? pre[(long)(row0 + r) * H + c] : 0.f;
   }
-#pragma unroll 8
-  for (int j = 0; j < Z2; ++j) {
-    const float wv = Whead[(long)j * H + c];
+  // 32 rows of W_head in flight at once (round 5): on the step's critical path beside the chip-filling weight-gradient group
+  // a memory round trip costs several microseconds, and eight loads per trip made this kernel 94 us in the step (16 alone)
+  for (int j0 = 0; j0 < Z2; j0 += 32) {
+    float wv[32];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) acc[r] += sh[r][j] * wv;
+    for (int u = 0; u < 32; ++u) wv[u] = Whead[(long)min(j0 + u, Z2 - 1) * H + c];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+#pragma unroll
+      for (int r = 0; r < RW; ++r) acc[r] += sh[r][j0 + u] * wv[u];
+    }
   }
   float cs = 0.f;
 #pragma unroll
