@@ -6,7 +6,9 @@
 //   dY = dlogits W_tok, dW_tok += dlogits^T y, db_out = colsum(dlogits)   (autograd of the above)
 // with two launches, both of the flash-attention kind (softmax over the vocabulary axis):
 //
-//   ark_vocab_ce_fwd  one workgroup per 64 rows; W_tok streams through an LDS-DMA ring in tiles of 64 tokens.
+//   ark_vocab_ce_fwd  one workgroup per 64 rows; W_tok streams through an LDS-DMA ring in stages of 64 tokens (D = 512) to
+//                     256 tokens (D <= 128: several 64-token blocks per stage, one barrier and one running-maximum update
+//                     per stage).
 //                     S^T = W_tile y^T on the matrix cores (TRANSPOSED on purpose: the accumulator then has the
 //                     row index on the lane and the tokens in its registers, so the online max / sum-exp are
 //                     per-lane scalars and exp(S^T - m) IS the B fragment of the second product -- no LDS
@@ -195,10 +197,7 @@ constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 // nothing to overlap with) several times as long; with TM blocks a wave has 2 TM independent accumulator chains in the
 // first product and one maximum / one barrier per 64 TM rows.  D = 512 keeps TM = 1 (registers: 192 of a wave's 256 hold
 // accumulators and its row).
-#ifndef ARK_VC_TM_CAP
-#define ARK_VC_TM_CAP 4
-#endif
-constexpr int vc_tm_cap(int dch) { return (dch <= 2 ? 4 : dch <= 4 ? 2 : 1) < ARK_VC_TM_CAP ? (dch <= 2 ? 4 : dch <= 4 ? 2 : 1) : ARK_VC_TM_CAP; }
+constexpr int vc_tm_cap(int dch) { return dch <= 2 ? 4 : dch <= 4 ? 2 : 1; }
 // ring depth by stage size (8 KB per image): small stages afford four slots -- three in flight per workgroup
 constexpr int vc_slots(int imgs) { return imgs <= 2 ? 4 : imgs <= 4 ? 3 : 2; }
 constexpr int vc_ring_bytes(int dch, int nw, int aux_per_wave, int tm) {
