@@ -496,17 +496,18 @@ __global__ __launch_bounds__(256) void colsum16_wide_kernel(const void* X_, long
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 512 + lane * 8;
   const int m0 = blockIdx.y * rows_per_wg, m1 = min(M, m0 + rows_per_wg);
+  constexpr int RF = 8;   // rows in flight per wave
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (col < N) {
-    for (int r = m0 + wave; r < m1; r += 16) {
-      H8 v[4];
+    for (int r = m0 + wave; r < m1; r += 4 * RF) {
+      H8 v[RF];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RF; ++u) {
         const int rr = min(r + 4 * u, m1 - 1);   // (a row past the end re-reads the last one and is not added)
         v[u] = *reinterpret_cast<const H8*>(X + (long)rr * ld + col);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < RF; ++u)
         if (r + 4 * u < m1) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) s[e] += (float)v[u][e];
@@ -677,11 +678,15 @@ extern "C" int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, i
     if (e != hipSuccess) return (int)e;
   }
   if (prec != PREC_F16 && prec != PREC_BF16) return ARK_ERR_ARG;
-  if (N % 8 == 0 && ld % 8 == 0 && ((uintptr_t)x16 & 15) == 0) {
+  if ((N + 7) / 8 * 8 <= ld && ld % 8 == 0 && ((uintptr_t)x16 & 15) == 0) {   // (a lane's 8 columns may reach into the row's padding)
     int rows_per_wg = 256;
     const int col_tiles = (N + 511) / 512;
-    // (syn-paths panel, 10 240 x 2 048: 15.1 / 12.8 / 14.4 / 21.7 us at 32 / 64 / 128 / 256 rows per workgroup -- 640 workgroups)
-    while (rows_per_wg > 16 && (long)col_tiles * ((M + rows_per_wg - 1) / rows_per_wg) < 600) rows_per_wg >>= 1;
+    // (10 240 x 2 048: 15.1 / 12.8 / 14.4 / 21.7 us at 32 / 64 / 128 / 256 rows per workgroup -- 640 workgroups; a NARROW panel
+    //  -- the [10 240, 45] dlogits of syn-paths -- keeps >= 32 KB per workgroup: every workgroup ends in one atomic per column,
+    //  and 640 of them on the same 45 addresses were most of that launch's 15 us)
+    const long row_bytes = 2L * (N < 512 ? (N + 7) / 8 * 8 : 512);
+    while (rows_per_wg > 16 && (long)col_tiles * ((M + rows_per_wg - 1) / rows_per_wg) < 600 && (rows_per_wg / 2) * row_bytes >= 32768)
+      rows_per_wg >>= 1;
     dim3 grid(col_tiles, (M + rows_per_wg - 1) / rows_per_wg);
     if (prec == PREC_F16) hipLaunchKernelGGL(colsum16_wide_kernel<PREC_F16>, grid, dim3(256), 0, st, x16, (long)ld, out, M, N, rows_per_wg);
     else hipLaunchKernelGGL(colsum16_wide_kernel<PREC_BF16>, grid, dim3(256), 0, st, x16, (long)ld, out, M, N, rows_per_wg);

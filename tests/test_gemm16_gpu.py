@@ -152,7 +152,7 @@ def test_gemm16_engines_agree_on_every_epilogue(epi, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", [L.PREC_F16, L.PREC_BF16])
-@pytest.mark.parametrize("M,N,ld,off", [(10240, 2048, 2048, 0), (1000, 520, 528, 0), (77, 2048, 2048, 0), (300, 100, 104, 0), (512, 512, 512, 3),
+@pytest.mark.parametrize("M,N,ld,off", [(10240, 2048, 2048, 0), (1000, 520, 528, 0), (77, 2048, 2048, 0), (300, 100, 104, 0), (300, 100, 100, 0), (10240, 45, 64, 0), (512, 512, 512, 3),
                                         (64, 24101, 24104, 0)])
 def test_column_sums_of_a_16_bit_panel(prec, M, N, ld, off):
     """ark_colsum16 (bias gradients from the 16-bit gradient panels) against fp64 sums: the 16-byte-load kernel (N, ld multiples
