@@ -3,6 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Kernels of the step's DEPENDENT CHAIN raise their waves' issue priority (s_setprio): in the tail they share CUs with the
+// chip-filling weight-gradient / Adam launches of the side queues, whose older waves otherwise win the SIMD arbitration.
+#ifndef ARK_NO_CHAIN_PRIO
+#define ARK_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define ARK_CHAIN_PRIO() ((void)0)
+#endif
+
 namespace ark {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

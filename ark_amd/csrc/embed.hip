@@ -131,6 +131,7 @@ struct PoolGatherArgs {
   int col_blocks;   // 0: one pool workgroup per graph; > 0: this many 64-column workgroups per graph (long graphs)
 };
 __global__ __launch_bounds__(256) void pool_gather_fwd_kernel(PoolGatherArgs p) {
+  ARK_CHAIN_PRIO();
   const int npool = p.col_blocks > 0 ? p.B * p.col_blocks : p.B;
   if ((int)blockIdx.x < npool) {
     if (p.col_blocks > 0)
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256) void enc_scatter_fused_kernel(const int64_t* _
                                                                 const float* __restrict__ inv_cnt, float* __restrict__ dE,
                                                                 float* __restrict__ dR, int B, int T, int D, int n_ent, int n_rel,
                                                                 long pad_eid, long pad_rid, int n_chunks) {
+  ARK_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* te = reinterpret_cast<float*>(smem);        // [n_ent][64]
   float* tr = te + (size_t)n_ent * 64;               // [n_rel][64]

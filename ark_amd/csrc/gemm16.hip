@@ -99,6 +99,7 @@ __device__ __forceinline__ void g16_colsum(const Gemm16Args& p, float cs, int co
 
 template <int PREC, int BM, int BN, int NBUF>
 __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args p) {
+  ARK_CHAIN_PRIO();
   using G = DmaTile<PREC, BM, BN, NBUF, 2, 2>;
   using h_t = typename G::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -148,6 +149,7 @@ __device__ __forceinline__ void put16x4(void* base, long idx, f32x4 v, int prec)
 // is only read as the next product's operand), ldc % 4 == 0, 16-byte aligned C / aux / bias, 8-byte aligned copies.
 template <int PREC, int BM, int BN, int NW, int NSLOT, bool CLAMP = false>
 __global__ __launch_bounds__(64 * NW) void gemm16_wpk_kernel(Gemm16Args p) {
+  ARK_CHAIN_PRIO();
   using G = WpkNT<PREC, BM, BN, NW, NSLOT>;
   using h_t = typename G::h_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -796,6 +798,7 @@ __global__ __launch_bounds__(256) void latent_zproj_fwd_kernel(const float* __re
                                                                const float* __restrict__ Wz, const float* __restrict__ bz,
                                                                float* __restrict__ h0, ZprojOut o, int B, int n_valid, int Z,
                                                                int D, int DC) {
+  ARK_CHAIN_PRIO();
   __shared__ float zs[128], ts[128];
   const int b = blockIdx.x / DC, dc = blockIdx.x % DC, tid = threadIdx.x;
   if (tid < Z) {

@@ -76,6 +76,7 @@ struct GruDiagArgs {
 // 19.1 -- was removed in round 5 together with its runner.)
 template <int PREC, int PRECB, int NBUF, int KI, int BM, int BU, int WGM = 2, int MODE = 0>
 __global__ __launch_bounds__(64 * WGM * (BU / 16)) void gru_diag_fwd_kernel(GruDiagArgs p) {
+  ARK_CHAIN_PRIO();
   constexpr int BN = 3 * BU, WGN = BU / 16, NTHR = 64 * WGM * WGN;
   using G = DmaTile<PREC, BM, BN, NBUF, WGM, WGN, KI>;
   constexpr int TM = G::TM, TN = G::TN;
@@ -377,6 +378,7 @@ struct GruDiagBwdArgs {
 
 template <int PREC, int NBUF, int KI, int BM, int BN = 64, int WGM = 2, bool ONEBAR = false>
 __global__ __launch_bounds__(128 * WGM) void gru_diag_bwd_kernel(GruDiagBwdArgs p) {
+  ARK_CHAIN_PRIO();
   static_assert(BN == 64 || BN == 32, "64 output columns per workgroup, or 32 for grids that would leave most CUs empty");
   using G = DmaTile<PREC, BM, BN, NBUF, WGM, 2, KI>;   // wave tile (BM/WGM) x (BN/2); WGM = 4: 128 x 64 on 8 waves
   constexpr int TM = G::TM, TN = G::TN, WN = BN / 2, NTHR = 128 * WGM;

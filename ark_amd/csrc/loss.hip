@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void latent_chain_bwd_kernel(float* __restrict
                                                                float* __restrict__ dhead, float* __restrict__ dA, void* dA16,
                                                                int prec16, float* __restrict__ dA_colsum, int B, int Z, int D,
                                                                int H) {
+  ARK_CHAIN_PRIO();
   static_assert((ZT <= 64 && RW == 4) || (ZT > 64 && RW == 1), "one wave per row; the wide-latent form: one workgroup per row");
   extern __shared__ __attribute__((aligned(16))) char smem_lc[];
   float* zs = reinterpret_cast<float*>(smem_lc);   // Wz^T: [Z][D + 1]
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(256) void latent_dz_head_kernel(float* __restrict__
                                                              const float* __restrict__ eps, const float* __restrict__ hyper,
                                                              const float* __restrict__ ext_dhead, float* __restrict__ dhead,
                                                              int B, int Z, int D) {
+  ARK_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) char smem_dz[];
   float* zs = reinterpret_cast<float*>(smem_dz);   // Wz^T: [Z][D + 1]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(256) void latent_dz_head_kernel(float* __restrict__
 __global__ __launch_bounds__(256) void latent_dA_kernel(const float* __restrict__ dhead, const float* __restrict__ Whead,
                                                         const float* __restrict__ pre, float* __restrict__ dA, void* dA16, int prec16,
                                                         float* __restrict__ dA_colsum, int B, int Z2, int H) {
+  ARK_CHAIN_PRIO();
   constexpr int RW = 8;
   __shared__ float sh[RW][256];   // (2Z <= 256: host check)
   const int row0 = blockIdx.x * RW;
