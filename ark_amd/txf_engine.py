@@ -177,73 +177,7 @@ class TxfEngine(Engine):
 
     # ------------------------------------------------------------------ plumbing the base class expects
     def refresh_shadows(self):
-        """16-bit copies (plain and transposed, product operand type) of every matrix parameter from the fp32 values: after
-        load_params / an external optimiser.  The engine's own Adam launches refresh the ranges they update (_adam_launch)."""
-        if self.fast_gemm:
-            self._shadow_launch(0, self.layout.total)
         self._shadow_ok = True
-
-    # ------------------------------------------------------------------ 16-bit weight copies, written once per update
-    # Round 5.  The dense products take 16-bit operands; the WEIGHT side used to be cast per product and step (35 cast launches
-    # + 12 transposing ones of 5-7 us each per t-ARK step at syn-paths: 190 us of 3.1 ms).  Every matrix parameter now has a
-    # plain [R, C] (forward element type) and a transposed [C, R] (backward element type) 16-bit copy that ONE batched launch
-    # per optimiser update rewrites
-    # (ark_weight_shadows, 12 matrices per launch, queued right behind the Adam launch of the same flat range -- also on the
-    # pipelined data-parallel update queue); _gemm finds them by the parameter's address and falls back to a per-call cast
-    # for anything else (slices of a parameter, non-parameter operands).
-    def _build_wshadows(self):
-        dev = self.device
-        self._wsh, self._wsh_list, self._wsh_chunks = {}, [], {}
-        for name, (off, shape, numel) in self.layout.entries.items():
-            if len(shape) != 2 or numel < 4096:
-                continue
-            R, C = int(shape[0]), int(shape[1])
-            w16 = torch.empty(R * C, device=dev, dtype=torch.int16)
-            wT16 = torch.empty(R * C, device=dev, dtype=torch.int16)
-            self._wsh[self.p[name].data_ptr()] = (w16, wT16, R, C)
-            self._wsh_list.append((off, self.p[name], w16, wT16, R, C))
-
-    def _shadow_launch(self, lo, hi):
-        import ctypes
-        if getattr(self, "_wsh", None) is None:
-            self._build_wshadows()
-        chunks = self._wsh_chunks.get((lo, hi))
-        if chunks is None:
-            jobs = [j for j in self._wsh_list if lo <= j[0] < hi]
-            chunks = []
-            for c0 in range(0, len(jobs), 12):
-                ch = jobs[c0:c0 + 12]
-                n = len(ch)
-                chunks.append((n, (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in ch]), (ctypes.c_void_p * n)(*[j[2].data_ptr() for j in ch]),
-                               (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in ch]), (ctypes.c_int * n)(*[j[4] for j in ch]),
-                               (ctypes.c_int * n)(*[j[5] for j in ch]), (ctypes.c_int * n)(*[self.prec_fwd] * n),
-                               (ctypes.c_int * n)(*[self.prec_bwd] * n), (ctypes.c_int * n)(*[j[4] for j in ch])))
-            self._wsh_chunks[(lo, hi)] = chunks
-        for (n, src, dst, dstT, R, C, pf, pb, ldT) in chunks:
-            _call("ark_weight_shadows", L.i32(n), src, dst, dstT, R, C, pf, pb, ldT, L.cur_stream())
-
-    def _adam_launch(self, which, g16=False):
-        super()._adam_launch(which, g16)
-        if self.fast_gemm:
-            lo, hi = {"all": (0, self.layout.total), "enc": (0, self.layout.dec_grad_offset),
-                      "dec": (self.layout.dec_grad_offset, self.layout.total)}[which]
-            self._shadow_launch(lo, hi)
-
-    def _wshadow(self, Bm, R, C, transposed, prec=None):
-        """the 16-bit copy of parameter matrix Bm [R, C] (transposed: as [C, R]) if Bm IS a whole parameter and the copies are
-        current, else None"""
-        if not self.fast_gemm:
-            return None
-        if not self._shadow_ok:
-            self.refresh_shadows()
-        sh = self._wsh.get(Bm.data_ptr()) if getattr(self, "_wsh", None) else None
-        if sh is None or sh[2] != R or sh[3] != C or Bm.numel() != R * C:
-            return None
-        # the plain copy has the forward products' element type, the transposed one the backward products' (mixed precision:
-        # fp16 / bf16 -- self.prec is whichever pass is running); a product that wants the other combination casts for itself
-        if (self.prec if prec is None else prec) != (self.prec_bwd if transposed else self.prec_fwd):
-            return None
-        return sh[1] if transposed else sh[0]
 
     def _default_norms(self, B):
         if self.vae:
@@ -360,13 +294,9 @@ class TxfEngine(Engine):
             w["ce_dY"] = torch.empty(R * D, device=dev)
             ns = int(L.lib().ark_vocab_ce_fwd_splits(L.i32(R), L.i32(V), L.i32(D), L.i32(0)))
             w["ce_ws"] = torch.empty(ns * (R * D + 4 * R), device=dev) if ns > 1 else None
-        w16 = self._wshadow(self.p["dec.out.weight"], self.V, self.D, False, prec=self.prec_fwd)   # (the optimiser update's own copy;
-        #                                                      both CE kernels take the forward element type, in either pass)
-        if w16 is None:
-            if getattr(self, "_ce_w16", None) is None:
-                self._ce_w16 = torch.empty(self.V * self.D, device=self.device, dtype=torch.int16)
-            w16 = self._ce_w16
-        return w["ce_y16"], w16, w["ce_lse"], w["ce_dY"], w["ce_ws"]
+        if getattr(self, "_ce_w16", None) is None:
+            self._ce_w16 = torch.empty(self.V * self.D, device=self.device, dtype=torch.int16)
+        return w["ce_y16"], self._ce_w16, w["ce_lse"], w["ce_dY"], w["ce_ws"]
 
     # ------------------------------------------------------------------ dense products, 16-bit fast path
     def _buf(self, slot, nbytes):
@@ -417,9 +347,7 @@ class TxfEngine(Engine):
         if a_lay == KM and K % 64 == 0 and lda == K and ((b_lay == KM and ldb == K) or (b_lay == MM and ldb == N)):
             # C[M,N] (+)= A[M,K] op(B): B is [N,K] (KM) or [K,N] (MM: its transposed 16-bit copy is made)
             A16 = self._cast("a", A, M * K, pr)
-            B16 = self._wshadow(Bm, N, K, False) if b_lay == KM else self._wshadow(Bm, K, N, True)
-            if B16 is None:
-                B16 = self._cast("b", Bm, N * K, pr) if b_lay == KM else self._cast_t("b", Bm, K, N, pr)
+            B16 = self._cast("b", Bm, N * K, pr) if b_lay == KM else self._cast_t("b", Bm, K, N, pr)
             if acc and epi == L.EPI_NONE and ldc == N:   # C += A op(B) in the product's own epilogue
                 _call("ark_gemm16", L.i32(pr), L.i32(L.EPI_ADD), L.ptr(A16), L.i64(K), L.ptr(B16), L.i64(K), L.ptr(C), L.i64(ldc),
                       L.ptr(None), L.ptr(None), L.i32(M), L.i32(N), L.i32(K), L.i32(0), st)
@@ -609,8 +537,7 @@ class TxfEngine(Engine):
             if fused:
                 y16, w16, lse, dY, ws = self._fused_ce_bufs(w, R)
                 _call("ark_cast16", L.i32(self.prec_fwd), L.ptr(x), L.ptr(y16), L.i64(R * D), st)
-                if w16 is getattr(self, "_ce_w16", None):   # (no optimiser-written copy of the output weight: cast it here)
-                    _call("ark_cast16", L.i32(self.prec_fwd), L.ptr(p["dec.out.weight"]), L.ptr(w16), L.i64(V * D), st)
+                _call("ark_cast16", L.i32(self.prec_fwd), L.ptr(p["dec.out.weight"]), L.ptr(w16), L.i64(V * D), st)
                 if with_dlogits and ws is not None:   # few rows: the vocabulary sweep split over workgroups + one merging launch
                     _call("ark_vocab_ce_fwd_ws", L.i32(self.prec_fwd), L.ptr(y16), L.ptr(w16), L.ptr(p["dec.out.bias"]), L.ptr(seq),
                           L.i64(ld_seq), L.ptr(self.hyper), L.ptr(w["row_loss"]), L.ptr(lse), L.ptr(dY), L.ptr(ws), L.i64(ws.numel()),
