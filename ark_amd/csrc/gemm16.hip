@@ -684,8 +684,8 @@ extern "C" int ark_colsum16(int prec, const void* x16, int64_t ld, float* out, i
     int rows_per_wg = 256;
     const int col_tiles = (N + 511) / 512;
     // (10 240 x 2 048: 15.1 / 12.8 / 14.4 / 21.7 us at 32 / 64 / 128 / 256 rows per workgroup -- 640 workgroups; a NARROW panel
-    //  -- the [10 240, 45] dlogits of syn-paths -- keeps >= 32 KB per workgroup: every workgroup ends in one atomic per column,
-    //  and 640 of them on the same 45 addresses were most of that launch's 15 us)
+    //  -- the [10 240, 45] dlogits of syn-paths -- keeps >= 32 KB per workgroup, 40 workgroups instead of 640 ending in one atomic
+    //  per column each: 15.3 -> 12.8 us, most of which is the fixed cost of a stand-alone launch over 1.3 MB)
     const long row_bytes = 2L * (N < 512 ? (N + 7) / 8 * 8 : 512);
     while (rows_per_wg > 16 && (long)col_tiles * ((M + rows_per_wg - 1) / rows_per_wg) < 600 && (rows_per_wg / 2) * row_bytes >= 32768)
       rows_per_wg >>= 1;
